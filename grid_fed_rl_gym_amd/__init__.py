@@ -1,0 +1,21 @@
+"""MI355X-native batched AC power-flow env.step() -- drop-in for the hot path of
+danieleschmidt/grid-fed-rl-gym (GridEnvironment.step / NewtonRaphsonSolver.solve).
+
+Host side is plain Python + NumPy over a C-ABI shared library (libgridstep.so, ctypes);
+all arithmetic on the path runs in hand-written HIP kernels for gfx950.  There is no CPU
+fallback: importing the solver/environment classes works anywhere, but constructing them
+without the built library or without a GPU raises.
+"""
+from .components import (Bus, Line, Load, PowerFlowSolution, BatchedPowerFlowSolution,
+                         PowerFlowError, InvalidActionError)
+from .feeders import (FeederSpec, flatten_feeder, flatten_network, to_objects, reference_env_network,
+                      with_reference_env_renewables, simple_radial, ieee13_like, ieee123_like,
+                      random_meshed)
+
+__all__ = [
+    "Bus", "Line", "Load", "PowerFlowSolution", "BatchedPowerFlowSolution", "PowerFlowError",
+    "InvalidActionError", "FeederSpec", "flatten_feeder", "flatten_network", "to_objects",
+    "reference_env_network", "with_reference_env_renewables", "simple_radial", "ieee13_like",
+    "ieee123_like", "random_meshed",
+]
+__version__ = "0.1.0"
