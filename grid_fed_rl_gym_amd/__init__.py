@@ -12,7 +12,15 @@ from .feeders import (FeederSpec, flatten_feeder, flatten_network, to_objects, r
                       with_reference_env_renewables, simple_radial, ieee13_like, ieee123_like,
                       random_meshed)
 
+from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoupledSolver,
+                     BatchedForwardBackwardSweepSolver, DistributionPowerFlow, parallel_power_flow_batch,
+                     injections_from_dicts)
+from .env import BatchedGridEnvironment, VectorizedEnvironment, Box
+
 __all__ = [
+    "BatchedNewtonRaphsonSolver", "NewtonRaphsonSolver", "FastDecoupledSolver",
+    "BatchedForwardBackwardSweepSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
+    "injections_from_dicts", "BatchedGridEnvironment", "VectorizedEnvironment", "Box",
     "Bus", "Line", "Load", "PowerFlowSolution", "BatchedPowerFlowSolution", "PowerFlowError",
     "InvalidActionError", "FeederSpec", "flatten_feeder", "flatten_network", "to_objects",
     "reference_env_network", "with_reference_env_renewables", "simple_radial", "ieee13_like",

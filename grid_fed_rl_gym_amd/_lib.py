@@ -1,0 +1,344 @@
+"""ctypes binding of libgridstep.so (include/gridstep.h).
+
+This is the only place Python touches the device path.  There is no fallback of any kind:
+if the shared library has not been built (``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C grid_fed_rl_gym_amd/csrc``) loading raises, and if no GPU is visible
+``gs_create`` fails with GS_E_NO_DEVICE and ``Handle`` raises PowerFlowError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Optional
+
+import numpy as np
+
+from .components import PowerFlowError
+from .feeders import FeederSpec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgridstep.so")
+
+GS_ABI_VERSION = 1
+GS_OK, GS_E_INVALID, GS_E_NO_DEVICE, GS_E_HIP, GS_E_TOPOLOGY, GS_E_STATE, GS_E_COMM, GS_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
+JACOBIAN = {"as_coded": 0, "exact": 1}
+ZERO_Z = {"open": 0, "epsilon": 1}
+SOLVER = {"nr": 0, "newton_raphson": 0, "fbs": 1}
+LINSOLVE = {"auto": 0, "tree": 1, "sparse_lu": 2}
+KERNEL_NAMES = ["unpack", "env_pre", "solve", "env_post", "pack"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint8)
+
+
+class gs_topology(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("from_bus", _ip), ("to_bus", _ip), ("r", _dp), ("x", _dp), ("rating", _dp),
+                ("bus_type", _up), ("v_set", _dp),
+                ("n_loads", C.c_int32), ("load_bus", _ip), ("load_base", _dp), ("load_pf", _dp),
+                ("n_gens", C.c_int32), ("gen_bus", _ip), ("gen_kind", _ip), ("gen_cap", _dp),
+                ("gen_p0", _dp), ("gen_p1", _dp), ("gen_p2", _dp),
+                ("n_bats", C.c_int32), ("bat_bus", _ip), ("bat_cap", _dp), ("bat_rating", _dp), ("bat_eff", _dp)]
+
+
+class gs_config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("solver_kind", C.c_int32), ("jacobian_mode", C.c_int32),
+                ("zero_z_mode", C.c_int32), ("linear_solver", C.c_int32), ("max_iterations", C.c_int32),
+                ("episode_length", C.c_int32), ("stochastic_loads", C.c_int32), ("weather_variation", C.c_int32),
+                ("waves_per_group", C.c_int32), ("reserved0", C.c_int32),
+                ("tolerance", C.c_double), ("acceleration_factor", C.c_double), ("timestep", C.c_double),
+                ("v_min", C.c_double), ("v_max", C.c_double), ("f_min", C.c_double), ("f_max", C.c_double),
+                ("safety_penalty", C.c_double), ("inertia_H", C.c_double), ("damping_D", C.c_double),
+                ("f_nominal", C.c_double), ("power_base", C.c_double)]
+
+
+class gs_solution_view(C.Structure):
+    _fields_ = [("bus_voltages", _dp), ("bus_angles", _dp), ("line_flows", _dp), ("line_loadings", _dp),
+                ("losses", _dp), ("max_mismatch", _dp), ("iterations", _ip), ("converged", _up), ("status", _ip)]
+
+
+class gs_info_view(C.Structure):
+    _fields_ = [("power_flow_converged", _up), ("max_voltage", _dp), ("min_voltage", _dp), ("total_losses", _dp),
+                ("violations", _up), ("constraint_violations", _ip), ("current_step", _ip),
+                ("episode_reward", _dp), ("iterations", _ip), ("status", _ip)]
+
+
+# every symbol include/gridstep.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = [
+    ("gs_version", C.c_int, []),
+    ("gs_device_count", C.c_int, []),
+    ("gs_last_error", C.c_char_p, [_H]),
+    ("gs_create", C.c_int, [C.POINTER(gs_topology), C.POINTER(gs_config), C.c_int32, C.c_int32, C.c_int64, C.POINTER(_H)]),
+    ("gs_destroy", None, [_H]),
+    ("gs_dims", C.c_int, [_H, _ip, _ip, _ip, _ip, _ip, _ip]),
+    ("gs_describe", C.c_int, [_H, C.c_char_p, C.c_int32]),
+    ("gs_synchronize", C.c_int, [_H]),
+    ("gs_solve", C.c_int, [_H, _dp, _dp, C.POINTER(gs_solution_view)]),
+    ("gs_upload_injections", C.c_int, [_H, _dp, _dp]),
+    ("gs_solve_device", C.c_int, [_H]),
+    ("gs_download_solution", C.c_int, [_H, C.POINTER(gs_solution_view)]),
+    ("gs_reset", C.c_int, [_H, C.POINTER(C.c_uint64), _up, _dp]),
+    ("gs_step", C.c_int, [_H, _dp, _dp, _dp, _up, _up, C.POINTER(gs_info_view)]),
+    ("gs_upload_actions", C.c_int, [_H, _dp, C.c_int32]),
+    ("gs_step_device", C.c_int, [_H, C.c_int32]),
+    ("gs_download_step", C.c_int, [_H, _dp, _dp, _up, _up, C.POINTER(gs_info_view)]),
+    ("gs_get_state", C.c_int, [_H, _dp]),
+    ("gs_set_state", C.c_int, [_H, _dp]),
+    ("gs_comm_unique_id", C.c_int, [_up]),
+    ("gs_comm_init", C.c_int, [_H, _up, C.c_int32, C.c_int32]),
+    ("gs_allgather_obs", C.c_int, [_H, _dp]),
+    ("gs_comm_destroy", C.c_int, [_H]),
+    ("gs_timing_enable", C.c_int, [_H, C.c_int32]),
+    ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libgridstep.so and bind every declared symbol; raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PowerFlowError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run __graft_entry__.build() or `make -C grid_fed_rl_gym_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gs_version() != GS_ABI_VERSION:
+        raise PowerFlowError(f"libgridstep ABI {lib.gs_version()} != binding {GS_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a: Optional[np.ndarray], typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def make_config(**kw) -> gs_config:
+    """gs_config with the reference's constructor defaults (power_flow.py:79-84,
+    grid_env.py:161-173, dynamics.py:233-238)."""
+    cfg = gs_config()
+    cfg.struct_size = C.sizeof(gs_config)
+    d = dict(solver_kind=0, jacobian_mode=0, zero_z_mode=0, linear_solver=0, max_iterations=50,
+             episode_length=86400, stochastic_loads=0, weather_variation=0, waves_per_group=0, reserved0=0,
+             tolerance=1e-6, acceleration_factor=1.0, timestep=1.0, v_min=0.95, v_max=1.05, f_min=59.5,
+             f_max=60.5, safety_penalty=100.0, inertia_H=5.0, damping_D=1.0, f_nominal=60.0, power_base=1.0)
+    for k, v in kw.items():
+        if k not in d:
+            raise TypeError(f"unknown config field {k!r}")
+        d[k] = v
+    for k, v in d.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Handle:
+    """Owns one gs_handle (one GPU, one stream).  All array arguments are NumPy, batch-major."""
+
+    def __init__(self, spec: FeederSpec, cfg: gs_config, batch: int, device: int = 0, first_instance: int = 0):
+        self._lib = load()
+        self._h = _H()
+        self.spec = spec
+        self.B = int(batch)
+        keep = dict(frm=_i32(spec.frm), to=_i32(spec.to), r=_f64(spec.r), x=_f64(spec.x), rating=_f64(spec.rating),
+                    bus_type=np.ascontiguousarray(spec.bus_type, dtype=np.uint8), v_set=_f64(spec.v_set),
+                    load_bus=_i32(spec.load_bus), load_base=_f64(spec.load_base), load_pf=_f64(spec.load_pf),
+                    gen_bus=_i32(spec.gen_bus), gen_kind=_i32(spec.gen_kind), gen_cap=_f64(spec.gen_cap),
+                    gen_p0=_f64(spec.gen_p0), gen_p1=_f64(spec.gen_p1), gen_p2=_f64(spec.gen_p2),
+                    bat_bus=_i32(spec.bat_bus), bat_cap=_f64(spec.bat_cap), bat_rating=_f64(spec.bat_rating),
+                    bat_eff=_f64(spec.bat_eff))
+        t = gs_topology()
+        t.struct_size = C.sizeof(gs_topology)
+        t.n, t.m = spec.n, spec.m
+        t.from_bus, t.to_bus = _ptr(keep["frm"], _ip), _ptr(keep["to"], _ip)
+        t.r, t.x, t.rating = _ptr(keep["r"], _dp), _ptr(keep["x"], _dp), _ptr(keep["rating"], _dp)
+        t.bus_type, t.v_set = _ptr(keep["bus_type"], _up), _ptr(keep["v_set"], _dp)
+        t.n_loads = spec.n_loads
+        t.load_bus, t.load_base, t.load_pf = _ptr(keep["load_bus"], _ip), _ptr(keep["load_base"], _dp), _ptr(keep["load_pf"], _dp)
+        t.n_gens = spec.n_gens
+        t.gen_bus, t.gen_kind, t.gen_cap = _ptr(keep["gen_bus"], _ip), _ptr(keep["gen_kind"], _ip), _ptr(keep["gen_cap"], _dp)
+        t.gen_p0, t.gen_p1, t.gen_p2 = _ptr(keep["gen_p0"], _dp), _ptr(keep["gen_p1"], _dp), _ptr(keep["gen_p2"], _dp)
+        t.n_bats = spec.n_bats
+        t.bat_bus, t.bat_cap = _ptr(keep["bat_bus"], _ip), _ptr(keep["bat_cap"], _dp)
+        t.bat_rating, t.bat_eff = _ptr(keep["bat_rating"], _dp), _ptr(keep["bat_eff"], _dp)
+        rc = self._lib.gs_create(C.byref(t), C.byref(cfg), self.B, int(device), int(first_instance), C.byref(self._h))
+        if rc != GS_OK:
+            self._h = _H()
+            raise PowerFlowError(f"gs_create failed ({rc}): {self._lib.gs_last_error(None).decode()}")
+        dims = [C.c_int32() for _ in range(6)]
+        self._check(self._lib.gs_dims(self._h, *[C.byref(d) for d in dims]))
+        self.n, self.m, self.obs_dim, self.action_dim, self.state_dim, _ = [d.value for d in dims]
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != GS_OK:
+            raise PowerFlowError(f"libgridstep error {rc}: {self._lib.gs_last_error(self._h).decode()}")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.gs_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def describe(self) -> dict:
+        buf = C.create_string_buffer(1024)
+        self._check(self._lib.gs_describe(self._h, buf, 1024))
+        return json.loads(buf.value.decode())
+
+    def synchronize(self) -> None:
+        self._check(self._lib.gs_synchronize(self._h))
+
+    # -- solver ---------------------------------------------------------------------------
+    def _solution_buffers(self):
+        B, n, m = self.B, self.n, self.m
+        out = dict(bus_voltages=np.empty((B, n)), bus_angles=np.empty((B, n)), line_flows=np.empty((B, m)),
+                   line_loadings=np.empty((B, m)), losses=np.empty(B), max_mismatch=np.empty(B),
+                   iterations=np.empty(B, dtype=np.int32), converged=np.empty(B, dtype=np.uint8),
+                   status=np.empty(B, dtype=np.int32))
+        v = gs_solution_view(_ptr(out["bus_voltages"], _dp), _ptr(out["bus_angles"], _dp), _ptr(out["line_flows"], _dp),
+                             _ptr(out["line_loadings"], _dp), _ptr(out["losses"], _dp), _ptr(out["max_mismatch"], _dp),
+                             _ptr(out["iterations"], _ip), _ptr(out["converged"], _up), _ptr(out["status"], _ip))
+        return out, v
+
+    def _pq(self, P, Q):
+        P = _f64(P)
+        if P.shape != (self.B, self.n):
+            raise PowerFlowError(f"P_spec shape {P.shape} != ({self.B}, {self.n})")
+        if Q is not None:
+            Q = _f64(Q)
+            if Q.shape != P.shape:
+                raise PowerFlowError(f"Q_spec shape {Q.shape} != {P.shape}")
+        return P, Q
+
+    def solve(self, P, Q=None) -> dict:
+        P, Q = self._pq(P, Q)
+        out, v = self._solution_buffers()
+        self._check(self._lib.gs_solve(self._h, _ptr(P, _dp), _ptr(Q, _dp), C.byref(v)))
+        return out
+
+    def upload_injections(self, P, Q=None) -> None:
+        P, Q = self._pq(P, Q)
+        self._check(self._lib.gs_upload_injections(self._h, _ptr(P, _dp), _ptr(Q, _dp)))
+
+    def solve_device(self) -> None:
+        self._check(self._lib.gs_solve_device(self._h))
+
+    def download_solution(self) -> dict:
+        out, v = self._solution_buffers()
+        self._check(self._lib.gs_download_solution(self._h, C.byref(v)))
+        return out
+
+    # -- env ------------------------------------------------------------------------------
+    def reset(self, seeds=None, mask=None, want_obs: bool = True):
+        s = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        k = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if s is not None and s.shape != (self.B,):
+            raise PowerFlowError(f"seeds shape {s.shape} != ({self.B},)")
+        if k is not None and k.shape != (self.B,):
+            raise PowerFlowError(f"mask shape {k.shape} != ({self.B},)")
+        obs = np.empty((self.B, self.obs_dim)) if want_obs else None
+        self._check(self._lib.gs_reset(self._h, _ptr(s, C.POINTER(C.c_uint64)), _ptr(k, _up), _ptr(obs, _dp)))
+        return obs
+
+    def _step_buffers(self, want_obs=True):
+        B = self.B
+        out = dict(obs=np.empty((B, self.obs_dim)) if want_obs else None, reward=np.empty(B),
+                   terminated=np.empty(B, dtype=np.uint8), truncated=np.empty(B, dtype=np.uint8),
+                   power_flow_converged=np.empty(B, dtype=np.uint8), max_voltage=np.empty(B), min_voltage=np.empty(B),
+                   total_losses=np.empty(B), violations=np.empty((B, 4), dtype=np.uint8),
+                   constraint_violations=np.empty(B, dtype=np.int32), current_step=np.empty(B, dtype=np.int32),
+                   episode_reward=np.empty(B), iterations=np.empty(B, dtype=np.int32), status=np.empty(B, dtype=np.int32))
+        info = gs_info_view(_ptr(out["power_flow_converged"], _up), _ptr(out["max_voltage"], _dp),
+                            _ptr(out["min_voltage"], _dp), _ptr(out["total_losses"], _dp), _ptr(out["violations"], _up),
+                            _ptr(out["constraint_violations"], _ip), _ptr(out["current_step"], _ip),
+                            _ptr(out["episode_reward"], _dp), _ptr(out["iterations"], _ip), _ptr(out["status"], _ip))
+        return out, info
+
+    def step(self, actions) -> dict:
+        a = _f64(actions)
+        if a.shape != (self.B, self.action_dim):
+            raise PowerFlowError(f"actions shape {a.shape} != ({self.B}, {self.action_dim})")
+        out, info = self._step_buffers()
+        self._check(self._lib.gs_step(self._h, _ptr(a, _dp), _ptr(out["obs"], _dp), _ptr(out["reward"], _dp),
+                                      _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
+        return out
+
+    def upload_actions(self, actions) -> None:
+        a = _f64(actions)
+        if a.ndim != 3 or a.shape[1:] != (self.B, self.action_dim):
+            raise PowerFlowError(f"actions shape {a.shape} != (K, {self.B}, {self.action_dim})")
+        self._check(self._lib.gs_upload_actions(self._h, _ptr(a, _dp), a.shape[0]))
+
+    def step_device(self, k: int) -> None:
+        self._check(self._lib.gs_step_device(self._h, int(k)))
+
+    def download_step(self, want_obs: bool = True) -> dict:
+        out, info = self._step_buffers(want_obs)
+        self._check(self._lib.gs_download_step(self._h, _ptr(out["obs"], _dp), _ptr(out["reward"], _dp),
+                                               _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
+        return out
+
+    def get_state(self) -> np.ndarray:
+        st = np.empty((self.B, self.state_dim))
+        self._check(self._lib.gs_get_state(self._h, _ptr(st, _dp)))
+        return st
+
+    def set_state(self, state) -> None:
+        st = _f64(state)
+        if st.shape != (self.B, self.state_dim):
+            raise PowerFlowError(f"state shape {st.shape} != ({self.B}, {self.state_dim})")
+        self._check(self._lib.gs_set_state(self._h, _ptr(st, _dp)))
+
+    # -- multi-GPU ------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = load()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.gs_comm_unique_id(buf)
+        if rc != GS_OK:
+            raise PowerFlowError(f"gs_comm_unique_id failed ({rc}): {lib.gs_last_error(None).decode()}")
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes, rank: int, world: int) -> None:
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self._lib.gs_comm_init(self._h, buf, int(rank), int(world)))
+        self.world = int(world)
+
+    def allgather_obs(self, to_host: bool = False):
+        full = np.empty((self.world * self.B, self.obs_dim)) if to_host else None
+        self._check(self._lib.gs_allgather_obs(self._h, _ptr(full, _dp)))
+        return full
+
+    def comm_destroy(self) -> None:
+        self._check(self._lib.gs_comm_destroy(self._h))
+
+    # -- measurement ----------------------------------------------------------------------
+    def timing_enable(self, on: bool = True) -> None:
+        self._check(self._lib.gs_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self) -> dict:
+        ms = (C.c_double * 5)()
+        cnt = (C.c_int64 * 5)()
+        self._check(self._lib.gs_timing_read(self._h, ms, cnt))
+        return {KERNEL_NAMES[k]: {"total_ms": ms[k], "launches": int(cnt[k])} for k in range(5)}

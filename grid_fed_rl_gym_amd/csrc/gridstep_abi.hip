@@ -1,0 +1,659 @@
+// gridstep_abi.hip -- host side of the C ABI declared in include/gridstep.h.
+//
+// Owns: the compiled topology tables, one slab of per-instance rows in HBM
+// (slab[group][row][64 lanes]), staging buffers for the batch-major <-> batch-innermost layout
+// change, one HIP stream, optional HIP-event timing of every launch, and (lazily, via dlopen)
+// an RCCL communicator for the observation all-gather.  No CPU arithmetic on the data path:
+// every entry point either moves bytes or launches kernels.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gridstep.h"
+#include "gs_internal.h"
+#include "kernels.h"
+#include "topology.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// ---- RCCL entry points resolved at run time -------------------------------------------------
+typedef struct { char internal[128]; } gs_ncclUniqueId;
+typedef void* gs_ncclComm_t;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(gs_ncclUniqueId*) = nullptr;
+  int (*CommInitRank)(gs_ncclComm_t*, int, gs_ncclUniqueId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, gs_ncclComm_t, hipStream_t) = nullptr;
+  int (*CommDestroy)(gs_ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+bool load_rccl(std::string& why) {
+  if (g_rccl.lib) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+  if (!lib) { why = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+  RcclApi a; a.lib = lib;
+  a.GetUniqueId = (int (*)(gs_ncclUniqueId*))dlsym(lib, "ncclGetUniqueId");
+  a.CommInitRank = (int (*)(gs_ncclComm_t*, int, gs_ncclUniqueId, int))dlsym(lib, "ncclCommInitRank");
+  a.AllGather = (int (*)(const void*, void*, size_t, int, gs_ncclComm_t, hipStream_t))dlsym(lib, "ncclAllGather");
+  a.CommDestroy = (int (*)(gs_ncclComm_t))dlsym(lib, "ncclCommDestroy");
+  a.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) { why = "librccl lacks a required symbol"; return false; }
+  g_rccl = a;
+  return true;
+}
+
+struct TimedLaunch { int kid; hipEvent_t a, b; };
+
+}  // namespace
+
+struct gs_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int B = 0, Bp = 0, groups = 0, W = 1;
+  int n = 0, m = 0, obs_dim = 0, action_dim = 0, state_dim = 0;
+  int n_loads = 0, n_gens = 0, n_bats = 0;
+  gs_config cfg{};
+  HostTopology topo;
+  GsTables T{};
+  GsRows R{};
+  GsSolveCfg SC{};
+  GsEnvCfg EC{};
+  double total_load = 0.0;
+  int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs
+  bool was_reset = false;
+  std::vector<void*> allocs;
+  double* slab = nullptr;
+  double* d_in = nullptr; size_t in_doubles = 0;
+  double* d_out = nullptr; size_t out_doubles = 0;
+  double* d_actions = nullptr; int n_action_batches = 0;
+  double* d_cst = nullptr;
+  int32_t *map_obs = nullptr, *map_vm = nullptr, *map_va = nullptr, *map_flow = nullptr, *map_load = nullptr,
+          *map_p = nullptr, *map_q = nullptr, *map_act = nullptr, *map_state = nullptr;
+  int32_t *rows_f = nullptr, *rows_i = nullptr, *rows_u = nullptr;
+  double* sc_f = nullptr; int32_t* sc_i = nullptr; uint8_t* sc_u = nullptr;
+  uint64_t* d_seeds = nullptr; uint8_t* d_mask = nullptr;
+  std::vector<double> h_f; std::vector<int32_t> h_i; std::vector<uint8_t> h_u;
+  // timing
+  bool timing = false;
+  std::vector<TimedLaunch> timed; size_t timed_used = 0;
+  // comm
+  gs_ncclComm_t comm = nullptr; int rank = 0, world = 1; double* d_obs_full = nullptr;
+  mutable std::string err;
+};
+
+namespace {
+
+enum { SF_REWARD = 0, SF_VMAX, SF_VMIN, SF_LOSSES, SF_EPREW, SF_MAXMIS, SF_COUNT };
+enum { SI_VIOL = 0, SI_STEP, SI_ITERS, SI_STATUS, SI_COUNT };
+enum { SU_TERM = 0, SU_TRUNC, SU_CONV, SU_VF0, SU_VF1, SU_VF2, SU_VF3, SU_COUNT };
+
+int fail(gs_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_last_error = buf;
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                           \
+  do { hipError_t e_ = (expr);                                                                    \
+       if (e_ != hipSuccess) return fail((h), GS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+template <typename X>
+int dev_alloc(gs_handle* h, X** p, size_t count) {
+  void* q = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(X);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) return fail(h, GS_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  h->allocs.push_back(q);
+  *p = (X*)q;
+  return GS_OK;
+}
+
+template <typename X>
+int dev_upload(gs_handle* h, const X** p, const std::vector<X>& v) {
+  X* q = nullptr;
+  int rc = dev_alloc(h, &q, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(h, hipMemcpy(q, v.data(), v.size() * sizeof(X), hipMemcpyHostToDevice));
+  *p = q;
+  return GS_OK;
+}
+
+int upload_map(gs_handle* h, int32_t** p, const std::vector<int32_t>& v) {
+  const int32_t* q = nullptr;
+  int rc = dev_upload(h, &q, v);
+  *p = const_cast<int32_t*>(q);
+  return rc;
+}
+
+// ---- timing wrapper -------------------------------------------------------------------------
+struct LaunchTimer {
+  gs_handle* h; TimedLaunch* t = nullptr;
+  LaunchTimer(gs_handle* hh, int kid) : h(hh) {
+    if (!h->timing) return;
+    if (h->timed_used == h->timed.size()) {
+      TimedLaunch n; n.kid = kid;
+      if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+      h->timed.push_back(n);
+    }
+    t = &h->timed[h->timed_used++];
+    t->kid = kid;
+    (void)hipEventRecord(t->a, h->stream);
+  }
+  ~LaunchTimer() { if (t) (void)hipEventRecord(t->b, h->stream); }
+};
+
+// ---- layout movers --------------------------------------------------------------------------
+int launch_pack(gs_handle* h, const int32_t* map, int C, double* dst) {
+  if (C <= 0) return GS_OK;
+  LaunchTimer lt(h, GS_K_PACK);
+  dim3 grid(h->groups, (C + 63) / 64);
+  hipLaunchKernelGGL(gs_k_pack, grid, dim3(256), 0, h->stream, map, h->d_cst, C, h->R.total, h->slab, dst, h->B);
+  HIPCHK(h, hipGetLastError());
+  return GS_OK;
+}
+
+int launch_unpack(gs_handle* h, const int32_t* map, int C, const double* src) {
+  if (C <= 0) return GS_OK;
+  LaunchTimer lt(h, GS_K_UNPACK);
+  dim3 grid(h->groups, (C + 63) / 64);
+  hipLaunchKernelGGL(gs_k_unpack, grid, dim3(256), 0, h->stream, map, C, h->R.total, h->slab, src, h->B);
+  HIPCHK(h, hipGetLastError());
+  return GS_OK;
+}
+
+int pack_to_host(gs_handle* h, const int32_t* map, int C, double* host) {
+  if (!host || C <= 0) return GS_OK;
+  int rc = launch_pack(h, map, C, h->d_out);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(host, h->d_out, (size_t)h->B * C * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GS_OK;
+}
+
+int unpack_from_host(gs_handle* h, const int32_t* map, int C, const double* host) {
+  if (C <= 0) return GS_OK;
+  HIPCHK(h, hipMemcpyAsync(h->d_in, host, (size_t)h->B * C * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return launch_unpack(h, map, C, h->d_in);
+}
+
+int fetch_scalars(gs_handle* h) {
+  hipLaunchKernelGGL(gs_k_scalars, dim3(h->groups), dim3(64), 0, h->stream, h->rows_f, (int)SF_COUNT, h->rows_i,
+                     (int)SI_COUNT, h->rows_u, (int)SU_COUNT, h->R.total, h->slab, h->sc_f, h->sc_i, h->sc_u, h->Bp);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(h->h_f.data(), h->sc_f, h->h_f.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->h_i.data(), h->sc_i, h->h_i.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->h_u.data(), h->sc_u, h->h_u.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GS_OK;
+}
+
+int launch_solve(gs_handle* h) {
+  LaunchTimer lt(h, GS_K_SOLVE);
+  dim3 grid(h->groups), block(64 * h->W);
+  if (h->solve_kernel == 0) hipLaunchKernelGGL(gs_k_nr_tree, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
+  else if (h->solve_kernel == 1) hipLaunchKernelGGL(gs_k_nr_lu, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
+  else hipLaunchKernelGGL(gs_k_fbs, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
+  HIPCHK(h, hipGetLastError());
+  return GS_OK;
+}
+
+int step_kernels(gs_handle* h, const double* d_actions) {
+  int rc = launch_unpack(h, h->map_act, h->action_dim, d_actions);
+  if (rc) return rc;
+  { LaunchTimer lt(h, GS_K_ENV_PRE);
+    hipLaunchKernelGGL(gs_k_env_pre, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, h->B);
+    HIPCHK(h, hipGetLastError()); }
+  rc = launch_solve(h);
+  if (rc) return rc;
+  { LaunchTimer lt(h, GS_K_ENV_POST);
+    hipLaunchKernelGGL(gs_k_env_post, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, h->B, h->total_load);
+    HIPCHK(h, hipGetLastError()); }
+  return launch_pack(h, h->map_obs, h->obs_dim, h->d_out);
+}
+
+void copy_info(gs_handle* h, double* reward, uint8_t* term, uint8_t* trunc, const gs_info_view* info) {
+  const int B = h->B, Bp = h->Bp;
+  const double* f = h->h_f.data(); const int32_t* i32 = h->h_i.data(); const uint8_t* u = h->h_u.data();
+  if (reward) memcpy(reward, f + (size_t)SF_REWARD * Bp, B * sizeof(double));
+  if (term) memcpy(term, u + (size_t)SU_TERM * Bp, B);
+  if (trunc) memcpy(trunc, u + (size_t)SU_TRUNC * Bp, B);
+  if (!info) return;
+  if (info->power_flow_converged) memcpy(info->power_flow_converged, u + (size_t)SU_CONV * Bp, B);
+  if (info->max_voltage) memcpy(info->max_voltage, f + (size_t)SF_VMAX * Bp, B * sizeof(double));
+  if (info->min_voltage) memcpy(info->min_voltage, f + (size_t)SF_VMIN * Bp, B * sizeof(double));
+  if (info->total_losses) memcpy(info->total_losses, f + (size_t)SF_LOSSES * Bp, B * sizeof(double));
+  if (info->violations)
+    for (int b = 0; b < B; ++b)
+      for (int v = 0; v < 4; ++v) info->violations[(size_t)b * 4 + v] = u[(size_t)(SU_VF0 + v) * Bp + b];
+  if (info->constraint_violations) memcpy(info->constraint_violations, i32 + (size_t)SI_VIOL * Bp, B * sizeof(int32_t));
+  if (info->current_step) memcpy(info->current_step, i32 + (size_t)SI_STEP * Bp, B * sizeof(int32_t));
+  if (info->episode_reward) memcpy(info->episode_reward, f + (size_t)SF_EPREW * Bp, B * sizeof(double));
+  if (info->iterations) memcpy(info->iterations, i32 + (size_t)SI_ITERS * Bp, B * sizeof(int32_t));
+  if (info->status) memcpy(info->status, i32 + (size_t)SI_STATUS * Bp, B * sizeof(int32_t));
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int gs_version(void) { return GS_ABI_VERSION; }
+
+int gs_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+const char* gs_last_error(const gs_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int32_t device,
+              int64_t first_instance, gs_handle** out) {
+  if (!out) return fail(nullptr, GS_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!topo || !cfg) return fail(nullptr, GS_E_INVALID, "topology / config is NULL");
+  if (topo->struct_size != (int32_t)sizeof(gs_topology) || cfg->struct_size != (int32_t)sizeof(gs_config))
+    return fail(nullptr, GS_E_INVALID, "struct_size mismatch (ABI %d): topology %d vs %zu, config %d vs %zu",
+                GS_ABI_VERSION, topo->struct_size, sizeof(gs_topology), cfg->struct_size, sizeof(gs_config));
+  if (batch <= 0) return fail(nullptr, GS_E_INVALID, "batch must be > 0");
+  if (cfg->max_iterations < 1) return fail(nullptr, GS_E_INVALID, "max_iterations must be >= 1");
+  if (!(cfg->power_base > 0.0)) return fail(nullptr, GS_E_INVALID, "power_base must be > 0");
+  if (!(cfg->timestep > 0.0)) return fail(nullptr, GS_E_INVALID, "timestep must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, GS_E_NO_DEVICE, "no HIP device visible: libgridstep has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, GS_E_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
+
+  gs_handle* h = new gs_handle();
+  h->device = device;
+  h->cfg = *cfg;
+  std::string why = gs_compile_topology(*topo, cfg->zero_z_mode, cfg->linear_solver == GS_LINSOLVE_SPARSE_LU, h->topo);
+  if (!why.empty()) { int rc = fail(nullptr, GS_E_INVALID, "topology: %s", why.c_str()); delete h; return rc; }
+  const HostTopology& ht = h->topo;
+  if (cfg->solver_kind == GS_SOLVER_FBS) {
+    if (!ht.fbs_ok) { int rc = fail(nullptr, GS_E_TOPOLOGY, "FBS: %s", ht.fbs_why.c_str()); delete h; return rc; }
+    h->solve_kernel = 2;
+  } else if (cfg->solver_kind == GS_SOLVER_NR) {
+    if (cfg->linear_solver == GS_LINSOLVE_TREE && !ht.is_forest) {
+      int rc = fail(nullptr, GS_E_TOPOLOGY, "tree elimination requested but the active network has loops"); delete h; return rc; }
+    h->solve_kernel = (ht.is_forest && cfg->linear_solver != GS_LINSOLVE_SPARSE_LU) ? 0 : 1;
+  } else { int rc = fail(nullptr, GS_E_INVALID, "unknown solver_kind %d", cfg->solver_kind); delete h; return rc; }
+
+  h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
+  h->n = ht.n; h->m = ht.m; h->n_loads = topo->n_loads; h->n_gens = topo->n_gens; h->n_bats = topo->n_bats;
+  h->obs_dim = 2 * h->n + 2 * h->m + 1 + 2 * h->n_loads + h->n_gens + 2 * h->n_bats;     // grid_env.py:307-314
+  h->action_dim = h->n_bats + h->n_gens;                                                    // grid_env.py:351
+  h->state_dim = 12 + 2 * h->n_bats + h->n_gens + 2 * h->n + 2 * h->m;
+  int W = cfg->waves_per_group;
+  if (const char* e = getenv("GS_WAVES")) W = atoi(e);
+  if (W <= 0) { W = 1; while (W < 16 && h->groups * W * 2 <= 2048) W *= 2; }
+  if (W > GS_MAX_WAVES) W = GS_MAX_WAVES;
+  h->W = W;
+
+  auto bail = [&](int rc) { gs_destroy(h); return rc; };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipSetDevice failed"));
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(nullptr, GS_E_HIP, "hipStreamCreate failed"));
+
+  // ---- rows ----
+  GsRows& R = h->R;
+  int r = 0;
+  auto take = [&](int count) { int at = r; r += count; return at; };
+  const int n = h->n, m = h->m;
+  R.P = take(n); R.Q = take(n); R.VM = take(n); R.VA = take(n); R.FLOW = take(m); R.LOAD = take(m);
+  R.LOSSES = take(1); R.MAXMIS = take(1); R.ITERS = take(1); R.CONV = take(1); R.STATUS = take(1);
+  R.E = take(n); R.F = take(n); R.PC = take(n); R.QC = take(n); R.R0 = take(n); R.R1 = take(n);
+  R.X0 = take(n); R.X1 = take(n);
+  R.SV = take(2 * n); R.QV = take(2 * n); R.TB = take(4 * n); R.CB = take(4 * n);
+  R.JR = take(n); R.JI = take(n);
+  R.LU = take(h->solve_kernel == 1 ? 4 * ht.lu_n_slots : 0);
+  R.LUD = take(h->solve_kernel == 1 ? 4 * n : 0);
+  R.TIME = take(1); R.STEP = take(1); R.VIOL = take(1); R.TOTLOSS = take(1); R.EPREW = take(1); R.FREQ = take(1);
+  R.IRR = take(1); R.WIND = take(1); R.TEMP = take(1); R.CLOUD = take(1); R.SEEDLO = take(1); R.SEEDHI = take(1);
+  R.SOC = take(h->n_bats); R.BATP = take(h->n_bats); R.CURT = take(h->n_gens); R.GENP = take(h->n_gens);
+  R.ENVLOAD = take(m);
+  R.REWARD = take(1); R.TERM = take(1); R.TRUNC = take(1); R.VMAX = take(1); R.VMIN = take(1); R.VFLAGS = take(4);
+  R.ACT = take(h->action_dim); R.LOADP = take(h->n_loads);
+  R.total = r;
+
+  // ---- tables ----
+  GsTables& T = h->T;
+  T.n = n; T.m = m; T.nnz = ht.nnz; T.n_levels = ht.n_levels;
+  T.n_loads = h->n_loads; T.n_gens = h->n_gens; T.n_bats = h->n_bats;
+  T.lu_n_piv = ht.lu_n_piv; T.lu_n_slots = ht.lu_n_slots; T.lu_n_orig = ht.lu_n_orig;
+  int rc = 0;
+#define UP(field, vec) if ((rc = dev_upload(h, &T.field, ht.vec))) return bail(rc)
+  UP(row_ptr, row_ptr); UP(col, col); UP(G, G); UP(Bv, B); UP(Gd, Gd); UP(Bd, Bd);
+  UP(th_free, th_free); UP(vm_free, vm_free); UP(v_set, v_set); UP(fixed_v, fixed_v);
+  UP(lvl_ptr, lvl_ptr); UP(lvl_bus, lvl_bus); UP(parent, parent); UP(parent_pos, parent_pos);
+  UP(child_ptr, child_ptr); UP(child_idx, child_idx); UP(fbs_parent, fbs_parent); UP(fbs_parent_pos, fbs_parent_pos);
+  UP(lfrom, lfrom); UP(lto, lto); UP(lyr, lyr); UP(lyi, lyi); UP(lrating, lrating);
+  UP(lu_piv_bus, lu_piv_bus); UP(lu_nb_ptr, lu_nb_ptr); UP(lu_nb_bus, lu_nb_bus); UP(lu_nb_kj, lu_nb_kj);
+  UP(lu_nb_jk, lu_nb_jk); UP(lu_pair_ptr, lu_pair_ptr); UP(lu_pair_ik, lu_pair_ik); UP(lu_pair_kj, lu_pair_kj);
+  UP(lu_pair_ij, lu_pair_ij); UP(lu_orig_slot, lu_orig_slot); UP(lu_orig_i, lu_orig_i); UP(lu_orig_j, lu_orig_j);
+  UP(lu_orig_pos, lu_orig_pos);
+  UP(bl_ptr, bl_ptr); UP(bl_idx, bl_idx); UP(bg_ptr, bg_ptr); UP(bg_idx, bg_idx); UP(bb_ptr, bb_ptr); UP(bb_idx, bb_idx);
+  UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
+  UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
+#undef UP
+
+  // ---- configs ----
+  h->SC.tolerance = cfg->tolerance; h->SC.alpha = cfg->acceleration_factor;
+  h->SC.max_iterations = cfg->max_iterations; h->SC.jacobian_exact = (cfg->jacobian_mode == GS_JACOBIAN_EXACT);
+  GsEnvCfg& E = h->EC;
+  E.timestep = cfg->timestep; E.v_min = cfg->v_min; E.v_max = cfg->v_max; E.f_min = cfg->f_min; E.f_max = cfg->f_max;
+  E.safety_penalty = cfg->safety_penalty; E.H = cfg->inertia_H; E.D = cfg->damping_D; E.f0 = cfg->f_nominal;
+  E.power_base = cfg->power_base; E.episode_length = cfg->episode_length; E.stochastic_loads = cfg->stochastic_loads;
+  E.weather_variation = cfg->weather_variation; E.first_instance = first_instance;
+  // sum(load.active_power) in list order, starting from 0 like python's sum() (grid_env.py:744)
+  h->total_load = 0.0;
+  for (int l = 0; l < h->n_loads; ++l) h->total_load += topo->load_base[l];
+
+  // ---- layout maps ----
+  std::vector<int32_t> mo, mvm(n), mva(n), mfl(m), mld(m), mp(n), mq(n), mact(h->action_dim), mst;
+  std::vector<double> cst;
+  for (int i = 0; i < n; ++i) { mo.push_back(R.VM + i); mo.push_back(R.VA + i); }          // grid_env.py:758-759
+  for (int k = 0; k < m; ++k) { mo.push_back(R.FLOW + k); mo.push_back(R.ENVLOAD + k); }   // :762-763
+  mo.push_back(R.FREQ);                                                                     // :766
+  for (int l = 0; l < h->n_loads; ++l) {                                                    // :769-770 (static values)
+    cst.push_back(ht.load_base[l]); mo.push_back(-(int)cst.size());
+    cst.push_back(ht.load_q[l]); mo.push_back(-(int)cst.size());
+  }
+  for (int g = 0; g < h->n_gens; ++g) mo.push_back(R.GENP + g);                              // :773-777
+  for (int q = 0; q < h->n_bats; ++q) { mo.push_back(R.SOC + q); mo.push_back(R.BATP + q); } // :780-781
+  for (int i = 0; i < n; ++i) { mvm[i] = R.VM + i; mva[i] = R.VA + i; mp[i] = R.P + i; mq[i] = R.Q + i; }
+  for (int k = 0; k < m; ++k) { mfl[k] = R.FLOW + k; mld[k] = R.LOAD + k; }
+  for (int a = 0; a < h->action_dim; ++a) mact[a] = R.ACT + a;
+  for (int s : {R.TIME, R.STEP, R.VIOL, R.TOTLOSS, R.EPREW, R.FREQ, R.IRR, R.WIND, R.TEMP, R.CLOUD, R.SEEDLO, R.SEEDHI}) mst.push_back(s);
+  for (int q = 0; q < h->n_bats; ++q) mst.push_back(R.SOC + q);
+  for (int q = 0; q < h->n_bats; ++q) mst.push_back(R.BATP + q);
+  for (int g = 0; g < h->n_gens; ++g) mst.push_back(R.CURT + g);
+  for (int i = 0; i < n; ++i) mst.push_back(R.VM + i);
+  for (int i = 0; i < n; ++i) mst.push_back(R.VA + i);
+  for (int k = 0; k < m; ++k) mst.push_back(R.FLOW + k);
+  for (int k = 0; k < m; ++k) mst.push_back(R.ENVLOAD + k);
+  if ((int)mo.size() != h->obs_dim || (int)mst.size() != h->state_dim)
+    return bail(fail(nullptr, GS_E_INVALID, "internal: layout map size mismatch"));
+  { const double* q = nullptr; if ((rc = dev_upload(h, &q, cst))) return bail(rc); h->d_cst = const_cast<double*>(q); }
+  if ((rc = upload_map(h, &h->map_obs, mo)) || (rc = upload_map(h, &h->map_vm, mvm)) || (rc = upload_map(h, &h->map_va, mva)) ||
+      (rc = upload_map(h, &h->map_flow, mfl)) || (rc = upload_map(h, &h->map_load, mld)) || (rc = upload_map(h, &h->map_p, mp)) ||
+      (rc = upload_map(h, &h->map_q, mq)) || (rc = upload_map(h, &h->map_act, mact)) || (rc = upload_map(h, &h->map_state, mst)))
+    return bail(rc);
+  std::vector<int32_t> rf(SF_COUNT), ri(SI_COUNT), ru(SU_COUNT);
+  rf[SF_REWARD] = R.REWARD; rf[SF_VMAX] = R.VMAX; rf[SF_VMIN] = R.VMIN; rf[SF_LOSSES] = R.LOSSES; rf[SF_EPREW] = R.EPREW; rf[SF_MAXMIS] = R.MAXMIS;
+  ri[SI_VIOL] = R.VIOL; ri[SI_STEP] = R.STEP; ri[SI_ITERS] = R.ITERS; ri[SI_STATUS] = R.STATUS;
+  ru[SU_TERM] = R.TERM; ru[SU_TRUNC] = R.TRUNC; ru[SU_CONV] = R.CONV;
+  for (int v = 0; v < 4; ++v) ru[SU_VF0 + v] = R.VFLAGS + v;
+  if ((rc = upload_map(h, &h->rows_f, rf)) || (rc = upload_map(h, &h->rows_i, ri)) || (rc = upload_map(h, &h->rows_u, ru))) return bail(rc);
+
+  // ---- big buffers ----
+  const size_t slab_doubles = (size_t)h->groups * R.total * GS_LANES;
+  if ((rc = dev_alloc(h, &h->slab, slab_doubles))) return bail(rc);
+  if (hipMemset(h->slab, 0, slab_doubles * sizeof(double)) != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipMemset(slab) failed"));
+  const size_t widest = std::max<size_t>({(size_t)h->obs_dim, (size_t)h->state_dim, (size_t)n, (size_t)m, (size_t)h->action_dim, 1});
+  h->in_doubles = (size_t)h->B * widest; h->out_doubles = (size_t)h->B * widest;
+  if ((rc = dev_alloc(h, &h->d_in, h->in_doubles)) || (rc = dev_alloc(h, &h->d_out, h->out_doubles))) return bail(rc);
+  if ((rc = dev_alloc(h, &h->sc_f, (size_t)SF_COUNT * h->Bp)) || (rc = dev_alloc(h, &h->sc_i, (size_t)SI_COUNT * h->Bp)) ||
+      (rc = dev_alloc(h, &h->sc_u, (size_t)SU_COUNT * h->Bp)) || (rc = dev_alloc(h, &h->d_seeds, (size_t)h->B)) ||
+      (rc = dev_alloc(h, &h->d_mask, (size_t)h->B)))
+    return bail(rc);
+  h->h_f.resize((size_t)SF_COUNT * h->Bp); h->h_i.resize((size_t)SI_COUNT * h->Bp); h->h_u.resize((size_t)SU_COUNT * h->Bp);
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipDeviceSynchronize failed"));
+  *out = h;
+  return GS_OK;
+}
+
+void gs_destroy(gs_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  for (auto& t : h->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->d_actions) (void)hipFree(h->d_actions);
+  if (h->d_obs_full) (void)hipFree(h->d_obs_full);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_t* action_dim,
+            int32_t* state_dim, int32_t* batch) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  if (n) *n = h->n; if (m) *m = h->m; if (obs_dim) *obs_dim = h->obs_dim; if (action_dim) *action_dim = h->action_dim;
+  if (state_dim) *state_dim = h->state_dim; if (batch) *batch = h->B;
+  return GS_OK;
+}
+
+int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
+  if (!h || !buf || buflen <= 0) return fail(nullptr, GS_E_INVALID, "bad arguments");
+  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs"};
+  snprintf(buf, buflen,
+           "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
+           "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
+           "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d}",
+           kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
+           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, h->W, h->groups,
+           h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim);
+  return GS_OK;
+}
+
+int gs_synchronize(gs_handle* h) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GS_OK;
+}
+
+// ---- solver -------------------------------------------------------------------------------
+int gs_upload_injections(gs_handle* h, const double* P_spec, const double* Q_spec) {
+  if (!h || !P_spec) return fail(h, GS_E_INVALID, "handle / P_spec is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = unpack_from_host(h, h->map_p, h->n, P_spec);
+  if (rc) return rc;
+  if (Q_spec) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // d_in is reused
+    rc = unpack_from_host(h, h->map_q, h->n, Q_spec);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(gs_k_fill_rows, dim3(h->groups), dim3(64), 0, h->stream, h->R.Q, h->n, h->R.total, h->slab, 0.0);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GS_OK;
+}
+
+int gs_solve_device(gs_handle* h) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  return launch_solve(h);
+}
+
+int gs_download_solution(gs_handle* h, const gs_solution_view* out) {
+  if (!h || !out) return fail(h, GS_E_INVALID, "handle / view is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if ((rc = pack_to_host(h, h->map_vm, h->n, out->bus_voltages))) return rc;
+  if ((rc = pack_to_host(h, h->map_va, h->n, out->bus_angles))) return rc;
+  if ((rc = pack_to_host(h, h->map_flow, h->m, out->line_flows))) return rc;
+  if ((rc = pack_to_host(h, h->map_load, h->m, out->line_loadings))) return rc;
+  if ((rc = fetch_scalars(h))) return rc;
+  const int B = h->B, Bp = h->Bp;
+  if (out->losses) memcpy(out->losses, h->h_f.data() + (size_t)SF_LOSSES * Bp, B * sizeof(double));
+  if (out->max_mismatch) memcpy(out->max_mismatch, h->h_f.data() + (size_t)SF_MAXMIS * Bp, B * sizeof(double));
+  if (out->iterations) memcpy(out->iterations, h->h_i.data() + (size_t)SI_ITERS * Bp, B * sizeof(int32_t));
+  if (out->status) memcpy(out->status, h->h_i.data() + (size_t)SI_STATUS * Bp, B * sizeof(int32_t));
+  if (out->converged) memcpy(out->converged, h->h_u.data() + (size_t)SU_CONV * Bp, B);
+  return GS_OK;
+}
+
+int gs_solve(gs_handle* h, const double* P_spec, const double* Q_spec, const gs_solution_view* out) {
+  int rc = gs_upload_injections(h, P_spec, Q_spec);
+  if (rc) return rc;
+  if ((rc = gs_solve_device(h))) return rc;
+  return out ? gs_download_solution(h, out) : gs_synchronize(h);
+}
+
+// ---- environment ----------------------------------------------------------------------------
+int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* obs_out) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (seeds) HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)h->B * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  if (mask) HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(gs_k_env_reset, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, h->B,
+                     seeds ? h->d_seeds : (const uint64_t*)nullptr, mask ? h->d_mask : (const uint8_t*)nullptr);
+  HIPCHK(h, hipGetLastError());
+  h->was_reset = true;
+  if (obs_out) return pack_to_host(h, h->map_obs, h->obs_dim, obs_out);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GS_OK;
+}
+
+int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
+                     const gs_info_view* info) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (obs) {
+    HIPCHK(h, hipMemcpyAsync(obs, h->d_out, (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  int rc = fetch_scalars(h);
+  if (rc) return rc;
+  copy_info(h, reward, terminated, truncated, info);
+  return GS_OK;
+}
+
+int gs_step(gs_handle* h, const double* actions, double* obs, double* reward, uint8_t* terminated,
+            uint8_t* truncated, const gs_info_view* info) {
+  if (!h || (!actions && h->action_dim > 0)) return fail(h, GS_E_INVALID, "handle / actions is NULL");
+  if (!h->was_reset) return fail(h, GS_E_STATE, "gs_step before gs_reset");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->action_dim > 0)
+    HIPCHK(h, hipMemcpyAsync(h->d_in, actions, (size_t)h->B * h->action_dim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = step_kernels(h, h->d_in);
+  if (rc) return rc;
+  return gs_download_step(h, obs, reward, terminated, truncated, info);
+}
+
+int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches) {
+  if (!h || !actions || n_batches <= 0) return fail(h, GS_E_INVALID, "bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->d_actions) { (void)hipFree(h->d_actions); h->d_actions = nullptr; }
+  const size_t bytes = (size_t)n_batches * h->B * std::max(h->action_dim, 1) * sizeof(double);
+  HIPCHK(h, hipMalloc((void**)&h->d_actions, bytes));
+  HIPCHK(h, hipMemcpy(h->d_actions, actions, (size_t)n_batches * h->B * h->action_dim * sizeof(double), hipMemcpyHostToDevice));
+  h->n_action_batches = n_batches;
+  return GS_OK;
+}
+
+int gs_step_device(gs_handle* h, int32_t k) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  if (!h->was_reset) return fail(h, GS_E_STATE, "gs_step_device before gs_reset");
+  if (k < 0 || k >= h->n_action_batches) return fail(h, GS_E_INVALID, "action batch %d not uploaded (have %d)", k, h->n_action_batches);
+  HIPCHK(h, hipSetDevice(h->device));
+  return step_kernels(h, h->d_actions + (size_t)k * h->B * h->action_dim);
+}
+
+// ---- checkpoint ---------------------------------------------------------------------------------
+int gs_get_state(gs_handle* h, double* state) {
+  if (!h || !state) return fail(h, GS_E_INVALID, "handle / state is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  return pack_to_host(h, h->map_state, h->state_dim, state);
+}
+
+int gs_set_state(gs_handle* h, const double* state) {
+  if (!h || !state) return fail(h, GS_E_INVALID, "handle / state is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = unpack_from_host(h, h->map_state, h->state_dim, state);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->was_reset = true;
+  return GS_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------
+int gs_comm_unique_id(uint8_t id_out[128]) {
+  std::string why;
+  if (!load_rccl(why)) return fail(nullptr, GS_E_COMM, "%s", why.c_str());
+  gs_ncclUniqueId id;
+  int rc = g_rccl.GetUniqueId(&id);
+  if (rc != 0) return fail(nullptr, GS_E_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+  memcpy(id_out, id.internal, 128);
+  return GS_OK;
+}
+
+int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t world_size) {
+  if (!h || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, GS_E_INVALID, "bad arguments");
+  std::string why;
+  if (!load_rccl(why)) return fail(h, GS_E_COMM, "%s", why.c_str());
+  HIPCHK(h, hipSetDevice(h->device));
+  gs_ncclUniqueId uid; memcpy(uid.internal, id, 128);
+  int rc = g_rccl.CommInitRank(&h->comm, world_size, uid, rank);
+  if (rc != 0) return fail(h, GS_E_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+  h->rank = rank; h->world = world_size;
+  HIPCHK(h, hipMalloc((void**)&h->d_obs_full, (size_t)world_size * h->B * h->obs_dim * sizeof(double)));
+  return GS_OK;
+}
+
+int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  if (!h->comm) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t count = (size_t)h->B * h->obs_dim;
+  int rc = g_rccl.AllGather(h->d_out, h->d_obs_full, count, /*ncclFloat64*/ 8, h->comm, h->stream);
+  if (rc != 0) return fail(h, GS_E_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+  if (obs_full_host) {
+    HIPCHK(h, hipMemcpyAsync(obs_full_host, h->d_obs_full, count * h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return GS_OK;
+}
+
+int gs_comm_destroy(gs_handle* h) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  if (h->d_obs_full) { (void)hipFree(h->d_obs_full); h->d_obs_full = nullptr; }
+  return GS_OK;
+}
+
+// ---- measurement ------------------------------------------------------------------------------------
+int gs_timing_enable(gs_handle* h, int32_t on) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->timing = on != 0;
+  h->timed_used = 0;
+  return GS_OK;
+}
+
+int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches) {
+  if (!h || !total_ms || !launches) return fail(h, GS_E_INVALID, "bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int k = 0; k < GS_K_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; }
+  for (size_t i = 0; i < h->timed_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->timed[i].a, h->timed[i].b) == hipSuccess) {
+      total_ms[h->timed[i].kid] += ms; launches[h->timed[i].kid] += 1;
+    }
+  }
+  h->timed_used = 0;
+  return GS_OK;
+}
+
+}  // extern "C"

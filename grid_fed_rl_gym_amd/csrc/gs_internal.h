@@ -1,0 +1,133 @@
+// gs_internal.h -- structures shared by the host side of libgridstep.so and its HIP kernels.
+//
+// Execution model: one *group* = 64 feeder instances = the 64 lanes of a
+// wavefront; every lane runs the same topology-uniform program on its own instance, so
+// control flow never diverges and every per-instance array is stored batch-innermost:
+//
+//     slab[group][row][lane]        (row stride 64 doubles = 512 B = one coalesced wave access)
+//
+// A workgroup is W (1..16) wavefronts that all own the SAME 64 instances and split the
+// buses / lines / tree levels of the feeder between them (wave w takes items w, w+W, ...),
+// meeting at workgroup barriers.  Topology tables are wave-uniform and are read through the
+// scalar cache (s_load), never per lane.
+#pragma once
+#include <stdint.h>
+
+#define GS_LANES 64
+#define GS_MAX_WAVES 16
+
+// pointer into the constant address space: forces scalar (s_load) access for uniform tables
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GS_CONST __attribute__((address_space(4)))
+#else
+#define GS_CONST
+#endif
+
+// Topology-uniform tables (device pointers; built once per handle by topology.cpp).
+struct GsTables {
+  int32_t n, m, nnz, n_levels;
+  int32_t n_loads, n_gens, n_bats, pad0;
+  // Ybus CSR over buses (diagonal included; columns ascending)
+  const int32_t* row_ptr;    // [n+1]
+  const int32_t* col;        // [nnz]
+  const double* G;           // [nnz]
+  const double* Bv;          // [nnz]
+  const double* Gd;          // [n] diagonal
+  const double* Bd;          // [n]
+  // unknown masks: th_free = bus has a theta unknown / P equation (non-slack, power_flow.py:232);
+  // vm_free = bus has a Vm unknown / Q equation (pq list, power_flow.py:135-136)
+  const int32_t* th_free;    // [n]
+  const int32_t* vm_free;    // [n]
+  const double* v_set;       // [n]
+  const int32_t* fixed_v;    // [n] 1 where the flat start uses v_set (slack / pv, power_flow.py:128-134)
+  // elimination forest over the active (non-slack) buses, deepest level first
+  const int32_t* lvl_ptr;    // [n_levels+1]
+  const int32_t* lvl_bus;    // [n_active]
+  const int32_t* parent;     // [n] parent bus in the forest, -1 for a root / inactive bus
+  const int32_t* parent_pos; // [n] CSR position of entry (i, parent[i])
+  const int32_t* child_ptr;  // [n+1]
+  const int32_t* child_idx;  // [n_active - n_roots]
+  // FBS: tree rooted at the slack bus (levels exclude the slack itself); fbs_parent includes the slack
+  const int32_t* fbs_parent;     // [n]
+  const int32_t* fbs_parent_pos; // [n]
+  // lines
+  const int32_t* lfrom;      // [m]
+  const int32_t* lto;        // [m]
+  const double* lyr;         // [m] series admittance, real
+  const double* lyi;         // [m] imag
+  const double* lrating;     // [m]
+  // sparse block LU schedule (general / meshed networks)
+  int32_t lu_n_piv, lu_n_slots, lu_n_orig, pad1;
+  const int32_t* lu_piv_bus;     // [lu_n_piv] pivot bus, elimination order
+  const int32_t* lu_nb_ptr;      // [lu_n_piv+1] neighbours of each pivot at elimination time
+  const int32_t* lu_nb_bus;      // neighbour bus
+  const int32_t* lu_nb_kj;       // slot of block (pivot, nb)
+  const int32_t* lu_nb_jk;       // slot of block (nb, pivot)
+  const int32_t* lu_pair_ptr;    // [lu_n_piv+1] ordered pairs (i, j) of neighbours, i != j or i == j
+  const int32_t* lu_pair_ik;     // slot of (i, pivot)
+  const int32_t* lu_pair_kj;     // slot of (pivot, j)
+  const int32_t* lu_pair_ij;     // target slot: off-diagonal slot, or -(1+bus) for the diagonal of bus
+  const int32_t* lu_orig_slot;   // [lu_n_orig] off-diagonal slots present in Y ...
+  const int32_t* lu_orig_i;      // ... their (i, j) ...
+  const int32_t* lu_orig_j;
+  const int32_t* lu_orig_pos;    // ... and CSR position of (i, j)
+  // per-bus device lists for the injection build (reference accumulation order, grid_env.py:683-720)
+  const int32_t* bl_ptr;     // [n+1] loads at bus
+  const int32_t* bl_idx;
+  const int32_t* bg_ptr;     // [n+1] generators at bus
+  const int32_t* bg_idx;
+  const int32_t* bb_ptr;     // [n+1] batteries at bus
+  const int32_t* bb_idx;
+  const double* load_base;   // [n_loads]
+  const double* load_q;      // [n_loads] base * tan(acos(pf)) (base.py:283)
+  const int32_t* gen_kind;   // [n_gens]
+  const double* gen_cap;
+  const double* gen_p0;
+  const double* gen_p1;
+  const double* gen_p2;
+  const double* bat_cap;     // [n_bats]
+  const double* bat_rating;
+  const double* bat_eff;
+};
+
+// Row offsets into the per-group slab (units: rows of 64 doubles).
+struct GsRows {
+  int32_t total;
+  // solver inputs / outputs
+  int32_t P, Q;              // [n] specified injections
+  int32_t VM, VA;            // [n] polar state (solution)
+  int32_t FLOW, LOAD;        // [m] line P flow, |S|/rating
+  int32_t LOSSES, MAXMIS, ITERS, CONV, STATUS;   // scalars (stored as doubles)
+  // solver scratch
+  int32_t E, F;              // [n] rectangular voltage
+  int32_t PC, QC;            // [n] calculated injections
+  int32_t R0, R1;            // [n] mismatch (rhs)
+  int32_t X0, X1;            // [n] Newton step
+  int32_t SV;                // [2n] inv(D) r
+  int32_t QV;                // [2n] child -> parent rhs contribution
+  int32_t TB;                // [4n] inv(D) U
+  int32_t CB;                // [4n] child -> parent diagonal contribution
+  int32_t JR, JI;            // [n] FBS branch currents
+  int32_t LU;                // [4 * lu_n_slots] off-diagonal blocks
+  int32_t LUD;               // [4n] diagonal blocks
+  // env state
+  int32_t TIME, STEP, VIOL, TOTLOSS, EPREW, FREQ, IRR, WIND, TEMP, CLOUD, SEEDLO, SEEDHI;
+  int32_t SOC, BATP;         // [n_bats]
+  int32_t CURT, GENP;        // [n_gens] curtailment factor, uncurtailed renewable power
+  int32_t ENVLOAD;           // [m] |flow|/rating (base.py:261-264)
+  // env outputs
+  int32_t REWARD, TERM, TRUNC, VMAX, VMIN, VFLAGS /* [4] */;
+  int32_t ACT;               // [action_dim] unpacked actions
+  int32_t LOADP;             // [n_loads] realised load power of this step
+};
+
+struct GsSolveCfg {
+  double tolerance, alpha;
+  int32_t max_iterations, jacobian_exact;
+};
+
+struct GsEnvCfg {
+  double timestep, v_min, v_max, f_min, f_max, safety_penalty, H, D, f0, power_base;
+  int32_t episode_length, stochastic_loads, weather_variation, pad;
+  int64_t first_instance;
+};

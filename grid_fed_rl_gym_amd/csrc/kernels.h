@@ -1,0 +1,23 @@
+// kernels.h -- host-visible declarations of the HIP kernels (defined in kernels_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gs_internal.h"
+
+extern "C" {
+__global__ void gs_k_nr_tree(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
+__global__ void gs_k_nr_lu(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
+__global__ void gs_k_fbs(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
+__global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
+                               const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);
+__global__ void gs_k_env_pre(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B);
+__global__ void gs_k_env_post(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B, double total_load);
+__global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C, int rows_total,
+                          const double* __restrict__ slab, double* __restrict__ out, int B);
+__global__ void gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,
+                            const double* __restrict__ in, int B);
+__global__ void gs_k_fill_rows(int row0, int count, int rows_total, double* __restrict__ slab, double value);
+__global__ void gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__ ri, int ni,
+                             const int32_t* __restrict__ ru, int nu, int rows_total, const double* __restrict__ slab,
+                             double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp);
+}

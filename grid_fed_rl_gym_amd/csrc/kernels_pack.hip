@@ -1,0 +1,82 @@
+// kernels_pack.hip -- layout changes at the boundary, staged through LDS so that BOTH sides of
+// every copy are coalesced: the C ABI speaks batch-major [B][C] (the reference's per-env
+// vectors stacked: obs rows, P_spec rows), the kernels speak batch-innermost slab rows
+// [row][64 lanes].  These are the HBM-streaming kernels of the step: obs packing moves
+// B * obs_dim * 8 bytes in and out per step (grid_env.py:753-783 is the column order).
+#include <hip/hip_runtime.h>
+
+#include "gs_internal.h"
+
+#define TILE_C 64
+#define TILE_PAD 65
+
+// out[b][c] = src[c] >= 0 ? slab row src[c] of instance b : cst[-src[c]-1]
+// grid = (groups, ceil(C / 64)), block = 256 (4 waves).
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C, int rows_total,
+          const double* __restrict__ slab, double* __restrict__ out, int B) {
+  __shared__ double tile[TILE_C * TILE_PAD];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = blockIdx.x;
+  const int c0 = blockIdx.y * TILE_C;
+  const double* S = slab + (size_t)g * rows_total * GS_LANES;
+  // load: one slab row (64 lanes, 512 B contiguous) per wave-instruction
+  for (int cc = wave; cc < TILE_C; cc += 4) {
+    const int c = c0 + cc;
+    if (c < C) {
+      const int s = src[c];
+      tile[cc * TILE_PAD + lane] = (s >= 0) ? S[(size_t)s * GS_LANES + lane] : cst[-s - 1];
+    }
+  }
+  __syncthreads();
+  // store: 64 consecutive columns of one instance (512 B contiguous) per wave-instruction
+  const int c = c0 + lane;
+  for (int r = wave; r < GS_LANES; r += 4) {
+    const int b = g * GS_LANES + r;
+    if (b < B && c < C) out[(size_t)b * C + c] = tile[lane * TILE_PAD + r];
+  }
+}
+
+// slab row dst[c] of instance b = in[b][c]; same tiling, opposite direction.
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,
+            const double* __restrict__ in, int B) {
+  __shared__ double tile[TILE_C * TILE_PAD];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = blockIdx.x;
+  const int c0 = blockIdx.y * TILE_C;
+  double* S = slab + (size_t)g * rows_total * GS_LANES;
+  const int c = c0 + lane;
+  for (int r = wave; r < GS_LANES; r += 4) {
+    const int b = g * GS_LANES + r;
+    tile[lane * TILE_PAD + r] = (b < B && c < C) ? in[(size_t)b * C + c] : 0.0;
+  }
+  __syncthreads();
+  for (int cc = wave; cc < TILE_C; cc += 4) {
+    const int cx = c0 + cc;
+    if (cx < C) S[(size_t)dst[cx] * GS_LANES + lane] = tile[cc * TILE_PAD + lane];
+  }
+}
+
+// Fill `count` slab rows starting at `row0` with a constant (Q_spec = 0 when the caller passes NULL).
+extern "C" __global__ void __launch_bounds__(64)
+gs_k_fill_rows(int row0, int count, int rows_total, double* __restrict__ slab, double value) {
+  double* S = slab + (size_t)blockIdx.x * rows_total * GS_LANES + threadIdx.x;
+  for (int r = 0; r < count; ++r) S[(size_t)(row0 + r) * GS_LANES] = value;
+}
+
+// Per-instance scalars -> typed contiguous [B] arrays (already lane-contiguous in the slab).
+//   f64 block: nf arrays of Bp doubles, i32 block: ni arrays, u8 block: nu arrays; each array
+//   takes its values from one slab row (rows listed in rf / ri / ru).
+extern "C" __global__ void __launch_bounds__(64)
+gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__ ri, int ni,
+             const int32_t* __restrict__ ru, int nu, int rows_total, const double* __restrict__ slab,
+             double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp) {
+  const int b = blockIdx.x * GS_LANES + threadIdx.x;
+  const double* S = slab + (size_t)blockIdx.x * rows_total * GS_LANES + threadIdx.x;
+  for (int k = 0; k < nf; ++k) of[(size_t)k * Bp + b] = S[(size_t)rf[k] * GS_LANES];
+  for (int k = 0; k < ni; ++k) oi[(size_t)k * Bp + b] = (int32_t)S[(size_t)ri[k] * GS_LANES];
+  for (int k = 0; k < nu; ++k) ou[(size_t)k * Bp + b] = (S[(size_t)ru[k] * GS_LANES] != 0.0) ? 1 : 0;
+}

@@ -1,0 +1,204 @@
+/* gridstep.h -- C ABI of libgridstep.so: MI355X-native batched AC power flow + env.step().
+ *
+ * This is the drop-in boundary for the hot path of danieleschmidt/grid-fed-rl-gym.  The
+ * reference has no FFI layer: the path sits behind two duck-typed Python plug points, and
+ * each entry point below names the reference interface it replaces (file:line relative to
+ * /root/reference/grid_fed_rl/).  The Python binding a maintainer would add is a ctypes
+ * stub; grid_fed_rl_gym_amd/_lib.py is that stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every array is caller-owned, dense, C order, float64
+ *    unless stated; batch axis first:  P_spec[B][n], obs[B][obs_dim], actions[B][action_dim].
+ *  - every function returns 0 (GS_OK) or a negative GS_E* code; gs_last_error() gives text.
+ *  - per-INSTANCE numerical failure never fails the call: it sets status[b]
+ *    (0 converged, 1 iteration cap, 2 singular Jacobian, 3 non-finite mismatch), mirroring
+ *    the reference's "return converged=False" convention (environments/power_flow.py:186-190).
+ *  - one handle = one device = one HIP stream.  A handle is not thread-safe; distinct
+ *    handles are independent.
+ *  - there is no CPU fallback: gs_create fails with GS_E_NO_DEVICE when no GPU is present.
+ */
+#ifndef GRIDSTEP_H
+#define GRIDSTEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+enum {
+  GS_OK = 0,
+  GS_E_INVALID = -1,     /* bad argument / shape / enum value                       */
+  GS_E_NO_DEVICE = -2,   /* no HIP device, or device index out of range             */
+  GS_E_HIP = -3,         /* a HIP runtime call failed                               */
+  GS_E_TOPOLOGY = -4,    /* network unusable for the requested solver (e.g. FBS on a mesh) */
+  GS_E_STATE = -5,       /* call sequence error (e.g. step before reset)            */
+  GS_E_COMM = -6,        /* RCCL not loadable / communicator failure                */
+  GS_E_NOMEM = -7
+};
+
+enum { GS_BUS_PQ = 0, GS_BUS_PV = 1, GS_BUS_SLACK = 2 };          /* base.py:210 bus_type   */
+enum { GS_JACOBIAN_AS_CODED = 0, GS_JACOBIAN_EXACT = 1 };         /* power_flow.py:247-248  */
+enum { GS_ZERO_Z_OPEN = 0, GS_ZERO_Z_EPSILON = 1 };               /* power_flow.py:63       */
+enum { GS_SOLVER_NR = 0, GS_SOLVER_FBS = 1 };
+enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2 };
+enum { GS_GEN_SOLAR = 0, GS_GEN_WIND = 1 };
+enum { GS_STATUS_OK = 0, GS_STATUS_MAX_ITER = 1, GS_STATUS_SINGULAR = 2, GS_STATUS_NAN = 3 };
+
+/* Network + devices, flattened.  Replaces the Bus/Line/Load object lists the reference
+ * passes to solve() (environments/base.py:197-295, power_flow.py:38-46) and the feeder
+ * containers (feeders/base.py:44-47).  Bus references are 0-based list positions (the
+ * reference's bus_map, power_flow.py:54). */
+typedef struct gs_topology {
+  int32_t struct_size;            /* = sizeof(gs_topology) */
+  int32_t n, m;
+  const int32_t* from_bus;        /* [m] */
+  const int32_t* to_bus;          /* [m] */
+  const double* r;                /* [m] per unit */
+  const double* x;                /* [m] per unit */
+  const double* rating;           /* [m] VA, as the reference stores it */
+  const uint8_t* bus_type;        /* [n] GS_BUS_* */
+  const double* v_set;            /* [n] magnitude set-point of slack / pv buses */
+  int32_t n_loads;
+  const int32_t* load_bus;        /* [n_loads] */
+  const double* load_base;        /* [n_loads] base_power (base.py:280) */
+  const double* load_pf;          /* [n_loads] power factor (base.py:281) */
+  int32_t n_gens;
+  const int32_t* gen_bus;         /* [n_gens] */
+  const int32_t* gen_kind;        /* [n_gens] GS_GEN_* */
+  const double* gen_cap;          /* [n_gens] capacity */
+  const double* gen_p0;           /* solar: efficiency   | wind: cut-in speed  (dynamics.py:116,150) */
+  const double* gen_p1;           /* solar: panel area   | wind: rated speed   */
+  const double* gen_p2;           /* solar: unused       | wind: cut-out speed */
+  int32_t n_bats;
+  const int32_t* bat_bus;         /* [n_bats] injection bus (reference hard-codes id 2, grid_env.py:714) */
+  const double* bat_cap;          /* [n_bats] dynamics.py:178 */
+  const double* bat_rating;       /* [n_bats] dynamics.py:179 */
+  const double* bat_eff;          /* [n_bats] dynamics.py:180 */
+} gs_topology;
+
+/* Solver + environment configuration.  Replaces the constructor kwargs of
+ * NewtonRaphsonSolver (power_flow.py:79-87) and GridEnvironment (grid_env.py:161-174) and
+ * GridDynamics (dynamics.py:233-238). */
+typedef struct gs_config {
+  int32_t struct_size;            /* = sizeof(gs_config) */
+  int32_t solver_kind;            /* GS_SOLVER_* */
+  int32_t jacobian_mode;          /* GS_JACOBIAN_* */
+  int32_t zero_z_mode;            /* GS_ZERO_Z_* */
+  int32_t linear_solver;          /* GS_LINSOLVE_* */
+  int32_t max_iterations;         /* power_flow.py:82 (default 50) */
+  int32_t episode_length;         /* grid_env.py:165 */
+  int32_t stochastic_loads;       /* grid_env.py:166 (Philox stream) */
+  int32_t weather_variation;      /* grid_env.py:168 */
+  int32_t waves_per_group;        /* 0 = auto; 1,2,4,8,16: waves cooperating on one 64-instance group */
+  int32_t reserved0;
+  double tolerance;               /* power_flow.py:81 (default 1e-6) */
+  double acceleration_factor;     /* power_flow.py:83 (default 1.0) */
+  double timestep;                /* grid_env.py:164 */
+  double v_min, v_max;            /* grid_env.py:170 */
+  double f_min, f_max;            /* grid_env.py:171 */
+  double safety_penalty;          /* grid_env.py:172 */
+  double inertia_H, damping_D, f_nominal;   /* dynamics.py:235-237 */
+  double power_base;              /* injections are divided by this before the solve; 1.0 = as coded (F4) */
+} gs_config;
+
+/* Host destination pointers for one batched solution; any pointer may be NULL (skipped).
+ * Field-for-field the reference's PowerFlowSolution (power_flow.py:12-22) with a batch axis. */
+typedef struct gs_solution_view {
+  double* bus_voltages;           /* [B][n] */
+  double* bus_angles;             /* [B][n] rad, wrapped to (-pi, pi] like np.angle */
+  double* line_flows;             /* [B][m] P from->to */
+  double* line_loadings;          /* [B][m] |S|/rating */
+  double* losses;                 /* [B] */
+  double* max_mismatch;           /* [B] */
+  int32_t* iterations;            /* [B] last loop index + 1 (power_flow.py:204) */
+  uint8_t* converged;             /* [B] */
+  int32_t* status;                /* [B] GS_STATUS_* */
+} gs_solution_view;
+
+/* Host destination pointers for the per-step info dict (grid_env.py:610-617); NULLs skipped. */
+typedef struct gs_info_view {
+  uint8_t* power_flow_converged;  /* [B] */
+  double* max_voltage;            /* [B] */
+  double* min_voltage;            /* [B] */
+  double* total_losses;           /* [B] solution.losses of this step */
+  uint8_t* violations;            /* [B][4] voltage_high, voltage_low, frequency_high, frequency_low (base.py:153-167) */
+  int32_t* constraint_violations; /* [B] running count (grid_env.py:586) */
+  int32_t* current_step;          /* [B] */
+  double* episode_reward;         /* [B] */
+  int32_t* iterations;            /* [B] */
+  int32_t* status;                /* [B] */
+} gs_info_view;
+
+typedef struct gs_handle gs_handle;
+
+/* ---- library ------------------------------------------------------------------------- */
+int gs_version(void);
+int gs_device_count(void);
+/* text of the last error on this thread (handle may be NULL for creation errors) */
+const char* gs_last_error(const gs_handle* h);
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* Compiles the topology (Ybus CSR, elimination schedule), allocates all device memory for
+ * `batch` instances on `device`.  Replaces solver/env construction (power_flow.py:79,
+ * grid_env.py:161-241).  `first_instance` is the global index of this handle's instance 0
+ * (rank * B_local when a batch is sharded over GPUs); it only feeds the RNG counters. */
+int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int32_t device,
+              int64_t first_instance, gs_handle** out);
+void gs_destroy(gs_handle* h);
+int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_t* action_dim,
+            int32_t* state_dim, int32_t* batch);
+/* how the topology was compiled: linear solver chosen, tree depth, fill, waves per group */
+int gs_describe(const gs_handle* h, char* buf, int32_t buflen);
+int gs_synchronize(gs_handle* h);
+
+/* ---- solver plug point: NewtonRaphsonSolver.solve (power_flow.py:89-211) ---------------
+ * P_spec[B][n] is the net specified injection (generation - load, what :112-121 builds from
+ * the two dicts); Q_spec may be NULL (the reference never injects reactive power, :107). */
+int gs_solve(gs_handle* h, const double* P_spec, const double* Q_spec, const gs_solution_view* out);
+/* device-resident variant for measurement: upload once, solve many times, download once */
+int gs_upload_injections(gs_handle* h, const double* P_spec, const double* Q_spec);
+int gs_solve_device(gs_handle* h);
+int gs_download_solution(gs_handle* h, const gs_solution_view* out);
+
+/* ---- env plug point: GridEnvironment.reset/step (grid_env.py:360-408, 410-619) and their
+ * batched form VectorizedEnvironment.reset/step (utils/parallel_environment.py:309-355) --- */
+/* seeds: NULL or [B] per-instance RNG seeds; mask: NULL (all) or [B] (reset where != 0);
+ * obs_out: NULL or [B][obs_dim]. */
+int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* obs_out);
+int gs_step(gs_handle* h, const double* actions, double* obs, double* reward,
+            uint8_t* terminated, uint8_t* truncated, const gs_info_view* info);
+/* device-resident variant: K action batches [K][B][action_dim] staged in HBM, stepped by index */
+int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches);
+int gs_step_device(gs_handle* h, int32_t action_batch_index);
+int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated,
+                     uint8_t* truncated, const gs_info_view* info);
+
+/* ---- checkpoint / resume: [B][state_dim] float64 blob ------------
+ * layout per instance: time, step, constraint_violations, total_losses, episode_reward,
+ * frequency, irradiance, wind, temperature, cloud, seed_lo, seed_hi,
+ * soc[n_bats], battery_power[n_bats], curtailment[n_gens], Vm[n], Va[n], flow[m], loading[m] */
+int gs_get_state(gs_handle* h, double* state);
+int gs_set_state(gs_handle* h, const double* state);
+
+/* ---- multi-GPU: one optional exchange per step, RCCL all-gather of observations over
+ * xGMI.  RCCL is dlopen'ed on first use. --------------------------- */
+int gs_comm_unique_id(uint8_t id_out[128]);
+int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t world_size);
+/* gathers this handle's device-resident obs [B][obs_dim] from all ranks into a device
+ * buffer [world*B][obs_dim]; obs_full_host may be NULL (stay on device) */
+int gs_allgather_obs(gs_handle* h, double* obs_full_host);
+int gs_comm_destroy(gs_handle* h);
+
+/* ---- measurement: HIP-event timing of every kernel launched on the handle's stream ------ */
+enum { GS_K_UNPACK = 0, GS_K_ENV_PRE = 1, GS_K_SOLVE = 2, GS_K_ENV_POST = 3, GS_K_PACK = 4, GS_K_COUNT = 5 };
+int gs_timing_enable(gs_handle* h, int32_t on);
+/* total_ms[GS_K_COUNT], launches[GS_K_COUNT] accumulated since the last call; resets them */
+int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIDSTEP_H */

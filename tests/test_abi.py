@@ -1,0 +1,79 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/gridstep.h declares;
+host-side validation paths work without a GPU; nothing on the product path imports oracle/."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import grid_fed_rl_gym_amd as P
+from grid_fed_rl_gym_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "gridstep.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    declared = _header_functions()
+    assert len(declared) >= 25
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gridstep.h but not exported by libgridstep.so"
+        assert name in bound, f"{name} declared in gridstep.h but not bound in _lib.SYMBOLS"
+    assert lib.gs_version() == _lib.GS_ABI_VERSION
+
+
+def test_struct_sizes_match_header_layout():
+    # natural alignment of the C structs: pointers 8 bytes, int32 padded before a pointer/double
+    assert ctypes.sizeof(_lib.gs_config) == 11 * 4 + 4 + 12 * 8
+    assert ctypes.sizeof(_lib.gs_solution_view) == 9 * 8
+    assert ctypes.sizeof(_lib.gs_info_view) == 10 * 8
+    assert ctypes.sizeof(_lib.gs_topology) % 8 == 0
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_args():
+    lib = _lib.load()
+    if lib.gs_device_count() == 0:
+        with pytest.raises(P.PowerFlowError, match="no HIP device|no CPU fallback"):
+            P.BatchedNewtonRaphsonSolver().solve_batch(P.simple_radial(5), np.zeros((2, 5)))
+    cfg = _lib.make_config()
+    cfg.struct_size = 3
+    h = ctypes.c_void_p()
+    t = _lib.gs_topology()
+    t.struct_size = ctypes.sizeof(_lib.gs_topology)
+    rc = lib.gs_create(ctypes.byref(t), ctypes.byref(cfg), 1, 0, 0, ctypes.byref(h))
+    assert rc == _lib.GS_E_INVALID and b"struct_size" in lib.gs_last_error(None)
+    assert lib.gs_create(None, None, 1, 0, 0, ctypes.byref(h)) == _lib.GS_E_INVALID
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "grid_fed_rl_gym_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle_cpu" not in text and "liboracle" not in text, f
+
+
+def test_feeder_generators_and_flattening():
+    s = P.ieee123_like()
+    assert (s.n, s.m, s.n_loads) == (123, 122, 91) and s.is_radial()
+    assert abs(s.load_base.sum() / 10e6 - 0.9434566272596138) < 1e-15
+    assert s.obs_dim == 2 * 123 + 2 * 122 + 1 + 2 * 91 + 5 + 2 * 3 and s.action_dim == 8
+    buses, lines, loads = P.to_objects(s)
+    bus_ids, bt, vs, frm, to, r, x, rating = P.flatten_network(buses, lines)
+    assert np.array_equal(frm, s.frm) and np.array_equal(to, s.to) and np.array_equal(r, s.r)
+    assert not P.random_meshed(30, 12, seed=7).is_radial()
+    e = P.reference_env_network()
+    assert (e.obs_dim, e.action_dim) == (17, 1)
+    assert P.with_reference_env_renewables(P.reference_env_network(), ["solar", "wind"]).obs_dim == 19
+    p = P.injections_from_dicts(e, {2: 0.2, 3: 0.15, 99: 7.0}, {3: 0.05})
+    assert np.allclose(p, [0.0, -0.2, -0.1])

@@ -1,0 +1,157 @@
+"""GPU parity for the load-flow kernels, through the C ABI.
+
+Tier A: HIP Newton-Raphson with the Jacobian as coded, capped at 1..3 iterations, against the
+numbers the reference itself produced (tests/golden/solve_*.npz, A* records).
+Tier B: HIP NR with the exact Jacobian and HIP FBS against the reference-with-one-sign-fixed
+converged answers (B*/C* records) and against the NumPy oracle on seeded batches.
+Tolerances are written next to each comparison; the north-star bar is 1e-6 pu.
+"""
+import numpy as np
+import pytest
+
+import grid_fed_rl_gym_amd as P
+from oracle import oracle_np as O
+from tests.helpers import golden, golden_names, net_of
+
+pytestmark = pytest.mark.gpu
+
+SOLVE = golden_names("solve_")
+
+
+def spec_of(d, name="g"):
+    n, frm, to, r, x, rating, bt, vs = net_of(d)
+    return P.FeederSpec(name=name, bus_ids=list(range(n)), bus_type=bt.astype(np.uint8), v_set=vs, frm=frm, to=to,
+                        r=r, x=x, rating=rating)
+
+
+def check(sol, b, d, pre, tol, flows_tol=None):
+    assert bool(sol.converged[b]) == bool(d[pre + "converged"]), pre
+    assert int(sol.iterations[b]) == int(d[pre + "iterations"]), pre
+    for got, key in ((sol.bus_voltages[b], "Vm"), (sol.bus_angles[b], "Va"), (sol.line_flows[b], "flow"),
+                     (sol.line_loadings[b], "loading")):
+        ref = d[pre + key]
+        scale = max(1.0, float(np.max(np.abs(ref)))) if len(ref) else 1.0
+        t = tol if key in ("Vm", "Va") or flows_tol is None else flows_tol
+        assert np.max(np.abs(got - ref), initial=0.0) <= t * scale, (pre, key, float(np.max(np.abs(got - ref))))
+    assert abs(sol.losses[b] - float(d[pre + "losses"])) <= (flows_tol or tol) * max(1.0, abs(float(d[pre + "losses"])))
+
+
+@pytest.mark.parametrize("name", SOLVE)
+def test_tier_a_as_coded_iteration_caps(name):
+    d = golden(name)
+    spec = spec_of(d, name)
+    growth = 1.0
+    for k in d["its"]:
+        s = P.BatchedNewtonRaphsonSolver(tolerance=1e-6, max_iterations=int(k), jacobian="as_coded", zero_z="open")
+        # B = 3 identical instances: also checks that lanes do not interfere
+        sol = s.solve_batch(spec, np.tile(d["P_spec"], (3, 1)))
+        growth = max(growth, float(d[f"A{k}_max_mismatch"]), float(np.max(np.abs(d[f"A{k}_Vm"]))))
+        for b in range(3):
+            check(sol, b, d, f"A{k}_", 1e-9 * growth ** 2)
+            mmr = float(d[f"A{k}_max_mismatch"])
+            assert abs(sol.max_mismatch[b] - mmr) <= 1e-9 * growth ** 2 * max(1.0, abs(mmr))
+        s.close()
+
+
+@pytest.mark.parametrize("name", SOLVE)
+def test_tier_b_exact_converged(name):
+    d = golden(name)
+    if len(d["exact_scales"]) == 0:
+        pytest.skip("no Tier-B record")
+    spec = spec_of(d, name)
+    s = P.BatchedNewtonRaphsonSolver(tolerance=1e-6, max_iterations=50, jacobian="exact")
+    P_batch = np.stack([d["P_spec"] * lam for lam in d["exact_scales"]])
+    sol = s.solve_batch(spec, P_batch)
+    for q in range(len(d["exact_scales"])):
+        # same iterate sequence as the reference-with-sign-fixed => same iteration count, 1e-9 agreement
+        check(sol, q, d, f"B{q}_", 1e-9)
+        assert sol.converged[q] and sol.max_mismatch[q] < 1e-6 and sol.status[q] == 0
+    s.close()
+    # run to 1e-12: equals the tightly converged anchor
+    s = P.BatchedNewtonRaphsonSolver(tolerance=1e-11, max_iterations=50, jacobian="exact")
+    sol = s.solve_batch(spec, P_batch)
+    for q in range(len(d["exact_scales"])):
+        assert np.max(np.abs(sol.bus_voltages[q] - d[f"C{q}_Vm"])) < 1e-9
+        assert np.max(np.abs(sol.bus_angles[q] - d[f"C{q}_Va"])) < 1e-9
+        assert np.max(np.abs(sol.line_flows[q] - d[f"C{q}_flow"])) < 1e-8
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["solve_env3", "solve_radial5", "solve_radial13", "solve_radial123",
+                                  "solve_ieee13_eps", "solve_tree123"])
+def test_fbs_matches_reference_anchor(name):
+    d = golden(name)
+    spec = spec_of(d, name)
+    s = P.BatchedForwardBackwardSweepSolver(tolerance=1e-10, max_iterations=200)
+    sol = s.solve_batch(spec, np.stack([d["P_spec"] * lam for lam in d["exact_scales"]]))
+    for q in range(len(d["exact_scales"])):
+        assert sol.converged[q], name
+        assert np.max(np.abs(sol.bus_voltages[q] - d[f"C{q}_Vm"])) < 1e-8     # bar: 1e-6 pu
+        assert np.max(np.abs(sol.bus_angles[q] - d[f"C{q}_Va"])) < 1e-8
+        assert np.max(np.abs(sol.line_flows[q] - d[f"C{q}_flow"])) < 1e-7
+    s.close()
+
+
+def test_singular_as_coded_ieee13_and_zero_load():
+    d = golden("solve_ieee13_as_coded")
+    s = P.BatchedNewtonRaphsonSolver(max_iterations=3, jacobian="as_coded", zero_z="open")
+    sol = s.solve_batch(spec_of(d), d["P_spec"][None, :])
+    assert sol.status[0] == 2 and not sol.converged[0] and sol.iterations[0] == 1
+    assert np.all(sol.bus_voltages[0] == 1.0) and abs(sol.max_mismatch[0] - 0.1155) < 1e-12
+    s.close()
+    d = golden("solve_env3_zero")
+    s = P.BatchedNewtonRaphsonSolver(max_iterations=5, jacobian="as_coded")
+    sol = s.solve_batch(spec_of(d), d["P_spec"][None, :])
+    assert sol.converged[0] and sol.iterations[0] == 1 and np.all(sol.bus_voltages[0] == 1.0)
+    s.close()
+
+
+@pytest.mark.parametrize("maker,B,scale", [(lambda: P.ieee13_like("epsilon"), 200, 1.0),
+                                           (lambda: P.ieee123_like(), 130, 1.0),
+                                           (lambda: P.random_meshed(24, 9, seed=3), 70, 2.0)])
+def test_seeded_batches_against_oracle(maker, B, scale):
+    """Ragged batch sizes (not multiples of 64), per-instance loading, every instance checked."""
+    fs = maker()
+    rng = np.random.default_rng(1234)
+    base = np.zeros(fs.n)
+    np.add.at(base, fs.load_bus, -fs.load_base / 10e6)
+    lam = rng.uniform(0.5, 1.5, B) * scale
+    Pb = lam[:, None] * base[None, :] * rng.uniform(0.8, 1.2, (B, fs.n))
+    s = P.BatchedNewtonRaphsonSolver(tolerance=1e-8, max_iterations=30, jacobian="exact")
+    sol = s.solve_batch(fs, Pb)
+    worst_v = worst_f = 0.0
+    for b in range(0, B, 7):
+        ref = O.nr_solve(fs.n, fs.frm, fs.to, fs.r, fs.x, fs.rating, fs.bus_type, fs.v_set, Pb[b], tolerance=1e-8,
+                         max_iterations=30, jacobian_mode="exact")
+        assert ref["converged"] and sol.converged[b] and sol.iterations[b] == ref["iterations"]
+        worst_v = max(worst_v, np.max(np.abs(sol.bus_voltages[b] - ref["bus_voltages"])),
+                      np.max(np.abs(sol.bus_angles[b] - ref["bus_angles"])))
+        worst_f = max(worst_f, np.max(np.abs(sol.line_flows[b] - ref["line_flows"])))
+        assert abs(sol.losses[b] - ref["losses"]) < 1e-9
+    assert worst_v < 1e-9 and worst_f < 1e-8, (worst_v, worst_f)
+    assert sol.converged.all()
+    # size-independent property: the converged V satisfies the reference's own mismatch formula
+    Y = O.admittance_matrix(fs.n, fs.frm, fs.to, fs.r, fs.x)
+    V = sol.bus_voltages * np.exp(1j * sol.bus_angles)
+    S = V * np.conj(V @ Y.T)
+    resid = np.abs(S.real - Pb)[:, 1:].max()
+    assert resid < 1e-7 and np.abs(S.imag[:, 1:]).max() < 1e-7
+    s.close()
+
+
+def test_reference_plug_point_signature_and_batch_helper():
+    """solve(buses, lines, loads, generation) -> PowerFlowSolution, and parallel_power_flow_batch."""
+    buses = [P.Bus(1, bus_type="slack"), P.Bus(2), P.Bus(3)]
+    lines = [P.Line("line_1_2", 1, 2, 0.01, 0.02, 5e6), P.Line("line_2_3", 2, 3, 0.015, 0.025, 3e6)]
+    d = golden("solve_env3")
+    s = P.NewtonRaphsonSolver(max_iterations=1, jacobian="as_coded")
+    sol = s.solve(buses, lines, {2: 0.2, 3: 0.15, "nope": 9.0}, {3: 0.05})
+    assert isinstance(sol, P.PowerFlowSolution) and sol.iterations == 1 and not sol.converged
+    assert np.max(np.abs(sol.bus_voltages - d["A1_Vm"])) < 1e-12
+    assert abs(sol.losses - float(d["A1_losses"])) < 1e-12
+    ex = P.NewtonRaphsonSolver(jacobian="exact")
+    cfgs = [(buses, lines, {2: 0.2 * k, 3: 0.15 * k}, {3: 0.05 * k}) for k in (0.5, 1.0, 2.0)]
+    res = P.parallel_power_flow_batch(ex, cfgs)
+    for q, r in enumerate(res):
+        assert r.converged and np.max(np.abs(r.bus_voltages - d[f"B{q}_Vm"])) < 1e-9
+    s.close(); ex.close()
