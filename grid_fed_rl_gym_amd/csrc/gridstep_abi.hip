@@ -209,6 +209,7 @@ int launch_solve(gs_handle* h) {
   dim3 grid(h->groups), block(64 * h->W);
   if (h->solve_kernel == 0) hipLaunchKernelGGL(gs_k_nr_tree, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   else if (h->solve_kernel == 1) hipLaunchKernelGGL(gs_k_nr_lu, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
+  else if (h->solve_kernel == 3) hipLaunchKernelGGL(gs_k_nr_dense, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   else hipLaunchKernelGGL(gs_k_fbs, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   HIPCHK(h, hipGetLastError());
   return GS_OK;
@@ -284,7 +285,10 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   gs_handle* h = new gs_handle();
   h->device = device;
   h->cfg = *cfg;
-  std::string why = gs_compile_topology(*topo, cfg->zero_z_mode, cfg->linear_solver == GS_LINSOLVE_SPARSE_LU, h->topo);
+  std::string why = gs_compile_topology(*topo, cfg->zero_z_mode, cfg->linear_solver == GS_LINSOLVE_SPARSE_LU,
+                                        cfg->solver_kind == GS_SOLVER_NR && cfg->jacobian_mode == GS_JACOBIAN_AS_CODED &&
+                                            (cfg->linear_solver == GS_LINSOLVE_AUTO || cfg->linear_solver == GS_LINSOLVE_DENSE_PIVOT),
+                                        h->topo);
   if (!why.empty()) { int rc = fail(nullptr, GS_E_INVALID, "topology: %s", why.c_str()); delete h; return rc; }
   const HostTopology& ht = h->topo;
   if (cfg->solver_kind == GS_SOLVER_FBS) {
@@ -293,7 +297,11 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   } else if (cfg->solver_kind == GS_SOLVER_NR) {
     if (cfg->linear_solver == GS_LINSOLVE_TREE && !ht.is_forest) {
       int rc = fail(nullptr, GS_E_TOPOLOGY, "tree elimination requested but the active network has loops"); delete h; return rc; }
-    h->solve_kernel = (ht.is_forest && cfg->linear_solver != GS_LINSOLVE_SPARSE_LU) ? 0 : 1;
+    int ls = cfg->linear_solver;
+    if (ls == GS_LINSOLVE_AUTO)
+      ls = (cfg->jacobian_mode == GS_JACOBIAN_AS_CODED) ? GS_LINSOLVE_DENSE_PIVOT
+                                                       : (ht.is_forest ? GS_LINSOLVE_TREE : GS_LINSOLVE_SPARSE_LU);
+    h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : 3;
   } else { int rc = fail(nullptr, GS_E_INVALID, "unknown solver_kind %d", cfg->solver_kind); delete h; return rc; }
 
   h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
@@ -325,6 +333,10 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   R.JR = take(n); R.JI = take(n);
   R.LU = take(h->solve_kernel == 1 ? 4 * ht.lu_n_slots : 0);
   R.LUD = take(h->solve_kernel == 1 ? 4 * n : 0);
+  const int dnN = ht.dn_N;
+  R.DA = take(h->solve_kernel == 3 ? dnN * dnN : 0);
+  R.DB = take(h->solve_kernel == 3 ? dnN : 0); R.DX = take(h->solve_kernel == 3 ? dnN : 0);
+  R.DPERM = take(h->solve_kernel == 3 ? dnN : 0);
   R.TIME = take(1); R.STEP = take(1); R.VIOL = take(1); R.TOTLOSS = take(1); R.EPREW = take(1); R.FREQ = take(1);
   R.IRR = take(1); R.WIND = take(1); R.TEMP = take(1); R.CLOUD = take(1); R.SEEDLO = take(1); R.SEEDHI = take(1);
   R.SOC = take(h->n_bats); R.BATP = take(h->n_bats); R.CURT = take(h->n_gens); R.GENP = take(h->n_gens);
@@ -338,6 +350,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   T.n = n; T.m = m; T.nnz = ht.nnz; T.n_levels = ht.n_levels;
   T.n_loads = h->n_loads; T.n_gens = h->n_gens; T.n_bats = h->n_bats;
   T.lu_n_piv = ht.lu_n_piv; T.lu_n_slots = ht.lu_n_slots; T.lu_n_orig = ht.lu_n_orig;
+  T.dn_N = ht.dn_N;
   int rc = 0;
 #define UP(field, vec) if ((rc = dev_upload(h, &T.field, ht.vec))) return bail(rc)
   UP(row_ptr, row_ptr); UP(col, col); UP(G, G); UP(Bv, B); UP(Gd, Gd); UP(Bd, Bd);
@@ -349,6 +362,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(lu_nb_jk, lu_nb_jk); UP(lu_pair_ptr, lu_pair_ptr); UP(lu_pair_ik, lu_pair_ik); UP(lu_pair_kj, lu_pair_kj);
   UP(lu_pair_ij, lu_pair_ij); UP(lu_orig_slot, lu_orig_slot); UP(lu_orig_i, lu_orig_i); UP(lu_orig_j, lu_orig_j);
   UP(lu_orig_pos, lu_orig_pos);
+  UP(dn_th_idx, dn_th_idx); UP(dn_vm_idx, dn_vm_idx);
   UP(bl_ptr, bl_ptr); UP(bl_idx, bl_idx); UP(bg_ptr, bg_ptr); UP(bg_idx, bg_idx); UP(bb_ptr, bb_ptr); UP(bb_idx, bb_idx);
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
@@ -443,7 +457,7 @@ int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_
 
 int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail(nullptr, GS_E_INVALID, "bad arguments");
-  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs"};
+  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot"};
   snprintf(buf, buflen,
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "

@@ -71,6 +71,11 @@ struct GsTables {
   const int32_t* lu_orig_i;      // ... their (i, j) ...
   const int32_t* lu_orig_j;
   const int32_t* lu_orig_pos;    // ... and CSR position of (i, j)
+  // dense partial-pivoting LU (reference-faithful linear solve, power_flow.py:187): unknown
+  // order [theta(non-slack, ascending) ; Vm(pq, ascending)] exactly as power_flow.py:232-240
+  int32_t dn_N, pad2;
+  const int32_t* dn_th_idx;      // [n] row/column of bus i's theta unknown / P equation, -1 if none
+  const int32_t* dn_vm_idx;      // [n] row/column of bus i's Vm unknown / Q equation, -1 if none
   // per-bus device lists for the injection build (reference accumulation order, grid_env.py:683-720)
   const int32_t* bl_ptr;     // [n+1] loads at bus
   const int32_t* bl_idx;
@@ -110,6 +115,8 @@ struct GsRows {
   int32_t JR, JI;            // [n] FBS branch currents
   int32_t LU;                // [4 * lu_n_slots] off-diagonal blocks
   int32_t LUD;               // [4n] diagonal blocks
+  int32_t DA;                // [N*N] dense Jacobian (dense kernel only)
+  int32_t DB, DX, DPERM;     // [N] rhs, solution, row permutation
   // env state
   int32_t TIME, STEP, VIOL, TOTLOSS, EPREW, FREQ, IRR, WIND, TEMP, CLOUD, SEEDLO, SEEDHI;
   int32_t SOC, BATP;         // [n_bats]

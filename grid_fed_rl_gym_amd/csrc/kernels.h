@@ -7,6 +7,7 @@
 extern "C" {
 __global__ void gs_k_nr_tree(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
 __global__ void gs_k_nr_lu(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
+__global__ void gs_k_nr_dense(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
 __global__ void gs_k_fbs(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);

@@ -501,3 +501,112 @@ gs_k_fbs(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
   for (int i = wave; i < T.n; i += W) ROW(R.VM + i) = hypot(ROW(R.E + i), ROW(R.F + i));
   finish(T, R, S, sh, wave, W, lane, false, st.mm, st.iters, st.conv, st.status);
 }
+
+// =============================================================================================
+// Newton-Raphson with a dense, partially pivoted LU per instance -- the reference-faithful
+// linear solve (np.linalg.solve = LAPACK dgesv, power_flow.py:187): same unknown order, same
+// pivot rule (largest |a_ik| in the column), exact-zero pivot = singular.  Row exchanges are
+// per instance, so matrix rows are reached through a per-lane permutation (a gather: each lane
+// reads its own row at its own lane slot).  This path exists for parity with the as-coded
+// Jacobian, whose 2x2 diagonal blocks can be exactly singular; it is not the fast path.
+// =============================================================================================
+#define DA_AT(prow, c) S[((size_t)R.DA + (size_t)(prow) * N + (size_t)(c)) * GS_LANES]
+
+extern "C" __global__ void __launch_bounds__(1024)
+gs_k_nr_dense(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
+  __shared__ GsShared sh;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = blockDim.x >> 6;
+  const int N = T.dn_N;
+  double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
+  const bool valid = (int)(blockIdx.x * GS_LANES + lane) < B;
+
+  NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
+  flat_start(T, R, S, wave, W);
+  __syncthreads();
+  bool stale = true;
+  int it = 0;
+  for (; it < C.max_iterations; ++it) {
+    to_rect(T, R, S, wave, W);
+    __syncthreads();
+    const double lmax = mismatch_rows(T, R, S, wave, W);
+    const double mm = wg_max(sh, it & 1, wave, W, lane, lmax);
+    nr_check(st, mm, it, C.tolerance);
+    stale = false;
+    if (__all(st.done)) break;
+
+    // ---- assemble the dense Jacobian and right-hand side ----
+    for (int q = wave; q < N * N; q += W) ROW(R.DA + q) = 0.0;
+    for (int q = wave; q < N; q += W) ROW(R.DPERM + q) = (double)q;
+    __syncthreads();
+    for (int i = wave; i < T.n; i += W) {
+      const int ri0 = cld(T.dn_th_idx, i), ri1 = cld(T.dn_vm_idx, i);
+      if (ri0 >= 0) ROW(R.DB + ri0) = ROW(R.R0 + i);
+      if (ri1 >= 0) ROW(R.DB + ri1) = ROW(R.R1 + i);
+      const int p1 = cld(T.row_ptr, i + 1);
+      for (int p = cld(T.row_ptr, i); p < p1; ++p) {
+        const int j = cld(T.col, p);
+        const int cj0 = cld(T.dn_th_idx, j), cj1 = cld(T.dn_vm_idx, j);
+        const Blk blk = (j == i) ? diag_block(T, R, S, i, C.jacobian_exact)
+                                 : offdiag_block(T, R, S, i, j, cld(T.G, p), cld(T.Bv, p));
+        if (ri0 >= 0 && cj0 >= 0) ROW(R.DA + ri0 * N + cj0) = blk.a00;
+        if (ri0 >= 0 && cj1 >= 0) ROW(R.DA + ri0 * N + cj1) = blk.a01;
+        if (ri1 >= 0 && cj0 >= 0) ROW(R.DA + ri1 * N + cj0) = blk.a10;
+        if (ri1 >= 0 && cj1 >= 0) ROW(R.DA + ri1 * N + cj1) = blk.a11;
+      }
+    }
+    __syncthreads();
+
+    // ---- LU with partial pivoting (per lane) ----
+    int sing = 0;
+    for (int k = 0; k < N; ++k) {
+      if (wave == 0) {
+        double best = -1.0; int bi = k;
+        for (int i = k; i < N; ++i) {
+          const int pi = (int)ROW(R.DPERM + i);
+          const double v = fabs(DA_AT(pi, k));
+          if (v > best) { best = v; bi = i; }
+        }
+        if (!(best > 0.0)) sing = 1;
+        const double pk = ROW(R.DPERM + k);
+        const double pb = S[(size_t)(R.DPERM + bi) * GS_LANES];
+        S[(size_t)(R.DPERM + bi) * GS_LANES] = pk;
+        ROW(R.DPERM + k) = pb;
+      }
+      __syncthreads();
+      const int pk = (int)ROW(R.DPERM + k);
+      const double akk = DA_AT(pk, k);
+      const double bk = S[(size_t)(R.DB + pk) * GS_LANES];
+      for (int i = k + 1 + wave; i < N; i += W) {
+        const int pi = (int)ROW(R.DPERM + i);
+        const double l = DA_AT(pi, k) / akk;
+        if (__any(l != 0.0)) {
+          for (int c = k + 1; c < N; ++c) DA_AT(pi, c) -= l * DA_AT(pk, c);
+          S[(size_t)(R.DB + pi) * GS_LANES] -= l * bk;
+        }
+      }
+      __syncthreads();
+    }
+    const int sing_all = wg_or(sh, it & 1, wave, W, lane, sing);
+    if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+    const bool upd = !st.done;
+    if (wave == 0) {
+      for (int k = N - 1; k >= 0; --k) {
+        const int pk = (int)ROW(R.DPERM + k);
+        double s = S[(size_t)(R.DB + pk) * GS_LANES];
+        for (int c = k + 1; c < N; ++c) s -= DA_AT(pk, c) * ROW(R.DX + c);
+        ROW(R.DX + k) = s / DA_AT(pk, k);
+      }
+      for (int i = 0; i < T.n; ++i) {
+        const int c0 = cld(T.dn_th_idx, i), c1 = cld(T.dn_vm_idx, i);
+        ROW(R.X0 + i) = (c0 >= 0) ? ROW(R.DX + c0) : 0.0;
+        ROW(R.X1 + i) = (c1 >= 0) ? ROW(R.DX + c1) : 0.0;
+        apply_step(T, R, S, i, C.alpha, upd);
+      }
+    }
+    __syncthreads();
+    stale = true;
+  }
+  finish(T, R, S, sh, wave, W, lane, stale, st.mm, st.iters, st.conv, st.status);
+}

@@ -35,7 +35,7 @@ Cx reciprocal(double r, double x) {
 
 }  // namespace
 
-std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want_lu, HostTopology& o) {
+std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want_lu, bool skip_lu, HostTopology& o) {
   const int n = t.n, m = t.m;
   if (n <= 0 || m < 0) return "n must be > 0 and m >= 0";
   if (!t.bus_type || !t.v_set) return "bus_type / v_set missing";
@@ -191,7 +191,7 @@ std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want
   }
 
   // ---- sparse block-LU schedule (meshed networks): minimum-degree order, symbolic fill -----
-  if (!forest || want_lu) {
+  if ((!forest || want_lu) && !skip_lu) {
     o.has_lu = true;
     std::vector<std::set<int>> g(n);
     for (int i = 0; i < n; ++i) for (int v : adj[i]) g[i].insert(v);
@@ -235,6 +235,15 @@ std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want
     o.lu_n_piv = o.n_active;
     o.lu_n_slots = (int)slot.size();
     o.lu_n_pairs = (int64_t)o.lu_pair_ik.size();
+  }
+
+  // ---- dense unknown numbering (power_flow.py:232-240, 291) -----------------------------------
+  o.dn_th_idx.assign(n, -1); o.dn_vm_idx.assign(n, -1);
+  {
+    int k = 0;
+    for (int i = 0; i < n; ++i) if (o.th_free[i]) o.dn_th_idx[i] = k++;
+    for (int i = 0; i < n; ++i) if (o.vm_free[i]) o.dn_vm_idx[i] = k++;
+    o.dn_N = k;
   }
 
   // ---- per-bus device lists (accumulation order of grid_env.py:689-718) --------------------

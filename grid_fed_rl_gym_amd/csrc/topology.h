@@ -34,6 +34,9 @@ struct HostTopology {
   std::vector<int32_t> lu_piv_bus, lu_nb_ptr, lu_nb_bus, lu_nb_kj, lu_nb_jk;
   std::vector<int32_t> lu_pair_ptr, lu_pair_ik, lu_pair_kj, lu_pair_ij;
   std::vector<int32_t> lu_orig_slot, lu_orig_i, lu_orig_j, lu_orig_pos;
+  // dense LU unknown numbering
+  int dn_N = 0;
+  std::vector<int32_t> dn_th_idx, dn_vm_idx;
   // per-bus device lists
   std::vector<int32_t> bl_ptr, bl_idx, bg_ptr, bg_idx, bb_ptr, bb_idx;
   std::vector<double> load_base, load_q, gen_cap, gen_p0, gen_p1, gen_p2, bat_cap, bat_rating, bat_eff;
@@ -42,4 +45,6 @@ struct HostTopology {
 
 // Returns "" on success, else an error message.  `want_lu` forces building the sparse-LU
 // schedule even for forests (GS_LINSOLVE_SPARSE_LU).
-std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want_lu, HostTopology& out);
+// schedule even for forests (GS_LINSOLVE_SPARSE_LU); `skip_lu` suppresses it (dense path: a
+// near-complete graph would need O(n^3) schedule entries for nothing).
+std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want_lu, bool skip_lu, HostTopology& out);

@@ -43,7 +43,11 @@ enum { GS_BUS_PQ = 0, GS_BUS_PV = 1, GS_BUS_SLACK = 2 };          /* base.py:210
 enum { GS_JACOBIAN_AS_CODED = 0, GS_JACOBIAN_EXACT = 1 };         /* power_flow.py:247-248  */
 enum { GS_ZERO_Z_OPEN = 0, GS_ZERO_Z_EPSILON = 1 };               /* power_flow.py:63       */
 enum { GS_SOLVER_NR = 0, GS_SOLVER_FBS = 1 };
-enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2 };
+/* AUTO: exact Jacobian -> TREE on radial networks, SPARSE_LU on meshed ones (2x2-block pivots,
+ * no row exchanges: safe because the exact diagonal blocks are rotation-like);
+ * as-coded Jacobian -> DENSE_PIVOT (partial pivoting like LAPACK dgesv, power_flow.py:187),
+ * because the as-coded diagonal blocks can be exactly singular (e.g. a leaf fed through r = x). */
+enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2, GS_LINSOLVE_DENSE_PIVOT = 3 };
 enum { GS_GEN_SOLAR = 0, GS_GEN_WIND = 1 };
 enum { GS_STATUS_OK = 0, GS_STATUS_MAX_ITER = 1, GS_STATUS_SINGULAR = 2, GS_STATUS_NAN = 3 };
 

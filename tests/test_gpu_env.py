@@ -1,0 +1,148 @@
+"""GPU parity for the batched environment step, through the C ABI.
+
+* G10: the reference's own deterministic trajectories of its hard-coded 3-bus env
+  (tests/golden/env_*.npz) -- observation, reward, flags, step by step, as coded.
+* seeded batches on the 13- and 123-bus feeders against the NumPy oracle (exact Jacobian,
+  per-unit scaling), including stochastic loads / weather on the shared Philox stream,
+  ragged batch sizes, masked reset and checkpoint round trips.
+"""
+import numpy as np
+import pytest
+
+import grid_fed_rl_gym_amd as P
+from oracle import oracle_np as O
+from tests.helpers import golden, oracle_spec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,sources", [("env_ref3_norenew_it1", []), ("env_ref3_solarwind_it1", ["solar", "wind"]),
+                                          ("env_ref3_solarwind_it2", ["solar", "wind"])])
+def test_reference_trajectory_as_coded(name, sources):
+    d = golden(name)
+    B = 5     # identical instances; all must reproduce the reference trajectory
+    env = P.BatchedGridEnvironment.reference_default(
+        num_envs=B, renewable_sources=sources, stochastic_loads=False, weather_variation=False,
+        episode_length=int(d["episode_length"]), jacobian="as_coded", zero_z="open", tolerance=1e-6,
+        max_iterations=int(d["max_it"]))
+    obs, info = env.reset(seed=0)
+    st = env.get_state()
+    st[:, env.state_column("time")] = float(d["t0"])
+    if float(d["wind_speed"]) >= 0:
+        st[:, env.state_column("wind")] = float(d["wind_speed"])
+    env.set_state(st)
+    assert obs.shape == (B, d["obs"].shape[1])
+    for k, a in enumerate(d["actions"]):
+        obs, rew, term, trunc, info = env.step(np.tile(a, (B, 1)))
+        ref = d["obs"][k + 1]
+        scale = np.maximum(1.0, np.abs(ref))
+        err = np.max(np.abs(obs - ref[None, :]) / scale[None, :])
+        # iterates are O(1e4..1e9) here (watts into a per-unit solve, F4); 1e-9 relative per entry
+        assert err < 1e-9, (k, err)
+        assert np.all(np.abs(rew - d["reward"][k]) <= 1e-9 * max(1.0, abs(d["reward"][k])))
+        assert np.all(term == bool(d["terminated"][k])) and np.all(trunc == bool(d["truncated"][k]))
+        assert np.all(info["power_flow_converged"] == bool(d["converged"][k]))
+        v = info["constraint_violations"]
+        got = [v["voltage_high"][0], v["voltage_low"][0], v["frequency_high"][0], v["frequency_low"][0]]
+        assert got == [bool(z) for z in d["violations"][k]]
+        assert np.all(np.abs(info["max_voltage"] - d["vmax"][k]) <= 1e-9 * max(1.0, abs(d["vmax"][k])))
+        assert np.all(np.abs(info["total_losses"] - d["losses"][k]) <= 1e-9 * max(1.0, abs(d["losses"][k])))
+    env.close()
+
+
+def _oracle_rollout(fs, cfg, actions, seeds, first_instance=0, t0=None):
+    """actions [T, B, A] -> lists of per-step (obs, rew, term, trunc, info) per instance."""
+    T, B, _ = actions.shape
+    spec = oracle_spec(fs, **cfg)
+    out = []
+    for b in range(B):
+        _, st = O.env_reset(spec, seed=int(seeds[b]), instance=first_instance + b)
+        if t0 is not None:
+            st.time = t0
+        traj = [O.env_step(spec, st, actions[t, b]) for t in range(T)]
+        out.append(traj)
+    return out
+
+
+@pytest.mark.parametrize("maker,B,T,solver,stoch", [
+    (lambda: P.ieee13_like("epsilon"), 70, 4, "nr", False),
+    (lambda: P.ieee13_like("epsilon"), 33, 3, "nr", True),
+    (lambda: P.ieee123_like(), 66, 3, "nr", False),
+    (lambda: P.ieee123_like(), 20, 2, "fbs", True),
+])
+def test_seeded_rollouts_against_oracle(maker, B, T, solver, stoch):
+    fs = maker()
+    rng = np.random.default_rng(5678)
+    actions = rng.uniform(-1, 1, (T, B, fs.action_dim))
+    seeds = np.arange(100, 100 + B, dtype=np.uint64)
+    t0 = 11.5 * 3600.0
+    env = P.BatchedGridEnvironment(fs, num_envs=B, stochastic_loads=stoch, weather_variation=stoch, solver=solver,
+                                   jacobian="exact", tolerance=1e-9, max_iterations=100, first_instance=1000)
+    env.reset(seed=seeds)
+    st = env.get_state()
+    st[:, env.state_column("time")] = t0
+    env.set_state(st)
+    cfg = dict(stochastic_loads=stoch, weather_variation=stoch, power_base=fs.base_power_va, solver=solver,
+               tolerance=1e-9, max_iterations=100, jacobian_mode="exact", zero_z="open")
+    ref = _oracle_rollout(fs, cfg, actions, seeds, first_instance=1000, t0=t0)
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(actions[t])
+        for b in range(0, B, 3):
+            o, r, te, tr, inf = ref[b][t]
+            scale = np.maximum(1.0, np.abs(o))
+            # voltages/angles/flows: 1e-8 (north-star bar 1e-6 pu); FBS and NR stop at mismatch < 1e-9
+            assert np.max(np.abs(obs[b] - o) / scale) < 1e-8, (t, b, int(np.argmax(np.abs(obs[b] - o) / scale)))
+            assert abs(rew[b] - r) <= 1e-7 * max(1.0, abs(r))
+            assert bool(term[b]) == te and bool(trunc[b]) == tr
+            assert bool(info["power_flow_converged"][b]) == inf["power_flow_converged"]
+            assert abs(info["total_losses"][b] - inf["total_losses"]) < 1e-8
+        assert info["power_flow_converged"].all()
+    env.close()
+
+
+def test_masked_reset_checkpoint_and_list_adapter():
+    fs = P.ieee13_like("epsilon")
+    B = 9
+    env = P.BatchedGridEnvironment(fs, num_envs=B, stochastic_loads=False, weather_variation=False, tolerance=1e-9)
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, (3, B, env.action_dim))
+    env.reset(seed=7)
+    env.step(a[0])
+    snap = env.get_state()
+    o1 = env.step(a[1])
+    env.set_state(snap)                      # resume from the checkpoint: identical continuation
+    o2 = env.step(a[1])
+    assert np.array_equal(o1[0], o2[0]) and np.array_equal(o1[1], o2[1])
+    mask = np.zeros(B, dtype=np.uint8); mask[[2, 5]] = 1
+    obs_r, _ = env.reset(seed=7, mask=mask)
+    st = env.get_state()
+    assert np.all(st[[2, 5], env.state_column("step")] == 0) and np.all(st[[0, 1, 3], env.state_column("step")] == 2)
+    assert np.all(obs_r[[2, 5], 0] == 1.0)
+    vec = P.VectorizedEnvironment(env)
+    obs_l, infos = vec.reset(seeds=list(range(B)))
+    assert len(obs_l) == B and obs_l[0].shape == (env.obs_dim,)
+    o, r, te, tr, inf = vec.step([a[2, b] for b in range(B)])
+    assert len(o) == len(r) == len(te) == len(tr) == len(inf) == B and isinstance(r[0], float)
+    assert set(inf[0]["constraint_violations"]) == {"voltage_high", "voltage_low", "frequency_high", "frequency_low"}
+    assert vec.get_performance_stats()["steps_per_second"] > 0
+    with pytest.raises(P.InvalidActionError):
+        env.step(np.zeros((B, env.action_dim + 1)))
+    bad = a[2].copy(); bad[4, 0] = np.nan
+    *_, info = env.step(bad)
+    assert info["action_invalid"][4] and not info["action_invalid"][0]
+    env.close()
+
+
+def test_truncation_after_ten_violating_steps_and_termination():
+    """base.py:140-167 / grid_env.py:604-606 through properties that do not depend on the oracle."""
+    fs = P.ieee13_like("epsilon")
+    env = P.BatchedGridEnvironment(fs, num_envs=4, stochastic_loads=False, weather_variation=False,
+                                   voltage_limits=(0.999, 1.05), episode_length=12, safety_penalty=100.0)
+    env.reset(seed=1)
+    z = np.zeros((4, env.action_dim))
+    for k in range(13):
+        obs, rew, term, trunc, info = env.step(z)
+        assert np.all(info["constraint_violations"]["voltage_low"])
+        assert np.all(trunc == (k + 1 > 10)) and np.all(term == (k + 1 >= 12))
+        assert np.all(info["constraint_violations_count"] == k + 1)
+    env.close()
