@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- env steps/sec of the batched AC power-flow env.step() on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ieee123_b8192|ieee13_b4096]
+                    [--solver nr|fbs] [--batch B] [--no-cpu-baseline]
+
+One "step" = one batched env.step(): actions -> batteries/curtailment -> weather -> injections
+-> AC load flow -> line flows -> frequency -> reward/flags -> observation block, for every
+instance of the batch, with the K action batches already resident in HBM.  The default
+workload is the configuration BASELINE.json's target is quoted on: the 123-bus radial feeder,
+8192 instances per GPU, reference defaults for stochastic loads and weather.
+
+For N > 1 the driver launches one process per GPU (torch.distributed.run); each rank owns a
+contiguous block of instances (weak scaling, per-GPU batch fixed) and the only exchange is the
+RCCL all-gather of the observation block after each step.  torch is imported only for the
+rendezvous (gloo barrier + max-over-ranks), never for compute; libgridstep.so is loaded first
+so that the process uses one HIP runtime.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from grid_fed_rl_gym_amd import _lib  # noqa: E402
+import grid_fed_rl_gym_amd as P  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor figure for MI355X FP64 vector
+
+WORKLOADS = {
+    "ieee123_b8192": dict(feeder="ieee123_like", batch=8192),
+    "ieee13_b4096": dict(feeder="ieee13_like", batch=4096),
+}
+
+
+def make_feeder(name):
+    return P.ieee123_like() if name == "ieee123_like" else P.ieee13_like("epsilon")
+
+
+def algorithmic_bytes_per_step(fs):
+    """B_step = 8 * [A + 2n (P,Q in) + 2n (Vm,Va out) + 2m (flow, loading)
+    + obs_dim + 8 scalars] bytes per env-step per instance."""
+    return 8 * (fs.action_dim + 2 * fs.n + 2 * fs.n + 2 * fs.m + fs.obs_dim + 8)
+
+
+def algorithmic_flops_per_iteration(fs):
+    """~180 n flops per Newton iteration on a radial feeder (FBS: ~30 n per sweep)."""
+    return 180 * fs.n
+
+
+def cpu_baseline(fs, env_kwargs, budget_s=15.0):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload.
+    Prefers the C/OpenMP port (oracle/liboracle_cpu.so) when it has been built, else the NumPy
+    restatement on one core."""
+    try:
+        from oracle import oracle_c
+        if oracle_c.available():
+            return oracle_c.bench_env_steps(fs, env_kwargs, budget_s)
+    except Exception as e:  # pragma: no cover - reported, not fatal
+        print(f"[bench] C oracle unavailable ({e}); timing the NumPy oracle", file=sys.stderr)
+    from oracle import oracle_np as O
+    from tests.helpers import oracle_spec
+    spec = oracle_spec(fs, stochastic_loads=env_kwargs["stochastic_loads"], weather_variation=env_kwargs["weather_variation"],
+                       power_base=fs.base_power_va, solver=env_kwargs["solver"], tolerance=env_kwargs["tolerance"],
+                       max_iterations=env_kwargs["max_iterations"], jacobian_mode="exact", zero_z="open")
+    rng = np.random.default_rng(5678)
+    n_done, t0 = 0, time.perf_counter()
+    b = 0
+    while time.perf_counter() - t0 < budget_s:
+        _, st = O.env_reset(spec, seed=b, instance=b)
+        st.time = 11.5 * 3600.0
+        for _ in range(4):
+            O.env_step(spec, st, rng.uniform(-1, 1, fs.action_dim))
+            n_done += 1
+        b += 1
+    dt = time.perf_counter() - t0
+    return {"value": n_done / dt, "unit": "env_steps/s", "cores": 1, "kind": "port",
+            "sample": f"NumPy oracle, {b} instances x 4 steps of the same workload in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="ieee123_b8192", choices=sorted(WORKLOADS))
+    ap.add_argument("--solver", default="nr", choices=["nr", "fbs"])
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's)")
+    ap.add_argument("--waves", type=int, default=0, help="wavefronts per 64-instance group (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        if world == 1 and args.gpus > 1:
+            print("[bench] --gpus > 1 needs `python -m torch.distributed.run --nproc-per-node N bench.py ...`", file=sys.stderr)
+            sys.exit(2)
+
+    _lib.load()                      # HIP runtime of /opt/rocm first; torch (if any) comes after
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    wl = WORKLOADS[args.workload]
+    fs = make_feeder(wl["feeder"])
+    B = args.batch or wl["batch"]
+    env_kwargs = dict(stochastic_loads=True, weather_variation=True, solver=args.solver, tolerance=1e-6,
+                      max_iterations=50 if args.solver == "nr" else 100)
+    env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=local_rank,
+                                   first_instance=rank * B, waves_per_group=args.waves, **env_kwargs)
+    h = env.handle
+    desc = h.describe()
+
+    # ---- inputs resident in HBM before the timed region ----
+    n_act = 8
+    rng = np.random.default_rng(5678 + rank)
+    actions = rng.uniform(-1, 1, (n_act, B, fs.action_dim))
+    h.upload_actions(actions)
+    seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.uint64)
+    env.reset(seed=seeds)
+    st = env.get_state()
+    st[:, env.state_column("time")] = 11.5 * 3600.0      # midday: loads near peak, PV producing
+    env.set_state(st)
+
+    use_gather = world > 1 and not args.no_allgather
+    if use_gather:
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(_lib.Handle.comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, src=0)
+        h.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+
+    def one_step(k):
+        h.step_device(k % n_act)
+        if use_gather:
+            h.allgather_obs(to_host=False)
+
+    def barrier():
+        h.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        one_step(k)
+    barrier()
+    h.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    h.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timing = h.timing_read()
+    h.timing_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- sanity of the timed work: every instance solved, accuracy figure vs the oracle on a sample ----
+    out = h.download_step(want_obs=True)
+    conv_frac = float(out["power_flow_converged"].mean())
+    mean_iters = float(out["iterations"].mean())
+
+    if rank == 0:
+        steps_per_s = world * B * args.steps / elapsed
+        bytes_step = algorithmic_bytes_per_step(fs)
+        solve = timing["solve"]
+        avg_solve_ms = solve["total_ms"] / max(solve["launches"], 1)
+        achieved_gbs = bytes_step * B / (avg_solve_ms * 1e-3) / 1e9 if avg_solve_ms > 0 else 0.0
+        flops_it = algorithmic_flops_per_iteration(fs) if args.solver == "nr" else 30 * fs.n
+        tflops = flops_it * mean_iters * B / (avg_solve_ms * 1e-3) / 1e12 if avg_solve_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(f"{args.workload}:{args.solver}", {}).get("solve_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "env steps/sec (batched feeders)", "value": steps_per_s, "unit": "env_steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{fs.name}, batch={B} per GPU, {'Newton-Raphson (exact Jacobian)' if args.solver == 'nr' else 'forward/backward sweep'}, "
+                                   f"stochastic loads + weather, tolerance 1e-6",
+                       "feeder_sha256": fs.sha256(), "n_buses": fs.n, "n_lines": fs.m, "obs_dim": fs.obs_dim,
+                       "action_dim": fs.action_dim, "batch_per_gpu": B, "global_batch": world * B,
+                       "solver": args.solver, "kernel": desc["kernel"], "waves_per_group": desc["waves_per_group"],
+                       "tree_levels": desc["levels"], "obs_allgather": bool(use_gather),
+                       "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "gs_k_" + {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs",
+                                              "nr_dense_pivot": "nr_dense"}[desc["kernel"]],
+                         "avg_launch_ms": avg_solve_ms, "algorithmic_bytes_per_launch": bytes_step * B,
+                         "fp64_valu": {"achieved_tflops": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                       "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "mean_iterations": mean_iters}},
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in timing.items()},
+            "converged_fraction": conv_frac,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(fs, env_kwargs)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+
+    if use_gather:
+        h.comm_destroy()
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,20 @@ def test_tier_a_as_coded_iteration_caps(name):
     d = golden(name)
     spec = spec_of(d, name)
     growth = 1.0
+    if name == "solve_noslack5":
+        # No bus holds its magnitude here (the defaulted slack stays in the pq list, power_flow.py:138-141),
+        # so the as-coded Jacobian is numerically singular (cond = 3.5e16 at the flat start): the
+        # reference's step has an arbitrary component along "all Vm shift together".  Pinned instead:
+        # flags, iteration count, angles, and magnitudes modulo that common shift.
+        s = P.BatchedNewtonRaphsonSolver(tolerance=1e-6, max_iterations=1, jacobian="as_coded", zero_z="open")
+        sol = s.solve_batch(spec, d["P_spec"][None, :])
+        assert not sol.converged[0] and sol.iterations[0] == 1 and sol.status[0] == 1
+        dv = sol.bus_voltages[0] - d["A1_Vm"]
+        assert np.max(np.abs(dv - dv.mean())) < 1e-9 and abs(dv.mean()) < 1e-3
+        assert np.max(np.abs(sol.bus_angles[0] - d["A1_Va"])) < 1e-9
+        assert abs(sol.max_mismatch[0] - float(d["A1_max_mismatch"])) < 1e-12
+        s.close()
+        return
     for k in d["its"]:
         s = P.BatchedNewtonRaphsonSolver(tolerance=1e-6, max_iterations=int(k), jacobian="as_coded", zero_z="open")
         # B = 3 identical instances: also checks that lanes do not interfere
