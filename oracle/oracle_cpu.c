@@ -1,0 +1,539 @@
+/* oracle_cpu.c -- CPU oracle, C99 + OpenMP, float64: the batched restatement of the reference's
+ * transition function that (a) cross-checks the HIP path at sizes the NumPy oracle is too slow
+ * for and (b) is the `cpu_baseline` of bench.py (kind "port").
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under grid_fed_rl_gym_amd/ links, loads or calls this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and only as the
+ * checker / the baseline being reported, never as the thing measured or shipped.
+ *
+ * Parity status: PINNED -- tests/test_oracle_c.py checks it against the golden fixtures captured
+ * from the reference (tests/golden/ npz files) and against oracle_np.py.
+ *
+ * It follows the reference's *dense* formulation (paths relative to
+ * /root/reference/grid_fed_rl/environments/):
+ *   dense Ybus                     power_flow.py:48-73
+ *   classification, flat start     power_flow.py:97-141
+ *   mismatch, convergence          power_flow.py:150-171
+ *   dense Jacobian                 power_flow.py:213-295   (J11 diagonal :248 as coded, or exact)
+ *   dense solve, partial pivoting  power_flow.py:187       (np.linalg.solve = LAPACK dgesv)
+ *   polar corrections              power_flow.py:297-327
+ *   line flows, losses             power_flow.py:329-358, 198-200
+ *   env step                       grid_env.py:410-619, 621-834; dynamics.py; base.py:140-167
+ * The only liberty taken with the dense Jacobian is that sin/cos are evaluated only where
+ * Y_ij != 0 (elsewhere the entry is a product with an exact zero).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PQ 0
+#define PV 1
+#define SLACK 2
+
+typedef struct {
+  int32_t n, m;
+  const int32_t *frm, *to;
+  const double *r, *x, *rating;
+  const uint8_t* bus_type;
+  const double* v_set;
+  int32_t n_loads;
+  const int32_t* load_bus;
+  const double *load_base, *load_pf;
+  int32_t n_gens;
+  const int32_t *gen_bus, *gen_kind;
+  const double *gen_cap, *gen_p0, *gen_p1, *gen_p2;
+  int32_t n_bats;
+  const int32_t* bat_bus;
+  const double *bat_cap, *bat_rating, *bat_eff;
+} orc_net;
+
+typedef struct {
+  int32_t solver_fbs, jacobian_exact, zero_z_eps, max_iterations;
+  int32_t episode_length, stochastic_loads, weather_variation, threads;
+  double tolerance, alpha, timestep, v_min, v_max, f_min, f_max, safety_penalty, H, D, f0, power_base;
+  int64_t first_instance;
+} orc_cfg;
+
+typedef struct {  /* one solution, caller-provided storage */
+  double *Vm, *Va, *flow, *loading;
+  double losses, max_mismatch;
+  int32_t iterations, converged, status;
+} orc_sol;
+
+/* ---- line admittance with CPython's complex-division operation order (power_flow.py:63) ---- */
+static void line_y(double r, double x, int eps, double* yr, double* yi) {
+  if (!(hypot(r, x) > 1e-12)) {
+    if (!eps) { *yr = 0.0; *yi = 0.0; return; }
+    r = 1e-4; x = 1e-4;
+  }
+  if (fabs(r) >= fabs(x)) {
+    double ratio = x / r, den = r + x * ratio;
+    *yr = (1.0 + 0.0 * ratio) / den; *yi = (0.0 - 1.0 * ratio) / den;
+  } else {
+    double ratio = r / x, den = r * ratio + x;
+    *yr = (1.0 * ratio + 0.0) / den; *yi = (0.0 * ratio - 1.0) / den;
+  }
+}
+
+typedef struct {
+  int n, m, slack, n_ns, n_pq, N;
+  double *G, *B;          /* dense n*n */
+  int *ns, *pq, *is_pq;   /* non-slack list, pq list */
+  double *lyr, *lyi;
+} orc_prep;
+
+static void prep_free(orc_prep* p) {
+  free(p->G); free(p->B); free(p->ns); free(p->pq); free(p->is_pq); free(p->lyr); free(p->lyi);
+}
+
+static void prep_build(const orc_net* t, int eps, orc_prep* p) {
+  int n = t->n, m = t->m;
+  p->n = n; p->m = m;
+  p->G = (double*)calloc((size_t)n * n, sizeof(double));
+  p->B = (double*)calloc((size_t)n * n, sizeof(double));
+  p->lyr = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
+  p->lyi = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
+  for (int k = 0; k < m; ++k) {
+    line_y(t->r[k], t->x[k], eps, &p->lyr[k], &p->lyi[k]);
+    int i = t->frm[k], j = t->to[k];
+    double yr = p->lyr[k], yi = p->lyi[k];
+    p->G[i * n + j] -= yr; p->B[i * n + j] -= yi;
+    p->G[j * n + i] -= yr; p->B[j * n + i] -= yi;
+    p->G[i * n + i] += yr; p->B[i * n + i] += yi;
+    p->G[j * n + j] += yr; p->B[j * n + j] += yi;
+  }
+  int slack = -1;
+  p->ns = (int*)malloc(sizeof(int) * n); p->pq = (int*)malloc(sizeof(int) * n); p->is_pq = (int*)calloc(n, sizeof(int));
+  p->n_pq = 0;
+  for (int i = 0; i < n; ++i) {
+    if (t->bus_type[i] == SLACK) slack = i;
+    else if (t->bus_type[i] == PQ) { p->pq[p->n_pq++] = i; p->is_pq[i] = 1; }
+  }
+  if (slack < 0) slack = 0;
+  p->slack = slack;
+  p->n_ns = 0;
+  for (int i = 0; i < n; ++i) if (i != slack) p->ns[p->n_ns++] = i;
+  p->N = p->n_ns + p->n_pq;
+}
+
+/* S = V conj(Y V), dense (power_flow.py:150) */
+static void calc_S(const orc_prep* p, const double* e, const double* f, double* P, double* Q) {
+  int n = p->n;
+  for (int i = 0; i < n; ++i) {
+    double ir = 0.0, ii = 0.0;           /* (Y V)_i */
+    const double *g = p->G + (size_t)i * n, *b = p->B + (size_t)i * n;
+    for (int j = 0; j < n; ++j) { ir += g[j] * e[j] - b[j] * f[j]; ii += g[j] * f[j] + b[j] * e[j]; }
+    P[i] = e[i] * ir + f[i] * ii;        /* V conj(I) */
+    Q[i] = f[i] * ir - e[i] * ii;
+  }
+}
+
+/* dense LU with partial pivoting, in place; returns 0, or 1 when a pivot is exactly zero */
+static int lu_solve(int N, double* A, double* b, double* x, int* perm) {
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  for (int k = 0; k < N; ++k) {
+    int piv = k; double best = fabs(A[(size_t)perm[k] * N + k]);
+    for (int i = k + 1; i < N; ++i) { double v = fabs(A[(size_t)perm[i] * N + k]); if (v > best) { best = v; piv = i; } }
+    if (!(best > 0.0)) return 1;
+    int tmp = perm[k]; perm[k] = perm[piv]; perm[piv] = tmp;
+    const double* rk = A + (size_t)perm[k] * N;
+    double akk = rk[k], bk = b[perm[k]];
+    for (int i = k + 1; i < N; ++i) {
+      double* ri = A + (size_t)perm[i] * N;
+      double l = ri[k] / akk;
+      if (l != 0.0) {
+        for (int c = k + 1; c < N; ++c) ri[c] -= l * rk[c];
+        b[perm[i]] -= l * bk;
+      }
+    }
+  }
+  for (int k = N - 1; k >= 0; --k) {
+    const double* rk = A + (size_t)perm[k] * N;
+    double s = b[perm[k]];
+    for (int c = k + 1; c < N; ++c) s -= rk[c] * x[c];
+    x[k] = s / rk[k];
+  }
+  return 0;
+}
+
+static void flows_and_losses(const orc_net* t, const orc_prep* p, const double* e, const double* f, orc_sol* s,
+                             double* P, double* Q) {
+  for (int k = 0; k < p->m; ++k) {
+    int i = t->frm[k], j = t->to[k];
+    double dr = e[i] - e[j], di = f[i] - f[j];
+    double ir = p->lyr[k] * dr - p->lyi[k] * di, ii = p->lyr[k] * di + p->lyi[k] * dr;
+    double sr = e[i] * ir + f[i] * ii, si = f[i] * ir - e[i] * ii;
+    s->flow[k] = sr;
+    s->loading[k] = t->rating[k] > 0 ? hypot(sr, si) / t->rating[k] : 0.0;
+  }
+  calc_S(p, e, f, P, Q);
+  double l = 0.0;
+  for (int i = 0; i < p->n; ++i) l += P[i];
+  s->losses = l;
+}
+
+/* NewtonRaphsonSolver.solve, one instance (power_flow.py:89-211) */
+static void nr_one(const orc_net* t, const orc_prep* p, const orc_cfg* c, const double* Pspec, const double* Qspec,
+                   orc_sol* s, double* work, int* iwork) {
+  int n = p->n, N = p->N, nn = p->n_ns, npq = p->n_pq;
+  double *e = work, *f = e + n, *Vm = f + n, *Va = Vm + n, *P = Va + n, *Q = P + n, *dP = Q + n, *dQ = dP + n;
+  double *rhs = dQ + n, *dx = rhs + N, *J = dx + N;
+  int* perm = iwork;
+  for (int i = 0; i < n; ++i) {
+    Vm[i] = (t->bus_type[i] == SLACK || t->bus_type[i] == PV) ? t->v_set[i] : 1.0;
+    Va[i] = 0.0;
+  }
+  int it = 0, conv = 0, status = 1;
+  double mm = INFINITY;
+  for (it = 0; it < c->max_iterations; ++it) {
+    for (int i = 0; i < n; ++i) { e[i] = Vm[i] * cos(Va[i]); f[i] = Vm[i] * sin(Va[i]); }
+    calc_S(p, e, f, P, Q);
+    mm = 0.0;
+    int nonfinite = 0;
+    for (int i = 0; i < n; ++i) { dP[i] = 0.0; dQ[i] = 0.0; }
+    for (int k = 0; k < nn; ++k) { int i = p->ns[k]; dP[i] = Pspec[i] - P[i]; }
+    for (int k = 0; k < npq; ++k) { int i = p->pq[k]; dQ[i] = (Qspec ? Qspec[i] : 0.0) - Q[i]; }
+    for (int i = 0; i < n; ++i) {
+      if (!isfinite(dP[i]) || !isfinite(dQ[i])) nonfinite = 1;
+      if (fabs(dP[i]) > mm) mm = fabs(dP[i]);
+      if (fabs(dQ[i]) > mm) mm = fabs(dQ[i]);
+    }
+    if (nonfinite) { mm = INFINITY; status = 3; break; }
+    if (mm < c->tolerance) { conv = 1; status = 0; break; }
+    /* dense Jacobian (power_flow.py:243-291) */
+    memset(J, 0, sizeof(double) * (size_t)N * N);
+    for (int a = 0; a < nn; ++a) {
+      int i = p->ns[a];
+      const double *g = p->G + (size_t)i * n, *b = p->B + (size_t)i * n;
+      for (int bcol = 0; bcol < nn; ++bcol) {
+        int j = p->ns[bcol];
+        if (i == j) {
+          double vvb = Vm[i] * Vm[i] * b[i];
+          J[(size_t)a * N + bcol] = c->jacobian_exact ? (-Q[i] - vvb) : (-Q[i] + vvb);
+        } else if (g[j] != 0.0 || b[j] != 0.0) {
+          double d = Va[i] - Va[j];
+          J[(size_t)a * N + bcol] = Vm[i] * Vm[j] * (g[j] * sin(d) - b[j] * cos(d));
+        }
+      }
+      for (int bcol = 0; bcol < npq; ++bcol) {
+        int j = p->pq[bcol];
+        if (i == j) J[(size_t)a * N + nn + bcol] = P[i] / Vm[i] + Vm[i] * g[i];
+        else if (g[j] != 0.0 || b[j] != 0.0) {
+          double d = Va[i] - Va[j];
+          J[(size_t)a * N + nn + bcol] = Vm[i] * (g[j] * cos(d) + b[j] * sin(d));
+        }
+      }
+    }
+    for (int a = 0; a < npq; ++a) {
+      int i = p->pq[a];
+      const double *g = p->G + (size_t)i * n, *b = p->B + (size_t)i * n;
+      for (int bcol = 0; bcol < nn; ++bcol) {
+        int j = p->ns[bcol];
+        if (i == j) J[(size_t)(nn + a) * N + bcol] = P[i] - Vm[i] * Vm[i] * g[i];
+        else if (g[j] != 0.0 || b[j] != 0.0) {
+          double d = Va[i] - Va[j];
+          J[(size_t)(nn + a) * N + bcol] = -Vm[i] * Vm[j] * (g[j] * cos(d) + b[j] * sin(d));
+        }
+      }
+      for (int bcol = 0; bcol < npq; ++bcol) {
+        int j = p->pq[bcol];
+        if (i == j) J[(size_t)(nn + a) * N + nn + bcol] = Q[i] / Vm[i] - Vm[i] * b[i];
+        else if (g[j] != 0.0 || b[j] != 0.0) {
+          double d = Va[i] - Va[j];
+          J[(size_t)(nn + a) * N + nn + bcol] = Vm[i] * (g[j] * sin(d) - b[j] * cos(d));
+        }
+      }
+    }
+    for (int k = 0; k < nn; ++k) rhs[k] = dP[p->ns[k]];
+    for (int k = 0; k < npq; ++k) rhs[nn + k] = dQ[p->pq[k]];
+    if (lu_solve(N, J, rhs, dx, perm)) { status = 2; break; }
+    /* _apply_corrections (power_flow.py:297-327): angles first, then magnitudes */
+    for (int k = 0; k < nn; ++k) Va[p->ns[k]] += c->alpha * dx[k];
+    for (int k = 0; k < npq; ++k) {
+      int i = p->pq[k];
+      Vm[i] += c->alpha * dx[nn + k];
+      if (Vm[i] < 0.0) { Vm[i] = -Vm[i]; Va[i] += M_PI; }
+    }
+  }
+  if (it == c->max_iterations) it = c->max_iterations - 1;
+  for (int i = 0; i < n; ++i) { e[i] = Vm[i] * cos(Va[i]); f[i] = Vm[i] * sin(Va[i]); }
+  flows_and_losses(t, p, e, f, s, P, Q);
+  for (int i = 0; i < n; ++i) { s->Vm[i] = Vm[i]; s->Va[i] = atan2(f[i], e[i]); }
+  s->iterations = it + 1; s->converged = conv; s->status = status; s->max_mismatch = mm;
+}
+
+/* Forward/backward sweep, one instance (new functionality; anchor = NR exact) */
+static int fbs_one(const orc_net* t, const orc_prep* p, const orc_cfg* c, const double* Pspec, const double* Qspec,
+                   orc_sol* s, double* work, int* iwork) {
+  int n = p->n;
+  double *e = work, *f = e + n, *P = f + n, *Q = P + n, *jr = Q + n, *ji = jr + n;
+  int *parent = iwork, *order = parent + n, *seen = order + n;
+  for (int i = 0; i < n; ++i) { parent[i] = -1; seen[i] = 0; }
+  int cnt = 0; order[cnt++] = p->slack; seen[p->slack] = 1;
+  for (int h = 0; h < cnt; ++h) {
+    int u = order[h];
+    for (int v = 0; v < n; ++v) {
+      if (v == u) continue;
+      if (p->G[(size_t)u * n + v] != 0.0 || p->B[(size_t)u * n + v] != 0.0) {
+        if (!seen[v]) { seen[v] = 1; parent[v] = u; order[cnt++] = v; }
+        else if (v != parent[u]) return 1;      /* loop */
+      }
+    }
+  }
+  if (cnt != n) return 1;
+  for (int i = 0; i < n; ++i) { e[i] = (t->bus_type[i] == SLACK || t->bus_type[i] == PV) ? t->v_set[i] : 1.0; f[i] = 0.0; }
+  int it = 0, conv = 0, status = 1; double mm = INFINITY;
+  for (it = 0; it < c->max_iterations; ++it) {
+    calc_S(p, e, f, P, Q);
+    mm = 0.0;
+    for (int i = 0; i < n; ++i) {
+      if (i == p->slack) continue;
+      double a = fabs(Pspec[i] - P[i]), b = fabs((Qspec ? Qspec[i] : 0.0) - Q[i]);
+      if (!isfinite(a) || !isfinite(b)) { mm = INFINITY; break; }
+      if (a > mm) mm = a;
+      if (b > mm) mm = b;
+    }
+    if (!(mm < INFINITY)) { status = 3; break; }
+    if (mm < c->tolerance) { conv = 1; status = 0; break; }
+    for (int i = 0; i < n; ++i) {
+      double pp = Pspec[i], qq = Qspec ? Qspec[i] : 0.0, d = e[i] * e[i] + f[i] * f[i];
+      jr[i] = -(pp * e[i] + qq * f[i]) / d; ji[i] = (qq * e[i] - pp * f[i]) / d;
+    }
+    jr[p->slack] = 0.0; ji[p->slack] = 0.0;
+    for (int h = cnt - 1; h >= 1; --h) { int v = order[h]; jr[parent[v]] += jr[v]; ji[parent[v]] += ji[v]; }
+    for (int h = 1; h < cnt; ++h) {
+      int v = order[h], u = parent[v];
+      double yr = -p->G[(size_t)v * n + u], yi = -p->B[(size_t)v * n + u], yd = yr * yr + yi * yi;
+      e[v] = e[u] - (jr[v] * yr + ji[v] * yi) / yd;
+      f[v] = f[u] - (ji[v] * yr - jr[v] * yi) / yd;
+    }
+  }
+  if (it == c->max_iterations) it = c->max_iterations - 1;
+  flows_and_losses(t, p, e, f, s, P, Q);
+  for (int i = 0; i < n; ++i) { s->Vm[i] = hypot(e[i], f[i]); s->Va[i] = atan2(f[i], e[i]); }
+  s->iterations = it + 1; s->converged = conv; s->status = status; s->max_mismatch = mm;
+  return 0;
+}
+
+static size_t work_doubles(const orc_prep* p) { return (size_t)10 * p->n + 2 * (size_t)p->N + (size_t)p->N * p->N + 16; }
+static size_t work_ints(const orc_prep* p) { return (size_t)3 * p->n + p->N + 16; }
+
+/* ---- batched solve: P[B][n], outputs [B][n] / [B][m] / [B] ------------------------------------ */
+int orc_solve_batch(const orc_net* t, const orc_cfg* c, int32_t B, const double* P, const double* Q, double* Vm, double* Va,
+                    double* flow, double* loading, double* losses, double* max_mismatch, int32_t* iterations,
+                    uint8_t* converged, int32_t* status) {
+  orc_prep p; prep_build(t, c->zero_z_eps, &p);
+  int bad = 0;
+#ifdef _OPENMP
+  int nt = c->threads > 0 ? c->threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+    double* work = (double*)malloc(sizeof(double) * work_doubles(&p));
+    int* iwork = (int*)malloc(sizeof(int) * work_ints(&p));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int b = 0; b < B; ++b) {
+      orc_sol s; s.Vm = Vm + (size_t)b * t->n; s.Va = Va + (size_t)b * t->n;
+      s.flow = flow + (size_t)b * t->m; s.loading = loading + (size_t)b * t->m;
+      const double* Pb = P + (size_t)b * t->n; const double* Qb = Q ? Q + (size_t)b * t->n : 0;
+      if (c->solver_fbs) { if (fbs_one(t, &p, c, Pb, Qb, &s, work, iwork)) { bad = 1; continue; } }
+      else nr_one(t, &p, c, Pb, Qb, &s, work, iwork);
+      losses[b] = s.losses; max_mismatch[b] = s.max_mismatch; iterations[b] = s.iterations;
+      converged[b] = (uint8_t)s.converged; status[b] = s.status;
+    }
+    free(work); free(iwork);
+  }
+  prep_free(&p);
+  return bad ? -4 : 0;
+}
+
+/* ---- Philox4x32-10, identical stream to oracle_np.py / kernels_env.hip ------------------------ */
+static void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static void rng_pair(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw, double* u0, double* u1) {
+  uint32_t r[4];
+  philox((uint32_t)inst, step, draw, 0x47535450u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  uint64_t x0 = ((uint64_t)r[0] << 32) | r[1], x1 = ((uint64_t)r[2] << 32) | r[3];
+  *u0 = (double)(x0 >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
+  *u1 = (double)(x1 >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
+}
+static double rng_normal(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw) {
+  double u0, u1; rng_pair(seed, inst, step, draw, &u0, &u1);
+  return sqrt(-2.0 * log(u0)) * cos(2.0 * M_PI * u1);
+}
+
+static const double kProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
+                                    0.7, 0.7, 0.6, 0.6, 0.7, 0.9, 1.0, 0.9, 0.8, 0.7, 0.6, 0.5};
+
+/* state blob columns: see include/gridstep.h (gs_get_state) */
+enum { S_TIME = 0, S_STEP, S_VIOL, S_TOTLOSS, S_EPREW, S_FREQ, S_IRR, S_WIND, S_TEMP, S_CLOUD, S_SEEDLO, S_SEEDHI, S_FIXED };
+
+static double renewable(const orc_net* t, const double* st, int g) {
+  double cap = t->gen_cap[g], p0 = t->gen_p0[g], p1 = t->gen_p1[g], p2 = t->gen_p2[g];
+  if (t->gen_kind[g] == 0) {                               /* dynamics.py:120-142 */
+    double hour = fmod(st[S_TIME] / 3600.0, 24.0);
+    double elev = (hour >= 6.0 && hour <= 18.0) ? sin(M_PI * (hour - 6.0) / 12.0) : 0.0;
+    double irr = 1000.0 * elev * (1.0 - 0.8 * st[S_CLOUD]);
+    double tf = 1.0 - 0.004 * fmax(0.0, st[S_TEMP] - 25.0);
+    return fmin(irr * p1 * p0 * tf, cap);
+  }
+  double w = st[S_WIND];                                   /* dynamics.py:158-170 */
+  if (w < p0 || w > p2) return 0.0;
+  if (w <= p1) { double q = (w - p0) / (p1 - p0); return cap * (q * q * q); }
+  return cap;
+}
+
+static void weather(const orc_cfg* c, double* st, uint64_t inst) {   /* grid_env.py:653-681 */
+  if (!c->weather_variation) return;
+  uint64_t seed = ((uint64_t)(uint32_t)st[S_SEEDHI] << 32) | (uint64_t)(uint32_t)st[S_SEEDLO];
+  uint32_t step = (uint32_t)st[S_STEP];
+  double hour = fmod(st[S_TIME] / 3600.0, 24.0);
+  double base = (hour >= 6.0 && hour <= 18.0) ? 1000.0 * sin(M_PI * (hour - 6.0) / 12.0) : 0.0;
+  double u, u2; rng_pair(seed, inst, step, 0, &u, &u2);
+  st[S_IRR] = base * (0.8 + 0.4 * u);
+  st[S_WIND] = fmax(0.0, fmin(30.0, st[S_WIND] + 0.5 * rng_normal(seed, inst, step, 1)));
+  st[S_TEMP] = 25.0 + 10.0 * sin(2.0 * M_PI * (hour - 12.0) / 24.0) + 2.0 * rng_normal(seed, inst, step, 2);
+  st[S_CLOUD] = fmax(0.0, fmin(1.0, st[S_CLOUD] + 0.1 * rng_normal(seed, inst, step, 3)));
+}
+
+int orc_state_dim(const orc_net* t) { return S_FIXED + 2 * t->n_bats + t->n_gens + 2 * t->n + 2 * t->m; }
+int orc_obs_dim(const orc_net* t) { return 2 * t->n + 2 * t->m + 1 + 2 * t->n_loads + t->n_gens + 2 * t->n_bats; }
+
+static void observe(const orc_net* t, const double* st, double* obs) {   /* grid_env.py:753-783 */
+  const double *soc = st + S_FIXED, *batp = soc + t->n_bats, *curt = batp + t->n_bats;
+  const double *Vm = curt + t->n_gens, *Va = Vm + t->n, *flow = Va + t->n, *envload = flow + t->m;
+  int o = 0;
+  for (int i = 0; i < t->n; ++i) { obs[o++] = Vm[i]; obs[o++] = Va[i]; }
+  for (int k = 0; k < t->m; ++k) { obs[o++] = flow[k]; obs[o++] = envload[k]; }
+  obs[o++] = st[S_FREQ];
+  for (int l = 0; l < t->n_loads; ++l) { obs[o++] = t->load_base[l]; obs[o++] = t->load_base[l] * tan(acos(t->load_pf[l])); }
+  for (int g = 0; g < t->n_gens; ++g) obs[o++] = renewable(t, st, g);
+  for (int q = 0; q < t->n_bats; ++q) { obs[o++] = soc[q]; obs[o++] = batp[q]; }
+}
+
+/* reset(seed) for every instance (grid_env.py:360-408) */
+int orc_env_reset(const orc_net* t, const orc_cfg* c, int32_t B, const uint64_t* seeds, double* state, double* obs) {
+  int sd = orc_state_dim(t), od = orc_obs_dim(t);
+  for (int b = 0; b < B; ++b) {
+    double* st = state + (size_t)b * sd;
+    memset(st, 0, sizeof(double) * sd);
+    uint64_t seed = seeds ? seeds[b] : 0;
+    st[S_SEEDLO] = (double)(uint32_t)seed; st[S_SEEDHI] = (double)(uint32_t)(seed >> 32);
+    st[S_FREQ] = 60.0; st[S_WIND] = 5.0; st[S_TEMP] = 25.0; st[S_CLOUD] = 0.3;
+    double *soc = st + S_FIXED, *curt = soc + 2 * t->n_bats, *Vm = curt + t->n_gens;
+    for (int q = 0; q < t->n_bats; ++q) soc[q] = 0.5;
+    for (int g = 0; g < t->n_gens; ++g) curt[g] = 1.0;
+    for (int i = 0; i < t->n; ++i) Vm[i] = 1.0;
+    weather(c, st, (uint64_t)(c->first_instance + b));
+    if (obs) observe(t, st, obs + (size_t)b * od);
+  }
+  return 0;
+}
+
+/* step(action) for every instance (grid_env.py:410-619 with the host hooks removed) */
+int orc_env_step(const orc_net* t, const orc_cfg* c, int32_t B, const double* actions, double* state, double* obs,
+                 double* reward, uint8_t* terminated, uint8_t* truncated, uint8_t* converged, int32_t* iterations,
+                 double* losses_out, double* vmax, double* vmin, uint8_t* viol4) {
+  orc_prep p; prep_build(t, c->zero_z_eps, &p);
+  int sd = orc_state_dim(t), od = orc_obs_dim(t), A = t->n_bats + t->n_gens, n = t->n, m = t->m;
+  double total_load = 0.0;
+  for (int l = 0; l < t->n_loads; ++l) total_load += t->load_base[l];
+  int bad = 0;
+#ifdef _OPENMP
+  int nt = c->threads > 0 ? c->threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+    double* work = (double*)malloc(sizeof(double) * (work_doubles(&p) + 6 * (size_t)n + 2 * (size_t)m + t->n_loads));
+    int* iwork = (int*)malloc(sizeof(int) * work_ints(&p));
+    double *Pspec = work + work_doubles(&p), *ls = Pspec + n, *gs = ls + n, *sVm = gs + n, *sVa = sVm + n;
+    double *sflow = sVa + n + n, *sload = sflow + m, *loadp = sload + m;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int b = 0; b < B; ++b) {
+      double* st = state + (size_t)b * sd;
+      const double* act = actions + (size_t)b * A;
+      double *soc = st + S_FIXED, *batp = soc + t->n_bats, *curt = batp + t->n_bats;
+      double *Vm = curt + t->n_gens, *Va = Vm + n, *flow = Va + n, *envload = flow + m;
+      double dt = c->timestep;
+      for (int q = 0; q < t->n_bats; ++q) {              /* grid_env.py:621-651, dynamics.py:189-220 */
+        double rating = t->bat_rating[q], cap = t->bat_cap[q], eff = t->bat_eff[q], cmd = act[q] * rating;
+        if (cmd > 0.0) { double pw = fmin(cmd, rating), e = fmin(pw * dt / 3600.0, soc[q] * cap * eff);
+          soc[q] -= e / (cap * eff); batp[q] = e * 3600.0 / dt; }
+        else if (cmd < 0.0) { double pw = fmin(-cmd, rating), e = fmin(pw * dt / 3600.0, (1.0 - soc[q]) * cap / eff);
+          soc[q] += e * eff / cap; batp[q] = -(e * 3600.0 / dt); }
+      }
+      for (int g = 0; g < t->n_gens; ++g) curt[g] = (act[t->n_bats + g] + 1.0) / 2.0;
+      st[S_TIME] += dt; st[S_STEP] += 1.0;
+      uint64_t inst = (uint64_t)(c->first_instance + b);
+      weather(c, st, inst);
+      if (c->stochastic_loads) {                          /* dynamics.py:54-75 */
+        uint64_t seed = ((uint64_t)(uint32_t)st[S_SEEDHI] << 32) | (uint64_t)(uint32_t)st[S_SEEDLO];
+        double hour = fmod(st[S_TIME] / 3600.0, 24.0); int hi = (int)hour; double frac = hour - hi;
+        double prof = kProfile[hi] * (1.0 - frac) + kProfile[(hi + 1) % 24] * frac;
+        for (int l = 0; l < t->n_loads; ++l)
+          loadp[l] = fmax(0.0, t->load_base[l] * (prof * (1.0 + 0.1 * rng_normal(seed, inst, (uint32_t)st[S_STEP], 16 + l))) * 1.0);
+      }
+      for (int i = 0; i < n; ++i) { ls[i] = 0.0; gs[i] = 0.0; }   /* grid_env.py:683-720 */
+      for (int l = 0; l < t->n_loads; ++l) ls[t->load_bus[l]] += c->stochastic_loads ? loadp[l] : t->load_base[l];
+      for (int g = 0; g < t->n_gens; ++g) gs[t->gen_bus[g]] += renewable(t, st, g) * curt[g];
+      for (int q = 0; q < t->n_bats; ++q) { if (batp[q] > 0.0) gs[t->bat_bus[q]] += batp[q]; else if (batp[q] < 0.0) ls[t->bat_bus[q]] += fabs(batp[q]); }
+      for (int i = 0; i < n; ++i) Pspec[i] = (0.0 - ls[i] / c->power_base) + gs[i] / c->power_base;
+      orc_sol s; s.Vm = sVm; s.Va = sVa; s.flow = sflow; s.loading = sload;
+      if (c->solver_fbs) { if (fbs_one(t, &p, c, Pspec, 0, &s, work, iwork)) { bad = 1; continue; } }
+      else nr_one(t, &p, c, Pspec, 0, &s, work, iwork);
+      int over = 0;                                       /* grid_env.py:722-739, base.py:261-264 */
+      for (int i = 0; i < n; ++i) { Vm[i] = s.Vm[i]; Va[i] = s.Va[i]; }
+      for (int k = 0; k < m; ++k) { flow[k] = s.flow[k]; envload[k] = t->rating[k] > 0 ? fabs(flow[k]) / t->rating[k] : 0.0; over += envload[k] > 0.8; }
+      st[S_TOTLOSS] += s.losses * dt / 3600.0;
+      double tg = 0.0, tc = 0.0;                          /* grid_env.py:741-751, dynamics.py:260-273 */
+      for (int g = 0; g < t->n_gens; ++g) { double pw = renewable(t, st, g); tg += pw; tc += pw * (1.0 - curt[g]); }
+      double imb = (tg - total_load - s.losses * c->power_base) / 1e6, fr = st[S_FREQ];
+      fr += ((imb - c->D * (fr - c->f0)) / (2.0 * c->H * c->f0)) * dt;
+      fr = fmax(55.0, fmin(65.0, fr)); st[S_FREQ] = fr;
+      double dev = 0.0, vx = -INFINITY, vn = INFINITY; int vh = 0, vl = 0;     /* grid_env.py:785-826 */
+      for (int i = 0; i < n; ++i) { dev += fabs(Vm[i] - 1.0); vx = fmax(vx, Vm[i]); vn = fmin(vn, Vm[i]); vh |= Vm[i] > c->v_max; vl |= Vm[i] < c->v_min; }
+      double rw = 0.0;
+      rw -= dev * 10.0; rw -= fabs(fr - 60.0) * 20.0; rw -= (double)(over * 50); rw -= st[S_TOTLOSS] * 0.1;
+      rw += (tg - tc) * 1e-5;
+      for (int q = 0; q < t->n_bats; ++q) rw += (soc[q] >= 0.2 && soc[q] <= 0.8) ? 1.0 : -5.0;
+      int fh = fr > c->f_max, fl = fr < c->f_min, tr = 0;
+      if (vh | vl | fh | fl) { st[S_VIOL] += 1.0; if (st[S_VIOL] > 10.0) { tr = 1; rw -= c->safety_penalty; } }
+      st[S_EPREW] += rw;
+      reward[b] = rw; terminated[b] = st[S_STEP] >= (double)c->episode_length; truncated[b] = (uint8_t)tr;
+      if (converged) converged[b] = (uint8_t)s.converged;
+      if (iterations) iterations[b] = s.iterations;
+      if (losses_out) losses_out[b] = s.losses;
+      if (vmax) vmax[b] = vx;
+      if (vmin) vmin[b] = vn;
+      if (viol4) { viol4[4 * b] = (uint8_t)vh; viol4[4 * b + 1] = (uint8_t)vl; viol4[4 * b + 2] = (uint8_t)fh; viol4[4 * b + 3] = (uint8_t)fl; }
+      if (obs) observe(t, st, obs + (size_t)b * od);
+    }
+    free(work); free(iwork);
+  }
+  prep_free(&p);
+  return bad ? -4 : 0;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
