@@ -1,0 +1,95 @@
+"""Batch sharding across the GPUs of one node: one process per GPU, no data-path collective.
+
+Every feeder instance's transition depends only on its own state and action (reference
+environments/grid_env.py:410-619 has no cross-environment term), so a batch of B_total
+instances splits into contiguous blocks, rank r owning ``shard_range(B_total, r, world)``.
+Seeds and RNG counters are keyed by the GLOBAL instance index, so results do not depend on the
+number of ranks.  The only exchange is optional and happens after the step: an all-gather of
+the observation block so that every rank (or a host-side learner) sees all observations --
+RCCL over xGMI through libgridstep (``transport="rccl"``, device buffers, equal shards) or any
+``torch.distributed`` process group on host arrays (``transport="host"``; this is what the
+world_size-2 gloo tests exercise, and what uneven shards use).
+"""
+from __future__ import annotations
+
+from typing import Any, Optional, Tuple
+
+import numpy as np
+
+from .env import BatchedGridEnvironment
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of rank's contiguous block; the first ``total % world`` ranks get one extra."""
+    if not (0 <= rank < world) or total < 0:
+        raise ValueError("bad shard arguments")
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def instance_seeds(global_seed: int, start: int, stop: int) -> np.ndarray:
+    """Seed of global instance b is ``global_seed + b`` (uint64 wrap-around)."""
+    return (np.uint64(global_seed) + np.arange(start, stop, dtype=np.uint64)).astype(np.uint64)
+
+
+def host_all_gather(local: np.ndarray, total: int, rank: int, world: int, group: Any = None) -> np.ndarray:
+    """All-gather of row blocks over a torch.distributed process group (any backend that takes
+    CPU tensors); shards may be uneven.  Returns the [total, ...] array in global order."""
+    import torch
+    import torch.distributed as dist
+    counts = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    width = int(np.prod(local.shape[1:], dtype=np.int64)) if local.ndim > 1 else 1
+    mx = max(counts)
+    pad = np.zeros((mx, width), dtype=local.dtype)
+    pad[:counts[rank]] = local.reshape(counts[rank], width)
+    outs = [torch.empty((mx, width), dtype=torch.from_numpy(pad).dtype) for _ in range(world)]
+    dist.all_gather(outs, torch.from_numpy(pad), group=group)
+    full = np.concatenate([outs[r].numpy()[:counts[r]] for r in range(world)], axis=0)
+    return full.reshape((total,) + tuple(local.shape[1:]))
+
+
+class ShardedGridEnvironment:
+    """This rank's block of a ``global_num_envs``-instance batched environment.
+
+    ``transport`` is "rccl" (all-gather of device-resident observations through libgridstep;
+    needs equal shards and a 128-byte RCCL unique id shared by the ranks) or "host".
+    """
+
+    def __init__(self, feeder: Any, global_num_envs: int, rank: int, world: int, device: Optional[int] = None,
+                 transport: str = "host", group: Any = None, **env_kwargs: Any) -> None:
+        self.global_num_envs, self.rank, self.world = int(global_num_envs), int(rank), int(world)
+        self.start, self.stop = shard_range(self.global_num_envs, self.rank, self.world)
+        self.transport, self.group = transport, group
+        if transport == "rccl" and self.global_num_envs % self.world != 0:
+            raise ValueError("the RCCL all-gather needs equal shards (global_num_envs % world == 0)")
+        self.env = BatchedGridEnvironment(feeder, num_envs=self.stop - self.start,
+                                          device=self.rank if device is None else device,
+                                          first_instance=self.start, **env_kwargs)
+        self._comm = False
+
+    def init_rccl(self, unique_id: bytes) -> None:
+        """``unique_id`` comes from rank 0's ``Handle.comm_unique_id()``, broadcast by the launcher."""
+        self.env.handle.comm_init(unique_id, self.rank, self.world)
+        self._comm = True
+
+    def reset(self, seed: int = 0):
+        return self.env.reset(seed=instance_seeds(seed, self.start, self.stop))
+
+    def step(self, local_actions):
+        return self.env.step(local_actions)
+
+    def gather_observations(self, local_obs: Optional[np.ndarray] = None) -> np.ndarray:
+        """[global_num_envs, obs_dim] on every rank."""
+        if self.transport == "rccl":
+            if not self._comm:
+                raise RuntimeError("init_rccl() first")
+            return self.env.handle.allgather_obs(to_host=True)
+        if local_obs is None:
+            raise ValueError("host transport gathers the array it is given")
+        return host_all_gather(local_obs, self.global_num_envs, self.rank, self.world, self.group)
+
+    def close(self) -> None:
+        if self._comm:
+            self.env.handle.comm_destroy()
+        self.env.close()

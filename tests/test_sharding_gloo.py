@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 gloo processes, each stepping its shard with the oracle as the
+stand-in for its GPU, reassembled with the product's host all-gather -- must equal the single
+process result bit for bit (seeds / RNG counters are keyed by the global instance index)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from grid_fed_rl_gym_amd.sharding import shard_range, instance_seeds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["GS_ROOT"])
+import torch.distributed as dist
+import grid_fed_rl_gym_amd as P
+from grid_fed_rl_gym_amd.sharding import shard_range, instance_seeds, host_all_gather
+from oracle import oracle_c as OC
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total, T = int(os.environ["GS_TOTAL"]), 3
+fs = P.ieee13_like("epsilon")
+net = OC.Net(fs)
+start, stop = shard_range(total, rank, world)
+cfg = OC.config(jacobian="exact", tolerance=1e-9, stochastic_loads=True, weather_variation=True,
+                power_base=fs.base_power_va, first_instance=start, threads=1)
+_, state = OC.env_reset(net, cfg, stop - start, instance_seeds(1234, start, stop))
+state[:, 0] = 12 * 3600.0
+actions = np.random.default_rng(99).uniform(-1, 1, (T, total, net.action_dim))   # same on every rank
+full = []
+for t in range(T):
+    out = OC.env_step(net, cfg, state, actions[t, start:stop])
+    full.append(host_all_gather(out["obs"], total, rank, world))
+    rew = host_all_gather(out["reward"], total, rank, world)
+if rank == 0:
+    np.savez(os.environ["GS_OUT"], obs=np.stack(full), reward=rew)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_ranges_cover_and_are_contiguous():
+    for total in (0, 1, 7, 64, 8192, 65536 + 3):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    assert np.array_equal(instance_seeds(10, 3, 6), np.array([13, 14, 15], dtype=np.uint64))
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+@pytest.mark.parametrize("total", [10, 13])     # even and uneven shards
+def test_two_rank_gloo_equals_single_process(total):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "worker.py")
+        open(script, "w").write(WORKER)
+        outs = {}
+        for world in (1, 2):
+            out = os.path.join(td, f"w{world}.npz")
+            env = dict(os.environ, GS_ROOT=ROOT, GS_TOTAL=str(total), GS_OUT=out, MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(29600 + world + total), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+            procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r))) for r in range(world)]
+            for p in procs:
+                assert p.wait(timeout=300) == 0
+            outs[world] = np.load(out)
+        assert np.array_equal(outs[1]["obs"], outs[2]["obs"])
+        assert np.array_equal(outs[1]["reward"], outs[2]["reward"])
+        assert outs[2]["obs"].shape[1] == total
