@@ -1,0 +1,154 @@
+// env_device.h -- device-side pieces of GridEnvironment.step()/reset() shared by the reset kernel
+// and the fused step kernels.  lane = instance; every function works on the caller's lane.
+//
+// Reference arithmetic restated (paths relative to /root/reference/grid_fed_rl/environments/):
+//   _apply_actions        grid_env.py:621-651, dynamics.py:189-220, 304-324
+//   _update_weather       grid_env.py:653-681         (Philox stream instead of python `random`)
+//   renewable models      dynamics.py:120-142, 158-170
+//   load model            dynamics.py:54-75           (Philox stream instead of np.random)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "gs_internal.h"
+
+#ifndef ROW
+#define ROW(r) S[(size_t)(r) * GS_LANES]
+#endif
+
+template <typename X>
+__device__ __forceinline__ X cld(const X* p, int i) {
+  return ((const GS_CONST X*)p)[i];
+}
+
+// ---- Philox4x32-10; same stream as oracle/oracle_np.py::philox4x32 and oracle_cpu.c ------------
+struct U4 { uint32_t a, b, c, d; };
+
+__device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  U4 o; o.a = c0; o.b = c1; o.c = c2; o.d = c3; return o;
+}
+
+__device__ __forceinline__ void rng_uniform_pair(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw,
+                                                 double* u0, double* u1) {
+  const U4 r = philox((uint32_t)instance, step, draw, 0x47535450u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint64_t x0 = ((uint64_t)r.a << 32) | r.b, x1 = ((uint64_t)r.c << 32) | r.d;
+  *u0 = (double)(x0 >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
+  *u1 = (double)(x1 >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw) {
+  double u0, u1;
+  rng_uniform_pair(seed, instance, step, draw, &u0, &u1);
+  return sqrt(-2.0 * log(u0)) * cos(2.0 * M_PI * u1);
+}
+
+enum { DRAW_IRRADIANCE = 0, DRAW_WIND = 1, DRAW_TEMP = 2, DRAW_CLOUD = 3, DRAW_LOAD0 = 16 };
+
+__device__ const double kDailyProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
+                                             0.7, 0.7, 0.6, 0.6, 0.7, 0.9, 1.0, 0.9, 0.8, 0.7, 0.6, 0.5};
+
+__device__ __forceinline__ uint64_t lane_seed(double* S, const GsRows& R) {
+  return ((uint64_t)(uint32_t)ROW(R.SEEDHI) << 32) | (uint64_t)(uint32_t)ROW(R.SEEDLO);
+}
+
+// grid_env.py:653-681
+__device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& E, double* S, uint64_t inst) {
+  if (!E.weather_variation) return;
+  const uint64_t seed = lane_seed(S, R);
+  const uint32_t step = (uint32_t)ROW(R.STEP);
+  const double hour = fmod(ROW(R.TIME) / 3600.0, 24.0);
+  const double base = (hour >= 6.0 && hour <= 18.0) ? 1000.0 * sin(M_PI * (hour - 6.0) / 12.0) : 0.0;
+  double u, u_unused;
+  rng_uniform_pair(seed, inst, step, DRAW_IRRADIANCE, &u, &u_unused);
+  ROW(R.IRR) = base * (0.8 + 0.4 * u);
+  ROW(R.WIND) = fmax(0.0, fmin(30.0, ROW(R.WIND) + 0.5 * rng_normal(seed, inst, step, DRAW_WIND)));
+  ROW(R.TEMP) = 25.0 + 10.0 * sin(2.0 * M_PI * (hour - 12.0) / 24.0) + 2.0 * rng_normal(seed, inst, step, DRAW_TEMP);
+  ROW(R.CLOUD) = fmax(0.0, fmin(1.0, ROW(R.CLOUD) + 0.1 * rng_normal(seed, inst, step, DRAW_CLOUD)));
+}
+
+// dynamics.py:120-142 / 158-170
+__device__ __forceinline__ double renewable_power(const GsTables& T, const GsRows& R, double* S, int g) {
+  const double cap = cld(T.gen_cap, g), p0 = cld(T.gen_p0, g), p1 = cld(T.gen_p1, g), p2 = cld(T.gen_p2, g);
+  if (cld(T.gen_kind, g) == 0) {
+    const double hour = fmod(ROW(R.TIME) / 3600.0, 24.0);
+    const double elev = (hour >= 6.0 && hour <= 18.0) ? sin(M_PI * (hour - 6.0) / 12.0) : 0.0;
+    const double irr = 1000.0 * elev * (1.0 - 0.8 * ROW(R.CLOUD));
+    const double tf = 1.0 - 0.004 * fmax(0.0, ROW(R.TEMP) - 25.0);
+    return fmin(irr * p1 * p0 * tf, cap);
+  }
+  const double w = ROW(R.WIND);
+  if (w < p0 || w > p2) return 0.0;
+  if (w <= p1) { const double q = (w - p0) / (p1 - p0); return cap * (q * q * q); }
+  return cap;
+}
+
+// _apply_actions + clock + weather for this lane: the part of step() that mutates scalar state
+// before the injections are formed (grid_env.py:621-651, 470-474).  `act` points at this
+// instance's action row (batch-major [B][A]).
+__device__ __forceinline__ void env_actions_clock_weather(const GsTables& T, const GsRows& R, const GsEnvCfg& E,
+                                                          double* S, const double* __restrict__ act, uint64_t inst) {
+  const double dt = E.timestep;
+  for (int q = 0; q < T.n_bats; ++q) {
+    const double rating = cld(T.bat_rating, q), cap = cld(T.bat_cap, q), eff = cld(T.bat_eff, q);
+    const double cmd = act[q] * rating;
+    double soc = ROW(R.SOC + q);
+    if (cmd > 0.0) {                                  // discharge, dynamics.py:206-220
+      const double p = fmin(cmd, rating);
+      const double e = fmin(p * dt / 3600.0, soc * cap * eff);
+      soc -= e / (cap * eff);
+      ROW(R.SOC + q) = soc;
+      ROW(R.BATP + q) = e * 3600.0 / dt;
+    } else if (cmd < 0.0) {                           // charge, dynamics.py:189-204
+      const double p = fmin(-cmd, rating);
+      const double max_e = (1.0 - soc) * cap;
+      const double e = fmin(p * dt / 3600.0, max_e / eff);
+      soc += e * eff / cap;
+      ROW(R.SOC + q) = soc;
+      ROW(R.BATP + q) = -(e * 3600.0 / dt);
+    }
+  }
+  for (int g = 0; g < T.n_gens; ++g) ROW(R.CURT + g) = (act[T.n_bats + g] + 1.0) / 2.0;
+  ROW(R.TIME) = ROW(R.TIME) + dt;                    // grid_env.py:470-471
+  ROW(R.STEP) = ROW(R.STEP) + 1.0;
+  weather_update(R, E, S, inst);
+}
+
+// realised power of load l (dynamics.py:54-75 when stochastic, base_power otherwise)
+__device__ __forceinline__ double load_power(const GsTables& T, const GsEnvCfg& E, int l, uint64_t seed, uint64_t inst,
+                                             uint32_t step, double prof) {
+  if (!E.stochastic_loads) return cld(T.load_base, l);
+  const double z = rng_normal(seed, inst, step, DRAW_LOAD0 + l);
+  return fmax(0.0, cld(T.load_base, l) * (prof * (1.0 + 0.1 * z)) * 1.0);
+}
+
+__device__ __forceinline__ double daily_profile(double time_s) {
+  const double hour = fmod(time_s / 3600.0, 24.0);
+  const int hi = (int)hour;
+  const double frac = hour - (double)hi;
+  return kDailyProfile[hi] * (1.0 - frac) + kDailyProfile[(hi + 1) % 24] * frac;
+}
+
+// per-bus injection in the reference's accumulation order (grid_env.py:689-718), then
+// P_spec = (0 - loads) + generation (power_flow.py:112-121); Q_spec = 0 (power_flow.py:107)
+__device__ __forceinline__ void bus_injection(const GsTables& T, const GsRows& R, const GsEnvCfg& E, double* S, int i) {
+  double ls = 0.0, gs = 0.0;
+  for (int p = cld(T.bl_ptr, i); p < cld(T.bl_ptr, i + 1); ++p) ls += ROW(R.LOADP + cld(T.bl_idx, p));
+  for (int p = cld(T.bg_ptr, i); p < cld(T.bg_ptr, i + 1); ++p) {
+    const int g = cld(T.bg_idx, p);
+    gs += ROW(R.GENP + g) * ROW(R.CURT + g);
+  }
+  for (int p = cld(T.bb_ptr, i); p < cld(T.bb_ptr, i + 1); ++p) {
+    const double bp = ROW(R.BATP + cld(T.bb_idx, p));
+    if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp);
+  }
+  ROW(R.P + i) = (0.0 - ls / E.power_base) + gs / E.power_base;
+  ROW(R.Q + i) = 0.0;
+}

@@ -216,15 +216,15 @@ int launch_solve(gs_handle* h) {
 }
 
 int step_kernels(gs_handle* h, const double* d_actions) {
-  int rc = launch_unpack(h, h->map_act, h->action_dim, d_actions);
-  if (rc) return rc;
-  { LaunchTimer lt(h, GS_K_ENV_PRE);
-    hipLaunchKernelGGL(gs_k_env_pre, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, h->B);
-    HIPCHK(h, hipGetLastError()); }
-  rc = launch_solve(h);
-  if (rc) return rc;
-  { LaunchTimer lt(h, GS_K_ENV_POST);
-    hipLaunchKernelGGL(gs_k_env_post, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, h->B, h->total_load);
+  // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
+  { LaunchTimer lt(h, GS_K_SOLVE);
+    dim3 grid(h->groups), block(64 * h->W);
+#define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, 0, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load)
+    if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
+    else if (h->solve_kernel == 1) GS_STEP(gs_k_step_nr_lu);
+    else if (h->solve_kernel == 3) GS_STEP(gs_k_step_nr_dense);
+    else GS_STEP(gs_k_step_fbs);
+#undef GS_STEP
     HIPCHK(h, hipGetLastError()); }
   return launch_pack(h, h->map_obs, h->obs_dim, h->d_out);
 }

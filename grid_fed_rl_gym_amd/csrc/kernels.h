@@ -4,15 +4,18 @@
 
 #include "gs_internal.h"
 
+#define GS_DECLARE_KERNELS(name)                                                                               \
+  __global__ void gs_k_##name(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);           \
+  __global__ void gs_k_step_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab,  \
+                                   int B, const double* __restrict__ actions, double total_load);
+
 extern "C" {
-__global__ void gs_k_nr_tree(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
-__global__ void gs_k_nr_lu(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
-__global__ void gs_k_nr_dense(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
-__global__ void gs_k_fbs(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
+GS_DECLARE_KERNELS(nr_tree)
+GS_DECLARE_KERNELS(nr_lu)
+GS_DECLARE_KERNELS(nr_dense)
+GS_DECLARE_KERNELS(fbs)
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);
-__global__ void gs_k_env_pre(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B);
-__global__ void gs_k_env_post(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B, double total_load);
 __global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C, int rows_total,
                           const double* __restrict__ slab, double* __restrict__ out, int B);
 __global__ void gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,

@@ -1,4 +1,4 @@
-// kernels_solve.hip -- batched AC load-flow kernels for gfx950 (MI355X, wave64).
+// kernels_solve.hip -- batched AC load-flow and fused env.step() kernels for gfx950 (MI355X, wave64).
 //
 // Mapping: lane = feeder instance, workgroup = W wavefronts sharing one
 // 64-instance group, waves split buses / lines / forest levels.  All per-instance data lives
@@ -13,10 +13,16 @@
 //   Jacobian entries    power_flow.py:243-287   (J11 diagonal sign: as coded :248, or exact)
 //   corrections         power_flow.py:297-327
 //   line flows, losses  power_flow.py:329-358, 198-200
+//   env step            grid_env.py:410-619 (see env_device.h for the pieces before the solve)
 // The linear solve (power_flow.py:187, LAPACK dgesv on the dense Jacobian) is replaced by a
 // 2x2-block elimination on the Jacobian's own sparsity: a level-scheduled forest sweep for
 // radial feeders, a statically scheduled block LU (host-side minimum-degree symbolic
-// factorisation) for meshed ones.
+// factorisation) for meshed ones; a dense partially pivoted LU is kept for as-coded parity.
+//
+// Every solver exists twice: gs_k_<solver> (solve only, behind gs_solve) and gs_k_step_<solver>
+// (the whole transition in one launch, behind gs_step): actions -> batteries / curtailment ->
+// clock -> weather -> renewables -> loads -> injections -> load flow -> line flows -> losses ->
+// grid state -> frequency -> reward -> flags.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -24,60 +30,61 @@
 #include "gs_internal.h"
 
 #define ROW(r) S[(size_t)(r) * GS_LANES]
-
-template <typename X>
-__device__ __forceinline__ X cld(const X* p, int i) {
-  return ((const GS_CONST X*)p)[i];
-}
+#include "env_device.h"
 
 __device__ __forceinline__ double finite_or_inf(double v) { return (fabs(v) < INFINITY) ? v : INFINITY; }
 
-// LDS scratch for cross-wave reductions, double-buffered by a phase parity so that a fast
-// wave can enter the next reduction before a slow one has finished reading the previous one.
+// LDS scratch for cross-wave reductions.  red/flag are double-buffered by an iteration parity so
+// that a fast wave can enter the next reduction before a slow one has finished reading the
+// previous one; `post` carries the partial results of the epilogue.
 struct GsShared {
   double red[2][GS_MAX_WAVES][GS_LANES];
   int flag[2][GS_MAX_WAVES][GS_LANES];
+  double post[4][GS_MAX_WAVES][GS_LANES];
+  int posti[2][GS_MAX_WAVES][GS_LANES];
 };
 
-__device__ __forceinline__ double wg_max(GsShared& sh, int par, int wave, int W, int lane, double v) {
-  sh.red[par][wave][lane] = v;
+struct Ctx {
+  const GsTables& T;
+  const GsRows& R;
+  double* S;
+  GsShared& sh;
+  int lane, wave, W;
+};
+
+__device__ __forceinline__ double wg_max(Ctx& c, int par, double v) {
+  c.sh.red[par][c.wave][c.lane] = v;
   __syncthreads();
-  double r = sh.red[par][0][lane];
-  for (int w = 1; w < W; ++w) r = fmax(r, sh.red[par][w][lane]);
+  double r = c.sh.red[par][0][c.lane];
+  for (int w = 1; w < c.W; ++w) r = fmax(r, c.sh.red[par][w][c.lane]);
   return r;
 }
 
-__device__ __forceinline__ double wg_sum(GsShared& sh, int par, int wave, int W, int lane, double v) {
-  sh.red[par][wave][lane] = v;
+__device__ __forceinline__ int wg_or(Ctx& c, int par, int v) {
+  c.sh.flag[par][c.wave][c.lane] = v;
   __syncthreads();
-  double r = sh.red[par][0][lane];
-  for (int w = 1; w < W; ++w) r += sh.red[par][w][lane];
-  return r;
-}
-
-__device__ __forceinline__ int wg_or(GsShared& sh, int par, int wave, int W, int lane, int v) {
-  sh.flag[par][wave][lane] = v;
-  __syncthreads();
-  int r = sh.flag[par][0][lane];
-  for (int w = 1; w < W; ++w) r |= sh.flag[par][w][lane];
+  int r = c.sh.flag[par][0][c.lane];
+  for (int w = 1; w < c.W; ++w) r |= c.sh.flag[par][w][c.lane];
   return r;
 }
 
 // ---- flat start (power_flow.py:103, 128-136) ---------------------------------------------
-__device__ __forceinline__ void flat_start(const GsTables& T, const GsRows& R, double* S, int wave, int W) {
-  for (int i = wave; i < T.n; i += W) {
+__device__ __forceinline__ void flat_start(Ctx& c) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  for (int i = c.wave; i < T.n; i += c.W) {
     ROW(R.VM + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
     ROW(R.VA + i) = 0.0;
   }
 }
 
 // ---- polar -> rectangular ------------------------------------------------------------------
-__device__ __forceinline__ void to_rect(const GsTables& T, const GsRows& R, double* S, int wave, int W) {
-  for (int i = wave; i < T.n; i += W) {
+__device__ __forceinline__ void to_rect(Ctx& c) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  for (int i = c.wave; i < T.n; i += c.W) {
     const double vm = ROW(R.VM + i), va = ROW(R.VA + i);
-    double s, c;
-    sincos(va, &s, &c);
-    ROW(R.E + i) = vm * c;
+    double s, cs;
+    sincos(va, &s, &cs);
+    ROW(R.E + i) = vm * cs;
     ROW(R.F + i) = vm * s;
   }
 }
@@ -85,9 +92,10 @@ __device__ __forceinline__ void to_rect(const GsTables& T, const GsRows& R, doub
 // ---- S = V conj(Y V) by CSR rows; dP, dQ; returns this wave's max |mismatch| (inf if non-finite)
 // With a_ij = e_i e_j + f_i f_j = Vi Vj cos(th_i - th_j), b_ij = f_i e_j - e_i f_j = Vi Vj sin(..):
 //   P_i = sum_j G_ij a_ij + B_ij b_ij,   Q_i = sum_j G_ij b_ij - B_ij a_ij.
-__device__ __forceinline__ double mismatch_rows(const GsTables& T, const GsRows& R, double* S, int wave, int W) {
+__device__ __forceinline__ double mismatch_rows(Ctx& c) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double lmax = 0.0;
-  for (int i = wave; i < T.n; i += W) {
+  for (int i = c.wave; i < T.n; i += c.W) {
     const double ei = ROW(R.E + i), fi = ROW(R.F + i);
     double P = 0.0, Q = 0.0;
     const int p0 = cld(T.row_ptr, i), p1 = cld(T.row_ptr, i + 1);
@@ -111,10 +119,12 @@ __device__ __forceinline__ double mismatch_rows(const GsTables& T, const GsRows&
   return lmax;
 }
 
-// ---- diagonal Jacobian block of bus i (power_flow.py:247-248, 259-260, 270-271, 283-284) ----
+// ---- Jacobian blocks --------------------------------------------------------------------------
 struct Blk { double a00, a01, a10, a11; };
 
-__device__ __forceinline__ Blk diag_block(const GsTables& T, const GsRows& R, double* S, int i, int exact) {
+// diagonal block of bus i (power_flow.py:247-248, 259-260, 270-271, 283-284)
+__device__ __forceinline__ Blk diag_block(Ctx& c, int i, int exact) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   const double vm = ROW(R.VM + i), P = ROW(R.PC + i), Q = ROW(R.QC + i);
   const double gd = cld(T.Gd, i), bd = cld(T.Bd, i);
   const int th = cld(T.th_free, i), vf = cld(T.vm_free, i);
@@ -127,8 +137,9 @@ __device__ __forceinline__ Blk diag_block(const GsTables& T, const GsRows& R, do
   return d;
 }
 
-// off-diagonal Jacobian block (row bus i, column bus j) (power_flow.py:251, 263, 274, 287)
-__device__ __forceinline__ Blk offdiag_block(const GsTables& T, const GsRows& R, double* S, int i, int j, double g, double b) {
+// off-diagonal block, row bus i, column bus j (power_flow.py:251, 263, 274, 287)
+__device__ __forceinline__ Blk offdiag_block(Ctx& c, int i, int j, double g, double b) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   const double ei = ROW(R.E + i), fi = ROW(R.F + i), ej = ROW(R.E + j), fj = ROW(R.F + j);
   const double vmj = ROW(R.VM + j);
   const double a = ei * ej + fi * fj;
@@ -174,7 +185,8 @@ __device__ __forceinline__ void store_blk(double* S, int row, const Blk& b) {
 
 // ---- apply the Newton step to bus i (power_flow.py:315-327); keeps Vm >= 0 like the
 // reference's abs/angle round trip does
-__device__ __forceinline__ void apply_step(const GsTables& T, const GsRows& R, double* S, int i, double alpha, bool upd) {
+__device__ __forceinline__ void apply_step(Ctx& c, int i, double alpha, bool upd) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   if (!upd) return;
   double vm = ROW(R.VM + i), va = ROW(R.VA + i);
   if (cld(T.th_free, i)) va += alpha * ROW(R.X0 + i);
@@ -184,41 +196,7 @@ __device__ __forceinline__ void apply_step(const GsTables& T, const GsRows& R, d
   ROW(R.VA + i) = va;
 }
 
-// ---- final: line flows (power_flow.py:340-356), losses (:198-200), wrapped angles, scalars ---
-__device__ __forceinline__ void finish(const GsTables& T, const GsRows& R, double* S, GsShared& sh, int wave, int W,
-                                       int lane, bool recompute, double mm, int iters, int conv, int status) {
-  if (recompute) {
-    __syncthreads();
-    to_rect(T, R, S, wave, W);
-    __syncthreads();
-    (void)mismatch_rows(T, R, S, wave, W);
-  }
-  __syncthreads();
-  double lsum = 0.0;
-  for (int i = wave; i < T.n; i += W) lsum += ROW(R.PC + i);
-  for (int k = wave; k < T.m; k += W) {
-    const int i = cld(T.lfrom, k), j = cld(T.lto, k);
-    const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k);
-    const double ei = ROW(R.E + i), fi = ROW(R.F + i);
-    const double dr = ei - ROW(R.E + j), di = fi - ROW(R.F + j);
-    const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
-    const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
-    ROW(R.FLOW + k) = sr;
-    ROW(R.LOAD + k) = (rating > 0.0) ? hypot(sr, si) / rating : 0.0;
-  }
-  const double losses = wg_sum(sh, 0, wave, W, lane, lsum);
-  // np.angle of V = Vm exp(j theta): wrap to (-pi, pi]
-  for (int i = wave; i < T.n; i += W) ROW(R.VA + i) = atan2(ROW(R.F + i), ROW(R.E + i));
-  if (wave == 0) {
-    ROW(R.LOSSES) = losses;
-    ROW(R.MAXMIS) = mm;
-    ROW(R.ITERS) = (double)iters;
-    ROW(R.CONV) = (double)conv;
-    ROW(R.STATUS) = (double)status;
-  }
-}
-
-// per-lane Newton bookkeeping shared by the two NR kernels (power_flow.py:148, 168-171, 204)
+// per-lane Newton bookkeeping (power_flow.py:148, 168-171, 204)
 struct NrState {
   double mm; int iters, conv, status; bool done;
 };
@@ -232,195 +210,250 @@ __device__ __forceinline__ void nr_check(NrState& st, double mm, int it, double 
   }
 }
 
+enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3 };
+
 // =============================================================================================
-// Newton-Raphson, radial (forest) Jacobian: level-scheduled 2x2-block elimination, zero fill.
+// Linear solves.  Each takes the mismatch in R0/R1 and the current E/F/VM/PC/QC rows, leaves the
+// Newton step applied to VM/VA for the lanes still iterating, and reports exact singularity.
+// =============================================================================================
+
+// ---- radial (forest) Jacobian: level-scheduled 2x2-block elimination, zero fill ---------------
 //   bottom-up:  D_i = J_ii - sum_children C_c ;  r_i = rhs_i - sum_children q_c
 //               T_i = D_i^-1 J_ip ; s_i = D_i^-1 r_i ; C_i = J_pi T_i ; q_i = J_pi s_i
 //   top-down:   x_i = s_i - T_i x_p
-// =============================================================================================
-extern "C" __global__ void __launch_bounds__(1024)
-gs_k_nr_tree(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
-  __shared__ GsShared sh;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int W = blockDim.x >> 6;
-  double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
-  const bool valid = (int)(blockIdx.x * GS_LANES + lane) < B;
-
-  NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
-  flat_start(T, R, S, wave, W);
-  __syncthreads();
-  bool stale = true;   // E/F/PC describe an older V than VM/VA
-  int it = 0;
-  for (; it < C.max_iterations; ++it) {
-    to_rect(T, R, S, wave, W);
+__device__ __forceinline__ void linsolve_tree(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  int sing = 0;
+  for (int lv = 0; lv < T.n_levels; ++lv) {
+    const int t1 = cld(T.lvl_ptr, lv + 1);
+    for (int t = cld(T.lvl_ptr, lv) + c.wave; t < t1; t += c.W) {
+      const int i = cld(T.lvl_bus, t);
+      Blk d = diag_block(c, i, C.jacobian_exact);
+      double r0 = ROW(R.R0 + i), r1 = ROW(R.R1 + i);
+      const int c1 = cld(T.child_ptr, i + 1);
+      for (int cp = cld(T.child_ptr, i); cp < c1; ++cp) {
+        const int ch = cld(T.child_idx, cp);
+        const Blk cb = load_blk(S, R.CB + 4 * ch);
+        d.a00 -= cb.a00; d.a01 -= cb.a01; d.a10 -= cb.a10; d.a11 -= cb.a11;
+        r0 -= ROW(R.QV + 2 * ch); r1 -= ROW(R.QV + 2 * ch + 1);
+      }
+      const Blk inv = inv2(d, &sing);
+      const double s0 = inv.a00 * r0 + inv.a01 * r1, s1 = inv.a10 * r0 + inv.a11 * r1;
+      ROW(R.SV + 2 * i) = s0; ROW(R.SV + 2 * i + 1) = s1;
+      const int p = cld(T.parent, i);
+      if (p >= 0) {
+        const int pp = cld(T.parent_pos, i);
+        const double g = cld(T.G, pp), b = cld(T.Bv, pp);
+        const Blk u = offdiag_block(c, i, p, g, b);    // J(i, p)
+        const Blk l = offdiag_block(c, p, i, g, b);    // J(p, i); Ybus is symmetric
+        const Blk tb = mul(inv, u);
+        store_blk(S, R.TB + 4 * i, tb);
+        store_blk(S, R.CB + 4 * i, mul(l, tb));
+        ROW(R.QV + 2 * i) = l.a00 * s0 + l.a01 * s1;
+        ROW(R.QV + 2 * i + 1) = l.a10 * s0 + l.a11 * s1;
+      }
+    }
     __syncthreads();
-    const double lmax = mismatch_rows(T, R, S, wave, W);
-    const double mm = wg_max(sh, it & 1, wave, W, lane, lmax);
-    nr_check(st, mm, it, C.tolerance);
-    stale = false;
-    if (__all(st.done)) break;
-
-    // ---- bottom-up elimination ----
-    int sing = 0;
-    for (int lv = 0; lv < T.n_levels; ++lv) {
-      const int t1 = cld(T.lvl_ptr, lv + 1);
-      for (int t = cld(T.lvl_ptr, lv) + wave; t < t1; t += W) {
-        const int i = cld(T.lvl_bus, t);
-        Blk d = diag_block(T, R, S, i, C.jacobian_exact);
-        double r0 = ROW(R.R0 + i), r1 = ROW(R.R1 + i);
-        const int c1 = cld(T.child_ptr, i + 1);
-        for (int cp = cld(T.child_ptr, i); cp < c1; ++cp) {
-          const int c = cld(T.child_idx, cp);
-          const Blk cb = load_blk(S, R.CB + 4 * c);
-          d.a00 -= cb.a00; d.a01 -= cb.a01; d.a10 -= cb.a10; d.a11 -= cb.a11;
-          r0 -= ROW(R.QV + 2 * c); r1 -= ROW(R.QV + 2 * c + 1);
-        }
-        const Blk inv = inv2(d, &sing);
-        const double s0 = inv.a00 * r0 + inv.a01 * r1, s1 = inv.a10 * r0 + inv.a11 * r1;
-        ROW(R.SV + 2 * i) = s0; ROW(R.SV + 2 * i + 1) = s1;
-        const int p = cld(T.parent, i);
-        if (p >= 0) {
-          const int pp = cld(T.parent_pos, i);
-          const double g = cld(T.G, pp), b = cld(T.Bv, pp);
-          const Blk u = offdiag_block(T, R, S, i, p, g, b);    // J(i, p)
-          const Blk l = offdiag_block(T, R, S, p, i, g, b);    // J(p, i); Ybus is symmetric
-          const Blk tb = mul(inv, u);
-          store_blk(S, R.TB + 4 * i, tb);
-          store_blk(S, R.CB + 4 * i, mul(l, tb));
-          ROW(R.QV + 2 * i) = l.a00 * s0 + l.a01 * s1;
-          ROW(R.QV + 2 * i + 1) = l.a10 * s0 + l.a11 * s1;
-        }
-      }
-      __syncthreads();
-    }
-    const int sing_all = wg_or(sh, it & 1, wave, W, lane, sing);
-    if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
-    const bool upd = !st.done;
-
-    // ---- top-down substitution + voltage update ----
-    for (int lv = T.n_levels - 1; lv >= 0; --lv) {
-      const int t1 = cld(T.lvl_ptr, lv + 1);
-      for (int t = cld(T.lvl_ptr, lv) + wave; t < t1; t += W) {
-        const int i = cld(T.lvl_bus, t);
-        double x0 = ROW(R.SV + 2 * i), x1 = ROW(R.SV + 2 * i + 1);
-        const int p = cld(T.parent, i);
-        if (p >= 0) {
-          const Blk tb = load_blk(S, R.TB + 4 * i);
-          const double xp0 = ROW(R.X0 + p), xp1 = ROW(R.X1 + p);
-          x0 -= tb.a00 * xp0 + tb.a01 * xp1;
-          x1 -= tb.a10 * xp0 + tb.a11 * xp1;
-        }
-        ROW(R.X0 + i) = x0; ROW(R.X1 + i) = x1;
-        apply_step(T, R, S, i, C.alpha, upd);
-      }
-      __syncthreads();
-    }
-    stale = true;
   }
-  finish(T, R, S, sh, wave, W, lane, stale, st.mm, st.iters, st.conv, st.status);
+  const int sing_all = wg_or(c, par, sing);
+  if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+  const bool upd = !st.done;
+  for (int lv = T.n_levels - 1; lv >= 0; --lv) {
+    const int t1 = cld(T.lvl_ptr, lv + 1);
+    for (int t = cld(T.lvl_ptr, lv) + c.wave; t < t1; t += c.W) {
+      const int i = cld(T.lvl_bus, t);
+      double x0 = ROW(R.SV + 2 * i), x1 = ROW(R.SV + 2 * i + 1);
+      const int p = cld(T.parent, i);
+      if (p >= 0) {
+        const Blk tb = load_blk(S, R.TB + 4 * i);
+        const double xp0 = ROW(R.X0 + p), xp1 = ROW(R.X1 + p);
+        x0 -= tb.a00 * xp0 + tb.a01 * xp1;
+        x1 -= tb.a10 * xp0 + tb.a11 * xp1;
+      }
+      ROW(R.X0 + i) = x0; ROW(R.X1 + i) = x1;
+      apply_step(c, i, C.alpha, upd);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- meshed Jacobian: statically scheduled 2x2-block sparse LU ------------------------------------
+// The host ordered the active buses by minimum degree and listed, for every pivot, its remaining
+// neighbours and every (i, j) block its elimination touches; fill blocks own slots.  Waves split
+// the pair updates of a pivot; pivots are sequential (one barrier each).
+__device__ __forceinline__ void linsolve_lu(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  for (int t = c.wave; t < T.lu_n_piv; t += c.W) {
+    const int i = cld(T.lu_piv_bus, t);
+    store_blk(S, R.LUD + 4 * i, diag_block(c, i, C.jacobian_exact));
+  }
+  for (int q = c.wave; q < T.lu_n_orig; q += c.W) {
+    const int pos = cld(T.lu_orig_pos, q);
+    store_blk(S, R.LU + 4 * cld(T.lu_orig_slot, q),
+              offdiag_block(c, cld(T.lu_orig_i, q), cld(T.lu_orig_j, q), cld(T.G, pos), cld(T.Bv, pos)));
+  }
+  for (int s = T.lu_n_orig + c.wave; s < T.lu_n_slots; s += c.W) {
+    Blk z; z.a00 = z.a01 = z.a10 = z.a11 = 0.0;
+    store_blk(S, R.LU + 4 * s, z);
+  }
+  __syncthreads();
+  int sing = 0;
+  for (int t = 0; t < T.lu_n_piv; ++t) {
+    const int k = cld(T.lu_piv_bus, t);
+    const Blk inv = inv2(load_blk(S, R.LUD + 4 * k), &sing);
+    const double rk0 = ROW(R.R0 + k), rk1 = ROW(R.R1 + k);
+    const double s0 = inv.a00 * rk0 + inv.a01 * rk1, s1 = inv.a10 * rk0 + inv.a11 * rk1;
+    const int q1 = cld(T.lu_pair_ptr, t + 1);
+    for (int q = cld(T.lu_pair_ptr, t) + c.wave; q < q1; q += c.W) {
+      const Blk aik = load_blk(S, R.LU + 4 * cld(T.lu_pair_ik, q));
+      const Blk akj = load_blk(S, R.LU + 4 * cld(T.lu_pair_kj, q));
+      const Blk upd = mul(mul(aik, inv), akj);
+      const int tgt = cld(T.lu_pair_ij, q);
+      const int row = (tgt >= 0) ? (R.LU + 4 * tgt) : (R.LUD + 4 * (-tgt - 1));
+      Blk a = load_blk(S, row);
+      a.a00 -= upd.a00; a.a01 -= upd.a01; a.a10 -= upd.a10; a.a11 -= upd.a11;
+      store_blk(S, row, a);
+    }
+    const int n1 = cld(T.lu_nb_ptr, t + 1);
+    for (int q = cld(T.lu_nb_ptr, t) + c.wave; q < n1; q += c.W) {
+      const int i = cld(T.lu_nb_bus, q);
+      const Blk aik = load_blk(S, R.LU + 4 * cld(T.lu_nb_jk, q));
+      ROW(R.R0 + i) -= aik.a00 * s0 + aik.a01 * s1;
+      ROW(R.R1 + i) -= aik.a10 * s0 + aik.a11 * s1;
+    }
+    __syncthreads();
+  }
+  const int sing_all = wg_or(c, par, sing);
+  if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+  const bool upd = !st.done;
+  if (c.wave == 0) {   // back substitution: sequential in reverse pivot order
+    for (int t = T.lu_n_piv - 1; t >= 0; --t) {
+      const int k = cld(T.lu_piv_bus, t);
+      int dummy = 0;
+      const Blk inv = inv2(load_blk(S, R.LUD + 4 * k), &dummy);
+      double r0 = ROW(R.R0 + k), r1 = ROW(R.R1 + k);
+      const int n1 = cld(T.lu_nb_ptr, t + 1);
+      for (int q = cld(T.lu_nb_ptr, t); q < n1; ++q) {
+        const int j = cld(T.lu_nb_bus, q);
+        const Blk akj = load_blk(S, R.LU + 4 * cld(T.lu_nb_kj, q));
+        const double xj0 = ROW(R.X0 + j), xj1 = ROW(R.X1 + j);
+        r0 -= akj.a00 * xj0 + akj.a01 * xj1;
+        r1 -= akj.a10 * xj0 + akj.a11 * xj1;
+      }
+      ROW(R.X0 + k) = inv.a00 * r0 + inv.a01 * r1;
+      ROW(R.X1 + k) = inv.a10 * r0 + inv.a11 * r1;
+      apply_step(c, k, C.alpha, upd);
+    }
+  }
+  __syncthreads();
+}
+
+// ---- dense, partially pivoted LU per instance: the reference-faithful linear solve -------------
+// (np.linalg.solve = LAPACK dgesv, power_flow.py:187): same unknown order, same pivot rule
+// (largest |a_ik| in the column), exact-zero pivot = singular.  Row exchanges are per instance,
+// so matrix rows are reached through a per-lane permutation (a gather: each lane reads its own
+// row at its own lane slot).  This path exists for parity with the as-coded Jacobian, whose 2x2
+// diagonal blocks can be exactly singular; it is not the fast path.
+#define DA_AT(prow, cc) S[((size_t)R.DA + (size_t)(prow) * N + (size_t)(cc)) * GS_LANES]
+
+__device__ __forceinline__ void linsolve_dense(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const int N = T.dn_N;
+  for (int q = c.wave; q < N * N; q += c.W) ROW(R.DA + q) = 0.0;
+  for (int q = c.wave; q < N; q += c.W) ROW(R.DPERM + q) = (double)q;
+  __syncthreads();
+  for (int i = c.wave; i < T.n; i += c.W) {
+    const int ri0 = cld(T.dn_th_idx, i), ri1 = cld(T.dn_vm_idx, i);
+    if (ri0 >= 0) ROW(R.DB + ri0) = ROW(R.R0 + i);
+    if (ri1 >= 0) ROW(R.DB + ri1) = ROW(R.R1 + i);
+    const int p1 = cld(T.row_ptr, i + 1);
+    for (int p = cld(T.row_ptr, i); p < p1; ++p) {
+      const int j = cld(T.col, p);
+      const int cj0 = cld(T.dn_th_idx, j), cj1 = cld(T.dn_vm_idx, j);
+      const Blk blk = (j == i) ? diag_block(c, i, C.jacobian_exact) : offdiag_block(c, i, j, cld(T.G, p), cld(T.Bv, p));
+      if (ri0 >= 0 && cj0 >= 0) ROW(R.DA + ri0 * N + cj0) = blk.a00;
+      if (ri0 >= 0 && cj1 >= 0) ROW(R.DA + ri0 * N + cj1) = blk.a01;
+      if (ri1 >= 0 && cj0 >= 0) ROW(R.DA + ri1 * N + cj0) = blk.a10;
+      if (ri1 >= 0 && cj1 >= 0) ROW(R.DA + ri1 * N + cj1) = blk.a11;
+    }
+  }
+  __syncthreads();
+  int sing = 0;
+  for (int k = 0; k < N; ++k) {
+    if (c.wave == 0) {
+      double best = -1.0; int bi = k;
+      for (int i = k; i < N; ++i) {
+        const int pi = (int)ROW(R.DPERM + i);
+        const double v = fabs(DA_AT(pi, k));
+        if (v > best) { best = v; bi = i; }
+      }
+      if (!(best > 0.0)) sing = 1;
+      const double pk = ROW(R.DPERM + k);
+      const double pb = S[(size_t)(R.DPERM + bi) * GS_LANES];
+      S[(size_t)(R.DPERM + bi) * GS_LANES] = pk;
+      ROW(R.DPERM + k) = pb;
+    }
+    __syncthreads();
+    const int pk = (int)ROW(R.DPERM + k);
+    const double akk = DA_AT(pk, k);
+    const double bk = S[(size_t)(R.DB + pk) * GS_LANES];
+    for (int i = k + 1 + c.wave; i < N; i += c.W) {
+      const int pi = (int)ROW(R.DPERM + i);
+      const double l = DA_AT(pi, k) / akk;
+      if (__any(l != 0.0)) {
+        for (int cc = k + 1; cc < N; ++cc) DA_AT(pi, cc) -= l * DA_AT(pk, cc);
+        S[(size_t)(R.DB + pi) * GS_LANES] -= l * bk;
+      }
+    }
+    __syncthreads();
+  }
+  const int sing_all = wg_or(c, par, sing);
+  if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+  const bool upd = !st.done;
+  if (c.wave == 0) {
+    for (int k = N - 1; k >= 0; --k) {
+      const int pk = (int)ROW(R.DPERM + k);
+      double s = S[(size_t)(R.DB + pk) * GS_LANES];
+      for (int cc = k + 1; cc < N; ++cc) s -= DA_AT(pk, cc) * ROW(R.DX + cc);
+      ROW(R.DX + k) = s / DA_AT(pk, k);
+    }
+    for (int i = 0; i < T.n; ++i) {
+      const int c0 = cld(T.dn_th_idx, i), c1 = cld(T.dn_vm_idx, i);
+      ROW(R.X0 + i) = (c0 >= 0) ? ROW(R.DX + c0) : 0.0;
+      ROW(R.X1 + i) = (c1 >= 0) ? ROW(R.DX + c1) : 0.0;
+      apply_step(c, i, C.alpha, upd);
+    }
+  }
+  __syncthreads();
 }
 
 // =============================================================================================
-// Newton-Raphson, general (meshed) Jacobian: statically scheduled 2x2-block sparse LU.
-// The host ordered the active buses by minimum degree and listed, for every pivot, its
-// remaining neighbours and every (i, j) block its elimination touches; fill blocks own slots.
-// Waves split the pair updates of a pivot; pivots are sequential (one barrier each).
+// Newton-Raphson driver (power_flow.py:143-193).  Returns with E/F/PC/QC describing the final V
+// (recomputed when the loop ended on the iteration cap, i.e. after an update).
 // =============================================================================================
-extern "C" __global__ void __launch_bounds__(1024)
-gs_k_nr_lu(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
-  __shared__ GsShared sh;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int W = blockDim.x >> 6;
-  double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
-  const bool valid = (int)(blockIdx.x * GS_LANES + lane) < B;
-
-  NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
-  flat_start(T, R, S, wave, W);
+template <int KIND>
+__device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState& st) {
+  flat_start(c);
   __syncthreads();
   bool stale = true;
-  int it = 0;
-  for (; it < C.max_iterations; ++it) {
-    to_rect(T, R, S, wave, W);
+  for (int it = 0; it < C.max_iterations; ++it) {
+    to_rect(c);
     __syncthreads();
-    const double lmax = mismatch_rows(T, R, S, wave, W);
-    const double mm = wg_max(sh, it & 1, wave, W, lane, lmax);
+    const double mm = wg_max(c, it & 1, mismatch_rows(c));
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
-
-    // ---- assemble: diagonal blocks, original off-diagonal blocks, zero the fill slots ----
-    for (int t = wave; t < T.lu_n_piv; t += W) {
-      const int i = cld(T.lu_piv_bus, t);
-      store_blk(S, R.LUD + 4 * i, diag_block(T, R, S, i, C.jacobian_exact));
-    }
-    for (int q = wave; q < T.lu_n_orig; q += W) {
-      const int pos = cld(T.lu_orig_pos, q);
-      store_blk(S, R.LU + 4 * cld(T.lu_orig_slot, q),
-                offdiag_block(T, R, S, cld(T.lu_orig_i, q), cld(T.lu_orig_j, q), cld(T.G, pos), cld(T.Bv, pos)));
-    }
-    for (int s = T.lu_n_orig + wave; s < T.lu_n_slots; s += W) {
-      Blk z; z.a00 = z.a01 = z.a10 = z.a11 = 0.0;
-      store_blk(S, R.LU + 4 * s, z);
-    }
-    __syncthreads();
-
-    // ---- right-looking elimination ----
-    int sing = 0;
-    for (int t = 0; t < T.lu_n_piv; ++t) {
-      const int k = cld(T.lu_piv_bus, t);
-      const Blk inv = inv2(load_blk(S, R.LUD + 4 * k), &sing);
-      const double rk0 = ROW(R.R0 + k), rk1 = ROW(R.R1 + k);
-      const double s0 = inv.a00 * rk0 + inv.a01 * rk1, s1 = inv.a10 * rk0 + inv.a11 * rk1;
-      const int q1 = cld(T.lu_pair_ptr, t + 1);
-      for (int q = cld(T.lu_pair_ptr, t) + wave; q < q1; q += W) {
-        const Blk aik = load_blk(S, R.LU + 4 * cld(T.lu_pair_ik, q));
-        const Blk akj = load_blk(S, R.LU + 4 * cld(T.lu_pair_kj, q));
-        const Blk upd = mul(mul(aik, inv), akj);
-        const int tgt = cld(T.lu_pair_ij, q);
-        const int row = (tgt >= 0) ? (R.LU + 4 * tgt) : (R.LUD + 4 * (-tgt - 1));
-        Blk a = load_blk(S, row);
-        a.a00 -= upd.a00; a.a01 -= upd.a01; a.a10 -= upd.a10; a.a11 -= upd.a11;
-        store_blk(S, row, a);
-      }
-      const int n1 = cld(T.lu_nb_ptr, t + 1);
-      for (int q = cld(T.lu_nb_ptr, t) + wave; q < n1; q += W) {
-        const int i = cld(T.lu_nb_bus, q);
-        const Blk aik = load_blk(S, R.LU + 4 * cld(T.lu_nb_jk, q));
-        ROW(R.R0 + i) -= aik.a00 * s0 + aik.a01 * s1;
-        ROW(R.R1 + i) -= aik.a10 * s0 + aik.a11 * s1;
-      }
-      __syncthreads();
-    }
-    const int sing_all = wg_or(sh, it & 1, wave, W, lane, sing);
-    if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
-    const bool upd = !st.done;
-
-    // ---- back substitution (sequential in reverse pivot order; wave 0) + update ----
-    if (wave == 0) {
-      for (int t = T.lu_n_piv - 1; t >= 0; --t) {
-        const int k = cld(T.lu_piv_bus, t);
-        int dummy = 0;
-        const Blk inv = inv2(load_blk(S, R.LUD + 4 * k), &dummy);
-        double r0 = ROW(R.R0 + k), r1 = ROW(R.R1 + k);
-        const int n1 = cld(T.lu_nb_ptr, t + 1);
-        for (int q = cld(T.lu_nb_ptr, t); q < n1; ++q) {
-          const int j = cld(T.lu_nb_bus, q);
-          const Blk akj = load_blk(S, R.LU + 4 * cld(T.lu_nb_kj, q));
-          const double xj0 = ROW(R.X0 + j), xj1 = ROW(R.X1 + j);
-          r0 -= akj.a00 * xj0 + akj.a01 * xj1;
-          r1 -= akj.a10 * xj0 + akj.a11 * xj1;
-        }
-        ROW(R.X0 + k) = inv.a00 * r0 + inv.a01 * r1;
-        ROW(R.X1 + k) = inv.a10 * r0 + inv.a11 * r1;
-        apply_step(T, R, S, k, C.alpha, upd);
-      }
-    }
-    __syncthreads();
+    if (KIND == KIND_TREE) linsolve_tree(c, C, st, it & 1);
+    else if (KIND == KIND_LU) linsolve_lu(c, C, st, it & 1);
+    else linsolve_dense(c, C, st, it & 1);
     stale = true;
   }
-  finish(T, R, S, sh, wave, W, lane, stale, st.mm, st.iters, st.conv, st.status);
+  if (stale) {
+    to_rect(c);
+    __syncthreads();
+    (void)mismatch_rows(c);
+  }
+  __syncthreads();
 }
 
 // =============================================================================================
@@ -431,34 +464,23 @@ gs_k_nr_lu(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B)
 //   backward:  J_i = -conj(S_i / V_i) + sum_children J_c        (branch current parent -> i)
 //   forward:   V_i = V_parent - J_i / y_i
 // =============================================================================================
-extern "C" __global__ void __launch_bounds__(1024)
-gs_k_fbs(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
-  __shared__ GsShared sh;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int W = blockDim.x >> 6;
-  double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
-  const bool valid = (int)(blockIdx.x * GS_LANES + lane) < B;
-
-  NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
-  for (int i = wave; i < T.n; i += W) {
+__device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& st) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  for (int i = c.wave; i < T.n; i += c.W) {
     ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
     ROW(R.F + i) = 0.0;
   }
   __syncthreads();
   bool stale = true;
-  int it = 0;
-  for (; it < C.max_iterations; ++it) {
-    const double lmax = mismatch_rows(T, R, S, wave, W);
-    const double mm = wg_max(sh, it & 1, wave, W, lane, lmax);
+  for (int it = 0; it < C.max_iterations; ++it) {
+    const double mm = wg_max(c, it & 1, mismatch_rows(c));
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
     const bool upd = !st.done;
-    // backward sweep, deepest level first
-    for (int lv = 0; lv < T.n_levels; ++lv) {
+    for (int lv = 0; lv < T.n_levels; ++lv) {          // backward sweep, deepest level first
       const int t1 = cld(T.lvl_ptr, lv + 1);
-      for (int t = cld(T.lvl_ptr, lv) + wave; t < t1; t += W) {
+      for (int t = cld(T.lvl_ptr, lv) + c.wave; t < t1; t += c.W) {
         const int i = cld(T.lvl_bus, t);
         const double e = ROW(R.E + i), f = ROW(R.F + i), p = ROW(R.P + i), q = ROW(R.Q + i);
         const double d = e * e + f * f;
@@ -466,25 +488,22 @@ gs_k_fbs(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
         double jr = -(p * e + q * f) / d, ji = (q * e - p * f) / d;
         const int c1 = cld(T.child_ptr, i + 1);
         for (int cp = cld(T.child_ptr, i); cp < c1; ++cp) {
-          const int c = cld(T.child_idx, cp);
-          jr += ROW(R.JR + c); ji += ROW(R.JI + c);
+          const int ch = cld(T.child_idx, cp);
+          jr += ROW(R.JR + ch); ji += ROW(R.JI + ch);
         }
         ROW(R.JR + i) = jr; ROW(R.JI + i) = ji;
       }
       __syncthreads();
     }
-    // forward sweep, roots first
-    for (int lv = T.n_levels - 1; lv >= 0; --lv) {
+    for (int lv = T.n_levels - 1; lv >= 0; --lv) {     // forward sweep, roots first
       const int t1 = cld(T.lvl_ptr, lv + 1);
-      for (int t = cld(T.lvl_ptr, lv) + wave; t < t1; t += W) {
+      for (int t = cld(T.lvl_ptr, lv) + c.wave; t < t1; t += c.W) {
         const int i = cld(T.lvl_bus, t);
         const int p = cld(T.fbs_parent, i), pp = cld(T.fbs_parent_pos, i);
-        // series admittance of the branch = -Y_ip (parallel lines merged)
-        const double yr = -cld(T.G, pp), yi = -cld(T.Bv, pp);
+        const double yr = -cld(T.G, pp), yi = -cld(T.Bv, pp);      // branch admittance = -Y_ip
         const double yd = yr * yr + yi * yi;
         const double jr = ROW(R.JR + i), ji = ROW(R.JI + i);
-        // J / y = J conj(y) / |y|^2
-        const double dr = (jr * yr + ji * yi) / yd, di = (ji * yr - jr * yi) / yd;
+        const double dr = (jr * yr + ji * yi) / yd, di = (ji * yr - jr * yi) / yd;   // J / y
         if (upd) {
           ROW(R.E + i) = ROW(R.E + p) - dr;
           ROW(R.F + i) = ROW(R.F + p) - di;
@@ -494,119 +513,162 @@ gs_k_fbs(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
     }
     stale = true;
   }
-  if (stale) {
-    (void)mismatch_rows(T, R, S, wave, W);
-  }
+  if (stale) (void)mismatch_rows(c);
   __syncthreads();
-  for (int i = wave; i < T.n; i += W) ROW(R.VM + i) = hypot(ROW(R.E + i), ROW(R.F + i));
-  finish(T, R, S, sh, wave, W, lane, false, st.mm, st.iters, st.conv, st.status);
+  for (int i = c.wave; i < T.n; i += c.W) ROW(R.VM + i) = hypot(ROW(R.E + i), ROW(R.F + i));
+  __syncthreads();
 }
 
 // =============================================================================================
-// Newton-Raphson with a dense, partially pivoted LU per instance -- the reference-faithful
-// linear solve (np.linalg.solve = LAPACK dgesv, power_flow.py:187): same unknown order, same
-// pivot rule (largest |a_ik| in the column), exact-zero pivot = singular.  Row exchanges are
-// per instance, so matrix rows are reached through a per-lane permutation (a gather: each lane
-// reads its own row at its own lane slot).  This path exists for parity with the as-coded
-// Jacobian, whose 2x2 diagonal blocks can be exactly singular; it is not the fast path.
+// Epilogue: line flows (power_flow.py:340-356), losses (:198-200), wrapped angles, scalars; with
+// ENV also everything of step() that follows the load flow (grid_env.py:553-617).
 // =============================================================================================
-#define DA_AT(prow, c) S[((size_t)R.DA + (size_t)(prow) * N + (size_t)(c)) * GS_LANES]
+template <int ENV>
+__device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  double lsum = 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
+  int over = 0, vflags = 0;
+  for (int i = c.wave; i < T.n; i += c.W) {
+    lsum += ROW(R.PC + i);
+    ROW(R.VA + i) = atan2(ROW(R.F + i), ROW(R.E + i));      // np.angle: wrap to (-pi, pi]
+    if (ENV) {
+      const double v = ROW(R.VM + i);                       // reward / flags, grid_env.py:790-792, base.py:156-159
+      dev += fabs(v - 1.0);
+      vmax = fmax(vmax, v); vmin = fmin(vmin, v);
+      vflags |= (v > E.v_max) ? 1 : 0;
+      vflags |= (v < E.v_min) ? 2 : 0;
+    }
+  }
+  for (int k = c.wave; k < T.m; k += c.W) {
+    const int i = cld(T.lfrom, k), j = cld(T.lto, k);
+    const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k);
+    const double ei = ROW(R.E + i), fi = ROW(R.F + i);
+    const double dr = ei - ROW(R.E + j), di = fi - ROW(R.F + j);
+    const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
+    const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
+    ROW(R.FLOW + k) = sr;
+    ROW(R.LOAD + k) = (rating > 0.0) ? hypot(sr, si) / rating : 0.0;
+    if (ENV) {                                                        // Line.update_state, base.py:261-264
+      const double ld = (rating > 0.0) ? fabs(sr) / rating : 0.0;
+      ROW(R.ENVLOAD + k) = ld;
+      over += (ld > 0.8) ? 1 : 0;
+    }
+  }
+  c.sh.post[0][c.wave][c.lane] = lsum;
+  if (ENV) {
+    c.sh.post[1][c.wave][c.lane] = dev;
+    c.sh.post[2][c.wave][c.lane] = vmax;
+    c.sh.post[3][c.wave][c.lane] = vmin;
+    c.sh.posti[0][c.wave][c.lane] = over;
+    c.sh.posti[1][c.wave][c.lane] = vflags;
+  }
+  __syncthreads();
+  if (c.wave != 0) return;
+  double losses = c.sh.post[0][0][c.lane];
+  for (int w = 1; w < c.W; ++w) losses += c.sh.post[0][w][c.lane];
+  ROW(R.LOSSES) = losses;
+  ROW(R.MAXMIS) = st.mm;
+  ROW(R.ITERS) = (double)st.iters;
+  ROW(R.CONV) = (double)st.conv;
+  ROW(R.STATUS) = (double)st.status;
+  if (!ENV) return;
+  dev = c.sh.post[1][0][c.lane]; vmax = c.sh.post[2][0][c.lane]; vmin = c.sh.post[3][0][c.lane];
+  over = c.sh.posti[0][0][c.lane]; vflags = c.sh.posti[1][0][c.lane];
+  for (int w = 1; w < c.W; ++w) {
+    dev += c.sh.post[1][w][c.lane];
+    vmax = fmax(vmax, c.sh.post[2][w][c.lane]); vmin = fmin(vmin, c.sh.post[3][w][c.lane]);
+    over += c.sh.posti[0][w][c.lane]; vflags |= c.sh.posti[1][w][c.lane];
+  }
+  const double dt = E.timestep;
+  const double totloss = ROW(R.TOTLOSS) + losses * dt / 3600.0;        // grid_env.py:739
+  ROW(R.TOTLOSS) = totloss;
+  double total_gen = 0.0, total_curt = 0.0;                            // grid_env.py:744-751, 807-816
+  for (int g = 0; g < T.n_gens; ++g) {
+    const double p = ROW(R.GENP + g);
+    total_gen += p;
+    total_curt += p * (1.0 - ROW(R.CURT + g));
+  }
+  const double imbalance = (total_gen - total_load - losses * E.power_base) / 1e6;
+  double f = ROW(R.FREQ);                                              // dynamics.py:260-273
+  f += ((imbalance - E.D * (f - E.f0)) / (2.0 * E.H * E.f0)) * dt;
+  f = fmax(55.0, fmin(65.0, f));
+  ROW(R.FREQ) = f;
+  double reward = 0.0;                                                 // grid_env.py:785-826
+  reward -= dev * 10.0;
+  reward -= fabs(f - 60.0) * 20.0;
+  reward -= (double)(over * 50);
+  reward -= totloss * 0.1;
+  reward += (total_gen - total_curt) * 1e-5;
+  for (int q = 0; q < T.n_bats; ++q) {
+    const double soc = ROW(R.SOC + q);
+    reward += (soc >= 0.2 && soc <= 0.8) ? 1.0 : -5.0;
+  }
+  const int vhigh = vflags & 1, vlow = (vflags >> 1) & 1, fhigh = f > E.f_max, flow_ = f < E.f_min;
+  double viol = ROW(R.VIOL), trunc = 0.0;
+  if (vhigh | vlow | fhigh | flow_) {
+    viol += 1.0;
+    if (viol > 10.0) { trunc = 1.0; reward -= E.safety_penalty; }     // grid_env.py:604-606
+  }
+  ROW(R.VIOL) = viol;
+  ROW(R.TRUNC) = trunc;
+  ROW(R.TERM) = (ROW(R.STEP) >= (double)E.episode_length) ? 1.0 : 0.0;   // base.py:140-142
+  ROW(R.REWARD) = reward;
+  ROW(R.EPREW) = ROW(R.EPREW) + reward;
+  ROW(R.VMAX) = vmax; ROW(R.VMIN) = vmin;
+  ROW(R.VFLAGS + 0) = (double)vhigh; ROW(R.VFLAGS + 1) = (double)vlow;
+  ROW(R.VFLAGS + 2) = (double)fhigh; ROW(R.VFLAGS + 3) = (double)flow_;
+}
 
-extern "C" __global__ void __launch_bounds__(1024)
-gs_k_nr_dense(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
+// Everything of step() that precedes the load flow, spread over the W waves (grid_env.py:433-477).
+__device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const uint64_t inst = (uint64_t)(E.first_instance + b);
+  if (c.wave == 0 && valid) env_actions_clock_weather(T, R, E, S, actions + (size_t)b * (T.n_bats + T.n_gens), inst);
+  __syncthreads();
+  for (int g = c.wave; g < T.n_gens; g += c.W) ROW(R.GENP + g) = renewable_power(T, R, S, g);
+  {
+    const uint64_t seed = lane_seed(S, R);
+    const uint32_t step = (uint32_t)ROW(R.STEP);
+    const double prof = E.stochastic_loads ? daily_profile(ROW(R.TIME)) : 1.0;
+    for (int l = c.wave; l < T.n_loads; l += c.W) ROW(R.LOADP + l) = load_power(T, E, l, seed, inst, step, prof);
+  }
+  __syncthreads();
+  for (int i = c.wave; i < T.n; i += c.W) bus_injection(T, R, E, S, i);
+  __syncthreads();
+}
+
+template <int KIND, int ENV>
+__device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
+                                          double* __restrict__ slab, int B, const double* __restrict__ actions,
+                                          double total_load) {
   __shared__ GsShared sh;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int W = blockDim.x >> 6;
-  const int N = T.dn_N;
   double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
-  const bool valid = (int)(blockIdx.x * GS_LANES + lane) < B;
-
+  const int b = blockIdx.x * GS_LANES + lane;
+  const bool valid = b < B;
+  Ctx c{T, R, S, sh, lane, wave, W};
+  if (ENV) prologue_env(c, E, actions, b, valid);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
-  flat_start(T, R, S, wave, W);
-  __syncthreads();
-  bool stale = true;
-  int it = 0;
-  for (; it < C.max_iterations; ++it) {
-    to_rect(T, R, S, wave, W);
-    __syncthreads();
-    const double lmax = mismatch_rows(T, R, S, wave, W);
-    const double mm = wg_max(sh, it & 1, wave, W, lane, lmax);
-    nr_check(st, mm, it, C.tolerance);
-    stale = false;
-    if (__all(st.done)) break;
-
-    // ---- assemble the dense Jacobian and right-hand side ----
-    for (int q = wave; q < N * N; q += W) ROW(R.DA + q) = 0.0;
-    for (int q = wave; q < N; q += W) ROW(R.DPERM + q) = (double)q;
-    __syncthreads();
-    for (int i = wave; i < T.n; i += W) {
-      const int ri0 = cld(T.dn_th_idx, i), ri1 = cld(T.dn_vm_idx, i);
-      if (ri0 >= 0) ROW(R.DB + ri0) = ROW(R.R0 + i);
-      if (ri1 >= 0) ROW(R.DB + ri1) = ROW(R.R1 + i);
-      const int p1 = cld(T.row_ptr, i + 1);
-      for (int p = cld(T.row_ptr, i); p < p1; ++p) {
-        const int j = cld(T.col, p);
-        const int cj0 = cld(T.dn_th_idx, j), cj1 = cld(T.dn_vm_idx, j);
-        const Blk blk = (j == i) ? diag_block(T, R, S, i, C.jacobian_exact)
-                                 : offdiag_block(T, R, S, i, j, cld(T.G, p), cld(T.Bv, p));
-        if (ri0 >= 0 && cj0 >= 0) ROW(R.DA + ri0 * N + cj0) = blk.a00;
-        if (ri0 >= 0 && cj1 >= 0) ROW(R.DA + ri0 * N + cj1) = blk.a01;
-        if (ri1 >= 0 && cj0 >= 0) ROW(R.DA + ri1 * N + cj0) = blk.a10;
-        if (ri1 >= 0 && cj1 >= 0) ROW(R.DA + ri1 * N + cj1) = blk.a11;
-      }
-    }
-    __syncthreads();
-
-    // ---- LU with partial pivoting (per lane) ----
-    int sing = 0;
-    for (int k = 0; k < N; ++k) {
-      if (wave == 0) {
-        double best = -1.0; int bi = k;
-        for (int i = k; i < N; ++i) {
-          const int pi = (int)ROW(R.DPERM + i);
-          const double v = fabs(DA_AT(pi, k));
-          if (v > best) { best = v; bi = i; }
-        }
-        if (!(best > 0.0)) sing = 1;
-        const double pk = ROW(R.DPERM + k);
-        const double pb = S[(size_t)(R.DPERM + bi) * GS_LANES];
-        S[(size_t)(R.DPERM + bi) * GS_LANES] = pk;
-        ROW(R.DPERM + k) = pb;
-      }
-      __syncthreads();
-      const int pk = (int)ROW(R.DPERM + k);
-      const double akk = DA_AT(pk, k);
-      const double bk = S[(size_t)(R.DB + pk) * GS_LANES];
-      for (int i = k + 1 + wave; i < N; i += W) {
-        const int pi = (int)ROW(R.DPERM + i);
-        const double l = DA_AT(pi, k) / akk;
-        if (__any(l != 0.0)) {
-          for (int c = k + 1; c < N; ++c) DA_AT(pi, c) -= l * DA_AT(pk, c);
-          S[(size_t)(R.DB + pi) * GS_LANES] -= l * bk;
-        }
-      }
-      __syncthreads();
-    }
-    const int sing_all = wg_or(sh, it & 1, wave, W, lane, sing);
-    if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
-    const bool upd = !st.done;
-    if (wave == 0) {
-      for (int k = N - 1; k >= 0; --k) {
-        const int pk = (int)ROW(R.DPERM + k);
-        double s = S[(size_t)(R.DB + pk) * GS_LANES];
-        for (int c = k + 1; c < N; ++c) s -= DA_AT(pk, c) * ROW(R.DX + c);
-        ROW(R.DX + k) = s / DA_AT(pk, k);
-      }
-      for (int i = 0; i < T.n; ++i) {
-        const int c0 = cld(T.dn_th_idx, i), c1 = cld(T.dn_vm_idx, i);
-        ROW(R.X0 + i) = (c0 >= 0) ? ROW(R.DX + c0) : 0.0;
-        ROW(R.X1 + i) = (c1 >= 0) ? ROW(R.DX + c1) : 0.0;
-        apply_step(T, R, S, i, C.alpha, upd);
-      }
-    }
-    __syncthreads();
-    stale = true;
-  }
-  finish(T, R, S, sh, wave, W, lane, stale, st.mm, st.iters, st.conv, st.status);
+  if (KIND == KIND_FBS) fbs_loop(c, C, st);
+  else newton_loop<KIND>(c, C, st);
+  epilogue<ENV>(c, E, st, total_load);
 }
+
+#define GS_DEFINE_KERNELS(name, KIND)                                                                         \
+  extern "C" __global__ void __launch_bounds__(1024)                                                          \
+  gs_k_##name(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {                         \
+    GsEnvCfg E{};                                                                                             \
+    main_body<KIND, 0>(T, R, C, E, slab, B, nullptr, 0.0);                                                    \
+  }                                                                                                           \
+  extern "C" __global__ void __launch_bounds__(1024)                                                          \
+  gs_k_step_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,          \
+                   const double* __restrict__ actions, double total_load) {                                   \
+    main_body<KIND, 1>(T, R, C, E, slab, B, actions, total_load);                                             \
+  }
+
+GS_DEFINE_KERNELS(nr_tree, KIND_TREE)
+GS_DEFINE_KERNELS(nr_lu, KIND_LU)
+GS_DEFINE_KERNELS(nr_dense, KIND_DENSE)
+GS_DEFINE_KERNELS(fbs, KIND_FBS)
