@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--solver", default="nr", choices=["nr", "fbs"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per 64-instance group (0 = auto)")
+    ap.add_argument("--tolerance", type=float, default=1e-6, help="ablation only; the headline uses 1e-6")
+    ap.add_argument("--max-iterations", type=int, default=0, help="ablation only; 0 = 50 (nr) / 100 (fbs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     args = ap.parse_args()
@@ -115,8 +117,8 @@ def main():
     wl = WORKLOADS[args.workload]
     fs = make_feeder(wl["feeder"])
     B = args.batch or wl["batch"]
-    env_kwargs = dict(stochastic_loads=True, weather_variation=True, solver=args.solver, tolerance=1e-6,
-                      max_iterations=50 if args.solver == "nr" else 100)
+    env_kwargs = dict(stochastic_loads=True, weather_variation=True, solver=args.solver, tolerance=args.tolerance,
+                      max_iterations=args.max_iterations or (50 if args.solver == "nr" else 100))
     env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=local_rank,
                                    first_instance=rank * B, waves_per_group=args.waves, **env_kwargs)
     h = env.handle
@@ -198,7 +200,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{fs.name}, batch={B} per GPU, {'Newton-Raphson (exact Jacobian)' if args.solver == 'nr' else 'forward/backward sweep'}, "
-                                   f"stochastic loads + weather, tolerance 1e-6",
+                                   f"stochastic loads + weather, tolerance {args.tolerance:g}",
                        "feeder_sha256": fs.sha256(), "n_buses": fs.n, "n_lines": fs.m, "obs_dim": fs.obs_dim,
                        "action_dim": fs.action_dim, "batch_per_gpu": B, "global_batch": world * B,
                        "solver": args.solver, "kernel": desc["kernel"], "waves_per_group": desc["waves_per_group"],
@@ -206,8 +208,8 @@ def main():
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gs_k_" + {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs",
-                                              "nr_dense_pivot": "nr_dense"}[desc["kernel"]],
+                         "kernel": "gs_k_step_" + {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs",
+                                                   "nr_dense_pivot": "nr_dense", "nr_tree_lds": "nr_tree_lds"}[desc["kernel"]],
                          "avg_launch_ms": avg_solve_ms, "algorithmic_bytes_per_launch": bytes_step * B,
                          "fp64_valu": {"achieved_tflops": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                                        "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "mean_iterations": mean_iters}},

@@ -74,7 +74,8 @@ struct gs_handle {
   GsSolveCfg SC{};
   GsEnvCfg EC{};
   double total_load = 0.0;
-  int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs
+  int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs, 3 dense, 4 tree with LDS messages
+  size_t dyn_lds = 0;
   bool was_reset = false;
   std::vector<void*> allocs;
   double* slab = nullptr;
@@ -207,10 +208,13 @@ int fetch_scalars(gs_handle* h) {
 int launch_solve(gs_handle* h) {
   LaunchTimer lt(h, GS_K_SOLVE);
   dim3 grid(h->groups), block(64 * h->W);
-  if (h->solve_kernel == 0) hipLaunchKernelGGL(gs_k_nr_tree, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
-  else if (h->solve_kernel == 1) hipLaunchKernelGGL(gs_k_nr_lu, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
-  else if (h->solve_kernel == 3) hipLaunchKernelGGL(gs_k_nr_dense, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
-  else hipLaunchKernelGGL(gs_k_fbs, grid, block, 0, h->stream, h->T, h->R, h->SC, h->slab, h->B);
+#define GS_SOLVE(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B)
+  if (h->solve_kernel == 0) GS_SOLVE(gs_k_nr_tree);
+  else if (h->solve_kernel == 4) GS_SOLVE(gs_k_nr_tree_lds);
+  else if (h->solve_kernel == 1) GS_SOLVE(gs_k_nr_lu);
+  else if (h->solve_kernel == 3) GS_SOLVE(gs_k_nr_dense);
+  else GS_SOLVE(gs_k_fbs);
+#undef GS_SOLVE
   HIPCHK(h, hipGetLastError());
   return GS_OK;
 }
@@ -219,8 +223,9 @@ int step_kernels(gs_handle* h, const double* d_actions) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
     dim3 grid(h->groups), block(64 * h->W);
-#define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, 0, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load)
+#define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load)
     if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
+    else if (h->solve_kernel == 4) GS_STEP(gs_k_step_nr_tree_lds);
     else if (h->solve_kernel == 1) GS_STEP(gs_k_step_nr_lu);
     else if (h->solve_kernel == 3) GS_STEP(gs_k_step_nr_dense);
     else GS_STEP(gs_k_step_fbs);
@@ -302,7 +307,12 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       ls = (cfg->jacobian_mode == GS_JACOBIAN_AS_CODED) ? GS_LINSOLVE_DENSE_PIVOT
                                                        : (ht.is_forest ? GS_LINSOLVE_TREE : GS_LINSOLVE_SPARSE_LU);
     h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : 3;
+    // forest sweeps through LDS messages when two adjacent levels fit next to the 24 KB static block
+    const size_t msg_bytes = (size_t)2 * ht.max_level_width * 6 * GS_LANES * sizeof(double);
+    if (h->solve_kernel == 0 && msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) h->solve_kernel = 4;
+    if (h->solve_kernel == 4) h->dyn_lds = msg_bytes;
   } else { int rc = fail(nullptr, GS_E_INVALID, "unknown solver_kind %d", cfg->solver_kind); delete h; return rc; }
+  h->dyn_lds = std::max<size_t>(40960, h->dyn_lds);     // the epilogue's cross-wave partials need 40 KB
 
   h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
   h->n = ht.n; h->m = ht.m; h->n_loads = topo->n_loads; h->n_gens = topo->n_gens; h->n_bats = topo->n_bats;
@@ -319,6 +329,16 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   if (hipSetDevice(device) != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipSetDevice failed"));
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(nullptr, GS_E_HIP, "hipStreamCreate failed"));
+
+  {
+    const void* fns[] = {(const void*)gs_k_nr_tree, (const void*)gs_k_step_nr_tree, (const void*)gs_k_nr_tree_lds,
+                         (const void*)gs_k_step_nr_tree_lds, (const void*)gs_k_nr_lu, (const void*)gs_k_step_nr_lu,
+                         (const void*)gs_k_nr_dense, (const void*)gs_k_step_nr_dense, (const void*)gs_k_fbs,
+                         (const void*)gs_k_step_fbs};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds) != hipSuccess)
+        return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", h->dyn_lds));
+  }
 
   // ---- rows ----
   GsRows& R = h->R;
@@ -356,7 +376,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(row_ptr, row_ptr); UP(col, col); UP(G, G); UP(Bv, B); UP(Gd, Gd); UP(Bd, Bd);
   UP(th_free, th_free); UP(vm_free, vm_free); UP(v_set, v_set); UP(fixed_v, fixed_v);
   UP(lvl_ptr, lvl_ptr); UP(lvl_bus, lvl_bus); UP(parent, parent); UP(parent_pos, parent_pos);
-  UP(child_ptr, child_ptr); UP(child_idx, child_idx); UP(fbs_parent, fbs_parent); UP(fbs_parent_pos, fbs_parent_pos);
+  UP(child_ptr, child_ptr); UP(child_idx, child_idx); UP(lvl_pos, lvl_pos);
+  T.max_level_width = ht.max_level_width;
+  UP(fbs_parent, fbs_parent); UP(fbs_parent_pos, fbs_parent_pos);
   UP(lfrom, lfrom); UP(lto, lto); UP(lyr, lyr); UP(lyi, lyi); UP(lrating, lrating);
   UP(lu_piv_bus, lu_piv_bus); UP(lu_nb_ptr, lu_nb_ptr); UP(lu_nb_bus, lu_nb_bus); UP(lu_nb_kj, lu_nb_kj);
   UP(lu_nb_jk, lu_nb_jk); UP(lu_pair_ptr, lu_pair_ptr); UP(lu_pair_ik, lu_pair_ik); UP(lu_pair_kj, lu_pair_kj);
@@ -457,7 +479,7 @@ int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_
 
 int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail(nullptr, GS_E_INVALID, "bad arguments");
-  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot"};
+  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds"};
   snprintf(buf, buflen,
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "

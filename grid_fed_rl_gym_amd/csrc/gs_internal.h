@@ -47,6 +47,8 @@ struct GsTables {
   const int32_t* parent_pos; // [n] CSR position of entry (i, parent[i])
   const int32_t* child_ptr;  // [n+1]
   const int32_t* child_idx;  // [n_active - n_roots]
+  const int32_t* lvl_pos;    // [n] position of bus i inside its level (message slot), -1 if inactive
+  int32_t max_level_width, pad3;
   // FBS: tree rooted at the slack bus (levels exclude the slack itself); fbs_parent includes the slack
   const int32_t* fbs_parent;     // [n]
   const int32_t* fbs_parent_pos; // [n]

@@ -11,6 +11,7 @@
 
 extern "C" {
 GS_DECLARE_KERNELS(nr_tree)
+GS_DECLARE_KERNELS(nr_tree_lds)
 GS_DECLARE_KERNELS(nr_lu)
 GS_DECLARE_KERNELS(nr_dense)
 GS_DECLARE_KERNELS(fbs)

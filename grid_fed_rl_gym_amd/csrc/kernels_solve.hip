@@ -40,9 +40,19 @@ __device__ __forceinline__ double finite_or_inf(double v) { return (fabs(v) < IN
 struct GsShared {
   double red[2][GS_MAX_WAVES][GS_LANES];
   int flag[2][GS_MAX_WAVES][GS_LANES];
-  double post[4][GS_MAX_WAVES][GS_LANES];
-  int posti[2][GS_MAX_WAVES][GS_LANES];
 };
+
+// Dynamic LDS (size chosen by the host, gs_dyn_lds_bytes()): during the forest sweeps it holds the
+// child -> parent / parent -> child messages of two adjacent levels, [slot][6][64 lanes]; in the
+// epilogue it is reused for the cross-wave partial results.
+extern __shared__ __attribute__((aligned(16))) double gs_dyn[];
+#define GS_MSG_DOUBLES 6
+#define GS_EPI_DOUBLES (4 * GS_MAX_WAVES * GS_LANES)   /* post[4][W][64] doubles, then posti[2][W][64] ints */
+
+// Barrier for waves that exchanged data through LDS only: wait for this wave's LDS traffic, then
+// rendezvous.  Unlike __syncthreads() it does not drain outstanding global loads/stores, so
+// prefetches issued before it stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct Ctx {
   const GsTables& T;
@@ -122,10 +132,8 @@ __device__ __forceinline__ double mismatch_rows(Ctx& c) {
 // ---- Jacobian blocks --------------------------------------------------------------------------
 struct Blk { double a00, a01, a10, a11; };
 
-// diagonal block of bus i (power_flow.py:247-248, 259-260, 270-271, 283-284)
-__device__ __forceinline__ Blk diag_block(Ctx& c, int i, int exact) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
-  const double vm = ROW(R.VM + i), P = ROW(R.PC + i), Q = ROW(R.QC + i);
+// diagonal block of bus i from values (power_flow.py:247-248, 259-260, 270-271, 283-284)
+__device__ __forceinline__ Blk diag_from(const GsTables& T, int i, int exact, double vm, double P, double Q) {
   const double gd = cld(T.Gd, i), bd = cld(T.Bd, i);
   const int th = cld(T.th_free, i), vf = cld(T.vm_free, i);
   Blk d;
@@ -137,11 +145,14 @@ __device__ __forceinline__ Blk diag_block(Ctx& c, int i, int exact) {
   return d;
 }
 
-// off-diagonal block, row bus i, column bus j (power_flow.py:251, 263, 274, 287)
-__device__ __forceinline__ Blk offdiag_block(Ctx& c, int i, int j, double g, double b) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
-  const double ei = ROW(R.E + i), fi = ROW(R.F + i), ej = ROW(R.E + j), fj = ROW(R.F + j);
-  const double vmj = ROW(R.VM + j);
+__device__ __forceinline__ Blk diag_block(Ctx& c, int i, int exact) {
+  const GsRows& R = c.R; double* S = c.S;
+  return diag_from(c.T, i, exact, ROW(R.VM + i), ROW(R.PC + i), ROW(R.QC + i));
+}
+
+// off-diagonal block, row bus i, column bus j, from values (power_flow.py:251, 263, 274, 287)
+__device__ __forceinline__ Blk offdiag_from(const GsTables& T, int i, int j, double g, double b, double ei, double fi,
+                                            double ej, double fj, double vmj) {
   const double a = ei * ej + fi * fj;
   const double bb = fi * ej - ei * fj;
   const double gs_bc = g * bb - b * a;     // Vi Vj (G sin - B cos)
@@ -154,6 +165,11 @@ __device__ __forceinline__ Blk offdiag_block(Ctx& c, int i, int j, double g, dou
   u.a10 = (vfi && thj) ? -gc_bs : 0.0;
   u.a11 = (vfi && vfj) ? gs_bc / vmj : 0.0;
   return u;
+}
+
+__device__ __forceinline__ Blk offdiag_block(Ctx& c, int i, int j, double g, double b) {
+  const GsRows& R = c.R; double* S = c.S;
+  return offdiag_from(c.T, i, j, g, b, ROW(R.E + i), ROW(R.F + i), ROW(R.E + j), ROW(R.F + j), ROW(R.VM + j));
 }
 
 __device__ __forceinline__ Blk mul(const Blk& x, const Blk& y) {
@@ -210,7 +226,7 @@ __device__ __forceinline__ void nr_check(NrState& st, double mm, int it, double 
   }
 }
 
-enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3 };
+enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3, KIND_TREE_LDS = 4 };
 
 // =============================================================================================
 // Linear solves.  Each takes the mismatch in R0/R1 and the current E/F/VM/PC/QC rows, leaves the
@@ -275,6 +291,153 @@ __device__ __forceinline__ void linsolve_tree(Ctx& c, const GsSolveCfg& C, NrSta
     }
     __syncthreads();
   }
+}
+
+// ---- the same forest elimination with its critical path taken out of HBM --------------------------
+// The sweeps are a chain of n_levels dependent phases; what makes a phase long is not arithmetic
+// but the round trip of its operands through L2/HBM and the store drain at the barrier.  Here
+//  * the child -> parent messages (C, q) and the parent -> child messages (x) of two adjacent
+//    levels live in LDS slots ([parity][position in level][6][64 lanes]);
+//  * the operands that do NOT depend on the sweep (V, calculated P/Q, mismatch of the bus and of
+//    its parent) are fetched one work item ahead, and the phases are separated by lds_barrier(),
+//    which leaves those global loads (and the T/s stores) in flight;
+//  * the rectangular voltage is recomputed in the top-down pass, right where V is updated.
+// T_i and s_i go to the slab (HBM) in the bottom-up pass and come back, prefetched, in the
+// top-down pass on the same wave.  Same arithmetic, same order of operations as linsolve_tree.
+struct BuOperands { double vm, pc, qc, r0, r1, ei, fi, ep, fp, vmp; int i, p; };
+struct TdOperands { double t00, t01, t10, t11, s0, s1, vm, va; int i, p; };
+
+__device__ __forceinline__ BuOperands fetch_bu(Ctx& c, int t) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  BuOperands o;
+  o.i = cld(T.lvl_bus, t);
+  o.p = cld(T.parent, o.i);
+  o.vm = ROW(R.VM + o.i); o.pc = ROW(R.PC + o.i); o.qc = ROW(R.QC + o.i);
+  o.r0 = ROW(R.R0 + o.i); o.r1 = ROW(R.R1 + o.i);
+  o.ei = ROW(R.E + o.i); o.fi = ROW(R.F + o.i);
+  const int pj = o.p >= 0 ? o.p : o.i;
+  o.ep = ROW(R.E + pj); o.fp = ROW(R.F + pj); o.vmp = ROW(R.VM + pj);
+  return o;
+}
+
+__device__ __forceinline__ TdOperands fetch_td(Ctx& c, int t) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  TdOperands o;
+  o.i = cld(T.lvl_bus, t);
+  o.p = cld(T.parent, o.i);
+  o.t00 = ROW(R.TB + 4 * o.i); o.t01 = ROW(R.TB + 4 * o.i + 1);
+  o.t10 = ROW(R.TB + 4 * o.i + 2); o.t11 = ROW(R.TB + 4 * o.i + 3);
+  o.s0 = ROW(R.SV + 2 * o.i); o.s1 = ROW(R.SV + 2 * o.i + 1);
+  o.vm = ROW(R.VM + o.i); o.va = ROW(R.VA + o.i);
+  return o;
+}
+
+// next work item of this wave in sweep order: same level if any is left, else the wave's first
+// item of the following level (dir = +1 bottom-up, -1 top-down); -1 when the sweep is over
+__device__ __forceinline__ int next_item(Ctx& c, int lv, int t, int dir, int* nlv) {
+  const GsTables& T = c.T;
+  if (t + c.W < cld(T.lvl_ptr, lv + 1)) { *nlv = lv; return t + c.W; }
+  for (int l = lv + dir; l >= 0 && l < T.n_levels; l += dir) {
+    const int t0 = cld(T.lvl_ptr, l) + c.wave;
+    if (t0 < cld(T.lvl_ptr, l + 1)) { *nlv = l; return t0; }
+  }
+  *nlv = -1;
+  return -1;
+}
+
+__device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const int maxw = T.max_level_width;
+  double* msg = gs_dyn + c.lane;                       // slot s, component k at msg[(s * 6 + k) * 64]
+#define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
+  int sing = 0;
+  // ---------------- bottom-up ----------------
+  int nlv = -1;
+  int tn = -1;
+  {  // first item of this wave
+    for (int l = 0; l < T.n_levels; ++l) {
+      const int t0 = cld(T.lvl_ptr, l) + c.wave;
+      if (t0 < cld(T.lvl_ptr, l + 1)) { nlv = l; tn = t0; break; }
+    }
+  }
+  BuOperands nx{};
+  if (tn >= 0) nx = fetch_bu(c, tn);
+  for (int lv = 0; lv < T.n_levels; ++lv) {
+    while (nlv == lv) {
+      const BuOperands o = nx;
+      const int t = tn;
+      tn = next_item(c, lv, t, +1, &nlv);
+      if (tn >= 0) nx = fetch_bu(c, tn);               // operands of the next item: in flight from here
+      const int i = o.i;
+      Blk d = diag_from(T, i, C.jacobian_exact, o.vm, o.pc, o.qc);
+      double r0 = o.r0, r1 = o.r1;
+      const int c1 = cld(T.child_ptr, i + 1);
+      for (int cp = cld(T.child_ptr, i); cp < c1; ++cp) {
+        const int slot = ((lv - 1) & 1) * maxw + cld(T.lvl_pos, cld(T.child_idx, cp));
+        d.a00 -= MSG(slot, 0); d.a01 -= MSG(slot, 1); d.a10 -= MSG(slot, 2); d.a11 -= MSG(slot, 3);
+        r0 -= MSG(slot, 4); r1 -= MSG(slot, 5);
+      }
+      const Blk inv = inv2(d, &sing);
+      const double s0 = inv.a00 * r0 + inv.a01 * r1, s1 = inv.a10 * r0 + inv.a11 * r1;
+      ROW(R.SV + 2 * i) = s0; ROW(R.SV + 2 * i + 1) = s1;
+      if (o.p >= 0) {
+        const int pp = cld(T.parent_pos, i);
+        const double g = cld(T.G, pp), b = cld(T.Bv, pp);
+        const Blk u = offdiag_from(T, i, o.p, g, b, o.ei, o.fi, o.ep, o.fp, o.vmp);    // J(i, p)
+        const Blk l = offdiag_from(T, o.p, i, g, b, o.ep, o.fp, o.ei, o.fi, o.vm);     // J(p, i)
+        const Blk tb = mul(inv, u);
+        store_blk(S, R.TB + 4 * i, tb);
+        const Blk cb = mul(l, tb);
+        const int slot = (lv & 1) * maxw + (t - cld(T.lvl_ptr, lv));
+        MSG(slot, 0) = cb.a00; MSG(slot, 1) = cb.a01; MSG(slot, 2) = cb.a10; MSG(slot, 3) = cb.a11;
+        MSG(slot, 4) = l.a00 * s0 + l.a01 * s1;
+        MSG(slot, 5) = l.a10 * s0 + l.a11 * s1;
+      }
+    }
+    lds_barrier();
+  }
+  const int sing_all = wg_or(c, par, sing);            // full barrier: also drains the T/s stores
+  if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+  const bool upd = !st.done;
+  // ---------------- top-down: substitution, voltage update, new rectangular voltage ----------------
+  nlv = -1; tn = -1;
+  for (int l = T.n_levels - 1; l >= 0; --l) {
+    const int t0 = cld(T.lvl_ptr, l) + c.wave;
+    if (t0 < cld(T.lvl_ptr, l + 1)) { nlv = l; tn = t0; break; }
+  }
+  TdOperands ny{};
+  if (tn >= 0) ny = fetch_td(c, tn);
+  for (int lv = T.n_levels - 1; lv >= 0; --lv) {
+    while (nlv == lv) {
+      const TdOperands o = ny;
+      const int t = tn;
+      tn = next_item(c, lv, t, -1, &nlv);
+      if (tn >= 0) ny = fetch_td(c, tn);
+      const int i = o.i;
+      double x0 = o.s0, x1 = o.s1;
+      if (o.p >= 0) {
+        const int ps = ((lv + 1) & 1) * maxw + cld(T.lvl_pos, o.p);
+        const double xp0 = MSG(ps, 0), xp1 = MSG(ps, 1);
+        x0 -= o.t00 * xp0 + o.t01 * xp1;
+        x1 -= o.t10 * xp0 + o.t11 * xp1;
+      }
+      const int slot = (lv & 1) * maxw + (t - cld(T.lvl_ptr, lv));
+      MSG(slot, 0) = x0; MSG(slot, 1) = x1;
+      double vm = o.vm, va = o.va;
+      if (upd) {                                       // power_flow.py:315-327
+        if (cld(T.th_free, i)) va += C.alpha * x0;
+        if (cld(T.vm_free, i)) vm += C.alpha * x1;
+        if (vm < 0.0) { vm = -vm; va += M_PI; }
+        ROW(R.VM + i) = vm; ROW(R.VA + i) = va;
+        double sn, cs;
+        sincos(va, &sn, &cs);
+        ROW(R.E + i) = vm * cs; ROW(R.F + i) = vm * sn;
+      }
+    }
+    lds_barrier();
+  }
+#undef MSG
+  __syncthreads();                                     // V, E, F of every bus visible to every wave
 }
 
 // ---- meshed Jacobian: statically scheduled 2x2-block sparse LU ------------------------------------
@@ -437,20 +600,25 @@ __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState
   __syncthreads();
   bool stale = true;
   for (int it = 0; it < C.max_iterations; ++it) {
-    to_rect(c);
-    __syncthreads();
+    if (KIND != KIND_TREE_LDS || it == 0) {             // the LDS forest solve refreshes E/F itself
+      to_rect(c);
+      __syncthreads();
+    }
     const double mm = wg_max(c, it & 1, mismatch_rows(c));
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
     if (KIND == KIND_TREE) linsolve_tree(c, C, st, it & 1);
+    else if (KIND == KIND_TREE_LDS) linsolve_tree_lds(c, C, st, it & 1);
     else if (KIND == KIND_LU) linsolve_lu(c, C, st, it & 1);
     else linsolve_dense(c, C, st, it & 1);
     stale = true;
   }
   if (stale) {
-    to_rect(c);
-    __syncthreads();
+    if (KIND != KIND_TREE_LDS) {
+      to_rect(c);
+      __syncthreads();
+    }
     (void)mismatch_rows(c);
   }
   __syncthreads();
@@ -554,31 +722,34 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
       over += (ld > 0.8) ? 1 : 0;
     }
   }
-  c.sh.post[0][c.wave][c.lane] = lsum;
+  double* post = gs_dyn + c.lane;                               // post[k][wave][lane]
+  int* posti = (int*)(gs_dyn + GS_EPI_DOUBLES) + c.lane;        // posti[k][wave][lane]
+#define POST(k, w) post[((k) * GS_MAX_WAVES + (w)) * GS_LANES]
+#define POSTI(k, w) posti[((k) * GS_MAX_WAVES + (w)) * GS_LANES]
+  POST(0, c.wave) = lsum;
   if (ENV) {
-    c.sh.post[1][c.wave][c.lane] = dev;
-    c.sh.post[2][c.wave][c.lane] = vmax;
-    c.sh.post[3][c.wave][c.lane] = vmin;
-    c.sh.posti[0][c.wave][c.lane] = over;
-    c.sh.posti[1][c.wave][c.lane] = vflags;
+    POST(1, c.wave) = dev; POST(2, c.wave) = vmax; POST(3, c.wave) = vmin;
+    POSTI(0, c.wave) = over; POSTI(1, c.wave) = vflags;
   }
   __syncthreads();
   if (c.wave != 0) return;
-  double losses = c.sh.post[0][0][c.lane];
-  for (int w = 1; w < c.W; ++w) losses += c.sh.post[0][w][c.lane];
+  double losses = POST(0, 0);
+  for (int w = 1; w < c.W; ++w) losses += POST(0, w);
   ROW(R.LOSSES) = losses;
   ROW(R.MAXMIS) = st.mm;
   ROW(R.ITERS) = (double)st.iters;
   ROW(R.CONV) = (double)st.conv;
   ROW(R.STATUS) = (double)st.status;
   if (!ENV) return;
-  dev = c.sh.post[1][0][c.lane]; vmax = c.sh.post[2][0][c.lane]; vmin = c.sh.post[3][0][c.lane];
-  over = c.sh.posti[0][0][c.lane]; vflags = c.sh.posti[1][0][c.lane];
+  dev = POST(1, 0); vmax = POST(2, 0); vmin = POST(3, 0);
+  over = POSTI(0, 0); vflags = POSTI(1, 0);
   for (int w = 1; w < c.W; ++w) {
-    dev += c.sh.post[1][w][c.lane];
-    vmax = fmax(vmax, c.sh.post[2][w][c.lane]); vmin = fmin(vmin, c.sh.post[3][w][c.lane]);
-    over += c.sh.posti[0][w][c.lane]; vflags |= c.sh.posti[1][w][c.lane];
+    dev += POST(1, w);
+    vmax = fmax(vmax, POST(2, w)); vmin = fmin(vmin, POST(3, w));
+    over += POSTI(0, w); vflags |= POSTI(1, w);
   }
+#undef POST
+#undef POSTI
   const double dt = E.timestep;
   const double totloss = ROW(R.TOTLOSS) + losses * dt / 3600.0;        // grid_env.py:739
   ROW(R.TOTLOSS) = totloss;
@@ -669,6 +840,7 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   }
 
 GS_DEFINE_KERNELS(nr_tree, KIND_TREE)
+GS_DEFINE_KERNELS(nr_tree_lds, KIND_TREE_LDS)
 GS_DEFINE_KERNELS(nr_lu, KIND_LU)
 GS_DEFINE_KERNELS(nr_dense, KIND_DENSE)
 GS_DEFINE_KERNELS(fbs, KIND_FBS)

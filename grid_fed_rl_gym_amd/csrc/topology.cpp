@@ -155,6 +155,9 @@ std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want
       o.max_level_width = std::max(o.max_level_width, (int)o.lvl_bus.size() - o.lvl_ptr[lv]);
     }
     o.lvl_ptr[o.n_levels] = (int)o.lvl_bus.size();
+    o.lvl_pos.assign(n, -1);
+    for (int lv = 0; lv < o.n_levels; ++lv)
+      for (int t = o.lvl_ptr[lv]; t < o.lvl_ptr[lv + 1]; ++t) o.lvl_pos[o.lvl_bus[t]] = t - o.lvl_ptr[lv];
     o.child_ptr.assign(n + 1, 0);
     std::vector<std::vector<int>> ch(n);
     for (int i = 0; i < n; ++i) if (active[i] && o.parent[i] >= 0) ch[o.parent[i]].push_back(i);
@@ -162,7 +165,7 @@ std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want
     o.child_ptr[n] = (int)o.child_idx.size();
   } else {
     o.parent.assign(n, -1); o.parent_pos.assign(n, -1);
-    o.lvl_ptr.assign(1, 0); o.child_ptr.assign(n + 1, 0);
+    o.lvl_ptr.assign(1, 0); o.child_ptr.assign(n + 1, 0); o.lvl_pos.assign(n, -1);
   }
 
   // ---- FBS eligibility: whole network is a tree under the slack, all other buses pq --------

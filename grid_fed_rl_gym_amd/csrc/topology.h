@@ -19,7 +19,7 @@ struct HostTopology {
   // forest over active buses
   bool is_forest = false;
   int n_levels = 0, n_active = 0, max_level_width = 0;
-  std::vector<int32_t> lvl_ptr, lvl_bus, parent, parent_pos, child_ptr, child_idx;
+  std::vector<int32_t> lvl_ptr, lvl_bus, parent, parent_pos, child_ptr, child_idx, lvl_pos;
   // FBS
   bool fbs_ok = false;
   std::string fbs_why;
