@@ -93,6 +93,7 @@ SYMBOLS = [
     ("gs_comm_destroy", C.c_int, [_H]),
     ("gs_timing_enable", C.c_int, [_H, C.c_int32]),
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
+    ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -336,6 +337,13 @@ class Handle:
     # -- measurement ----------------------------------------------------------------------
     def timing_enable(self, on: bool = True) -> None:
         self._check(self._lib.gs_timing_enable(self._h, 1 if on else 0))
+
+    STAMP_NAMES = ["prologue", "init", "mismatch", "bottom_up", "flag", "top_down", "final_mismatch", "epilogue"]
+
+    def debug_stamps(self) -> dict:
+        buf = (C.c_uint64 * 8)()
+        self._check(self._lib.gs_debug_stamps(self._h, buf, 8))
+        return {n: int(buf[k]) for k, n in enumerate(self.STAMP_NAMES)}
 
     def timing_read(self) -> dict:
         ms = (C.c_double * 5)()

@@ -21,7 +21,7 @@ __device__ __forceinline__ X cld(const X* p, int i) {
   return ((const GS_CONST X*)p)[i];
 }
 
-// ---- Philox4x32-10; same stream as oracle/oracle_np.py::philox4x32 and oracle_cpu.c ------------
+// ---- Philox4x32-10 (Salmon et al. 2011), key = seed, counter = (instance, step, draw, tag) ------
 struct U4 { uint32_t a, b, c, d; };
 
 __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {

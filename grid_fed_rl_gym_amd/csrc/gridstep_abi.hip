@@ -76,6 +76,7 @@ struct gs_handle {
   double total_load = 0.0;
   int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs, 3 dense, 4 tree with LDS messages
   size_t dyn_lds = 0;
+  unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
   std::vector<void*> allocs;
   double* slab = nullptr;
@@ -348,7 +349,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   R.P = take(n); R.Q = take(n); R.VM = take(n); R.VA = take(n); R.FLOW = take(m); R.LOAD = take(m);
   R.LOSSES = take(1); R.MAXMIS = take(1); R.ITERS = take(1); R.CONV = take(1); R.STATUS = take(1);
   R.E = take(n); R.F = take(n); R.PC = take(n); R.QC = take(n); R.R0 = take(n); R.R1 = take(n);
-  R.X0 = take(n); R.X1 = take(n);
+  R.X0 = take(n); R.X1 = take(n); R.RVM = take(n);
   R.SV = take(2 * n); R.QV = take(2 * n); R.TB = take(4 * n); R.CB = take(4 * n);
   R.JR = take(n); R.JI = take(n);
   R.LU = take(h->solve_kernel == 1 ? 4 * ht.lu_n_slots : 0);
@@ -365,6 +366,74 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   R.ACT = take(h->action_dim); R.LOADP = take(h->n_loads);
   R.total = r;
 
+  // ---- per-wave work lists of the forest sweeps (records in the order each wave meets them) ----
+  std::vector<GsItemRec> witems;
+  std::vector<int32_t> wl_ptr(h->W + 1, 0), ovf_slot;
+  if (ht.is_forest) {
+    const int maxw = ht.max_level_width;
+    for (int w = 0; w < h->W; ++w) {
+      wl_ptr[w] = (int)witems.size();
+      for (int lv = 0; lv < ht.n_levels; ++lv)
+        for (int t = ht.lvl_ptr[lv] + w; t < ht.lvl_ptr[lv + 1]; t += h->W) {
+          GsItemRec r{};
+          const int i = ht.lvl_bus[t], p = ht.parent[i];
+          r.bus = i; r.parent = p; r.level = lv;
+          r.slot = (lv & 1) * maxw + (t - ht.lvl_ptr[lv]);
+          r.parent_slot = p >= 0 ? ((lv + 1) & 1) * maxw + ht.lvl_pos[p] : 0;
+          r.flags = (ht.th_free[i] ? 1 : 0) | (ht.vm_free[i] ? 2 : 0) |
+                    (p >= 0 && ht.th_free[p] ? 4 : 0) | (p >= 0 && ht.vm_free[p] ? 8 : 0);
+          r.n_children = ht.child_ptr[i + 1] - ht.child_ptr[i];
+          r.ovf0 = (int)ovf_slot.size();
+          for (int q = 0; q < r.n_children; ++q) {
+            const int ch = ht.child_idx[ht.child_ptr[i] + q];
+            const int cs = ((lv - 1) & 1) * maxw + ht.lvl_pos[ch];
+            if (q < GS_ITEM_CHILDREN) r.child_slot[q] = cs; else ovf_slot.push_back(cs);
+          }
+          if (p >= 0) { r.g = ht.G[ht.parent_pos[i]]; r.b = ht.B[ht.parent_pos[i]]; }
+          r.gd = ht.Gd[i]; r.bd = ht.Bd[i];
+          witems.push_back(r);
+        }
+    }
+    wl_ptr[h->W] = (int)witems.size();
+  }
+
+  // mismatch records: each bus' Ybus row in chunks of GS_ELL_K entries (same entry order as the
+  // CSR row); buses are dealt to the waves longest row first so that every wave gets about the
+  // same number of records
+  std::vector<GsBusRec> wbus;
+  std::vector<int32_t> wb_ptr(h->W + 1, 0);
+  {
+    std::vector<int> order(ht.n), nrec(ht.n);
+    for (int i = 0; i < ht.n; ++i) { order[i] = i; nrec[i] = std::max(1, (ht.row_ptr[i + 1] - ht.row_ptr[i] + GS_ELL_K - 1) / GS_ELL_K); }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return nrec[a] > nrec[b2]; });
+    std::vector<std::vector<int>> mine(h->W);
+    std::vector<int> load(h->W, 0);
+    for (int i : order) {
+      int best = 0;
+      for (int w = 1; w < h->W; ++w) if (load[w] < load[best]) best = w;
+      mine[best].push_back(i); load[best] += nrec[i];
+    }
+    for (int w = 0; w < h->W; ++w) {
+      wb_ptr[w] = (int)wbus.size();
+      std::sort(mine[w].begin(), mine[w].end());
+      for (int i : mine[w]) {
+        const int p0 = ht.row_ptr[i], p1 = ht.row_ptr[i + 1];
+        for (int c0 = 0; c0 < nrec[i]; ++c0) {
+          GsBusRec r{};
+          r.bus = i;
+          r.flags = (ht.th_free[i] ? 1 : 0) | (ht.vm_free[i] ? 2 : 0) | (c0 + 1 < nrec[i] ? 4 : 0) | (c0 > 0 ? 8 : 0);
+          for (int k = 0; k < GS_ELL_K; ++k) {
+            const int p = p0 + c0 * GS_ELL_K + k;
+            if (p < p1) { r.col[k] = ht.col[p]; r.G[k] = ht.G[p]; r.B[k] = ht.B[p]; }
+            else { r.col[k] = i; r.G[k] = 0.0; r.B[k] = 0.0; }
+          }
+          wbus.push_back(r);
+        }
+      }
+    }
+    wb_ptr[h->W] = (int)wbus.size();
+  }
+
   // ---- tables ----
   GsTables& T = h->T;
   T.n = n; T.m = m; T.nnz = ht.nnz; T.n_levels = ht.n_levels;
@@ -373,10 +442,14 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   T.dn_N = ht.dn_N;
   int rc = 0;
 #define UP(field, vec) if ((rc = dev_upload(h, &T.field, ht.vec))) return bail(rc)
+  UP(ell_col, ell_col); UP(ell_G, ell_G); UP(ell_B, ell_B); UP(rem_ptr, rem_ptr); UP(rem_col, rem_col);
+  UP(rem_G, rem_G); UP(rem_B, rem_B);
   UP(row_ptr, row_ptr); UP(col, col); UP(G, G); UP(Bv, B); UP(Gd, Gd); UP(Bd, Bd);
   UP(th_free, th_free); UP(vm_free, vm_free); UP(v_set, v_set); UP(fixed_v, fixed_v);
   UP(lvl_ptr, lvl_ptr); UP(lvl_bus, lvl_bus); UP(parent, parent); UP(parent_pos, parent_pos);
   UP(child_ptr, child_ptr); UP(child_idx, child_idx); UP(lvl_pos, lvl_pos);
+  if ((rc = dev_upload(h, &T.wbus, wbus)) || (rc = dev_upload(h, &T.wb_ptr, wb_ptr))) return bail(rc);
+  if ((rc = dev_upload(h, &T.witems, witems)) || (rc = dev_upload(h, &T.wl_ptr, wl_ptr)) || (rc = dev_upload(h, &T.ovf_slot, ovf_slot))) return bail(rc);
   T.max_level_width = ht.max_level_width;
   UP(fbs_parent, fbs_parent); UP(fbs_parent_pos, fbs_parent_pos);
   UP(lfrom, lfrom); UP(lto, lto); UP(lyr, lyr); UP(lyi, lyi); UP(lrating, lrating);
@@ -669,6 +742,26 @@ int gs_comm_destroy(gs_handle* h) {
 }
 
 // ---- measurement ------------------------------------------------------------------------------------
+int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
+  if (!h || !cycles_out || n < 1 || n > 16) return fail(h, GS_E_INVALID, "bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!h->d_stamps) {
+    int rc = dev_alloc(h, &h->d_stamps, 16);
+    if (rc) return rc;
+    HIPCHK(h, hipMemset(h->d_stamps, 0, 16 * sizeof(unsigned long long)));
+    h->SC.stamps = h->d_stamps;
+    h->SC.stamp_wave = getenv("GS_STAMP_WAVE") ? atoi(getenv("GS_STAMP_WAVE")) : 0;
+    for (int k = 0; k < n; ++k) cycles_out[k] = 0;
+    return GS_OK;
+  }
+  unsigned long long tmp[16];
+  HIPCHK(h, hipMemcpy(tmp, h->d_stamps, sizeof tmp, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemset(h->d_stamps, 0, sizeof tmp));
+  for (int k = 0; k < n; ++k) cycles_out[k] = tmp[k];
+  return GS_OK;
+}
+
 int gs_timing_enable(gs_handle* h, int32_t on) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -15,6 +15,7 @@
 
 #define GS_LANES 64
 #define GS_MAX_WAVES 16
+#define GS_ELL_K 4        // Ybus rows are stored in chunks of 4 entries (padded with exact zeros)
 
 // pointer into the constant address space: forces scalar (s_load) access for uniform tables
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -22,6 +23,25 @@
 #else
 #define GS_CONST
 #endif
+
+// One forest work item (a bus, in the order ONE wave meets it in the sweeps) with everything the
+// sweep needs that does not depend on the instance: read as one contiguous scalar load, and the
+// next record of the wave is the next 96 bytes (prefetched one item ahead).
+#define GS_ITEM_CHILDREN 8
+struct GsItemRec {
+  int32_t bus, parent, slot, parent_slot;     // message slots already include the level parity
+  int32_t n_children, flags, level, ovf0;     // flags: bit0 th_i, bit1 vf_i, bit2 th_p, bit3 vf_p; ovf0: first overflow child
+  int32_t child_slot[GS_ITEM_CHILDREN];       // slots of the first 8 children (more: ovf_slot[ovf0 ...])
+  double g, b, gd, bd;                        // Y(bus, parent) and Y(bus, bus)
+};
+
+// One bus of the mismatch pass, in the order ONE wave meets it: its Ybus row in ELL(8) form.
+struct GsBusRec {
+  int32_t bus, flags, pad0, pad1;             // flags: bit0 th_free, bit1 vm_free, bit2 row continues in the next record,
+                                              //        bit3 this record continues the previous one
+  int32_t col[GS_ELL_K];                      // neighbours (self included), padded with self
+  double G[GS_ELL_K], B[GS_ELL_K];            // padded with exact zeros
+};
 
 // Topology-uniform tables (device pointers; built once per handle by topology.cpp).
 struct GsTables {
@@ -32,6 +52,15 @@ struct GsTables {
   const int32_t* col;        // [nnz]
   const double* G;           // [nnz]
   const double* Bv;          // [nnz]
+  // the same rows in ELL form for the mismatch: entry k of row i at [i * GS_ELL_K + k], rows
+  // shorter than GS_ELL_K padded with (col = i, G = B = 0); longer rows continue in rem_*
+  const int32_t* ell_col;    // [n * GS_ELL_K]
+  const double* ell_G;       // [n * GS_ELL_K]
+  const double* ell_B;       // [n * GS_ELL_K]
+  const int32_t* rem_ptr;    // [n+1]
+  const int32_t* rem_col;
+  const double* rem_G;
+  const double* rem_B;
   const double* Gd;          // [n] diagonal
   const double* Bd;          // [n]
   // unknown masks: th_free = bus has a theta unknown / P equation (non-slack, power_flow.py:232);
@@ -48,6 +77,12 @@ struct GsTables {
   const int32_t* child_ptr;  // [n+1]
   const int32_t* child_idx;  // [n_active - n_roots]
   const int32_t* lvl_pos;    // [n] position of bus i inside its level (message slot), -1 if inactive
+  // per-wave work lists of the forest sweeps (built for the handle's waves_per_group)
+  const GsItemRec* witems;   // records grouped by wave, bottom-up order inside a wave
+  const int32_t* wl_ptr;     // [W+1]
+  const int32_t* ovf_slot;   // child slots beyond the 8 kept in the record
+  const GsBusRec* wbus;      // mismatch records grouped by wave (buses dealt to waves by row length, longest first)
+  const int32_t* wb_ptr;     // [W+1]
   int32_t max_level_width, pad3;
   // FBS: tree rooted at the slack bus (levels exclude the slack itself); fbs_parent includes the slack
   const int32_t* fbs_parent;     // [n]
@@ -110,6 +145,7 @@ struct GsRows {
   int32_t PC, QC;            // [n] calculated injections
   int32_t R0, R1;            // [n] mismatch (rhs)
   int32_t X0, X1;            // [n] Newton step
+  int32_t RVM;               // [n] 1 / Vm (kept by the LDS forest solve)
   int32_t SV;                // [2n] inv(D) r
   int32_t QV;                // [2n] child -> parent rhs contribution
   int32_t TB;                // [4n] inv(D) U
@@ -133,6 +169,8 @@ struct GsRows {
 struct GsSolveCfg {
   double tolerance, alpha;
   int32_t max_iterations, jacobian_exact;
+  unsigned long long* stamps;   // diagnostic: per-phase cycle sums of block 0 / wave stamp_wave (NULL = off)
+  int32_t stamp_wave, pad;
 };
 
 struct GsEnvCfg {

@@ -60,7 +60,21 @@ struct Ctx {
   double* S;
   GsShared& sh;
   int lane, wave, W;
+  unsigned long long* stamps;
+  unsigned long long tlast;
+  int stamp_wave;
 };
+
+// Diagnostic phase stamps (gs_debug_stamps): block 0 / wave 0 / lane 0 adds the cycles since its
+// previous stamp to slot `k`.  Off (one scalar branch) unless the host armed a buffer; the values
+// go to that buffer only and feed nothing.
+enum { ST_PROLOGUE = 0, ST_INIT, ST_MISMATCH, ST_BOTTOM_UP, ST_FLAG, ST_TOP_DOWN, ST_FINAL_MISMATCH, ST_EPILOGUE, ST_COUNT };
+__device__ __forceinline__ void stamp(Ctx& c, int k) {
+  if (c.stamps == nullptr) return;
+  const unsigned long long now = __builtin_readcyclecounter();
+  if (blockIdx.x == 0 && c.wave == c.stamp_wave && c.lane == 0) c.stamps[k] += now - c.tlast;
+  c.tlast = now;
+}
 
 __device__ __forceinline__ double wg_max(Ctx& c, int par, double v) {
   c.sh.red[par][c.wave][c.lane] = v;
@@ -82,8 +96,12 @@ __device__ __forceinline__ int wg_or(Ctx& c, int par, int v) {
 __device__ __forceinline__ void flat_start(Ctx& c) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   for (int i = c.wave; i < T.n; i += c.W) {
-    ROW(R.VM + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+    const double vm = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+    ROW(R.VM + i) = vm;
     ROW(R.VA + i) = 0.0;
+    ROW(R.E + i) = vm;          // vm * cos(0), vm * sin(0): exact
+    ROW(R.F + i) = 0.0;
+    ROW(R.RVM + i) = 1.0 / vm;
   }
 }
 
@@ -105,23 +123,43 @@ __device__ __forceinline__ void to_rect(Ctx& c) {
 __device__ __forceinline__ double mismatch_rows(Ctx& c) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double lmax = 0.0;
-  for (int i = c.wave; i < T.n; i += c.W) {
+  const int k0 = cld(T.wb_ptr, c.wave), k1 = cld(T.wb_ptr, c.wave + 1);
+  const GS_CONST GsBusRec* recs = (const GS_CONST GsBusRec*)T.wbus;
+  // header + neighbour indices of the wave's next bus are fetched one bus ahead (scalar loads in
+  // flight while the current bus computes); all vector loads of a bus are issued back to back
+  int hb = 0, hf = 0, hc[GS_ELL_K] = {};
+  if (k0 < k1) {
+    hb = recs[k0].bus; hf = recs[k0].flags;
+#pragma unroll
+    for (int k = 0; k < GS_ELL_K; ++k) hc[k] = recs[k0].col[k];
+  }
+  double P = 0.0, Q = 0.0;
+  for (int q = k0; q < k1; ++q) {
+    const int i = hb, fl = hf;
     const double ei = ROW(R.E + i), fi = ROW(R.F + i);
-    double P = 0.0, Q = 0.0;
-    const int p0 = cld(T.row_ptr, i), p1 = cld(T.row_ptr, i + 1);
-    for (int p = p0; p < p1; ++p) {
-      const int j = cld(T.col, p);
-      const double g = cld(T.G, p), b = cld(T.Bv, p);
-      const double ej = ROW(R.E + j), fj = ROW(R.F + j);
-      const double a = ei * ej + fi * fj;
-      const double bb = fi * ej - ei * fj;
+    double ej[GS_ELL_K], fj[GS_ELL_K];
+#pragma unroll
+    for (int k = 0; k < GS_ELL_K; ++k) { ej[k] = ROW(R.E + hc[k]); fj[k] = ROW(R.F + hc[k]); }
+    const double ps = ROW(R.P + i), qs = ROW(R.Q + i);
+    if (q + 1 < k1) {
+      hb = recs[q + 1].bus; hf = recs[q + 1].flags;
+#pragma unroll
+      for (int k = 0; k < GS_ELL_K; ++k) hc[k] = recs[q + 1].col[k];
+    }
+    if (!(fl & 8)) { P = 0.0; Q = 0.0; }               // a continuation record keeps accumulating
+#pragma unroll
+    for (int k = 0; k < GS_ELL_K; ++k) {
+      const double g = recs[q].G[k], b = recs[q].B[k];
+      const double a = ei * ej[k] + fi * fj[k];
+      const double bb = fi * ej[k] - ei * fj[k];
       P += g * a + b * bb;
       Q += g * bb - b * a;
     }
+    if (fl & 4) continue;                              // the row continues in the next record
     ROW(R.PC + i) = P;
     ROW(R.QC + i) = Q;
-    const double dP = cld(T.th_free, i) ? (ROW(R.P + i) - P) : 0.0;
-    const double dQ = cld(T.vm_free, i) ? (ROW(R.Q + i) - Q) : 0.0;
+    const double dP = (fl & 1) ? (ps - P) : 0.0;
+    const double dQ = (fl & 2) ? (qs - Q) : 0.0;
     ROW(R.R0 + i) = dP;
     ROW(R.R1 + i) = dQ;
     lmax = fmax(lmax, fmax(finite_or_inf(fabs(dP)), finite_or_inf(fabs(dQ))));
@@ -304,140 +342,188 @@ __device__ __forceinline__ void linsolve_tree(Ctx& c, const GsSolveCfg& C, NrSta
 //  * the rectangular voltage is recomputed in the top-down pass, right where V is updated.
 // T_i and s_i go to the slab (HBM) in the bottom-up pass and come back, prefetched, in the
 // top-down pass on the same wave.  Same arithmetic, same order of operations as linsolve_tree.
-struct BuOperands { double vm, pc, qc, r0, r1, ei, fi, ep, fp, vmp; int i, p; };
-struct TdOperands { double t00, t01, t10, t11, s0, s1, vm, va; int i, p; };
+struct BuOperands { double vm, rvm, pc, qc, r0, r1, ei, fi, ep, fp, rvmp; };
+struct TdOperands { double t00, t01, t10, t11, s0, s1, vm, va, rvm, e, f; };
 
-__device__ __forceinline__ BuOperands fetch_bu(Ctx& c, int t) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+__device__ __forceinline__ GsItemRec load_item(const GsTables& T, int k) {
+  const GS_CONST GsItemRec* p = (const GS_CONST GsItemRec*)T.witems + k;
+  GsItemRec r;
+  r.bus = p->bus; r.parent = p->parent; r.slot = p->slot; r.parent_slot = p->parent_slot;
+  r.n_children = p->n_children; r.flags = p->flags; r.level = p->level; r.ovf0 = p->ovf0;
+#pragma unroll
+  for (int q = 0; q < GS_ITEM_CHILDREN; ++q) r.child_slot[q] = p->child_slot[q];
+  r.g = p->g; r.b = p->b; r.gd = p->gd; r.bd = p->bd;
+  return r;
+}
+
+__device__ __forceinline__ BuOperands fetch_bu(Ctx& c, const GsItemRec& r) {
+  const GsRows& R = c.R; double* S = c.S;
   BuOperands o;
-  o.i = cld(T.lvl_bus, t);
-  o.p = cld(T.parent, o.i);
-  o.vm = ROW(R.VM + o.i); o.pc = ROW(R.PC + o.i); o.qc = ROW(R.QC + o.i);
-  o.r0 = ROW(R.R0 + o.i); o.r1 = ROW(R.R1 + o.i);
-  o.ei = ROW(R.E + o.i); o.fi = ROW(R.F + o.i);
-  const int pj = o.p >= 0 ? o.p : o.i;
-  o.ep = ROW(R.E + pj); o.fp = ROW(R.F + pj); o.vmp = ROW(R.VM + pj);
+  const int i = r.bus, pj = r.parent >= 0 ? r.parent : r.bus;
+  o.vm = ROW(R.VM + i); o.rvm = ROW(R.RVM + i); o.pc = ROW(R.PC + i); o.qc = ROW(R.QC + i);
+  o.r0 = ROW(R.R0 + i); o.r1 = ROW(R.R1 + i);
+  o.ei = ROW(R.E + i); o.fi = ROW(R.F + i);
+  o.ep = ROW(R.E + pj); o.fp = ROW(R.F + pj); o.rvmp = ROW(R.RVM + pj);
   return o;
 }
 
-__device__ __forceinline__ TdOperands fetch_td(Ctx& c, int t) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+__device__ __forceinline__ TdOperands fetch_td(Ctx& c, const GsItemRec& r) {
+  const GsRows& R = c.R; double* S = c.S;
   TdOperands o;
-  o.i = cld(T.lvl_bus, t);
-  o.p = cld(T.parent, o.i);
-  o.t00 = ROW(R.TB + 4 * o.i); o.t01 = ROW(R.TB + 4 * o.i + 1);
-  o.t10 = ROW(R.TB + 4 * o.i + 2); o.t11 = ROW(R.TB + 4 * o.i + 3);
-  o.s0 = ROW(R.SV + 2 * o.i); o.s1 = ROW(R.SV + 2 * o.i + 1);
-  o.vm = ROW(R.VM + o.i); o.va = ROW(R.VA + o.i);
+  const int i = r.bus;
+  o.t00 = ROW(R.TB + 4 * i); o.t01 = ROW(R.TB + 4 * i + 1);
+  o.t10 = ROW(R.TB + 4 * i + 2); o.t11 = ROW(R.TB + 4 * i + 3);
+  o.s0 = ROW(R.SV + 2 * i); o.s1 = ROW(R.SV + 2 * i + 1);
+  o.vm = ROW(R.VM + i); o.va = ROW(R.VA + i); o.rvm = ROW(R.RVM + i);
+  o.e = ROW(R.E + i); o.f = ROW(R.F + i);
   return o;
 }
 
-// next work item of this wave in sweep order: same level if any is left, else the wave's first
-// item of the following level (dir = +1 bottom-up, -1 top-down); -1 when the sweep is over
-__device__ __forceinline__ int next_item(Ctx& c, int lv, int t, int dir, int* nlv) {
-  const GsTables& T = c.T;
-  if (t + c.W < cld(T.lvl_ptr, lv + 1)) { *nlv = lv; return t + c.W; }
-  for (int l = lv + dir; l >= 0 && l < T.n_levels; l += dir) {
-    const int t0 = cld(T.lvl_ptr, l) + c.wave;
-    if (t0 < cld(T.lvl_ptr, l + 1)) { *nlv = l; return t0; }
-  }
-  *nlv = -1;
-  return -1;
+// J(i, j) / J(j, i) of the edge bus-parent from values and record flags (no table look-ups)
+__device__ __forceinline__ Blk edge_block(double g, double b, double ei, double fi, double ej, double fj, double rvmj,
+                                          int thi, int vfi, int thj, int vfj) {
+  const double a = ei * ej + fi * fj;
+  const double bb = fi * ej - ei * fj;
+  const double gs_bc = g * bb - b * a;
+  const double gc_bs = g * a + b * bb;
+  Blk u;
+  u.a00 = (thi && thj) ? gs_bc : 0.0;
+  u.a01 = (thi && vfj) ? gc_bs * rvmj : 0.0;
+  u.a10 = (vfi && thj) ? -gc_bs : 0.0;
+  u.a11 = (vfi && vfj) ? gs_bc * rvmj : 0.0;
+  return u;
 }
 
 __device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
-  const int maxw = T.max_level_width;
   double* msg = gs_dyn + c.lane;                       // slot s, component k at msg[(s * 6 + k) * 64]
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
+  const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
   int sing = 0;
   // ---------------- bottom-up ----------------
-  int nlv = -1;
-  int tn = -1;
-  {  // first item of this wave
-    for (int l = 0; l < T.n_levels; ++l) {
-      const int t0 = cld(T.lvl_ptr, l) + c.wave;
-      if (t0 < cld(T.lvl_ptr, l + 1)) { nlv = l; tn = t0; break; }
-    }
-  }
-  BuOperands nx{};
-  if (tn >= 0) nx = fetch_bu(c, tn);
-  for (int lv = 0; lv < T.n_levels; ++lv) {
-    while (nlv == lv) {
-      const BuOperands o = nx;
-      const int t = tn;
-      tn = next_item(c, lv, t, +1, &nlv);
-      if (tn >= 0) nx = fetch_bu(c, tn);               // operands of the next item: in flight from here
-      const int i = o.i;
-      Blk d = diag_from(T, i, C.jacobian_exact, o.vm, o.pc, o.qc);
+  {
+    int lv = 0;
+    GsItemRec rn{};
+    BuOperands on{};
+    if (k0 < k1) { rn = load_item(T, k0); on = fetch_bu(c, rn); }
+    for (int k = k0; k < k1; ++k) {
+      const GsItemRec r = rn;
+      const BuOperands o = on;
+      if (k + 1 < k1) { rn = load_item(T, k + 1); on = fetch_bu(c, rn); }   // next item: in flight from here
+      while (lv < r.level) { lds_barrier(); ++lv; }
+      const int i = r.bus;
+      const int thi = r.flags & 1, vfi = (r.flags >> 1) & 1, thp = (r.flags >> 2) & 1, vfp = (r.flags >> 3) & 1;
+      // diagonal block (power_flow.py:247-248, 259-260, 270-271, 283-284)
+      const double rvm = o.rvm;
+      Blk d;
+      {
+        const double vvb = o.vm * o.vm * r.bd;
+        d.a00 = thi ? (C.jacobian_exact ? (-o.qc - vvb) : (-o.qc + vvb)) : 1.0;
+        d.a01 = (thi && vfi) ? (o.pc * rvm + o.vm * r.gd) : 0.0;
+        d.a10 = (thi && vfi) ? (o.pc - o.vm * o.vm * r.gd) : 0.0;
+        d.a11 = vfi ? (o.qc * rvm - o.vm * r.bd) : 1.0;
+      }
       double r0 = o.r0, r1 = o.r1;
-      const int c1 = cld(T.child_ptr, i + 1);
-      for (int cp = cld(T.child_ptr, i); cp < c1; ++cp) {
-        const int slot = ((lv - 1) & 1) * maxw + cld(T.lvl_pos, cld(T.child_idx, cp));
+      const int nch = r.n_children;
+#pragma unroll
+      for (int q = 0; q < GS_ITEM_CHILDREN; ++q) {       // static indices: the record stays in SGPRs
+        if (q < nch) {
+          const int slot = r.child_slot[q];
+          d.a00 -= MSG(slot, 0); d.a01 -= MSG(slot, 1); d.a10 -= MSG(slot, 2); d.a11 -= MSG(slot, 3);
+          r0 -= MSG(slot, 4); r1 -= MSG(slot, 5);
+        }
+      }
+      for (int q = GS_ITEM_CHILDREN; q < nch; ++q) {
+        const int slot = cld(T.ovf_slot, r.ovf0 + q - GS_ITEM_CHILDREN);
         d.a00 -= MSG(slot, 0); d.a01 -= MSG(slot, 1); d.a10 -= MSG(slot, 2); d.a11 -= MSG(slot, 3);
         r0 -= MSG(slot, 4); r1 -= MSG(slot, 5);
       }
       const Blk inv = inv2(d, &sing);
       const double s0 = inv.a00 * r0 + inv.a01 * r1, s1 = inv.a10 * r0 + inv.a11 * r1;
       ROW(R.SV + 2 * i) = s0; ROW(R.SV + 2 * i + 1) = s1;
-      if (o.p >= 0) {
-        const int pp = cld(T.parent_pos, i);
-        const double g = cld(T.G, pp), b = cld(T.Bv, pp);
-        const Blk u = offdiag_from(T, i, o.p, g, b, o.ei, o.fi, o.ep, o.fp, o.vmp);    // J(i, p)
-        const Blk l = offdiag_from(T, o.p, i, g, b, o.ep, o.fp, o.ei, o.fi, o.vm);     // J(p, i)
+      if (r.parent >= 0) {
+        const double rvmp = o.rvmp;
+        const Blk u = edge_block(r.g, r.b, o.ei, o.fi, o.ep, o.fp, rvmp, thi, vfi, thp, vfp);    // J(i, p)
+        const Blk l = edge_block(r.g, r.b, o.ep, o.fp, o.ei, o.fi, rvm, thp, vfp, thi, vfi);     // J(p, i)
         const Blk tb = mul(inv, u);
         store_blk(S, R.TB + 4 * i, tb);
         const Blk cb = mul(l, tb);
-        const int slot = (lv & 1) * maxw + (t - cld(T.lvl_ptr, lv));
-        MSG(slot, 0) = cb.a00; MSG(slot, 1) = cb.a01; MSG(slot, 2) = cb.a10; MSG(slot, 3) = cb.a11;
-        MSG(slot, 4) = l.a00 * s0 + l.a01 * s1;
-        MSG(slot, 5) = l.a10 * s0 + l.a11 * s1;
+        MSG(r.slot, 0) = cb.a00; MSG(r.slot, 1) = cb.a01; MSG(r.slot, 2) = cb.a10; MSG(r.slot, 3) = cb.a11;
+        MSG(r.slot, 4) = l.a00 * s0 + l.a01 * s1;
+        MSG(r.slot, 5) = l.a10 * s0 + l.a11 * s1;
       }
     }
-    lds_barrier();
+    while (lv < T.n_levels) { lds_barrier(); ++lv; }
   }
+  stamp(c, ST_BOTTOM_UP);
   const int sing_all = wg_or(c, par, sing);            // full barrier: also drains the T/s stores
+  stamp(c, ST_FLAG);
   if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
   const bool upd = !st.done;
   // ---------------- top-down: substitution, voltage update, new rectangular voltage ----------------
-  nlv = -1; tn = -1;
-  for (int l = T.n_levels - 1; l >= 0; --l) {
-    const int t0 = cld(T.lvl_ptr, l) + c.wave;
-    if (t0 < cld(T.lvl_ptr, l + 1)) { nlv = l; tn = t0; break; }
-  }
-  TdOperands ny{};
-  if (tn >= 0) ny = fetch_td(c, tn);
-  for (int lv = T.n_levels - 1; lv >= 0; --lv) {
-    while (nlv == lv) {
-      const TdOperands o = ny;
-      const int t = tn;
-      tn = next_item(c, lv, t, -1, &nlv);
-      if (tn >= 0) ny = fetch_td(c, tn);
-      const int i = o.i;
+  {
+    int lv = T.n_levels - 1;
+    GsItemRec rn{};
+    TdOperands on{};
+    if (k0 < k1) { rn = load_item(T, k1 - 1); on = fetch_td(c, rn); }
+    for (int k = k1 - 1; k >= k0; --k) {
+      const GsItemRec r = rn;
+      const TdOperands o = on;
+      if (k - 1 >= k0) { rn = load_item(T, k - 1); on = fetch_td(c, rn); }
+      while (lv > r.level) { lds_barrier(); --lv; }
+      const int i = r.bus;
       double x0 = o.s0, x1 = o.s1;
-      if (o.p >= 0) {
-        const int ps = ((lv + 1) & 1) * maxw + cld(T.lvl_pos, o.p);
-        const double xp0 = MSG(ps, 0), xp1 = MSG(ps, 1);
+      if (r.parent >= 0) {
+        const double xp0 = MSG(r.parent_slot, 0), xp1 = MSG(r.parent_slot, 1);
         x0 -= o.t00 * xp0 + o.t01 * xp1;
         x1 -= o.t10 * xp0 + o.t11 * xp1;
       }
-      const int slot = (lv & 1) * maxw + (t - cld(T.lvl_ptr, lv));
-      MSG(slot, 0) = x0; MSG(slot, 1) = x1;
-      double vm = o.vm, va = o.va;
+      MSG(r.slot, 0) = x0; MSG(r.slot, 1) = x1;
       if (upd) {                                       // power_flow.py:315-327
-        if (cld(T.th_free, i)) va += C.alpha * x0;
-        if (cld(T.vm_free, i)) vm += C.alpha * x1;
-        if (vm < 0.0) { vm = -vm; va += M_PI; }
-        ROW(R.VM + i) = vm; ROW(R.VA + i) = va;
-        double sn, cs;
-        sincos(va, &sn, &cs);
-        ROW(R.E + i) = vm * cs; ROW(R.F + i) = vm * sn;
+        const double dth = (r.flags & 1) ? C.alpha * x0 : 0.0;
+        const double vmn = (r.flags & 2) ? o.vm + C.alpha * x1 : o.vm;
+        double vm = vmn, va = o.va + dth;
+        double en, fn;
+        if (__any(fabs(dth) > 0.5 || !(vmn > 0.0))) {    // large step or sign flip somewhere in the wave: full evaluation
+          if (vm < 0.0) { vm = -vm; va += M_PI; }
+          double sn, cs;
+          sincos(va, &sn, &cs);
+          en = vm * cs; fn = vm * sn;
+        } else {
+          // V' = (Vm'/Vm) V e^{j dth}: rotate the rectangular voltage by the increment; sin/cos of a
+          // small angle from their Taylor series (|dth| <= 0.5: truncation < 1e-21)
+          const double z = dth * dth;
+          double sp = -1.0 / 355687428096000.0;                    // -1/17!
+          sp = sp * z + 1.0 / 1307674368000.0;                     // 1/15!
+          sp = sp * z - 1.0 / 6227020800.0;                        // -1/13!
+          sp = sp * z + 1.0 / 39916800.0;                          // 1/11!
+          sp = sp * z - 1.0 / 362880.0;                            // -1/9!
+          sp = sp * z + 1.0 / 5040.0;                              // 1/7!
+          sp = sp * z - 1.0 / 120.0;                               // -1/5!
+          sp = sp * z + 1.0 / 6.0;                                 // 1/3!
+          const double sn = dth - dth * z * sp;
+          double cp = 1.0 / 20922789888000.0;                      // 1/16!
+          cp = cp * z - 1.0 / 87178291200.0;                       // -1/14!
+          cp = cp * z + 1.0 / 479001600.0;                         // 1/12!
+          cp = cp * z - 1.0 / 3628800.0;                           // -1/10!
+          cp = cp * z + 1.0 / 40320.0;                             // 1/8!
+          cp = cp * z - 1.0 / 720.0;                               // -1/6!
+          cp = cp * z + 1.0 / 24.0;                                // 1/4!
+          cp = cp * z - 0.5;                                       // -1/2!
+          const double cs = 1.0 + z * cp;
+          const double ratio = vmn * o.rvm;
+          en = ratio * (o.e * cs - o.f * sn);
+          fn = ratio * (o.e * sn + o.f * cs);
+        }
+        ROW(R.VM + i) = vm; ROW(R.VA + i) = va; ROW(R.RVM + i) = 1.0 / vm;
+        ROW(R.E + i) = en; ROW(R.F + i) = fn;
       }
     }
-    lds_barrier();
+    while (lv >= 0) { lds_barrier(); --lv; }
   }
 #undef MSG
   __syncthreads();                                     // V, E, F of every bus visible to every wave
+  stamp(c, ST_TOP_DOWN);
 }
 
 // ---- meshed Jacobian: statically scheduled 2x2-block sparse LU ------------------------------------
@@ -600,11 +686,15 @@ __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState
   __syncthreads();
   bool stale = true;
   for (int it = 0; it < C.max_iterations; ++it) {
-    if (KIND != KIND_TREE_LDS || it == 0) {             // the LDS forest solve refreshes E/F itself
+    if (KIND != KIND_TREE_LDS && it > 0) {              // flat_start wrote E/F; the LDS forest solve refreshes them itself
       to_rect(c);
       __syncthreads();
     }
-    const double mm = wg_max(c, it & 1, mismatch_rows(c));
+    if (it == 0) stamp(c, ST_INIT);
+    const double lm = mismatch_rows(c);
+    stamp(c, ST_MISMATCH);
+    const double mm = wg_max(c, it & 1, lm);
+    stamp(c, ST_FINAL_MISMATCH);
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
@@ -622,6 +712,7 @@ __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState
     (void)mismatch_rows(c);
   }
   __syncthreads();
+  stamp(c, ST_FINAL_MISMATCH);
 }
 
 // =============================================================================================
@@ -691,14 +782,17 @@ __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& s
 // Epilogue: line flows (power_flow.py:340-356), losses (:198-200), wrapped angles, scalars; with
 // ENV also everything of step() that follows the load flow (grid_env.py:553-617).
 // =============================================================================================
-template <int ENV>
+template <int ENV, int WRAP_VA>
 __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double lsum = 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int over = 0, vflags = 0;
   for (int i = c.wave; i < T.n; i += c.W) {
     lsum += ROW(R.PC + i);
-    ROW(R.VA + i) = atan2(ROW(R.F + i), ROW(R.E + i));      // np.angle: wrap to (-pi, pi]
+    {                                                       // np.angle: wrap theta to (-pi, pi]
+      const double va = ROW(R.VA + i);
+      ROW(R.VA + i) = WRAP_VA ? va - (2.0 * M_PI) * rint(va * (1.0 / (2.0 * M_PI))) : atan2(ROW(R.F + i), ROW(R.E + i));
+    }
     if (ENV) {
       const double v = ROW(R.VM + i);                       // reward / flags, grid_env.py:790-792, base.py:156-159
       dev += fabs(v - 1.0);
@@ -715,7 +809,7 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
     const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
     const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
     ROW(R.FLOW + k) = sr;
-    ROW(R.LOAD + k) = (rating > 0.0) ? hypot(sr, si) / rating : 0.0;
+    ROW(R.LOAD + k) = (rating > 0.0) ? sqrt(sr * sr + si * si) / rating : 0.0;
     if (ENV) {                                                        // Line.update_state, base.py:261-264
       const double ld = (rating > 0.0) ? fabs(sr) / rating : 0.0;
       ROW(R.ENVLOAD + k) = ld;
@@ -819,12 +913,15 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
   const int b = blockIdx.x * GS_LANES + lane;
   const bool valid = b < B;
-  Ctx c{T, R, S, sh, lane, wave, W};
+  Ctx c{T, R, S, sh, lane, wave, W, C.stamps, 0ull, C.stamp_wave};
+  if (C.stamps) c.tlast = __builtin_readcyclecounter();
   if (ENV) prologue_env(c, E, actions, b, valid);
+  stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
   else newton_loop<KIND>(c, C, st);
-  epilogue<ENV>(c, E, st, total_load);
+  epilogue<ENV, KIND != KIND_FBS>(c, E, st, total_load);   // FBS keeps no polar angle: atan2 there
+  stamp(c, ST_EPILOGUE);
 }
 
 #define GS_DEFINE_KERNELS(name, KIND)                                                                         \

@@ -1,6 +1,7 @@
 // topology.cpp -- see topology.h.  Reference behaviour being matched is cited inline
 // (paths relative to /root/reference/grid_fed_rl/).
 #include "topology.h"
+#include "gs_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -86,6 +87,19 @@ std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want
   }
   o.row_ptr[n] = (int)o.col.size();
   o.nnz = (int)o.col.size();
+  // ELL(8) + CSR remainder view of the same rows, same entry order
+  const int K = GS_ELL_K;
+  o.ell_col.assign((size_t)n * K, 0); o.ell_G.assign((size_t)n * K, 0.0); o.ell_B.assign((size_t)n * K, 0.0);
+  o.rem_ptr.assign(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    o.rem_ptr[i] = (int)o.rem_col.size();
+    for (int k = 0; k < K; ++k) o.ell_col[(size_t)i * K + k] = i;
+    for (int p = o.row_ptr[i], k = 0; p < o.row_ptr[i + 1]; ++p, ++k) {
+      if (k < K) { o.ell_col[(size_t)i * K + k] = o.col[p]; o.ell_G[(size_t)i * K + k] = o.G[p]; o.ell_B[(size_t)i * K + k] = o.B[p]; }
+      else { o.rem_col.push_back(o.col[p]); o.rem_G.push_back(o.G[p]); o.rem_B.push_back(o.B[p]); }
+    }
+  }
+  o.rem_ptr[n] = (int)o.rem_col.size();
   auto pos_of = [&](int i, int j) -> int {
     for (int p = o.row_ptr[i]; p < o.row_ptr[i + 1]; ++p) if (o.col[p] == j) return p;
     return -1;

@@ -14,6 +14,8 @@ struct HostTopology {
   // Ybus CSR
   std::vector<int32_t> row_ptr, col;
   std::vector<double> G, B, Gd, Bd;
+  std::vector<int32_t> ell_col, rem_ptr, rem_col;
+  std::vector<double> ell_G, ell_B, rem_G, rem_B;
   std::vector<int32_t> th_free, vm_free, fixed_v;
   std::vector<double> v_set;
   // forest over active buses

@@ -199,6 +199,10 @@ int gs_comm_destroy(gs_handle* h);
 /* ---- measurement: HIP-event timing of every kernel launched on the handle's stream ------ */
 enum { GS_K_UNPACK = 0, GS_K_ENV_PRE = 1, GS_K_SOLVE = 2, GS_K_ENV_POST = 3, GS_K_PACK = 4, GS_K_COUNT = 5 };
 int gs_timing_enable(gs_handle* h, int32_t on);
+/* diagnostic build aid: the first call arms per-phase cycle counters inside the solver kernels
+ * (block 0 / wave 0; phases: prologue, init, mismatch, bottom-up, flag, top-down, final mismatch,
+ * epilogue), later calls return the sums accumulated since the previous call and clear them. */
+int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n);
 /* total_ms[GS_K_COUNT], launches[GS_K_COUNT] accumulated since the last call; resets them */
 int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches);
 
