@@ -397,6 +397,26 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     wl_ptr[h->W] = (int)witems.size();
   }
 
+  std::vector<GsInjRec> winj;
+  std::vector<int32_t> wi_ptr(h->W + 1, 0);
+  for (int w = 0; w < h->W; ++w) {
+    wi_ptr[w] = (int)winj.size();
+    for (int i = w; i < ht.n; i += h->W) {
+      GsInjRec r{};
+      r.bus = i;
+      r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
+      r.generic = (r.nl > 2 || r.ng > 2 || r.nb > 2) ? 1 : 0;
+      if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
+      if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
+      if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
+      if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
+      if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
+      if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
+      winj.push_back(r);
+    }
+  }
+  wi_ptr[h->W] = (int)winj.size();
+
   // mismatch records: each bus' Ybus row in chunks of GS_ELL_K entries (same entry order as the
   // CSR row); buses are dealt to the waves longest row first so that every wave gets about the
   // same number of records
@@ -448,6 +468,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(th_free, th_free); UP(vm_free, vm_free); UP(v_set, v_set); UP(fixed_v, fixed_v);
   UP(lvl_ptr, lvl_ptr); UP(lvl_bus, lvl_bus); UP(parent, parent); UP(parent_pos, parent_pos);
   UP(child_ptr, child_ptr); UP(child_idx, child_idx); UP(lvl_pos, lvl_pos);
+  if ((rc = dev_upload(h, &T.winj, winj)) || (rc = dev_upload(h, &T.wi_ptr, wi_ptr))) return bail(rc);
   if ((rc = dev_upload(h, &T.wbus, wbus)) || (rc = dev_upload(h, &T.wb_ptr, wb_ptr))) return bail(rc);
   if ((rc = dev_upload(h, &T.witems, witems)) || (rc = dev_upload(h, &T.wl_ptr, wl_ptr)) || (rc = dev_upload(h, &T.ovf_slot, ovf_slot))) return bail(rc);
   T.max_level_width = ht.max_level_width;

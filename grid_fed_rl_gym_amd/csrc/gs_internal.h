@@ -43,6 +43,13 @@ struct GsBusRec {
   double G[GS_ELL_K], B[GS_ELL_K];            // padded with exact zeros
 };
 
+// Devices attached to one bus, for the injection build (order = the reference's accumulation
+// order, grid_env.py:689-718).  Buses with more than 2 devices of a kind set `generic` and go
+// through the per-bus lists instead.
+struct GsInjRec {
+  int32_t bus, generic, nl, ng, nb, l0, l1, g0, g1, b0, b1, pad;
+};
+
 // Topology-uniform tables (device pointers; built once per handle by topology.cpp).
 struct GsTables {
   int32_t n, m, nnz, n_levels;
@@ -81,6 +88,8 @@ struct GsTables {
   const GsItemRec* witems;   // records grouped by wave, bottom-up order inside a wave
   const int32_t* wl_ptr;     // [W+1]
   const int32_t* ovf_slot;   // child slots beyond the 8 kept in the record
+  const GsInjRec* winj;      // injection records grouped by wave (wave w: buses w, w+W, ...)
+  const int32_t* wi_ptr;     // [W+1]
   const GsBusRec* wbus;      // mismatch records grouped by wave (buses dealt to waves by row length, longest first)
   const int32_t* wb_ptr;     // [W+1]
   int32_t max_level_width, pad3;

@@ -888,17 +888,40 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
 __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   const uint64_t inst = (uint64_t)(E.first_instance + b);
-  if (c.wave == 0 && valid) env_actions_clock_weather(T, R, E, S, actions + (size_t)b * (T.n_bats + T.n_gens), inst);
+  // every wave derives the new clock from the old rows, then wave 0 alone advances the scalar
+  // state (actions, clock, weather, renewables) while the other waves draw the load powers
+  const double tnew = ROW(R.TIME) + E.timestep;
+  const uint32_t snew = (uint32_t)(ROW(R.STEP) + 1.0);
+  const uint64_t seed = lane_seed(S, R);
   __syncthreads();
-  for (int g = c.wave; g < T.n_gens; g += c.W) ROW(R.GENP + g) = renewable_power(T, R, S, g);
-  {
-    const uint64_t seed = lane_seed(S, R);
-    const uint32_t step = (uint32_t)ROW(R.STEP);
-    const double prof = E.stochastic_loads ? daily_profile(ROW(R.TIME)) : 1.0;
-    for (int l = c.wave; l < T.n_loads; l += c.W) ROW(R.LOADP + l) = load_power(T, E, l, seed, inst, step, prof);
+  if (c.wave == 0) {
+    if (valid) env_actions_clock_weather(T, R, E, S, actions + (size_t)b * (T.n_bats + T.n_gens), inst);
+    for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power(T, R, S, g);
+  }
+  if (c.W == 1 || c.wave > 0) {
+    const int l0 = (c.W > 1) ? c.wave - 1 : 0, ls = (c.W > 1) ? c.W - 1 : 1;
+    const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
+    for (int l = l0; l < T.n_loads; l += ls) ROW(R.LOADP + l) = load_power(T, E, l, seed, inst, snew, prof);
   }
   __syncthreads();
-  for (int i = c.wave; i < T.n; i += c.W) bus_injection(T, R, E, S, i);
+  {
+    const GS_CONST GsInjRec* recs = (const GS_CONST GsInjRec*)T.winj;
+    const int k1 = cld(T.wi_ptr, c.wave + 1);
+    for (int k = cld(T.wi_ptr, c.wave); k < k1; ++k) {
+      const int i = recs[k].bus;
+      if (recs[k].generic) { bus_injection(T, R, E, S, i); continue; }
+      // same accumulation order as bus_injection: loads, then generators, then batteries
+      double ls = 0.0, gs = 0.0;
+      if (recs[k].nl > 0) ls += ROW(R.LOADP + recs[k].l0);
+      if (recs[k].nl > 1) ls += ROW(R.LOADP + recs[k].l1);
+      if (recs[k].ng > 0) gs += ROW(R.GENP + recs[k].g0) * ROW(R.CURT + recs[k].g0);
+      if (recs[k].ng > 1) gs += ROW(R.GENP + recs[k].g1) * ROW(R.CURT + recs[k].g1);
+      if (recs[k].nb > 0) { const double bp = ROW(R.BATP + recs[k].b0); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+      if (recs[k].nb > 1) { const double bp = ROW(R.BATP + recs[k].b1); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+      ROW(R.P + i) = (0.0 - ls / E.power_base) + gs / E.power_base;
+      ROW(R.Q + i) = 0.0;
+    }
+  }
   __syncthreads();
 }
 
