@@ -209,7 +209,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "gs_k_step_" + {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs",
-                                                   "nr_dense_pivot": "nr_dense", "nr_tree_lds": "nr_tree_lds"}[desc["kernel"]],
+                                                   "nr_dense_pivot": "nr_dense", "nr_tree_lds": "nr_tree_lds",
+                                                   "fbs_lds": "fbs_lds"}[desc["kernel"]],
                          "avg_launch_ms": avg_solve_ms, "algorithmic_bytes_per_launch": bytes_step * B,
                          "fp64_valu": {"achieved_tflops": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                                        "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "mean_iterations": mean_iters}},

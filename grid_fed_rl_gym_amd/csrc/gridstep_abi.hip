@@ -214,6 +214,7 @@ int launch_solve(gs_handle* h) {
   else if (h->solve_kernel == 4) GS_SOLVE(gs_k_nr_tree_lds);
   else if (h->solve_kernel == 1) GS_SOLVE(gs_k_nr_lu);
   else if (h->solve_kernel == 3) GS_SOLVE(gs_k_nr_dense);
+  else if (h->solve_kernel == 5) GS_SOLVE(gs_k_fbs_lds);
   else GS_SOLVE(gs_k_fbs);
 #undef GS_SOLVE
   HIPCHK(h, hipGetLastError());
@@ -229,6 +230,7 @@ int step_kernels(gs_handle* h, const double* d_actions) {
     else if (h->solve_kernel == 4) GS_STEP(gs_k_step_nr_tree_lds);
     else if (h->solve_kernel == 1) GS_STEP(gs_k_step_nr_lu);
     else if (h->solve_kernel == 3) GS_STEP(gs_k_step_nr_dense);
+    else if (h->solve_kernel == 5) GS_STEP(gs_k_step_fbs_lds);
     else GS_STEP(gs_k_step_fbs);
 #undef GS_STEP
     HIPCHK(h, hipGetLastError()); }
@@ -300,6 +302,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   if (cfg->solver_kind == GS_SOLVER_FBS) {
     if (!ht.fbs_ok) { int rc = fail(nullptr, GS_E_TOPOLOGY, "FBS: %s", ht.fbs_why.c_str()); delete h; return rc; }
     h->solve_kernel = 2;
+    const size_t msg_bytes = (size_t)2 * ht.max_level_width * 6 * GS_LANES * sizeof(double);
+    if (msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) { h->solve_kernel = 5; h->dyn_lds = msg_bytes; }
   } else if (cfg->solver_kind == GS_SOLVER_NR) {
     if (cfg->linear_solver == GS_LINSOLVE_TREE && !ht.is_forest) {
       int rc = fail(nullptr, GS_E_TOPOLOGY, "tree elimination requested but the active network has loops"); delete h; return rc; }
@@ -335,7 +339,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const void* fns[] = {(const void*)gs_k_nr_tree, (const void*)gs_k_step_nr_tree, (const void*)gs_k_nr_tree_lds,
                          (const void*)gs_k_step_nr_tree_lds, (const void*)gs_k_nr_lu, (const void*)gs_k_step_nr_lu,
                          (const void*)gs_k_nr_dense, (const void*)gs_k_step_nr_dense, (const void*)gs_k_fbs,
-                         (const void*)gs_k_step_fbs};
+                         (const void*)gs_k_step_fbs, (const void*)gs_k_fbs_lds, (const void*)gs_k_step_fbs_lds};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", h->dyn_lds));
@@ -391,6 +395,12 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
           }
           if (p >= 0) { r.g = ht.G[ht.parent_pos[i]]; r.b = ht.B[ht.parent_pos[i]]; }
           r.gd = ht.Gd[i]; r.bd = ht.Bd[i];
+          if (h->solve_kernel == 5) {       // FBS flavour: parent includes the slack, (g, b) := z = 1 / y
+            const int fp = ht.fbs_parent[i], pos = ht.fbs_parent_pos[i];
+            const double yr = -ht.G[pos], yi = -ht.B[pos], yd = yr * yr + yi * yi;
+            r.g = yr / yd; r.b = -yi / yd;
+            if (p < 0) { r.parent = fp; r.flags |= 16; }
+          }
           witems.push_back(r);
         }
     }
@@ -573,7 +583,7 @@ int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_
 
 int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail(nullptr, GS_E_INVALID, "bad arguments");
-  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds"};
+  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds", "fbs_lds"};
   snprintf(buf, buflen,
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "

@@ -15,6 +15,7 @@ GS_DECLARE_KERNELS(nr_tree_lds)
 GS_DECLARE_KERNELS(nr_lu)
 GS_DECLARE_KERNELS(nr_dense)
 GS_DECLARE_KERNELS(fbs)
+GS_DECLARE_KERNELS(fbs_lds)
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);
 __global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C, int rows_total,

@@ -264,7 +264,7 @@ __device__ __forceinline__ void nr_check(NrState& st, double mm, int it, double 
   }
 }
 
-enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3, KIND_TREE_LDS = 4 };
+enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3, KIND_TREE_LDS = 4, KIND_FBS_LDS = 5 };
 
 // =============================================================================================
 // Linear solves.  Each takes the mismatch in R0/R1 and the current E/F/VM/PC/QC rows, leaves the
@@ -778,6 +778,86 @@ __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& s
   __syncthreads();
 }
 
+// ---- the same sweep with its level messages in LDS and its operands prefetched -------------------
+// Records are the per-wave forest items with parent = the FBS parent (the slack for a root) and
+// (g, b) replaced by the branch impedance z = 1/y, so the forward step is a multiply.
+__device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrState& st) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  double* msg = gs_dyn + c.lane;
+#define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
+  for (int i = c.wave; i < T.n; i += c.W) {
+    ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+    ROW(R.F + i) = 0.0;
+  }
+  __syncthreads();
+  const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
+  bool stale = true;
+  for (int it = 0; it < C.max_iterations; ++it) {
+    const double mm = wg_max(c, it & 1, mismatch_rows(c));
+    nr_check(st, mm, it, C.tolerance);
+    stale = false;
+    if (__all(st.done)) break;
+    const bool upd = !st.done;
+    {  // backward sweep: J_i = -conj(S_i / V_i) + sum_children J_c
+      int lv = 0;
+      GsItemRec rn{};
+      double e = 0, f = 0, p = 0, q = 0;
+      if (k0 < k1) { rn = load_item(T, k0); e = ROW(R.E + rn.bus); f = ROW(R.F + rn.bus); p = ROW(R.P + rn.bus); q = ROW(R.Q + rn.bus); }
+      for (int k = k0; k < k1; ++k) {
+        const GsItemRec r = rn;
+        const double ce = e, cf = f, cp = p, cq = q;
+        if (k + 1 < k1) { rn = load_item(T, k + 1); e = ROW(R.E + rn.bus); f = ROW(R.F + rn.bus); p = ROW(R.P + rn.bus); q = ROW(R.Q + rn.bus); }
+        while (lv < r.level) { lds_barrier(); ++lv; }
+        const double rd = 1.0 / (ce * ce + cf * cf);
+        double jr = -(cp * ce + cq * cf) * rd, ji = (cq * ce - cp * cf) * rd;
+        const int nch = r.n_children;
+#pragma unroll
+        for (int u = 0; u < GS_ITEM_CHILDREN; ++u) {
+          if (u < nch) { jr += MSG(r.child_slot[u], 0); ji += MSG(r.child_slot[u], 1); }
+        }
+        for (int u = GS_ITEM_CHILDREN; u < nch; ++u) {
+          const int slot = cld(T.ovf_slot, r.ovf0 + u - GS_ITEM_CHILDREN);
+          jr += MSG(slot, 0); ji += MSG(slot, 1);
+        }
+        MSG(r.slot, 0) = jr; MSG(r.slot, 1) = ji;
+        ROW(R.JR + r.bus) = jr; ROW(R.JI + r.bus) = ji;
+      }
+      while (lv < T.n_levels) { lds_barrier(); ++lv; }
+    }
+    __syncthreads();                                   // J rows drained before the same wave reloads them
+    {  // forward sweep: V_i = V_parent - z_i J_i
+      int lv = T.n_levels - 1;
+      GsItemRec rn{};
+      double jr = 0, ji = 0;
+      if (k0 < k1) { rn = load_item(T, k1 - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); }
+      for (int k = k1 - 1; k >= k0; --k) {
+        const GsItemRec r = rn;
+        const double cjr = jr, cji = ji;
+        if (k - 1 >= k0) { rn = load_item(T, k - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); }
+        while (lv > r.level) { lds_barrier(); --lv; }
+        double ep, fp;
+        if (r.flags & 16) { ep = ROW(R.E + r.parent); fp = ROW(R.F + r.parent); }     // parent is the slack bus
+        else { ep = MSG(r.parent_slot, 0); fp = MSG(r.parent_slot, 1); }
+        double en = ep - (cjr * r.g - cji * r.b), fn = fp - (cjr * r.b + cji * r.g);    // (g, b) hold z = 1/y here
+        if (!upd) { en = ROW(R.E + r.bus); fn = ROW(R.F + r.bus); }
+        MSG(r.slot, 0) = en; MSG(r.slot, 1) = fn;
+        if (upd) { ROW(R.E + r.bus) = en; ROW(R.F + r.bus) = fn; }
+      }
+      while (lv >= 0) { lds_barrier(); --lv; }
+    }
+    __syncthreads();
+    stale = true;
+  }
+#undef MSG
+  if (stale) (void)mismatch_rows(c);
+  __syncthreads();
+  for (int i = c.wave; i < T.n; i += c.W) {
+    const double e = ROW(R.E + i), f = ROW(R.F + i);
+    ROW(R.VM + i) = sqrt(e * e + f * f);
+  }
+  __syncthreads();
+}
+
 // =============================================================================================
 // Epilogue: line flows (power_flow.py:340-356), losses (:198-200), wrapped angles, scalars; with
 // ENV also everything of step() that follows the load flow (grid_env.py:553-617).
@@ -942,8 +1022,9 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
+  else if (KIND == KIND_FBS_LDS) fbs_loop_lds(c, C, st);
   else newton_loop<KIND>(c, C, st);
-  epilogue<ENV, KIND != KIND_FBS>(c, E, st, total_load);   // FBS keeps no polar angle: atan2 there
+  epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS>(c, E, st, total_load);   // FBS keeps no polar angle: atan2 there
   stamp(c, ST_EPILOGUE);
 }
 
@@ -964,3 +1045,4 @@ GS_DEFINE_KERNELS(nr_tree_lds, KIND_TREE_LDS)
 GS_DEFINE_KERNELS(nr_lu, KIND_LU)
 GS_DEFINE_KERNELS(nr_dense, KIND_DENSE)
 GS_DEFINE_KERNELS(fbs, KIND_FBS)
+GS_DEFINE_KERNELS(fbs_lds, KIND_FBS_LDS)
