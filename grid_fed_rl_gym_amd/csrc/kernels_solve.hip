@@ -120,6 +120,9 @@ __device__ __forceinline__ void to_rect(Ctx& c) {
 // ---- S = V conj(Y V) by CSR rows; dP, dQ; returns this wave's max |mismatch| (inf if non-finite)
 // With a_ij = e_i e_j + f_i f_j = Vi Vj cos(th_i - th_j), b_ij = f_i e_j - e_i f_j = Vi Vj sin(..):
 //   P_i = sum_j G_ij a_ij + B_ij b_ij,   Q_i = sum_j G_ij b_ij - B_ij a_ij.
+// STORE: 0 = P_calc only (FBS: all it needs is the losses), 1 = P_calc, Q_calc (LDS forest solve forms
+// the right-hand side itself), 2 = also the mismatch rows R0/R1 (the other linear solves)
+template <int STORE>
 __device__ __forceinline__ double mismatch_rows(Ctx& c) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double lmax = 0.0;
@@ -157,11 +160,10 @@ __device__ __forceinline__ double mismatch_rows(Ctx& c) {
     }
     if (fl & 4) continue;                              // the row continues in the next record
     ROW(R.PC + i) = P;
-    ROW(R.QC + i) = Q;
+    if (STORE >= 1) ROW(R.QC + i) = Q;
     const double dP = (fl & 1) ? (ps - P) : 0.0;
     const double dQ = (fl & 2) ? (qs - Q) : 0.0;
-    ROW(R.R0 + i) = dP;
-    ROW(R.R1 + i) = dQ;
+    if (STORE >= 2) { ROW(R.R0 + i) = dP; ROW(R.R1 + i) = dQ; }
     lmax = fmax(lmax, fmax(finite_or_inf(fabs(dP)), finite_or_inf(fabs(dQ))));
   }
   return lmax;
@@ -361,7 +363,7 @@ __device__ __forceinline__ BuOperands fetch_bu(Ctx& c, const GsItemRec& r) {
   BuOperands o;
   const int i = r.bus, pj = r.parent >= 0 ? r.parent : r.bus;
   o.vm = ROW(R.VM + i); o.rvm = ROW(R.RVM + i); o.pc = ROW(R.PC + i); o.qc = ROW(R.QC + i);
-  o.r0 = ROW(R.R0 + i); o.r1 = ROW(R.R1 + i);
+  o.r0 = ROW(R.P + i); o.r1 = ROW(R.Q + i);          // specified injections; the mismatch is formed in the sweep
   o.ei = ROW(R.E + i); o.fi = ROW(R.F + i);
   o.ep = ROW(R.E + pj); o.fp = ROW(R.F + pj); o.rvmp = ROW(R.RVM + pj);
   return o;
@@ -423,7 +425,7 @@ __device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, N
         d.a10 = (thi && vfi) ? (o.pc - o.vm * o.vm * r.gd) : 0.0;
         d.a11 = vfi ? (o.qc * rvm - o.vm * r.bd) : 1.0;
       }
-      double r0 = o.r0, r1 = o.r1;
+      double r0 = thi ? (o.r0 - o.pc) : 0.0, r1 = vfi ? (o.r1 - o.qc) : 0.0;   // power_flow.py:159-165
       const int nch = r.n_children;
 #pragma unroll
       for (int q = 0; q < GS_ITEM_CHILDREN; ++q) {       // static indices: the record stays in SGPRs
@@ -691,7 +693,7 @@ __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState
       __syncthreads();
     }
     if (it == 0) stamp(c, ST_INIT);
-    const double lm = mismatch_rows(c);
+    const double lm = mismatch_rows<KIND == KIND_TREE_LDS ? 1 : 2>(c);
     stamp(c, ST_MISMATCH);
     const double mm = wg_max(c, it & 1, lm);
     stamp(c, ST_FINAL_MISMATCH);
@@ -709,7 +711,7 @@ __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState
       to_rect(c);
       __syncthreads();
     }
-    (void)mismatch_rows(c);
+    (void)mismatch_rows<0>(c);
   }
   __syncthreads();
   stamp(c, ST_FINAL_MISMATCH);
@@ -732,7 +734,7 @@ __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& s
   __syncthreads();
   bool stale = true;
   for (int it = 0; it < C.max_iterations; ++it) {
-    const double mm = wg_max(c, it & 1, mismatch_rows(c));
+    const double mm = wg_max(c, it & 1, mismatch_rows<0>(c));
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
@@ -772,7 +774,7 @@ __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& s
     }
     stale = true;
   }
-  if (stale) (void)mismatch_rows(c);
+  if (stale) (void)mismatch_rows<0>(c);
   __syncthreads();
   for (int i = c.wave; i < T.n; i += c.W) ROW(R.VM + i) = hypot(ROW(R.E + i), ROW(R.F + i));
   __syncthreads();
@@ -793,7 +795,7 @@ __device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrStat
   const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
   bool stale = true;
   for (int it = 0; it < C.max_iterations; ++it) {
-    const double mm = wg_max(c, it & 1, mismatch_rows(c));
+    const double mm = wg_max(c, it & 1, mismatch_rows<0>(c));
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
@@ -849,7 +851,7 @@ __device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrStat
     stale = true;
   }
 #undef MSG
-  if (stale) (void)mismatch_rows(c);
+  if (stale) (void)mismatch_rows<0>(c);
   __syncthreads();
   for (int i = c.wave; i < T.n; i += c.W) {
     const double e = ROW(R.E + i), f = ROW(R.F + i);
