@@ -352,10 +352,17 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   const int n = h->n, m = h->m;
   R.P = take(n); R.Q = take(n); R.VM = take(n); R.VA = take(n); R.FLOW = take(m); R.LOAD = take(m);
   R.LOSSES = take(1); R.MAXMIS = take(1); R.ITERS = take(1); R.CONV = take(1); R.STATUS = take(1);
-  R.E = take(n); R.F = take(n); R.PC = take(n); R.QC = take(n); R.R0 = take(n); R.R1 = take(n);
-  R.X0 = take(n); R.X1 = take(n); R.RVM = take(n);
-  R.SV = take(2 * n); R.QV = take(2 * n); R.TB = take(4 * n); R.CB = take(4 * n);
-  R.JR = take(n); R.JI = take(n);
+  // scratch rows are allocated only for the kernel that uses them: the slab is what the step
+  // streams through L2 / Infinity Cache, so every unused row costs residency
+  const int sk = h->solve_kernel;
+  const bool k_tree = sk == 0, k_lu = sk == 1, k_fbs = sk == 2 || sk == 5, k_dense = sk == 3, k_tree_lds = sk == 4;
+  const bool k_rhs = k_tree || k_lu || k_dense;
+  R.E = take(n); R.F = take(n); R.PC = take(n); R.QC = take(n);
+  R.R0 = take(k_rhs ? n : 0); R.R1 = take(k_rhs ? n : 0);
+  R.X0 = take(k_rhs ? n : 0); R.X1 = take(k_rhs ? n : 0); R.RVM = take(n);
+  R.SV = take(k_tree || k_tree_lds ? 2 * n : 0); R.QV = take(k_tree ? 2 * n : 0);
+  R.TB = take(k_tree || k_tree_lds ? 4 * n : 0); R.CB = take(k_tree ? 4 * n : 0);
+  R.JR = take(k_fbs ? n : 0); R.JI = take(k_fbs ? n : 0);
   R.LU = take(h->solve_kernel == 1 ? 4 * ht.lu_n_slots : 0);
   R.LUD = take(h->solve_kernel == 1 ? 4 * n : 0);
   const int dnN = ht.dn_N;

@@ -128,7 +128,9 @@ def env_step(net: Net, cfg: orc_cfg, state, actions) -> dict:
 def bench_env_steps(fs, env_kwargs, budget_s=15.0) -> dict:
     """cpu_baseline leg of bench.py: the C/OpenMP port on all host cores, bounded sample."""
     net = Net(fs)
-    threads = lib().orc_max_threads()
+    # the GPU box exposes all host threads but grants a 16-core share per GPU; never oversubscribe
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else lib().orc_max_threads()
+    threads = max(1, min(lib().orc_max_threads(), avail, 16))
     cfg = config(solver=env_kwargs["solver"], jacobian="exact", max_iterations=env_kwargs["max_iterations"],
                  tolerance=env_kwargs["tolerance"], stochastic_loads=env_kwargs["stochastic_loads"],
                  weather_variation=env_kwargs["weather_variation"], power_base=fs.base_power_va, threads=threads)
@@ -143,5 +145,5 @@ def bench_env_steps(fs, env_kwargs, budget_s=15.0) -> dict:
         n_done += B
     dt = time.perf_counter() - t0
     return {"value": n_done / dt, "unit": "env_steps/s", "cores": threads, "kind": "port",
-            "sample": f"C/OpenMP oracle (dense NR as the reference), {n_done} env-steps of the same workload "
+            "sample": f"C/OpenMP oracle ({'dense Newton-Raphson as the reference codes it' if env_kwargs['solver'] == 'nr' else 'forward/backward sweep, dense mismatch'}), {n_done} env-steps of the same workload "
                       f"(batches of {B}) in {dt:.1f} s on {threads} threads"}
