@@ -107,7 +107,9 @@ def main():
             print("[bench] --gpus > 1 needs `python -m torch.distributed.run --nproc-per-node N bench.py ...`", file=sys.stderr)
             sys.exit(2)
 
-    _lib.load()                      # HIP runtime of /opt/rocm first; torch (if any) comes after
+    lib = _lib.load()                # HIP runtime of /opt/rocm first; torch (if any) comes after
+    n_dev = max(lib.gs_device_count(), 1)
+    device = local_rank % n_dev      # ranks share a device only when rehearsing N > 1 on a smaller box
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -119,7 +121,7 @@ def main():
     B = args.batch or wl["batch"]
     env_kwargs = dict(stochastic_loads=True, weather_variation=True, solver=args.solver, tolerance=args.tolerance,
                       max_iterations=args.max_iterations or (50 if args.solver == "nr" else 100))
-    env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=local_rank,
+    env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=device,
                                    first_instance=rank * B, waves_per_group=args.waves, **env_kwargs)
     h = env.handle
     desc = h.describe()
@@ -135,7 +137,7 @@ def main():
     st[:, env.state_column("time")] = 11.5 * 3600.0      # midday: loads near peak, PV producing
     env.set_state(st)
 
-    use_gather = world > 1 and not args.no_allgather
+    use_gather = world > 1 and not args.no_allgather and n_dev >= world
     if use_gather:
         import torch
         uid = torch.zeros(128, dtype=torch.uint8)

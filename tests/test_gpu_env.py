@@ -146,3 +146,19 @@ def test_truncation_after_ten_violating_steps_and_termination():
         assert np.all(trunc == (k + 1 > 10)) and np.all(term == (k + 1 >= 12))
         assert np.all(info["constraint_violations_count"] == k + 1)
     env.close()
+
+
+def test_rccl_allgather_single_rank():
+    """gs_comm_* through RCCL with world_size 1 (all a 1-GPU box allows): the gathered block is the
+    step's observation block; exercises dlopen(librccl), communicator setup and the device-side gather."""
+    from grid_fed_rl_gym_amd.sharding import ShardedGridEnvironment
+    from grid_fed_rl_gym_amd._lib import Handle
+    fs = P.ieee13_like("epsilon")
+    env = ShardedGridEnvironment(fs, global_num_envs=48, rank=0, world=1, device=0, transport="rccl",
+                                 stochastic_loads=True, weather_variation=True)
+    env.init_rccl(Handle.comm_unique_id())
+    env.reset(seed=3)
+    obs, *_ = env.step(np.random.default_rng(1).uniform(-1, 1, (48, fs.action_dim)))
+    full = env.gather_observations()
+    assert full.shape == (48, fs.obs_dim) and np.array_equal(full, obs)
+    env.close()
