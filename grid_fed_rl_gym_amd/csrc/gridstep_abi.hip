@@ -406,6 +406,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
             const int fp = ht.fbs_parent[i], pos = ht.fbs_parent_pos[i];
             const double yr = -ht.G[pos], yi = -ht.B[pos], yd = yr * yr + yi * yi;
             r.g = yr / yd; r.b = -yi / yd;
+            r.gd = yr; r.bd = yi;
             if (p < 0) { r.parent = fp; r.flags |= 16; }
           }
           witems.push_back(r);

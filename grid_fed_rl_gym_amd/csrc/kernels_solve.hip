@@ -780,10 +780,74 @@ __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& s
   __syncthreads();
 }
 
-// ---- the same sweep with its level messages in LDS and its operands prefetched -------------------
-// Records are the per-wave forest items with parent = the FBS parent (the slack for a root) and
-// (g, b) replaced by the branch impedance z = 1/y, so the forward step is a multiply.
-__device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrState& st) {
+// ---- the same sweep with its level messages in LDS, its operands prefetched, and the mismatch
+// evaluated INSIDE the backward sweep ------------------------------------------------------------
+// S_calc = V conj(Y V) (power_flow.py:150) is restated branch by branch: with K_i = y_i (V_i - V_parent)
+// the current bus i sends towards its parent, (Y V)_i = K_i - sum_children K_c, so a bus can form
+// its own mismatch from its parent's voltage and its children's K -- which travel up in the same
+// LDS message as the branch currents J.  One sweep therefore yields both the convergence test at the
+// current V and the currents for the next forward sweep; there is no separate mismatch pass.
+// Records are the per-wave forest items with parent = the FBS parent (the slack for a root),
+// (g, b) = z = 1/y of the branch to the parent and (gd, bd) = y.
+struct FbsOperands { double e, f, p, q, ep, fp; };
+
+__device__ __forceinline__ FbsOperands fetch_fbs(Ctx& c, const GsItemRec& r) {
+  const GsRows& R = c.R; double* S = c.S;
+  FbsOperands o;
+  o.e = ROW(R.E + r.bus); o.f = ROW(R.F + r.bus); o.p = ROW(R.P + r.bus); o.q = ROW(R.Q + r.bus);
+  o.ep = ROW(R.E + r.parent); o.fp = ROW(R.F + r.parent);
+  return o;
+}
+
+__device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lmax_out, double* psum_out) {
+  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  double* msg = gs_dyn + c.lane;
+#define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
+  double lmax = 0.0, psum = 0.0;
+  int lv = 0;
+  GsItemRec rn{};
+  FbsOperands on{};
+  if (k0 < k1) { rn = load_item(T, k0); on = fetch_fbs(c, rn); }
+  for (int k = k0; k < k1; ++k) {
+    const GsItemRec r = rn;
+    const FbsOperands o = on;
+    if (k + 1 < k1) { rn = load_item(T, k + 1); on = fetch_fbs(c, rn); }
+    while (lv < r.level) { lds_barrier(); ++lv; }
+    // current towards the parent implied by the voltages: K = y (V_i - V_p)
+    const double dr = o.e - o.ep, di = o.f - o.fp;
+    const double kr = r.gd * dr - r.bd * di, ki = r.gd * di + r.bd * dr;
+    double sjr = 0.0, sji = 0.0, skr = 0.0, ski = 0.0;
+    const int nch = r.n_children;
+#pragma unroll
+    for (int u = 0; u < GS_ITEM_CHILDREN; ++u) {
+      if (u < nch) {
+        const int slot = r.child_slot[u];
+        sjr += MSG(slot, 0); sji += MSG(slot, 1); skr += MSG(slot, 2); ski += MSG(slot, 3);
+      }
+    }
+    for (int u = GS_ITEM_CHILDREN; u < nch; ++u) {
+      const int slot = cld(T.ovf_slot, r.ovf0 + u - GS_ITEM_CHILDREN);
+      sjr += MSG(slot, 0); sji += MSG(slot, 1); skr += MSG(slot, 2); ski += MSG(slot, 3);
+    }
+    // (Y V)_i = K_i - sum K_c ;  S_calc = V conj(Y V) ; mismatch (power_flow.py:150-168)
+    const double icr = kr - skr, ici = ki - ski;
+    const double pc = o.e * icr + o.f * ici, qc = o.f * icr - o.e * ici;
+    const double dP = o.p - pc, dQ = o.q - qc;
+    lmax = fmax(lmax, fmax(finite_or_inf(fabs(dP)), finite_or_inf(fabs(dQ))));
+    psum += pc;
+    if (r.flags & 16) psum -= o.ep * kr + o.fp * ki;    // the slack's share: Re(V_s conj(-K_root))
+    // branch current for the next forward sweep: J_i = -conj(S_spec / V_i) + sum J_c
+    const double rd = 1.0 / (o.e * o.e + o.f * o.f);
+    const double jr = sjr - (o.p * o.e + o.q * o.f) * rd, ji = sji + (o.q * o.e - o.p * o.f) * rd;
+    MSG(r.slot, 0) = jr; MSG(r.slot, 1) = ji; MSG(r.slot, 2) = kr; MSG(r.slot, 3) = ki;
+    ROW(R.JR + r.bus) = jr; ROW(R.JI + r.bus) = ji;
+  }
+  while (lv < T.n_levels) { lds_barrier(); ++lv; }
+#undef MSG
+  *lmax_out = lmax; *psum_out = psum;
+}
+
+__device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrState& st) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double* msg = gs_dyn + c.lane;
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
@@ -794,39 +858,15 @@ __device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrStat
   __syncthreads();
   const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
   bool stale = true;
+  double psum = 0.0;
   for (int it = 0; it < C.max_iterations; ++it) {
-    const double mm = wg_max(c, it & 1, mismatch_rows<0>(c));
+    double lmax;
+    fbs_backward(c, k0, k1, &lmax, &psum);
+    const double mm = wg_max(c, it & 1, lmax);          // full barrier: also drains the J rows
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
     const bool upd = !st.done;
-    {  // backward sweep: J_i = -conj(S_i / V_i) + sum_children J_c
-      int lv = 0;
-      GsItemRec rn{};
-      double e = 0, f = 0, p = 0, q = 0;
-      if (k0 < k1) { rn = load_item(T, k0); e = ROW(R.E + rn.bus); f = ROW(R.F + rn.bus); p = ROW(R.P + rn.bus); q = ROW(R.Q + rn.bus); }
-      for (int k = k0; k < k1; ++k) {
-        const GsItemRec r = rn;
-        const double ce = e, cf = f, cp = p, cq = q;
-        if (k + 1 < k1) { rn = load_item(T, k + 1); e = ROW(R.E + rn.bus); f = ROW(R.F + rn.bus); p = ROW(R.P + rn.bus); q = ROW(R.Q + rn.bus); }
-        while (lv < r.level) { lds_barrier(); ++lv; }
-        const double rd = 1.0 / (ce * ce + cf * cf);
-        double jr = -(cp * ce + cq * cf) * rd, ji = (cq * ce - cp * cf) * rd;
-        const int nch = r.n_children;
-#pragma unroll
-        for (int u = 0; u < GS_ITEM_CHILDREN; ++u) {
-          if (u < nch) { jr += MSG(r.child_slot[u], 0); ji += MSG(r.child_slot[u], 1); }
-        }
-        for (int u = GS_ITEM_CHILDREN; u < nch; ++u) {
-          const int slot = cld(T.ovf_slot, r.ovf0 + u - GS_ITEM_CHILDREN);
-          jr += MSG(slot, 0); ji += MSG(slot, 1);
-        }
-        MSG(r.slot, 0) = jr; MSG(r.slot, 1) = ji;
-        ROW(R.JR + r.bus) = jr; ROW(R.JI + r.bus) = ji;
-      }
-      while (lv < T.n_levels) { lds_barrier(); ++lv; }
-    }
-    __syncthreads();                                   // J rows drained before the same wave reloads them
     {  // forward sweep: V_i = V_parent - z_i J_i
       int lv = T.n_levels - 1;
       GsItemRec rn{};
@@ -840,7 +880,7 @@ __device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrStat
         double ep, fp;
         if (r.flags & 16) { ep = ROW(R.E + r.parent); fp = ROW(R.F + r.parent); }     // parent is the slack bus
         else { ep = MSG(r.parent_slot, 0); fp = MSG(r.parent_slot, 1); }
-        double en = ep - (cjr * r.g - cji * r.b), fn = fp - (cjr * r.b + cji * r.g);    // (g, b) hold z = 1/y here
+        double en = ep - (cjr * r.g - cji * r.b), fn = fp - (cjr * r.b + cji * r.g);
         if (!upd) { en = ROW(R.E + r.bus); fn = ROW(R.F + r.bus); }
         MSG(r.slot, 0) = en; MSG(r.slot, 1) = fn;
         if (upd) { ROW(R.E + r.bus) = en; ROW(R.F + r.bus) = fn; }
@@ -851,13 +891,17 @@ __device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrStat
     stale = true;
   }
 #undef MSG
-  if (stale) (void)mismatch_rows<0>(c);
+  if (stale) {                                          // iteration cap: losses at the final V
+    double lmax;
+    fbs_backward(c, k0, k1, &lmax, &psum);
+  }
   __syncthreads();
   for (int i = c.wave; i < T.n; i += c.W) {
     const double e = ROW(R.E + i), f = ROW(R.F + i);
     ROW(R.VM + i) = sqrt(e * e + f * f);
   }
   __syncthreads();
+  return psum;
 }
 
 // =============================================================================================
@@ -865,12 +909,13 @@ __device__ __forceinline__ void fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrStat
 // ENV also everything of step() that follows the load flow (grid_env.py:553-617).
 // =============================================================================================
 template <int ENV, int WRAP_VA>
-__device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load) {
+__device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
+                                         double psum) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
-  double lsum = 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
+  double lsum = have_psum ? psum : 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int over = 0, vflags = 0;
   for (int i = c.wave; i < T.n; i += c.W) {
-    lsum += ROW(R.PC + i);
+    if (!have_psum) lsum += ROW(R.PC + i);
     {                                                       // np.angle: wrap theta to (-pi, pi]
       const double va = ROW(R.VA + i);
       ROW(R.VA + i) = WRAP_VA ? va - (2.0 * M_PI) * rint(va * (1.0 / (2.0 * M_PI))) : atan2(ROW(R.F + i), ROW(R.E + i));
@@ -1023,10 +1068,11 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   if (ENV) prologue_env(c, E, actions, b, valid);
   stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
+  double psum = 0.0;
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
-  else if (KIND == KIND_FBS_LDS) fbs_loop_lds(c, C, st);
+  else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds(c, C, st);
   else newton_loop<KIND>(c, C, st);
-  epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS>(c, E, st, total_load);   // FBS keeps no polar angle: atan2 there
+  epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS>(c, E, st, total_load, KIND == KIND_FBS_LDS, psum);   // FBS keeps no polar angle: atan2 there
   stamp(c, ST_EPILOGUE);
 }
 
