@@ -7,8 +7,10 @@
 One "step" = one batched env.step(): actions -> batteries/curtailment -> weather -> injections
 -> AC load flow -> line flows -> frequency -> reward/flags -> observation block, for every
 instance of the batch, with the K action batches already resident in HBM.  The default
-workload is the configuration BASELINE.json's target is quoted on: the 123-bus radial feeder,
-8192 instances per GPU, reference defaults for stochastic loads and weather.
+workload is the configuration BASELINE.json's target is quoted on (configs[2]): the 123-bus radial
+feeder, 8192 instances per GPU, forward/backward-sweep load flow, reference defaults for stochastic
+loads and weather.  The same line also carries the Newton-Raphson measurement ("also"), the accuracy
+of the GPU voltages against the CPU oracle's Newton-Raphson, and the CPU baseline.
 
 For N > 1 the driver launches one process per GPU (torch.distributed.run); each rank owns a
 contiguous block of instances (weak scaling, per-GPU batch fixed) and the only exchange is the
@@ -90,7 +92,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ieee123_b8192", choices=sorted(WORKLOADS))
-    ap.add_argument("--solver", default="nr", choices=["nr", "fbs"])
+    ap.add_argument("--solver", default="fbs", choices=["nr", "fbs"],
+                    help="fbs = BASELINE.json config 3 (DistributionPowerFlow); nr = the reference's Newton-Raphson")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second measurement with the other solver")
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per 64-instance group (0 = auto)")
     ap.add_argument("--tolerance", type=float, default=1e-6, help="ablation only; the headline uses 1e-6")
@@ -119,76 +123,121 @@ def main():
     wl = WORKLOADS[args.workload]
     fs = make_feeder(wl["feeder"])
     B = args.batch or wl["batch"]
-    env_kwargs = dict(stochastic_loads=True, weather_variation=True, solver=args.solver, tolerance=args.tolerance,
-                      max_iterations=args.max_iterations or (50 if args.solver == "nr" else 100))
-    env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=device,
-                                   first_instance=rank * B, waves_per_group=args.waves, **env_kwargs)
-    h = env.handle
-    desc = h.describe()
-
-    # ---- inputs resident in HBM before the timed region ----
     n_act = 8
     rng = np.random.default_rng(5678 + rank)
     actions = rng.uniform(-1, 1, (n_act, B, fs.action_dim))
-    h.upload_actions(actions)
     seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.uint64)
-    env.reset(seed=seeds)
-    st = env.get_state()
-    st[:, env.state_column("time")] = 11.5 * 3600.0      # midday: loads near peak, PV producing
-    env.set_state(st)
+    want_gather = world > 1 and not args.no_allgather and n_dev >= world
+    kernel_names = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
+                    "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds"}
 
-    use_gather = world > 1 and not args.no_allgather and n_dev >= world
-    if use_gather:
-        import torch
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(_lib.Handle.comm_unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, src=0)
-        h.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+    def env_kwargs_of(solver):
+        return dict(stochastic_loads=True, weather_variation=True, solver=solver, tolerance=args.tolerance,
+                    max_iterations=args.max_iterations or (50 if solver == "nr" else 100))
 
-    def one_step(k):
-        h.step_device(k % n_act)
+    def measure(solver, use_gather):
+        """W untimed + K timed batched steps of one solver; returns the measurement as a dict."""
+        env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=device,
+                                       first_instance=rank * B, waves_per_group=args.waves, **env_kwargs_of(solver))
+        h = env.handle
+        desc = h.describe()
+        h.upload_actions(actions)                               # inputs resident in HBM before the timed region
+        env.reset(seed=seeds)
+        st = env.get_state()
+        st[:, env.state_column("time")] = 11.5 * 3600.0          # midday: loads near peak, PV producing
+        env.set_state(st)
         if use_gather:
-            h.allgather_obs(to_host=False)
+            import torch
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(_lib.Handle.comm_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(uid, src=0)
+            h.comm_init(bytes(uid.numpy().tobytes()), rank, world)
 
-    def barrier():
+        def one_step(k):
+            h.step_device(k % n_act)
+            if use_gather:
+                h.allgather_obs(to_host=False)
+
+        def barrier():
+            h.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        for k in range(args.warmup):
+            one_step(k)
+        barrier()
+        h.timing_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(args.warmup + k)
         h.synchronize()
         if dist is not None:
             dist.barrier()
+        elapsed = time.perf_counter() - t0
+        timing = h.timing_read()
+        h.timing_enable(False)
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        out = h.download_step(want_obs=False)                    # sanity of the timed work: every instance solved
+        m = dict(solver=solver, elapsed=elapsed, timing=timing, desc=desc,
+                 converged_fraction=float(out["power_flow_converged"].mean()),
+                 mean_iterations=float(out["iterations"].mean()))
+        if use_gather:
+            h.comm_destroy()
+        env.close()
+        return m
 
-    for k in range(args.warmup):
-        one_step(k)
-    barrier()
-    h.timing_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k)
-    h.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timing = h.timing_read()
-    h.timing_enable(False)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def accuracy(solver):
+        """max |V| error of the HIP path against the CPU oracle on a 64-instance, 3-step sample of the workload."""
+        try:
+            from oracle import oracle_c as OC
+            if not OC.available():
+                return None
+        except Exception:
+            return None
+        b = 64
+        env = P.BatchedGridEnvironment(fs, num_envs=b, jacobian="exact", zero_z="open", device=device, **env_kwargs_of(solver))
+        env.reset(seed=np.arange(b, dtype=np.uint64))
+        st = env.get_state(); st[:, env.state_column("time")] = 11.5 * 3600.0; env.set_state(st)
+        net = OC.Net(fs)
+        kw = env_kwargs_of(solver)
+        # the oracle always runs Newton-Raphson (the reference's solver), tightly converged
+        cfg = OC.config(solver="nr", jacobian="exact", max_iterations=50, tolerance=1e-10, stochastic_loads=True,
+                        weather_variation=True, power_base=fs.base_power_va, threads=8)
+        _, cst = OC.env_reset(net, cfg, b, np.arange(b, dtype=np.uint64)); cst[:, 0] = 11.5 * 3600.0
+        dv = da = 0.0
+        for k in range(3):
+            obs, *_ = env.step(actions[k, :b])
+            ref = OC.env_step(net, cfg, cst, actions[k, :b])["obs"]
+            dv = max(dv, float(np.max(np.abs(obs[:, 0:2 * fs.n:2] - ref[:, 0:2 * fs.n:2]))))
+            da = max(da, float(np.max(np.abs(obs[:, 1:2 * fs.n:2] - ref[:, 1:2 * fs.n:2]))))
+        env.close()
+        return {"max_abs_dVm_pu": dv, "max_abs_dVa_rad": da, "against": "C oracle, Newton-Raphson (reference algorithm) converged to 1e-10",
+                "sample": f"{b} instances x 3 steps of the workload", "gpu_tolerance": kw["tolerance"]}
 
-    # ---- sanity of the timed work: every instance solved, accuracy figure vs the oracle on a sample ----
-    out = h.download_step(want_obs=True)
-    conv_frac = float(out["power_flow_converged"].mean())
-    mean_iters = float(out["iterations"].mean())
+    main_m = measure(args.solver, want_gather)
+    other = None
+    if world == 1 and not args.no_secondary:
+        other = measure("nr" if args.solver == "fbs" else "fbs", False)
 
     if rank == 0:
-        steps_per_s = world * B * args.steps / elapsed
+        def summarize(m):
+            steps_per_s = world * B * args.steps / m["elapsed"]
+            solve = m["timing"]["solve"]
+            avg_ms = solve["total_ms"] / max(solve["launches"], 1)
+            return steps_per_s, avg_ms
+
+        steps_per_s, avg_solve_ms = summarize(main_m)
+        desc = main_m["desc"]
         bytes_step = algorithmic_bytes_per_step(fs)
-        solve = timing["solve"]
-        avg_solve_ms = solve["total_ms"] / max(solve["launches"], 1)
         achieved_gbs = bytes_step * B / (avg_solve_ms * 1e-3) / 1e9 if avg_solve_ms > 0 else 0.0
         flops_it = algorithmic_flops_per_iteration(fs) if args.solver == "nr" else 30 * fs.n
-        tflops = flops_it * mean_iters * B / (avg_solve_ms * 1e-3) / 1e12 if avg_solve_ms > 0 else 0.0
+        tflops = flops_it * main_m["mean_iterations"] * B / (avg_solve_ms * 1e-3) / 1e12 if avg_solve_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
@@ -196,38 +245,46 @@ def main():
                 traffic = json.load(open(tfile)).get(f"{args.workload}:{args.solver}", {}).get("solve_bytes_per_launch")
             except Exception:
                 traffic = None
+        solver_text = {"nr": "Newton-Raphson (exact Jacobian)", "fbs": "forward/backward sweep (DistributionPowerFlow)"}
         result = {
             "metric": "env steps/sec (batched feeders)", "value": steps_per_s, "unit": "env_steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * main_m["elapsed"] / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{fs.name}, batch={B} per GPU, {'Newton-Raphson (exact Jacobian)' if args.solver == 'nr' else 'forward/backward sweep'}, "
+            "config": {"workload": f"{fs.name}, batch={B} per GPU, {solver_text[args.solver]}, "
                                    f"stochastic loads + weather, tolerance {args.tolerance:g}",
                        "feeder_sha256": fs.sha256(), "n_buses": fs.n, "n_lines": fs.m, "obs_dim": fs.obs_dim,
                        "action_dim": fs.action_dim, "batch_per_gpu": B, "global_batch": world * B,
                        "solver": args.solver, "kernel": desc["kernel"], "waves_per_group": desc["waves_per_group"],
-                       "tree_levels": desc["levels"], "obs_allgather": bool(use_gather),
+                       "tree_levels": desc["levels"], "obs_allgather": bool(want_gather),
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gs_k_step_" + {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs",
-                                                   "nr_dense_pivot": "nr_dense", "nr_tree_lds": "nr_tree_lds",
-                                                   "fbs_lds": "fbs_lds"}[desc["kernel"]],
+                         "kernel": "gs_k_step_" + kernel_names[desc["kernel"]],
                          "avg_launch_ms": avg_solve_ms, "algorithmic_bytes_per_launch": bytes_step * B,
                          "fp64_valu": {"achieved_tflops": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "mean_iterations": mean_iters}},
-            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in timing.items()},
-            "converged_fraction": conv_frac,
+                                       "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                                       "mean_iterations": main_m["mean_iterations"]}},
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in main_m["timing"].items()},
+            "converged_fraction": main_m["converged_fraction"],
         }
+        if other is not None:
+            o_sps, o_ms = summarize(other)
+            result["also"] = {"solver": other["solver"], "kernel": "gs_k_step_" + kernel_names[other["desc"]["kernel"]],
+                              "value": o_sps, "unit": "env_steps/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
+                              "avg_launch_ms": o_ms, "mean_iterations": other["mean_iterations"],
+                              "converged_fraction": other["converged_fraction"]}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(fs, env_kwargs)
+            result["accuracy"] = accuracy(args.solver)
+            # the reference's CPU path is dense Newton-Raphson: that port is THE baseline; the CPU port of
+            # the solver the GPU ran is reported next to it when it differs
+            result["cpu_baseline"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=12.0)
+            if args.solver != "nr":
+                result["cpu_baseline_same_solver"] = cpu_baseline(fs, env_kwargs_of(args.solver), budget_s=8.0)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
 
-    if use_gather:
-        h.comm_destroy()
-    env.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
