@@ -225,7 +225,8 @@ int step_kernels(gs_handle* h, const double* d_actions) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
     dim3 grid(h->groups), block(64 * h->W);
-#define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load)
+    GsPackArgs pa{h->map_obs, h->d_cst, h->d_out, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, h->dyn_lds / (64 * 65 * sizeof(double))))};
+#define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa)
     if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
     else if (h->solve_kernel == 4) GS_STEP(gs_k_step_nr_tree_lds);
     else if (h->solve_kernel == 1) GS_STEP(gs_k_step_nr_lu);
@@ -234,7 +235,7 @@ int step_kernels(gs_handle* h, const double* d_actions) {
     else GS_STEP(gs_k_step_fbs);
 #undef GS_STEP
     HIPCHK(h, hipGetLastError()); }
-  return launch_pack(h, h->map_obs, h->obs_dim, h->d_out);
+  return GS_OK;     // the observation block was written by the step kernel itself
 }
 
 void copy_info(gs_handle* h, double* reward, uint8_t* term, uint8_t* trunc, const gs_info_view* info) {

@@ -175,6 +175,13 @@ struct GsRows {
   int32_t LOADP;             // [n_loads] realised load power of this step
 };
 
+struct GsPackArgs {
+  const int32_t* map;      // obs column -> slab row, or -(1 + constant index)
+  const double* cst;
+  double* out;             // [B][obs_dim]
+  int32_t obs_dim, tiles_per_pass;   // 64-column tiles staged in LDS per pass
+};
+
 struct GsSolveCfg {
   double tolerance, alpha;
   int32_t max_iterations, jacobian_exact;

@@ -861,8 +861,11 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
   double psum = 0.0;
   for (int it = 0; it < C.max_iterations; ++it) {
     double lmax;
+    if (it == 0) stamp(c, ST_INIT);
     fbs_backward(c, k0, k1, &lmax, &psum);
+    stamp(c, ST_BOTTOM_UP);
     const double mm = wg_max(c, it & 1, lmax);          // full barrier: also drains the J rows
+    stamp(c, ST_FLAG);
     nr_check(st, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
@@ -888,6 +891,7 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
       while (lv >= 0) { lds_barrier(); --lv; }
     }
     __syncthreads();
+    stamp(c, ST_TOP_DOWN);
     stale = true;
   }
 #undef MSG
@@ -909,7 +913,7 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
 // ENV also everything of step() that follows the load flow (grid_env.py:553-617).
 // =============================================================================================
 template <int ENV, int WRAP_VA>
-__device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
+__device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
                                          double psum) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double lsum = have_psum ? psum : 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
@@ -1011,6 +1015,51 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
   ROW(R.VFLAGS + 2) = (double)fhigh; ROW(R.VFLAGS + 3) = (double)flow_;
 }
 
+template <int ENV, int WRAP_VA>
+__device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
+                                         double psum) {
+  epilogue_impl<ENV, WRAP_VA>(c, E, st, total_load, have_psum, psum);   // waves != 0 leave it after the reduction
+}
+
+// Observation block of this group, batch-major, written straight from the step kernel: 64-column
+// tiles of slab rows are transposed through LDS so that both the row reads (512 B) and the
+// obs[b][c0..c0+63] writes (512 B) are coalesced.  Column order: grid_env.py:753-783.
+__device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, int B) {
+  const double* Sg = c.S - c.lane;                     // group base
+  const int g = blockIdx.x;
+  const int TG = A.tiles_per_pass;                     // 64-column tiles staged per pass (LDS permitting)
+  const int span = 64 * TG;
+  for (int c0 = 0; c0 < A.obs_dim; c0 += span) {
+    // gather: this wave's rows of the pass, four independent loads in flight at a time
+    for (int j = c.wave; j < span; j += 4 * c.W) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = j + u * c.W, col = c0 + cc;
+        v[u] = 0.0;
+        if (cc < span && col < A.obs_dim) {
+          const int s = cld(A.map, col);
+          v[u] = (s >= 0) ? Sg[(size_t)s * GS_LANES + c.lane] : cld(A.cst, -s - 1);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = j + u * c.W;
+        if (cc < span) gs_dyn[(cc >> 6) * (64 * 65) + (cc & 63) * 65 + c.lane] = v[u];
+      }
+    }
+    __syncthreads();
+    for (int t = 0; t < TG; ++t) {
+      const int col = c0 + t * 64 + c.lane;
+      for (int r = c.wave; r < GS_LANES; r += c.W) {
+        const int b = g * GS_LANES + r;
+        if (b < B && col < A.obs_dim) A.out[(size_t)b * A.obs_dim + col] = gs_dyn[t * (64 * 65) + c.lane * 65 + r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Everything of step() that precedes the load flow, spread over the W waves (grid_env.py:433-477).
 __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
@@ -1055,7 +1104,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
 template <int KIND, int ENV>
 __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                           double* __restrict__ slab, int B, const double* __restrict__ actions,
-                                          double total_load) {
+                                          double total_load, const GsPackArgs& PA) {
   __shared__ GsShared sh;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1073,6 +1122,10 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds(c, C, st);
   else newton_loop<KIND>(c, C, st);
   epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS>(c, E, st, total_load, KIND == KIND_FBS_LDS, psum);   // FBS keeps no polar angle: atan2 there
+  if (ENV && PA.out != nullptr) {
+    __syncthreads();                                   // every row of the group's new state is visible
+    pack_observations(c, PA, B);
+  }
   stamp(c, ST_EPILOGUE);
 }
 
@@ -1080,12 +1133,13 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   extern "C" __global__ void __launch_bounds__(1024)                                                          \
   gs_k_##name(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {                         \
     GsEnvCfg E{};                                                                                             \
-    main_body<KIND, 0>(T, R, C, E, slab, B, nullptr, 0.0);                                                    \
+    GsPackArgs PA{};                                                                                          \
+    main_body<KIND, 0>(T, R, C, E, slab, B, nullptr, 0.0, PA);                                                \
   }                                                                                                           \
   extern "C" __global__ void __launch_bounds__(1024)                                                          \
   gs_k_step_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,          \
-                   const double* __restrict__ actions, double total_load) {                                   \
-    main_body<KIND, 1>(T, R, C, E, slab, B, actions, total_load);                                             \
+                   const double* __restrict__ actions, double total_load, GsPackArgs PA) {                    \
+    main_body<KIND, 1>(T, R, C, E, slab, B, actions, total_load, PA);                                         \
   }
 
 GS_DEFINE_KERNELS(nr_tree, KIND_TREE)
