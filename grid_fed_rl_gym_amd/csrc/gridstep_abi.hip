@@ -341,9 +341,12 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
                          (const void*)gs_k_step_nr_tree_lds, (const void*)gs_k_nr_lu, (const void*)gs_k_step_nr_lu,
                          (const void*)gs_k_nr_dense, (const void*)gs_k_step_nr_dense, (const void*)gs_k_fbs,
                          (const void*)gs_k_step_fbs, (const void*)gs_k_fbs_lds, (const void*)gs_k_step_fbs_lds};
+    // the attribute is per function, i.e. shared by every handle of the process: always raise it to
+    // the most any handle may ask for (160 KB per workgroup minus the 24 KB static block)
+    const int max_dyn = 160 * 1024 - 24576;
     for (const void* f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds) != hipSuccess)
-        return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", h->dyn_lds));
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn) != hipSuccess)
+        return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", max_dyn));
   }
 
   // ---- rows ----

@@ -186,3 +186,18 @@ def test_batched_rollout_collection():
     assert np.allclose(ds.denormalize_action(ds.actions), raw)
     assert np.allclose(ds.actions, (raw - raw.mean(0)) / (raw.std(0) + 1e-6))
     env.close()
+
+
+def test_handles_with_different_lds_footprints_coexist():
+    """A 123-bus NR handle (120 KB of dynamic LDS) keeps working after a small FBS handle was created."""
+    big = P.BatchedGridEnvironment(P.ieee123_like(), num_envs=4, stochastic_loads=False, weather_variation=False)
+    big.reset(seed=0)
+    o1 = big.step(np.zeros((4, big.action_dim)))[0]
+    small = P.BatchedGridEnvironment(P.ieee13_like("epsilon"), num_envs=4, solver="fbs", stochastic_loads=False,
+                                     weather_variation=False)
+    small.reset(seed=0)
+    small.step(np.zeros((4, small.action_dim)))
+    big.reset(seed=0)
+    o2 = big.step(np.zeros((4, big.action_dim)))[0]
+    assert np.array_equal(o1, o2)
+    big.close(); small.close()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile: kernel-trace stats + separate PMC passes (FETCH_SIZE, WRITE_SIZE) for one bench config.
-#   TAG=r01_nr BENCH_ARGS="--solver nr" ./tools_profile.sh
+#   TAG=r01_nr BENCH_ARGS="--solver nr" tools/profile.sh
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-r01}
 mkdir -p $R/gpurun_out
