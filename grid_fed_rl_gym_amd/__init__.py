@@ -18,12 +18,14 @@ from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoup
 from .env import BatchedGridEnvironment, VectorizedEnvironment, Box
 from .rollout import collect_random_data, GridDataset
 from .sharding import ShardedGridEnvironment, shard_range
+from .unbalanced import UnbalancedPowerFlow, UnbalancedFeederSpec, UnbalancedSolution, unbalanced_from_single_phase, ieee8500_like
 
 __all__ = [
     "BatchedNewtonRaphsonSolver", "NewtonRaphsonSolver", "FastDecoupledSolver",
     "BatchedForwardBackwardSweepSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
     "injections_from_dicts", "BatchedGridEnvironment", "VectorizedEnvironment", "Box",
     "collect_random_data", "GridDataset", "ShardedGridEnvironment", "shard_range",
+    "UnbalancedPowerFlow", "UnbalancedFeederSpec", "UnbalancedSolution", "unbalanced_from_single_phase", "ieee8500_like",
     "Bus", "Line", "Load", "PowerFlowSolution", "BatchedPowerFlowSolution", "PowerFlowError",
     "InvalidActionError", "FeederSpec", "flatten_feeder", "flatten_network", "to_objects",
     "reference_env_network", "with_reference_env_renewables", "simple_radial", "ieee13_like",

@@ -95,6 +95,8 @@ SYMBOLS = [
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
 ]
+# the gs3_* entry points (three-phase solver) are bound in unbalanced.py
+
 
 _lib: Optional[C.CDLL] = None
 

@@ -206,6 +206,53 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n);
 /* total_ms[GS_K_COUNT], launches[GS_K_COUNT] accumulated since the last call; resets them */
 int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches);
 
+/* ======================================================================================
+ * Three-phase unbalanced radial load flow (BASELINE.json config 5).  NEW functionality: the
+ * reference names UnbalancedPowerFlow (README.md:187-197, API_REFERENCE.md:420) but contains no
+ * implementation, so there is no reference interface to cite beyond the solver plug point
+ * (environments/power_flow.py:38-46) whose record layout the outputs follow, with a phase axis.
+ * Mapping differs from the single-phase path: one workgroup per instance, lanes over the nodes
+ * of a tree level (networks of thousands of nodes, batches of ~1000).
+ * ====================================================================================== */
+typedef struct gs3_topology {
+  int32_t struct_size;            /* = sizeof(gs3_topology) */
+  int32_t n;                      /* nodes; node `source` is the three-phase source (slack) */
+  int32_t source;
+  int32_t reserved;
+  const int32_t* parent;          /* [n] upstream node of each node, -1 for the source */
+  const uint8_t* phases;          /* [n] bit mask (1 = a, 2 = b, 4 = c) of the phases the node's upstream line carries;
+                                     must be a subset of the parent's mask; the source has 7 */
+  const double* z_re;             /* [n][3][3] series impedance of the upstream line, per unit (ignored for the source) */
+  const double* z_im;             /* [n][3][3] */
+  const double* v_source;         /* [3] source voltage magnitudes; angles are 0, -120, +120 degrees */
+} gs3_topology;
+
+typedef struct gs3_solution_view {
+  double* v_re;                   /* [B][n][3] phase-to-neutral voltage, rectangular; absent phases = 0 */
+  double* v_im;                   /* [B][n][3] */
+  double* losses;                 /* [B] total real losses (sum over phases) */
+  double* max_mismatch;           /* [B] */
+  int32_t* iterations;            /* [B] */
+  uint8_t* converged;             /* [B] */
+} gs3_solution_view;
+
+typedef struct gs3_handle gs3_handle;
+
+int gs3_create(const gs3_topology* topo, double tolerance, int32_t max_iterations, int32_t batch, int32_t device,
+               gs3_handle** out);
+void gs3_destroy(gs3_handle* h);
+const char* gs3_last_error(const gs3_handle* h);
+/* P_spec / Q_spec [B][n][3]: net injection per node and phase (generation - load), per unit */
+int gs3_solve(gs3_handle* h, const double* P_spec, const double* Q_spec, const gs3_solution_view* out);
+/* device-resident variant for measurement */
+int gs3_upload_injections(gs3_handle* h, const double* P_spec, const double* Q_spec);
+int gs3_solve_device(gs3_handle* h);
+int gs3_download_solution(gs3_handle* h, const gs3_solution_view* out);
+int gs3_synchronize(gs3_handle* h);
+/* average milliseconds of the solve kernel over the launches since the last call (HIP events) */
+int gs3_timing_read(gs3_handle* h, double* total_ms, int64_t* launches);
+int gs3_describe(const gs3_handle* h, char* buf, int32_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

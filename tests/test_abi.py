@@ -16,14 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "gridstep.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gs_[a-z_0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(gs3?_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
     lib = _lib.load()
     declared = _header_functions()
     assert len(declared) >= 25
-    bound = {name for name, _, _ in _lib.SYMBOLS}
+    from grid_fed_rl_gym_amd.unbalanced import GS3_SYMBOLS
+    bound = {name for name, _, _ in _lib.SYMBOLS} | {name for name, _, _ in GS3_SYMBOLS}
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gridstep.h but not exported by libgridstep.so"
         assert name in bound, f"{name} declared in gridstep.h but not bound in _lib.SYMBOLS"

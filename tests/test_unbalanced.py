@@ -1,0 +1,109 @@
+"""Three-phase unbalanced load flow (BASELINE.json config 5): new functionality, no reference code
+(parity unpinned by the reference).  Anchors: the balanced/uncoupled limit equals the single-phase
+solution pinned by the reference-derived fixtures; the 3-phase oracle; the Y3 residual property."""
+import numpy as np
+import pytest
+
+import grid_fed_rl_gym_amd as P
+from grid_fed_rl_gym_amd.unbalanced import UnbalancedPowerFlow, UnbalancedFeederSpec, unbalanced_from_single_phase, ieee8500_like
+from oracle import oracle3_np as O3
+from tests.helpers import golden, net_of
+
+
+def _fs_of(d):
+    n, frm, to, r, x, rating, bt, vs = net_of(d)
+    return P.FeederSpec(name="g", bus_ids=list(range(n)), bus_type=bt.astype(np.uint8), v_set=vs, frm=frm, to=to, r=r, x=x, rating=rating)
+
+
+def _random_case(n, seed, lateral=0.35):
+    rng = np.random.default_rng(seed)
+    parent = np.full(n, -1, dtype=np.int32); phases = np.full(n, 7, dtype=np.uint8); z = np.zeros((n, 3, 3), dtype=complex)
+    for b in range(1, n):
+        p = int(rng.integers(0, b)); parent[b] = p
+        m = int(phases[p])
+        if m == 7 and rng.random() < lateral:
+            m = [1, 2, 4, 3, 5, 6][int(rng.integers(0, 6))]
+        phases[b] = m
+        zs = complex(rng.uniform(0.004, 0.01), rng.uniform(0.008, 0.02))
+        z[b] = zs * np.eye(3) + rng.uniform(0.2, 0.4) * zs * (1 - np.eye(3))
+    return UnbalancedFeederSpec("rnd", parent, phases, z)
+
+
+@pytest.mark.parametrize("name", ["solve_radial13", "solve_tree123"])
+def test_oracle_balanced_limit_equals_reference_anchor(name):
+    """CPU: uncoupled lines + balanced loads -> every phase is the single-phase Tier-B solution."""
+    d = golden(name)
+    spec = unbalanced_from_single_phase(_fs_of(d), coupling=0.0)
+    lam = float(d["exact_scales"][1])
+    Pn = np.repeat((d["P_spec"] * lam)[:, None], 3, axis=1)
+    sol = O3.fbs3_solve(spec.parent, spec.phases, spec.z, spec.source, spec.v_source, Pn, np.zeros_like(Pn), tolerance=1e-11, max_iterations=300)
+    assert sol["converged"]
+    V1 = d["C1_Vm"] * np.exp(1j * d["C1_Va"])
+    for ph in range(3):
+        assert np.max(np.abs(sol["voltages"][:, ph] - V1 * O3.A120[ph])) < 1e-9
+    assert abs(sol["losses"] - 3 * float(d["C1_losses"])) < 1e-9
+    res, _ = O3.residual(spec.parent, spec.phases, spec.z, spec.source, sol["voltages"], Pn, np.zeros_like(Pn))
+    assert res < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["solve_radial13", "solve_tree123"])
+def test_gpu_balanced_limit_equals_reference_anchor(name):
+    d = golden(name)
+    spec = unbalanced_from_single_phase(_fs_of(d), coupling=0.0)
+    Pb = np.stack([np.repeat((d["P_spec"] * lam)[:, None], 3, axis=1) for lam in d["exact_scales"]])
+    s = UnbalancedPowerFlow(tolerance=1e-11, max_iterations=300)
+    sol = s.solve_batch(spec, Pb)
+    for q in range(len(d["exact_scales"])):
+        V1 = d[f"C{q}_Vm"] * np.exp(1j * d[f"C{q}_Va"])
+        assert sol.converged[q]
+        for ph in range(3):
+            assert np.max(np.abs(sol.voltages[q, :, ph] - V1 * O3.A120[ph])) < 1e-9      # bar: 1e-6 pu
+        assert abs(sol.losses[q] - 3 * float(d[f"C{q}_losses"])) < 1e-9
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,seed", [(40, 5, 1), (150, 70, 2), (333, 9, 3)])
+def test_gpu_unbalanced_against_oracle(n, B, seed):
+    spec = _random_case(n, seed)
+    rng = np.random.default_rng(seed + 100)
+    pres = ((spec.phases[:, None] >> np.arange(3)[None, :]) & 1).astype(bool)
+    Pb = np.where(pres[None], -rng.uniform(0.0002, 0.003, (B, n, 3)), 0.0); Pb[:, 0] = 0
+    Qb = Pb * rng.uniform(0.2, 0.5, (B, n, 3))
+    s = UnbalancedPowerFlow(tolerance=1e-9, max_iterations=200)
+    sol = s.solve_batch(spec, Pb, Qb)
+    assert sol.converged.all()
+    for b in range(0, B, max(1, B // 4)):
+        ref = O3.fbs3_solve(spec.parent, spec.phases, spec.z, 0, spec.v_source, Pb[b], Qb[b], tolerance=1e-9, max_iterations=200)
+        assert ref["converged"] and ref["iterations"] == sol.iterations[b]
+        assert np.max(np.abs(sol.voltages[b] - ref["voltages"])) < 1e-10
+        assert abs(sol.losses[b] - ref["losses"]) < 1e-10 and abs(sol.max_mismatch[b] - ref["max_mismatch"]) < 1e-12
+        res, ploss = O3.residual(spec.parent, spec.phases, spec.z, 0, sol.voltages[b], Pb[b], Qb[b])
+        assert res < 1e-8 and abs(ploss - sol.losses[b]) < 1e-8      # sum of S_calc over all nodes = losses
+        assert np.all(sol.voltages[b][~pres] == 0)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_8500_node_property():
+    """Full-size feeder: the converged voltages satisfy S = V conj(Y3 V) (independent assembly)."""
+    spec, Pn, Qn = ieee8500_like()
+    B = 3
+    lam = np.array([0.6, 1.0, 1.3])
+    s = UnbalancedPowerFlow(tolerance=1e-8, max_iterations=200)
+    sol = s.solve_batch(spec, lam[:, None, None] * Pn[None], lam[:, None, None] * Qn[None])
+    assert sol.converged.all() and sol.iterations.max() < 60
+    assert 0.85 < np.abs(sol.voltages[1][np.abs(sol.voltages[1]) > 0]).min() < 1.0
+    res, _ = O3.residual(spec.parent, spec.phases, spec.z, 0, sol.voltages[1], Pn, Qn)
+    assert res < 1e-7
+    s.close()
+
+
+def test_topology_validation_cpu():
+    spec, Pn, Qn = ieee8500_like(n=300, seed=5)
+    assert spec.n == 300 and Pn.shape == (300, 3) and (Pn <= 0).all()
+    pres = ((spec.phases[:, None] >> np.arange(3)[None, :]) & 1).astype(bool)
+    assert np.all(Pn[~pres] == 0)
+    for b in range(1, 300):
+        assert spec.phases[b] & ~spec.phases[spec.parent[b]] == 0
