@@ -38,6 +38,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor figure for MI355X FP64 vector
 WORKLOADS = {
     "ieee123_b8192": dict(feeder="ieee123_like", batch=8192),
     "ieee13_b4096": dict(feeder="ieee13_like", batch=4096),
+    "ieee8500_3ph_b1024": dict(feeder="ieee8500_like", batch=1024),      # BASELINE.json config 5 (solver only)
 }
 
 
@@ -86,6 +87,64 @@ def cpu_baseline(fs, env_kwargs, budget_s=15.0):
             "sample": f"NumPy oracle, {b} instances x 4 steps of the same workload in {dt:.1f} s"}
 
 
+def bench_unbalanced(args, device):
+    """BASELINE.json config 5: 8500-node three-phase unbalanced FBS, batch 1024 -- load-flow solves/s.
+    A "step" is one batched solve from a flat start; injections resident in HBM."""
+    from grid_fed_rl_gym_amd.unbalanced import UnbalancedPowerFlow, ieee8500_like
+    spec, Pn, Qn = ieee8500_like()
+    B = args.batch or WORKLOADS[args.workload]["batch"]
+    lam = np.random.default_rng(1234).uniform(0.5, 1.5, B)
+    Pb, Qb = lam[:, None, None] * Pn[None], lam[:, None, None] * Qn[None]
+    s = UnbalancedPowerFlow(tolerance=args.tolerance, max_iterations=args.max_iterations or 100, device=device)
+    s.upload(spec, Pb, Qb)
+    for _ in range(args.warmup):
+        s.solve_device()
+    s.synchronize(); s.timing_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.solve_device()
+    s.synchronize()
+    elapsed = time.perf_counter() - t0
+    total_ms, launches = s.timing_read()
+    sol = s.download()
+    desc = s.describe()
+    avg_ms = total_ms / max(launches, 1)
+    mean_it = float(sol.iterations.mean())
+    # SURVEY.md section 8(d): per FBS iteration 4 * 48 n bytes read+write per instance (V and I, 3 phases, complex)
+    alg_bytes = 4 * 48 * spec.n * mean_it * B
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    result = {"metric": "three-phase load-flow solves/sec (batched feeders)", "value": B * args.steps / elapsed, "unit": "solves/s",
+              "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": f"{spec.name}, 3-phase unbalanced FBS, batch={B}, per-instance loading U(0.5,1.5), tolerance {args.tolerance:g}",
+                         "n_nodes": spec.n, "tree_levels": desc["levels"], "max_level_width": desc["max_level_width"],
+                         "batch_per_gpu": B, "kernel": "gs3_k_solve"},
+              "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "gs3_k_solve", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                           "mean_iterations": mean_it},
+              "converged_fraction": float(sol.converged.mean()),
+              "min_voltage_pu": float(np.abs(sol.voltages)[np.abs(sol.voltages) > 0].min())}
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import oracle_c as OC
+            threads = max(1, min(OC.lib().orc_max_threads(), len(os.sched_getaffinity(0)), 16))
+            nb = 4 * threads
+            t1 = time.perf_counter(); done = 0
+            while time.perf_counter() - t1 < 10.0:
+                out = OC.solve3_batch(spec, Pb[:nb], Qb[:nb], tolerance=args.tolerance, threads=threads); done += nb
+            dt = time.perf_counter() - t1
+            ref = OC.solve3_batch(spec, Pb[:4], Qb[:4], tolerance=args.tolerance, threads=threads)
+            result["accuracy"] = {"max_abs_dV_pu": float(np.max(np.abs(sol.voltages[:4] - ref["voltages"]))),
+                                  "against": "C oracle (same algorithm; the reference has no 3-phase solver: parity unpinned)"}
+            result["cpu_baseline"] = {"value": done / dt, "unit": "solves/s", "cores": threads, "kind": "port",
+                                      "sample": f"C/OpenMP oracle, {done} solves (batches of {nb}) in {dt:.1f} s on {threads} threads"}
+        except Exception as e:
+            result["cpu_baseline"] = None
+            print(f"[bench] C oracle unavailable: {e}", file=sys.stderr)
+    print(json.dumps(result), flush=True)
+    s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +179,12 @@ def main():
         dist = dist_mod
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
+    if args.workload == "ieee8500_3ph_b1024":
+        if world != 1:
+            print("[bench] the 3-phase workload is a single-GPU measurement", file=sys.stderr)
+            sys.exit(2)
+        bench_unbalanced(args, device)
+        return
     wl = WORKLOADS[args.workload]
     fs = make_feeder(wl["feeder"])
     B = args.batch or wl["batch"]

@@ -230,7 +230,7 @@ def ieee8500_like(n: int = 8500, seed: int = 8500, lateral_probability: float = 
         elif m in (3, 5, 6) and rng.random() < 0.2:
             m = [q for q in (1, 2, 4) if q & m][int(rng.integers(0, 2))]
         phases[b] = m
-        zs = complex(rng.uniform(0.00003, 0.00006), rng.uniform(0.00006, 0.00012))
+        zs = complex(rng.uniform(0.0045, 0.009), rng.uniform(0.009, 0.018))   # gives V_min ~ 0.95 pu at nominal load
         z[b] = zs * np.eye(3) + 0.3 * zs * (1 - np.eye(3))
     kw = rng.uniform(1.0, 15.0, (n, 3))
     present = ((phases[:, None] >> np.arange(3)[None, :]) & 1).astype(bool)

@@ -147,3 +147,36 @@ def bench_env_steps(fs, env_kwargs, budget_s=15.0) -> dict:
     return {"value": n_done / dt, "unit": "env_steps/s", "cores": threads, "kind": "port",
             "sample": f"C/OpenMP oracle ({'dense Newton-Raphson as the reference codes it' if env_kwargs['solver'] == 'nr' else 'forward/backward sweep, dense mismatch'}), {n_done} env-steps of the same workload "
                       f"(batches of {B}) in {dt:.1f} s on {threads} threads"}
+
+
+def solve3_batch(spec, P, Q, tolerance=1e-6, max_iterations=100, threads=0) -> dict:
+    """Three-phase FBS on the CPU (orc3_solve_batch).  ``spec`` is an UnbalancedFeederSpec-like object
+    whose nodes satisfy parent[i] < i with the source at 0 (the generators in unbalanced.py do)."""
+    n = len(spec.parent)
+    parent = np.ascontiguousarray(spec.parent, dtype=np.int32)
+    phases = np.ascontiguousarray(spec.phases, dtype=np.uint8)
+    z = np.asarray(spec.z)
+    pres = ((phases[:, None] >> np.arange(3)[None, :]) & 1).astype(bool)
+    y = np.zeros_like(z)
+    zz = z.copy()
+    for i in range(1, n):
+        idx = np.nonzero(pres[i])[0]
+        m = np.zeros((3, 3), dtype=complex); m[np.ix_(idx, idx)] = z[i][np.ix_(idx, idx)]
+        zz[i] = m
+        y[i][np.ix_(idx, idx)] = np.linalg.inv(z[i][np.ix_(idx, idx)])
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)   # noqa: E731
+    zre, zim, yre, yim = f(zz.real.reshape(n, 9)), f(zz.imag.reshape(n, 9)), f(y.real.reshape(n, 9)), f(y.imag.reshape(n, 9))
+    P = f(P); Q = f(np.zeros_like(P) if Q is None else Q)
+    B = P.shape[0]
+    out = dict(v_re=np.empty((B, n, 3)), v_im=np.empty((B, n, 3)), losses=np.empty(B), max_mismatch=np.empty(B),
+               iterations=np.empty(B, dtype=np.int32), converged=np.empty(B, dtype=np.uint8))
+    vs = f(spec.v_source)
+    rc = lib().orc3_solve_batch(C.c_int32(n), _p(parent, _ip), _p(phases, _up), _p(zre, _dp), _p(zim, _dp), _p(yre, _dp),
+                                _p(yim, _dp), _p(vs, _dp), C.c_int32(B), _p(P, _dp), _p(Q, _dp), C.c_double(tolerance),
+                                C.c_int32(max_iterations), C.c_int32(threads), _p(out["v_re"], _dp), _p(out["v_im"], _dp),
+                                _p(out["losses"], _dp), _p(out["max_mismatch"], _dp), _p(out["iterations"], _ip),
+                                _p(out["converged"], _up))
+    if rc != 0:
+        raise RuntimeError(f"orc3_solve_batch failed ({rc})")
+    out["voltages"] = out["v_re"] + 1j * out["v_im"]
+    return out

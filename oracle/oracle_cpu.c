@@ -537,3 +537,89 @@ int orc_max_threads(void) {
   return 1;
 #endif
 }
+
+/* =============================================================================================
+ * Three-phase unbalanced forward/backward sweep (BASELINE config 5).  No reference code exists for
+ * it: parity unpinned by the reference; this C version mirrors oracle3_np.py and is
+ * the cpu_baseline of the 3-phase bench.  Nodes must be numbered so that parent[i] < i (source 0).
+ * z_re/z_im: [n][9] line blocks; y_re/y_im: [n][9] their inverses on the present phases.
+ * ============================================================================================= */
+int orc3_solve_batch(int32_t n, const int32_t* parent, const uint8_t* phases, const double* z_re, const double* z_im,
+                     const double* y_re, const double* y_im, const double* v_source, int32_t B, const double* P,
+                     const double* Q, double tol, int32_t max_it, int32_t threads, double* v_re, double* v_im,
+                     double* losses, double* max_mismatch, int32_t* iterations, uint8_t* converged) {
+  const double ang[3] = {0.0, -2.0 * M_PI / 3.0, 2.0 * M_PI / 3.0};
+  double vsr[3], vsi[3];
+  for (int ph = 0; ph < 3; ++ph) { vsr[ph] = v_source[ph] * cos(ang[ph]); vsi[ph] = v_source[ph] * sin(ang[ph]); }
+  for (int i = 1; i < n; ++i) if (parent[i] < 0 || parent[i] >= i) return -4;
+#ifdef _OPENMP
+  int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+#endif
+  for (int b = 0; b < B; ++b) {
+    double* vr = v_re + (size_t)b * n * 3; double* vi = v_im + (size_t)b * n * 3;
+    const double* p = P + (size_t)b * n * 3; const double* q = Q + (size_t)b * n * 3;
+    double* w = (double*)malloc(sizeof(double) * (size_t)n * 12);
+    double *jr = w, *ji = w + 3 * (size_t)n, *kr = w + 6 * (size_t)n, *ki = w + 9 * (size_t)n;
+    for (int i = 0; i < n; ++i) for (int ph = 0; ph < 3; ++ph) {
+      int on = (phases[i] >> ph) & 1;
+      vr[3 * i + ph] = on ? vsr[ph] : 0.0; vi[3 * i + ph] = on ? vsi[ph] : 0.0;
+    }
+    int it = 0, conv = 0; double mm = INFINITY, loss = 0.0;
+    for (it = 0; it < max_it; ++it) {
+      for (size_t k = 0; k < (size_t)n * 12; ++k) w[k] = 0.0;     /* J and K accumulate children */
+      mm = 0.0; loss = 0.0;
+      for (int i = n - 1; i >= 1; --i) {
+        int pt = parent[i];
+        double k_r[3], k_i[3];
+        for (int r = 0; r < 3; ++r) {
+          double ar = 0.0, ai = 0.0;
+          for (int c = 0; c < 3; ++c) {
+            double dr = vr[3 * i + c] - vr[3 * pt + c], di = vi[3 * i + c] - vi[3 * pt + c];
+            double yr = y_re[(size_t)i * 9 + 3 * r + c], yi = y_im[(size_t)i * 9 + 3 * r + c];
+            ar += yr * dr - yi * di; ai += yr * di + yi * dr;
+          }
+          k_r[r] = ar; k_i[r] = ai;
+        }
+        for (int ph = 0; ph < 3; ++ph) {
+          /* jr/ji/kr/ki of node i hold the sums over its children at this point */
+          double sjr = jr[3 * i + ph], sji = ji[3 * i + ph], skr = kr[3 * i + ph], ski = ki[3 * i + ph];
+          double jjr = sjr, jji = sji;
+          if ((phases[i] >> ph) & 1) {
+            double e = vr[3 * i + ph], f = vi[3 * i + ph], pp = p[3 * i + ph], qq = q[3 * i + ph];
+            double icr = k_r[ph] - skr, ici = k_i[ph] - ski;
+            double pc = e * icr + f * ici, qc = f * icr - e * ici;
+            double dP = fabs(pp - pc), dQ = fabs(qq - qc);
+            if (!(dP < INFINITY) || !(dQ < INFINITY)) mm = INFINITY;
+            if (dP > mm) mm = dP;
+            if (dQ > mm) mm = dQ;
+            loss += pc;
+            if (pt == 0) loss -= vr[ph] * k_r[ph] + vi[ph] * k_i[ph];
+            double rd = 1.0 / (e * e + f * f);
+            jjr -= (pp * e + qq * f) * rd; jji += (qq * e - pp * f) * rd;
+          }
+          jr[3 * i + ph] = jjr; ji[3 * i + ph] = jji;
+          jr[3 * pt + ph] += jjr; ji[3 * pt + ph] += jji;
+          kr[3 * pt + ph] += k_r[ph]; ki[3 * pt + ph] += k_i[ph];
+        }
+      }
+      if (!(mm < INFINITY)) break;
+      if (mm < tol) { conv = 1; break; }
+      for (int i = 1; i < n; ++i) {
+        int pt = parent[i];
+        for (int r = 0; r < 3; ++r) {
+          double ar = 0.0, ai = 0.0;
+          for (int c = 0; c < 3; ++c) {
+            double zr = z_re[(size_t)i * 9 + 3 * r + c], zi = z_im[(size_t)i * 9 + 3 * r + c];
+            ar += zr * jr[3 * i + c] - zi * ji[3 * i + c]; ai += zr * ji[3 * i + c] + zi * jr[3 * i + c];
+          }
+          int on = (phases[i] >> r) & 1;
+          vr[3 * i + r] = on ? vr[3 * pt + r] - ar : 0.0; vi[3 * i + r] = on ? vi[3 * pt + r] - ai : 0.0;
+        }
+      }
+    }
+    losses[b] = loss; max_mismatch[b] = mm; iterations[b] = it < max_it ? it + 1 : max_it; converged[b] = (uint8_t)conv;
+    free(w);
+  }
+  return 0;
+}
