@@ -107,3 +107,19 @@ def test_topology_validation_cpu():
     assert np.all(Pn[~pres] == 0)
     for b in range(1, 300):
         assert spec.phases[b] & ~spec.phases[spec.parent[b]] == 0
+
+
+def test_c_oracle_matches_numpy_oracle_cpu():
+    """The C/OpenMP three-phase port (bench cpu_baseline) against the NumPy oracle."""
+    import subprocess, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    from oracle import oracle_c as OC
+    spec, Pn, Qn = ieee8500_like(n=500, seed=9)
+    lam = np.array([0.7, 1.4])
+    out = OC.solve3_batch(spec, lam[:, None, None] * Pn[None], lam[:, None, None] * Qn[None], tolerance=1e-9, threads=2)
+    for b in range(2):
+        ref = O3.fbs3_solve(spec.parent, spec.phases, spec.z, 0, spec.v_source, lam[b] * Pn, lam[b] * Qn, tolerance=1e-9)
+        assert ref["converged"] and out["converged"][b] and out["iterations"][b] == ref["iterations"]
+        assert np.max(np.abs(out["voltages"][b] - ref["voltages"])) < 1e-12
+        assert abs(out["losses"][b] - ref["losses"]) < 1e-12
