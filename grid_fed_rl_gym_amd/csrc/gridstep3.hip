@@ -11,19 +11,16 @@
 // workgroup per instance, lanes over the nodes of a tree level.  Nodes are renumbered in
 // breadth-first order, so a level is a contiguous index range, the children of a node are a
 // contiguous range of the next level, and every per-node array is read and written coalesced.
-// Per-instance state (24 doubles per node: V, S_spec, J, K; 1.6 MB at 8500 nodes) lives in HBM --
-// this configuration is HBM-streaming by construction.
-//
-//   backward (deepest level first):  K_t = Y_t (V_t - V_parent)              current implied by the voltages
-//                                    S_calc = V_t conj(K_t - sum_children K)  -> mismatch, losses
-//                                    J_t = -conj(S_spec / V_t) + sum_children J
-//   forward  (root's children first): V_t = V_parent - Z_t J_t
+// Per-instance state (18 doubles per node: V, S_spec, D = Z J; 1.2 MB at 8500 nodes) lives in HBM --
+// this configuration is HBM-streaming by construction.  What one level hands
+// to the next (J going up, V going down) travels through LDS; see gs3_solve_body for the sweep pair.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,22 +30,22 @@
 namespace {
 
 struct Topo3 {
-  int32_t n, n_levels;
+  int32_t n, n_levels, cap;  // cap = widest level (LDS message rows)
   const int32_t* lvl_ptr;    // [n_levels + 1]; level 0 = the source alone
-  const int32_t* par;        // [n] position of the parent (level order)
-  const int32_t* cfirst;     // [n] first child position
-  const int32_t* ccount;     // [n]
-  const int32_t* mask;       // [n] phase mask of the node
+  const int4* idx;           // [n] {parent position, first child position, child count, phase mask} (level order)
   const double* zr;          // [9][n] series impedance of the upstream line (rows/cols of absent phases zeroed)
   const double* zi;
-  const double* yr;          // [9][n] its inverse on the present phases
-  const double* yi;
   double vsr[3], vsi[3];     // source voltage
 };
 
-enum { C_VR = 0, C_VI = 3, C_P = 6, C_Q = 9, C_JR = 12, C_JI = 15, C_KR = 18, C_KI = 21, C_COUNT = 24 };
+// C_DR/C_DI: the voltage drop Z_t J_t of the upstream line.  C_JR/C_JI (line currents) exist only when the
+// level messages cannot go through LDS (h->lds_bytes == 0); the state then has 24 rows per node.
+enum { C_VR = 0, C_VI = 3, C_P = 6, C_Q = 9, C_DR = 12, C_DI = 15, C_COUNT = 18, C_JR = 18, C_JI = 21, C_COUNT_NOLDS = 24 };
 
-#define ST(comp, t) S[(size_t)(comp) * n + (t)]
+// row base in SGPRs + one 32-bit byte offset per thread
+#define ST(comp, t) (*(double*)((char*)(S + (size_t)(comp) * n) + ((unsigned)(t) << 3)))
+#define ZT(tab, k, t) (*(const double*)((const char*)((tab) + (size_t)(k) * n) + ((unsigned)(t) << 3)))
+#define GS3_CONST __attribute__((address_space(4)))
 
 __device__ __forceinline__ double block_max(double v, double* sh) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -72,127 +69,213 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return r;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern __shared__ double gs3_msg[];   // [2 (level parity)][6][cap]: J of a level on the way up, V on the way down
+
+// Level barrier.  With LDS messages nothing a level writes to HBM is read by another thread (a node keeps
+// its thread in both sweeps), so the barrier only has to order LDS and the loads prefetched for the next
+// level stay in flight across it.
+template <bool LDSMSG> __device__ __forceinline__ void level_barrier() {
+  if (LDSMSG) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
+struct UpIn { int4 ix; double vr[3], vi[3], p[3], q[3]; };                // what a node needs on the way up
+struct DownIn { int4 ix; double dr[3], di[3], vr[3], vi[3], p[3], q[3]; };     // ... and on the way down
+
+// One sweep pair per iteration, the power mismatch evaluated on the way DOWN.
+//   backward (deepest level first):   J_t = -conj(S_spec / V_t) + sum_children J   (children through LDS)
+//                                     D_t = Z_t J_t  -> HBM                         (the only use of J_t later)
+//   forward  (root's children first): V_t = V_parent - D_t                          (parent through LDS)
+// After a forward sweep V_t - V_parent = -Z_t J_t holds exactly, so the current the new voltages imply on
+// line t is -J_t and the current drawn at node t is the injection current conj(S_spec / V_old) the backward
+// sweep used: the mismatch S_spec - V_new conj(I_old) needs neither Y = Z^-1 nor the children's line
+// currents, and it is the number the NEXT backward sweep of the textbook loop would report -- one sweep
+// earlier.  The flat start is never written to memory: with V = V_source everywhere the implied currents
+// are zero and the first mismatch is |S_spec|.
+// Each level step prefetches the own rows of the next level before its barrier, so a step costs LDS
+// latency plus arithmetic rather than a round trip to HBM.
+template <bool LDSMSG>
+__device__ __forceinline__ void gs3_solve_body(const Topo3& T, double* __restrict__ S, double tol, int max_it,
+                                               double* sh, double& losses, double& mm, int& it_out, int& conv_out) {
+  const int n = T.n, cap = T.cap, L = T.n_levels, tid = threadIdx.x, nth = blockDim.x;
+  const GS3_CONST int32_t* lvl = (const GS3_CONST int32_t*)T.lvl_ptr;
+  int iters = max_it, conv = 0;
+  mm = INFINITY; losses = 0.0;
+  if (tid < 3) { ST(C_VR + tid, 0) = T.vsr[tid]; ST(C_VI + tid, 0) = T.vsi[tid]; }     // the source row
+  for (int it = 0; it < max_it; ++it) {
+    const bool first = it == 0;
+    auto load_up = [&](int t) {
+      UpIn u;
+      u.ix = (*(const int4*)((const char*)T.idx + ((unsigned)t << 4)));
+      for (int ph = 0; ph < 3; ++ph) {
+        const bool on = (u.ix.w >> ph) & 1;
+        u.vr[ph] = first ? (on ? T.vsr[ph] : 0.0) : ST(C_VR + ph, t);
+        u.vi[ph] = first ? (on ? T.vsi[ph] : 0.0) : ST(C_VI + ph, t);
+        u.p[ph] = ST(C_P + ph, t); u.q[ph] = ST(C_Q + ph, t);
+      }
+      return u;
+    };
+    auto load_down = [&](int t) {
+      DownIn d;
+      d.ix = (*(const int4*)((const char*)T.idx + ((unsigned)t << 4)));
+      for (int ph = 0; ph < 3; ++ph) {
+        const bool on = (d.ix.w >> ph) & 1;
+        d.dr[ph] = ST(C_DR + ph, t); d.di[ph] = ST(C_DI + ph, t);
+        d.vr[ph] = first ? (on ? T.vsr[ph] : 0.0) : ST(C_VR + ph, t);
+        d.vi[ph] = first ? (on ? T.vsi[ph] : 0.0) : ST(C_VI + ph, t);
+        d.p[ph] = ST(C_P + ph, t); d.q[ph] = ST(C_Q + ph, t);
+      }
+      return d;
+    };
+
+    // ---- backward
+    double lmax = 0.0, psrc = 0.0;
+    UpIn un = {};
+    { const int t = lvl[L - 1] + tid; if (L > 1 && t < lvl[L]) un = load_up(t); }
+    for (int l = L - 1; l >= 1; --l) {
+      const int t0 = lvl[l], t1 = lvl[l + 1];
+      double* up = gs3_msg + (size_t)(l & 1) * 6 * cap;
+      const double* dn = gs3_msg + (size_t)((l + 1) & 1) * 6 * cap;
+      UpIn u = un;
+      if (l > 1) { const int t = lvl[l - 1] + tid; if (t < t0) un = load_up(t); }
+      for (int t = t0 + tid; t < t1; t += nth) {
+        if (t != t0 + tid) u = load_up(t);
+        // own injection current first: V, P, Q are dead before the impedance rows arrive
+        double jr[3], ji[3];
+        for (int ph = 0; ph < 3; ++ph) {
+          jr[ph] = 0.0; ji[ph] = 0.0;
+          if ((u.ix.w >> ph) & 1) {
+            if (first) {
+              const double dP = fabs(u.p[ph]), dQ = fabs(u.q[ph]);
+              lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
+            }
+            const double rd = 1.0 / (u.vr[ph] * u.vr[ph] + u.vi[ph] * u.vi[ph]);
+            jr[ph] = -(u.p[ph] * u.vr[ph] + u.q[ph] * u.vi[ph]) * rd;
+            ji[ph] = -(u.p[ph] * u.vi[ph] - u.q[ph] * u.vr[ph]) * rd;
+          }
+        }
+        asm volatile("" ::: "memory");
+        double zr[9], zi[9];
+        for (int k = 0; k < 9; ++k) { zr[k] = ZT(T.zr, k, t); zi[k] = ZT(T.zi, k, t); }
+        for (int ch = u.ix.y; ch < u.ix.y + u.ix.z; ++ch)
+          for (int ph = 0; ph < 3; ++ph) {
+            if (LDSMSG) { jr[ph] += dn[ph * cap + (ch - t1)]; ji[ph] += dn[(3 + ph) * cap + (ch - t1)]; }
+            else { jr[ph] += ST(C_JR + ph, ch); ji[ph] += ST(C_JI + ph, ch); }
+          }
+        for (int ph = 0; ph < 3; ++ph) {
+          if (l == 1 && ((u.ix.w >> ph) & 1)) psrc += T.vsr[ph] * jr[ph] + T.vsi[ph] * ji[ph];     // the source's share of sum P_calc
+          if (LDSMSG) { up[ph * cap + (t - t0)] = jr[ph]; up[(3 + ph) * cap + (t - t0)] = ji[ph]; }
+          else { ST(C_JR + ph, t) = jr[ph]; ST(C_JI + ph, t) = ji[ph]; }
+        }
+        for (int r = 0; r < 3; ++r) {
+          double ar = 0.0, ai = 0.0;
+          for (int cc = 0; cc < 3; ++cc) {
+            ar += zr[3 * r + cc] * jr[cc] - zi[3 * r + cc] * ji[cc];
+            ai += zr[3 * r + cc] * ji[cc] + zi[3 * r + cc] * jr[cc];
+          }
+          ST(C_DR + r, t) = ar; ST(C_DI + r, t) = ai;
+        }
+      }
+      level_barrier<LDSMSG>();
+    }
+    if (first) {
+      mm = block_max(lmax, sh);
+      losses = 0.0;
+      if (!(mm < INFINITY) || mm < tol) {     // no sweep will follow: the answer is the flat start itself
+        for (int t = 1 + tid; t < n; t += nth) {
+          const int m = (*(const int4*)((const char*)T.idx + ((unsigned)t << 4))).w;
+          for (int ph = 0; ph < 3; ++ph) {
+            const bool on = (m >> ph) & 1;
+            ST(C_VR + ph, t) = on ? T.vsr[ph] : 0.0; ST(C_VI + ph, t) = on ? T.vsi[ph] : 0.0;
+          }
+        }
+        iters = 1; conv = mm < tol;
+        break;
+      }
+    }
+
+    // ---- forward, with the mismatch / losses at the new voltages
+    lmax = 0.0;
+    double psum = psrc;
+    DownIn dnx = {};
+    { const int t = lvl[1] + tid; if (L > 1 && t < lvl[2]) dnx = load_down(t); }
+    for (int l = 1; l < L; ++l) {
+      const int t0 = lvl[l], t1 = lvl[l + 1], p0 = lvl[l - 1];
+      double* dnw = gs3_msg + (size_t)(l & 1) * 6 * cap;
+      const double* upr = gs3_msg + (size_t)((l - 1) & 1) * 6 * cap;
+      DownIn d = dnx;
+      if (l + 1 < L) { const int t = t1 + tid; if (t < lvl[l + 2]) dnx = load_down(t); }
+      for (int t = t0 + tid; t < t1; t += nth) {
+        if (t != t0 + tid) d = load_down(t);
+        const int m = d.ix.w, pt = d.ix.x;
+        for (int r = 0; r < 3; ++r) {
+          double pr, pi;
+          if (l == 1) { pr = T.vsr[r]; pi = T.vsi[r]; }
+          else if (LDSMSG) { pr = upr[r * cap + (pt - p0)]; pi = upr[(3 + r) * cap + (pt - p0)]; }
+          else { pr = ST(C_VR + r, pt); pi = ST(C_VI + r, pt); }
+          const bool on = (m >> r) & 1;
+          const double wr = on ? pr - d.dr[r] : 0.0, wi = on ? pi - d.di[r] : 0.0;
+          ST(C_VR + r, t) = wr; ST(C_VI + r, t) = wi;
+          if (LDSMSG) { dnw[r * cap + (t - t0)] = wr; dnw[(3 + r) * cap + (t - t0)] = wi; }
+          if (on) {
+            const double rd = 1.0 / (d.vr[r] * d.vr[r] + d.vi[r] * d.vi[r]);
+            const double ior = (d.p[r] * d.vr[r] + d.q[r] * d.vi[r]) * rd, ioi = (d.p[r] * d.vi[r] - d.q[r] * d.vr[r]) * rd;
+            const double pc = wr * ior + wi * ioi, qc = wi * ior - wr * ioi;
+            const double dP = fabs(d.p[r] - pc), dQ = fabs(d.q[r] - qc);
+            lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
+            psum += pc;
+          }
+        }
+      }
+      level_barrier<LDSMSG>();
+    }
+    if (it + 1 < max_it) {        // what the backward sweep of iteration it + 1 would find
+      mm = block_max(lmax, sh);
+      losses = block_sum(psum, sh);
+      if (!(mm < INFINITY)) { iters = it + 2; break; }
+      if (mm < tol) { iters = it + 2; conv = 1; break; }
+    }
+  }
+  it_out = iters;
+  conv_out = conv;
+}
+
+template <bool LDSMSG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 gs3_k_solve(Topo3 T, double* __restrict__ state, int B, double tol, int max_it, double* __restrict__ out_loss,
             double* __restrict__ out_mm, int32_t* __restrict__ out_it, uint8_t* __restrict__ out_conv) {
   __shared__ double sh[8];
-  const int n = T.n;
   const int b = blockIdx.x;
-  double* S = state + (size_t)b * C_COUNT * n;
-  // flat start: every present phase at the source voltage
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    const int m = T.mask[t];
-    for (int ph = 0; ph < 3; ++ph) {
-      const bool on = (m >> ph) & 1;
-      ST(C_VR + ph, t) = on ? T.vsr[ph] : 0.0;
-      ST(C_VI + ph, t) = on ? T.vsi[ph] : 0.0;
-    }
-  }
-  __syncthreads();
-  int it = 0, conv = 0;
-  double mm = INFINITY, losses = 0.0;
-  for (it = 0; it < max_it; ++it) {
-    double lmax = 0.0, psum = 0.0;
-    for (int l = T.n_levels - 1; l >= 1; --l) {
-      const int t1 = T.lvl_ptr[l + 1];
-      for (int t = T.lvl_ptr[l] + threadIdx.x; t < t1; t += blockDim.x) {
-        const int m = T.mask[t], pt = T.par[t];
-        double vr[3], vi[3], dr[3], di[3], pr[3], pi[3];
-        for (int ph = 0; ph < 3; ++ph) {
-          vr[ph] = ST(C_VR + ph, t); vi[ph] = ST(C_VI + ph, t);
-          pr[ph] = ST(C_VR + ph, pt); pi[ph] = ST(C_VI + ph, pt);
-          dr[ph] = vr[ph] - pr[ph]; di[ph] = vi[ph] - pi[ph];
-        }
-        double kr[3], ki[3];
-        for (int r = 0; r < 3; ++r) {
-          double ar = 0.0, ai = 0.0;
-          for (int cc = 0; cc < 3; ++cc) {
-            const double yr = T.yr[(size_t)(3 * r + cc) * n + t], yi = T.yi[(size_t)(3 * r + cc) * n + t];
-            ar += yr * dr[cc] - yi * di[cc];
-            ai += yr * di[cc] + yi * dr[cc];
-          }
-          kr[r] = ar; ki[r] = ai;
-        }
-        double sjr[3] = {0, 0, 0}, sji[3] = {0, 0, 0}, skr[3] = {0, 0, 0}, ski[3] = {0, 0, 0};
-        const int c0 = T.cfirst[t], c1 = c0 + T.ccount[t];
-        for (int ch = c0; ch < c1; ++ch)
-          for (int ph = 0; ph < 3; ++ph) {
-            sjr[ph] += ST(C_JR + ph, ch); sji[ph] += ST(C_JI + ph, ch);
-            skr[ph] += ST(C_KR + ph, ch); ski[ph] += ST(C_KI + ph, ch);
-          }
-        for (int ph = 0; ph < 3; ++ph) {
-          double jr = sjr[ph], ji = sji[ph];
-          if ((m >> ph) & 1) {
-            const double p = ST(C_P + ph, t), q = ST(C_Q + ph, t);
-            const double icr = kr[ph] - skr[ph], ici = ki[ph] - ski[ph];
-            const double pc = vr[ph] * icr + vi[ph] * ici, qc = vi[ph] * icr - vr[ph] * ici;
-            const double dP = fabs(p - pc), dQ = fabs(q - qc);
-            lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
-            psum += pc;
-            if (pt == 0) psum -= pr[ph] * kr[ph] + pi[ph] * ki[ph];     // the source's share
-            const double rd = 1.0 / (vr[ph] * vr[ph] + vi[ph] * vi[ph]);
-            jr -= (p * vr[ph] + q * vi[ph]) * rd;
-            ji += (q * vr[ph] - p * vi[ph]) * rd;
-          }
-          ST(C_JR + ph, t) = jr; ST(C_JI + ph, t) = ji;
-          ST(C_KR + ph, t) = kr[ph]; ST(C_KI + ph, t) = ki[ph];
-        }
-      }
-      __syncthreads();
-    }
-    mm = block_max(lmax, sh);
-    losses = block_sum(psum, sh);
-    if (!(mm < INFINITY)) break;
-    if (mm < tol) { conv = 1; break; }
-    for (int l = 1; l < T.n_levels; ++l) {
-      const int t1 = T.lvl_ptr[l + 1];
-      for (int t = T.lvl_ptr[l] + threadIdx.x; t < t1; t += blockDim.x) {
-        const int m = T.mask[t], pt = T.par[t];
-        double jr[3], ji[3];
-        for (int ph = 0; ph < 3; ++ph) { jr[ph] = ST(C_JR + ph, t); ji[ph] = ST(C_JI + ph, t); }
-        for (int r = 0; r < 3; ++r) {
-          double ar = 0.0, ai = 0.0;
-          for (int cc = 0; cc < 3; ++cc) {
-            const double zr = T.zr[(size_t)(3 * r + cc) * n + t], zi = T.zi[(size_t)(3 * r + cc) * n + t];
-            ar += zr * jr[cc] - zi * ji[cc];
-            ai += zr * ji[cc] + zi * jr[cc];
-          }
-          const bool on = (m >> r) & 1;
-          ST(C_VR + r, t) = on ? ST(C_VR + r, pt) - ar : 0.0;
-          ST(C_VI + r, t) = on ? ST(C_VI + r, pt) - ai : 0.0;
-        }
-      }
-      __syncthreads();
-    }
-  }
+  double losses, mm; int it, conv;
+  gs3_solve_body<LDSMSG>(T, state + (size_t)b * (LDSMSG ? C_COUNT : C_COUNT_NOLDS) * T.n, tol, max_it, sh, losses, mm, it, conv);
   if (threadIdx.x == 0) {
     out_loss[b] = losses;
     out_mm[b] = mm;
-    out_it[b] = (it < max_it) ? it + 1 : max_it;
+    out_it[b] = it;
     out_conv[b] = (uint8_t)conv;
   }
 }
 
 // P/Q [B][n][3] in caller node order -> state rows in level order
 extern "C" __global__ void __launch_bounds__(256)
-gs3_k_scatter_in(int n, const int32_t* __restrict__ node_of, const double* __restrict__ P, const double* __restrict__ Q,
+gs3_k_scatter_in(int n, int rows, const int32_t* __restrict__ node_of, const double* __restrict__ P, const double* __restrict__ Q,
                  double* __restrict__ state) {
   const int b = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  double* S = state + (size_t)b * C_COUNT * n;
+  double* S = state + (size_t)b * rows * n;
   const size_t src = ((size_t)b * n + node_of[t]) * 3;
   for (int ph = 0; ph < 3; ++ph) { ST(C_P + ph, t) = P[src + ph]; ST(C_Q + ph, t) = Q ? Q[src + ph] : 0.0; }
 }
 
 // V in level order -> [B][n][3] in caller node order
 extern "C" __global__ void __launch_bounds__(256)
-gs3_k_gather_out(int n, const int32_t* __restrict__ pos_of, const double* __restrict__ state, double* __restrict__ vre,
+gs3_k_gather_out(int n, int rows, const int32_t* __restrict__ pos_of, const double* __restrict__ state, double* __restrict__ vre,
                  double* __restrict__ vim) {
   const int b = blockIdx.y;
   const int node = blockIdx.x * blockDim.x + threadIdx.x;
   if (node >= n) return;
-  const double* S = state + (size_t)b * C_COUNT * n;
+  const double* S = state + (size_t)b * rows * n;
   const int t = pos_of[node];
   const size_t dst = ((size_t)b * n + node) * 3;
   for (int ph = 0; ph < 3; ++ph) { vre[dst + ph] = ST(C_VR + ph, t); vim[dst + ph] = ST(C_VI + ph, t); }
@@ -203,7 +286,7 @@ thread_local std::string g3_error;
 }  // namespace
 
 struct gs3_handle {
-  int device = 0, n = 0, B = 0, n_levels = 0, max_width = 0, max_it = 50;
+  int device = 0, n = 0, B = 0, n_levels = 0, max_width = 0, max_it = 50, threads = 256, lds_bytes = 0, rows = C_COUNT;
   double tol = 1e-6;
   hipStream_t stream = nullptr;
   Topo3 T{};
@@ -305,7 +388,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   h->device = device; h->n = n; h->B = batch; h->tol = tolerance; h->max_it = max_iterations; h->n_levels = n_levels;
   for (int l = 0; l < n_levels; ++l) h->max_width = std::max(h->max_width, lvl_ptr[l + 1] - lvl_ptr[l]);
   std::vector<int32_t> par(n, 0), cfirst(n, 0), ccount(n, 0), mask(n, 7);
-  std::vector<double> zr((size_t)9 * n, 0.0), zi((size_t)9 * n, 0.0), yr((size_t)9 * n, 0.0), yi((size_t)9 * n, 0.0);
+  std::vector<double> zr((size_t)9 * n, 0.0), zi((size_t)9 * n, 0.0);
   for (int tt = 0; tt < n; ++tt) {
     const int node = node_of[tt];
     mask[tt] = t->phases[node];
@@ -318,10 +401,9 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
       const bool on = ((mask[tt] >> (q / 3)) & 1) && ((mask[tt] >> (q % 3)) & 1);
       a[q] = on ? t->z_re[(size_t)node * 9 + q] : 0.0; bb[q] = on ? t->z_im[(size_t)node * 9 + q] : 0.0;
     }
-    masked_inverse(a, bb, mask[tt], ya, yb);
+    masked_inverse(a, bb, mask[tt], ya, yb);     // validation only: the sweeps never need Y
     for (int q = 0; q < 9; ++q) {
       zr[(size_t)q * n + tt] = a[q]; zi[(size_t)q * n + tt] = bb[q];
-      yr[(size_t)q * n + tt] = ya[q]; yi[(size_t)q * n + tt] = yb[q];
       if (!std::isfinite(ya[q]) || !std::isfinite(yb[q])) { delete h; return fail3(nullptr, GS_E_TOPOLOGY, "line into node %d has a singular impedance block", node); }
     }
   }
@@ -329,22 +411,27 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail3(nullptr, GS_E_HIP, "device / stream setup failed"));
   Topo3& T = h->T;
-  T.n = n; T.n_levels = n_levels;
+  T.n = n; T.n_levels = n_levels; T.cap = h->max_width;
   const double ang[3] = {0.0, -2.0 * M_PI / 3.0, 2.0 * M_PI / 3.0};
   for (int ph = 0; ph < 3; ++ph) { T.vsr[ph] = t->v_source[ph] * std::cos(ang[ph]); T.vsi[ph] = t->v_source[ph] * std::sin(ang[ph]); }
   int rc;
-  if ((rc = upload3(h, &T.lvl_ptr, lvl_ptr)) || (rc = upload3(h, &T.par, par)) || (rc = upload3(h, &T.cfirst, cfirst)) ||
-      (rc = upload3(h, &T.ccount, ccount)) || (rc = upload3(h, &T.mask, mask)) || (rc = upload3(h, &T.zr, zr)) ||
-      (rc = upload3(h, &T.zi, zi)) || (rc = upload3(h, &T.yr, yr)) || (rc = upload3(h, &T.yi, yi)))
+  std::vector<int4> idx(n);
+  for (int tt = 0; tt < n; ++tt) idx[tt] = make_int4(par[tt], cfirst[tt], ccount[tt], mask[tt]);
+  if ((rc = upload3(h, &T.lvl_ptr, lvl_ptr)) || (rc = upload3(h, &T.idx, idx)) || (rc = upload3(h, &T.zr, zr)) || (rc = upload3(h, &T.zi, zi)))
     return bail(rc);
+  // level messages through LDS when two parities of the widest level fit beside three other resident workgroups
+  h->lds_bytes = 2 * 6 * h->max_width * (int)sizeof(double);
+  if (h->lds_bytes > 38 * 1024 || getenv("GS3_NO_LDS")) h->lds_bytes = 0;
+  h->rows = h->lds_bytes ? C_COUNT : C_COUNT_NOLDS;
   { const int32_t* q = nullptr; if ((rc = upload3(h, &q, node_of))) return bail(rc); h->d_node_of = const_cast<int32_t*>(q); }
   { const int32_t* q = nullptr; if ((rc = upload3(h, &q, pos_of))) return bail(rc); h->d_pos_of = const_cast<int32_t*>(q); }
+  if (const char* e = getenv("GS3_THREADS")) h->threads = std::max(64, std::min(256, atoi(e) / 64 * 64));
   const size_t bn3 = (size_t)batch * n * 3;
-  if ((rc = alloc3(h, &h->d_state, (size_t)batch * C_COUNT * n)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
+  if ((rc = alloc3(h, &h->d_state, (size_t)batch * h->rows * n)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
       (rc = alloc3(h, &h->d_vre, bn3)) || (rc = alloc3(h, &h->d_vim, bn3)) || (rc = alloc3(h, &h->d_loss, batch)) ||
       (rc = alloc3(h, &h->d_mm, batch)) || (rc = alloc3(h, &h->d_it, batch)) || (rc = alloc3(h, &h->d_conv, batch)))
     return bail(rc);
-  if (hipMemset(h->d_state, 0, (size_t)batch * C_COUNT * n * sizeof(double)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
+  if (hipMemset(h->d_state, 0, (size_t)batch * h->rows * n * sizeof(double)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
   *out = h;
   return GS_OK;
 }
@@ -366,7 +453,7 @@ int gs3_upload_injections(gs3_handle* h, const double* P, const double* Q) {
   HIP3(h, hipMemcpyAsync(h->d_p, P, bytes, hipMemcpyHostToDevice, h->stream));
   if (Q) HIP3(h, hipMemcpyAsync(h->d_q, Q, bytes, hipMemcpyHostToDevice, h->stream));
   dim3 grid((h->n + 255) / 256, h->B);
-  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->d_node_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
+  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->rows, h->d_node_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
   HIP3(h, hipGetLastError());
   HIP3(h, hipStreamSynchronize(h->stream));
   return GS_OK;
@@ -382,7 +469,10 @@ int gs3_solve_device(gs3_handle* h) {
   }
   auto& e = h->ev[h->ev_used++];
   HIP3(h, hipEventRecord(e.first, h->stream));
-  hipLaunchKernelGGL(gs3_k_solve, dim3(h->B), dim3(256), 0, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
+  if (h->lds_bytes)
+    hipLaunchKernelGGL(gs3_k_solve<true>, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
+  else
+    hipLaunchKernelGGL(gs3_k_solve<false>, dim3(h->B), dim3(h->threads), 0, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
   HIP3(h, hipGetLastError());
   HIP3(h, hipEventRecord(e.second, h->stream));
   return GS_OK;
@@ -394,7 +484,7 @@ int gs3_download_solution(gs3_handle* h, const gs3_solution_view* out) {
   const size_t bn3 = (size_t)h->B * h->n * 3;
   if (out->v_re || out->v_im) {
     dim3 grid((h->n + 255) / 256, h->B);
-    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->d_pos_of, h->d_state, h->d_vre, h->d_vim);
+    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->rows, h->d_pos_of, h->d_state, h->d_vre, h->d_vim);
     HIP3(h, hipGetLastError());
     if (out->v_re) HIP3(h, hipMemcpyAsync(out->v_re, h->d_vre, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (out->v_im) HIP3(h, hipMemcpyAsync(out->v_im, h->d_vim, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -436,8 +526,8 @@ int gs3_timing_read(gs3_handle* h, double* total_ms, int64_t* launches) {
 
 int gs3_describe(const gs3_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail3(nullptr, GS_E_INVALID, "bad arguments");
-  snprintf(buf, buflen, "{\"kernel\": \"fbs3\", \"n\": %d, \"levels\": %d, \"max_level_width\": %d, \"batch\": %d, \"state_bytes\": %zu}",
-           h->n, h->n_levels, h->max_width, h->B, (size_t)h->B * C_COUNT * h->n * sizeof(double));
+  snprintf(buf, buflen, "{\"kernel\": \"fbs3\", \"n\": %d, \"levels\": %d, \"max_level_width\": %d, \"batch\": %d, \"lds_messages\": %d, \"state_bytes\": %zu}",
+           h->n, h->n_levels, h->max_width, h->B, h->lds_bytes, (size_t)h->B * h->rows * h->n * sizeof(double));
   return GS_OK;
 }
 
