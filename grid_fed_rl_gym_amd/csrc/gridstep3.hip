@@ -8,12 +8,18 @@
 // single-phase solution that IS pinned by the reference (tests/test_unbalanced.py).
 //
 // Mapping (differs from the single-phase kernels, which put one instance on each lane): one
-// workgroup per instance, lanes over the nodes of a tree level.  Nodes are renumbered in
-// breadth-first order, so a level is a contiguous index range, the children of a node are a
-// contiguous range of the next level, and every per-node array is read and written coalesced.
-// Per-instance state (18 doubles per node: V, S_spec, D = Z J; 1.2 MB at 8500 nodes) lives in HBM --
-// this configuration is HBM-streaming by construction.  What one level hands
-// to the next (J going up, V going down) travels through LDS; see gs3_solve_body for the sweep pair.
+// workgroup per instance, lanes over the PHASE CONDUCTORS ("slots") of a tree level.  A distribution
+// feeder is mostly single-phase laterals (1.1 conductors per node on the 8500-node case), so storing
+// three phases per node would move 2.7x the bytes that carry information.  Nodes are numbered
+// breadth-first; inside a level the slots are ordered phase-major (all phase-a conductors in node
+// order, then b, then c).  Consequences:
+//   * a level is a contiguous slot range and every per-slot row is read and written coalesced,
+//   * the same-phase children of a slot are a contiguous range of the next level,
+//   * the other phases of the same node ("siblings", needed for the mutual impedances) are two
+//     slot indices in the same level.
+// Per-instance state is 6 doubles per slot (V, S_spec, D = voltage drop of the upstream line) and lives
+// in HBM -- this configuration is HBM-streaming by construction.  What one
+// level hands to the next (J going up, V going down) travels through LDS.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -30,21 +36,24 @@
 namespace {
 
 struct Topo3 {
-  int32_t n, n_levels, cap;  // cap = widest level (LDS message rows)
-  const int32_t* lvl_ptr;    // [n_levels + 1]; level 0 = the source alone
-  const int4* idx;           // [n] {parent position, first child position, child count, phase mask} (level order)
-  const double* zr;          // [9][n] series impedance of the upstream line (rows/cols of absent phases zeroed)
-  const double* zi;
+  int32_t n, ns, n_levels, cap;   // nodes, slots, levels, widest level in slots
+  const int32_t* lvl_ptr;    // [PAD + n_levels + 1 + PAD] slot ranges, padded with empty levels; level 0 = the three source conductors
+  const int4* idx;           // [ns] {parent slot, first child slot, child count | phase << 28, sibling slot A}
+  const int32_t* sibb;       // [ns] sibling slot B (A / B = the lower / higher of the two other phases; -1 = absent)
+  const double2* z;          // [3][ns] row of the upstream line's Z for this conductor: (re, im) x {own, A, B}
   double vsr[3], vsi[3];     // source voltage
 };
 
-// C_DR/C_DI: the voltage drop Z_t J_t of the upstream line.  C_JR/C_JI (line currents) exist only when the
-// level messages cannot go through LDS (h->lds_bytes == 0); the state then has 24 rows per node.
-enum { C_VR = 0, C_VI = 3, C_P = 6, C_Q = 9, C_DR = 12, C_DI = 15, C_COUNT = 18, C_JR = 18, C_JI = 21, C_COUNT_NOLDS = 24 };
+// rows of the per-instance state, [row][ns] of (re, im) / (P, Q) pairs -- one 16-byte load per lane and row;
+// J only when the level messages cannot go through LDS
+enum { C_V = 0, C_S, C_D, C_COUNT, C_J = C_COUNT, C_COUNT_NOLDS };
+enum { Z_D = 0, Z_A, Z_B };
 
 // row base in SGPRs + one 32-bit byte offset per thread
-#define ST(comp, t) (*(double*)((char*)(S + (size_t)(comp) * n) + ((unsigned)(t) << 3)))
-#define ZT(tab, k, t) (*(const double*)((const char*)((tab) + (size_t)(k) * n) + ((unsigned)(t) << 3)))
+#define ST(row, s) (*(double2*)((char*)(S + (size_t)(row) * ns) + ((unsigned)(s) << 4)))
+#define ZT(row, s) (*(const double2*)((const char*)(T.z + (size_t)(row) * ns) + ((unsigned)(s) << 4)))
+#define IDX(s) (*(const int4*)((const char*)T.idx + ((unsigned)(s) << 4)))
+#define SIBB(s) (*(const int32_t*)((const char*)T.sibb + ((unsigned)(s) << 2)))
 #define GS3_CONST __attribute__((address_space(4)))
 
 __device__ __forceinline__ double block_max(double v, double* sh) {
@@ -69,9 +78,14 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return r;
 }
 
-extern __shared__ double gs3_msg[];   // [2 (level parity)][6][cap]: J of a level on the way up, V on the way down
+#define GS3_LVL_PAD 8             /* empty levels on either side of the level table */
+#ifndef GS3_PREFETCH_LEVELS
+#define GS3_PREFETCH_LEVELS 1     /* levels whose rows are in flight ahead of the one being processed */
+#endif
 
-// Level barrier.  With LDS messages nothing a level writes to HBM is read by another thread (a node keeps
+extern __shared__ double gs3_msg[];   // [2 (level parity)][2 (re, im)][cap]: J of a level on the way up, V on the way down
+
+// Level barrier.  With LDS messages nothing a level writes to HBM is read by another thread (a slot keeps
 // its thread in both sweeps), so the barrier only has to order LDS and the loads prefetched for the next
 // level stay in flight across it.
 template <bool LDSMSG> __device__ __forceinline__ void level_barrier() {
@@ -79,156 +93,263 @@ template <bool LDSMSG> __device__ __forceinline__ void level_barrier() {
   else __syncthreads();
 }
 
-struct UpIn { int4 ix; double vr[3], vi[3], p[3], q[3]; };                // what a node needs on the way up
-struct DownIn { int4 ix; double dr[3], di[3], vr[3], vi[3], p[3], q[3]; };     // ... and on the way down
+struct ZRow { double dr, di, ar, ai, br, bi; };               // a conductor's row of Z
+struct UpIn { int4 ix; int sb; double vr, vi, p, q; ZRow z; };   // what a slot needs on the way up
+struct DownIn { int4 ix; double dr, di, vr, vi, p, q; };      // ... and on the way down
 
 // One sweep pair per iteration, the power mismatch evaluated on the way DOWN.
-//   backward (deepest level first):   J_t = -conj(S_spec / V_t) + sum_children J   (children through LDS)
-//                                     D_t = Z_t J_t  -> HBM                         (the only use of J_t later)
-//   forward  (root's children first): V_t = V_parent - D_t                          (parent through LDS)
-// After a forward sweep V_t - V_parent = -Z_t J_t holds exactly, so the current the new voltages imply on
-// line t is -J_t and the current drawn at node t is the injection current conj(S_spec / V_old) the backward
-// sweep used: the mismatch S_spec - V_new conj(I_old) needs neither Y = Z^-1 nor the children's line
-// currents, and it is the number the NEXT backward sweep of the textbook loop would report -- one sweep
-// earlier.  The flat start is never written to memory: with V = V_source everywhere the implied currents
-// are zero and the first mismatch is |S_spec|.
-// Each level step prefetches the own rows of the next level before its barrier, so a step costs LDS
-// latency plus arithmetic rather than a round trip to HBM.
-template <bool LDSMSG>
-__device__ __forceinline__ void gs3_solve_body(const Topo3& T, double* __restrict__ S, double tol, int max_it,
-                                               double* sh, double& losses, double& mm, int& it_out, int& conv_out) {
-  const int n = T.n, cap = T.cap, L = T.n_levels, tid = threadIdx.x, nth = blockDim.x;
-  const GS3_CONST int32_t* lvl = (const GS3_CONST int32_t*)T.lvl_ptr;
-  int iters = max_it, conv = 0;
-  mm = INFINITY; losses = 0.0;
-  if (tid < 3) { ST(C_VR + tid, 0) = T.vsr[tid]; ST(C_VI + tid, 0) = T.vsi[tid]; }     // the source row
-  for (int it = 0; it < max_it; ++it) {
-    const bool first = it == 0;
-    auto load_up = [&](int t) {
-      UpIn u;
-      u.ix = (*(const int4*)((const char*)T.idx + ((unsigned)t << 4)));
-      for (int ph = 0; ph < 3; ++ph) {
-        const bool on = (u.ix.w >> ph) & 1;
-        u.vr[ph] = first ? (on ? T.vsr[ph] : 0.0) : ST(C_VR + ph, t);
-        u.vi[ph] = first ? (on ? T.vsi[ph] : 0.0) : ST(C_VI + ph, t);
-        u.p[ph] = ST(C_P + ph, t); u.q[ph] = ST(C_Q + ph, t);
-      }
-      return u;
-    };
-    auto load_down = [&](int t) {
-      DownIn d;
-      d.ix = (*(const int4*)((const char*)T.idx + ((unsigned)t << 4)));
-      for (int ph = 0; ph < 3; ++ph) {
-        const bool on = (d.ix.w >> ph) & 1;
-        d.dr[ph] = ST(C_DR + ph, t); d.di[ph] = ST(C_DI + ph, t);
-        d.vr[ph] = first ? (on ? T.vsr[ph] : 0.0) : ST(C_VR + ph, t);
-        d.vi[ph] = first ? (on ? T.vsi[ph] : 0.0) : ST(C_VI + ph, t);
-        d.p[ph] = ST(C_P + ph, t); d.q[ph] = ST(C_Q + ph, t);
-      }
-      return d;
-    };
+//   backward (deepest level first):   J_s = -conj(S_spec / V_s) + sum over same-phase children   (through LDS)
+//                                     D_s = sum_phases Z[s][.] J[.]  -> HBM        (siblings' J through LDS)
+//   forward  (root's children first): V_s = V_parent - D_s                          (parent through LDS)
+// After a forward sweep V - V_parent = -Z J holds exactly, so the current the new voltages imply on a line is
+// -J and the current drawn at a node is the injection current conj(S_spec / V_old) the backward sweep used:
+// the mismatch S_spec - V_new conj(I_old) needs neither Y = Z^-1 nor the children's line currents, and it is
+// the number the NEXT backward sweep of the textbook loop would report -- one sweep earlier.  The flat start
+// is never written to memory: with V = V_source everywhere the implied currents are zero and the first
+// mismatch is |S_spec|.
+// Every level step prefetches the rows of the next level before its barrier, and D of a level is finished
+// one step late (its Z row is requested when the level is processed and consumed after the barrier that
+// publishes the siblings' J), so a step costs LDS latency plus arithmetic rather than round trips to HBM.
+// The steady-state level step issues the same memory instructions whatever the level looks like: rows are
+// requested unconditionally at a clamped slot (a lane beyond the end of its level re-reads the level's last
+// slot), the level table is padded with empty levels at both ends, passes beyond the first (levels wider
+// than the workgroup) run in their own loop, and the first iteration (flat start, nothing to read for V) is
+// its own instantiation.  Only then can the compiler wait for exactly the rows it needs (s_waitcnt vmcnt(N)
+// with the younger prefetches still in flight) instead of draining the queue.
+struct Sweep3 {
+  const Topo3& T;
+  double2* __restrict__ S;
+  int ns, cap, L, nth, nw, wave, lane;   // nw wavefronts; wave is wave-uniform (an SGPR)
+  const GS3_CONST int32_t* lvl;      // lvl[-PAD .. L + PAD]
 
-    // ---- backward
-    double lmax = 0.0, psrc = 0.0;
-    UpIn un = {};
-    { const int t = lvl[L - 1] + tid; if (L > 1 && t < lvl[L]) un = load_up(t); }
+  __device__ __forceinline__ double src_r(int ph) const { return ph == 0 ? T.vsr[0] : (ph == 1 ? T.vsr[1] : T.vsr[2]); }
+  __device__ __forceinline__ double src_i(int ph) const { return ph == 0 ? T.vsi[0] : (ph == 1 ? T.vsi[1] : T.vsi[2]); }
+  static __device__ __forceinline__ int clamp_to(int s, int end) { return min(s, max(end - 1, 0)); }
+  // Which slots of level l a wavefront takes rotates with l: the widths are rarely a multiple of the workgroup, the
+  // waves that find no slot in a level skip its arithmetic, and the rotation spreads that saving over all four SIMDs.
+  // A slot still keeps its thread in both sweeps (the mapping depends on l only).
+  __device__ __forceinline__ int wlo(int l) const { return ((wave + l + 64) % nw) << 6; }     // l >= -GS3_LVL_PAD
+  __device__ __forceinline__ int off(int l) const { return wlo(l) + lane; }
+
+  template <bool FIRST> __device__ __forceinline__ UpIn load_up(int s) const {
+    UpIn u;
+    u.ix = IDX(s); u.sb = SIBB(s);
+    const int ph = (unsigned)u.ix.z >> 28;
+    if (FIRST) { u.vr = src_r(ph); u.vi = src_i(ph); }
+    else { const double2 v = ST(C_V, s); u.vr = v.x; u.vi = v.y; }
+    const double2 pq = ST(C_S, s); u.p = pq.x; u.q = pq.y;
+    u.z = load_z(s);
+    return u;
+  }
+  __device__ __forceinline__ ZRow load_z(int s) const {
+    ZRow z;
+    const double2 d = ZT(Z_D, s), a = ZT(Z_A, s), b = ZT(Z_B, s);
+    z.dr = d.x; z.di = d.y; z.ar = a.x; z.ai = a.y; z.br = b.x; z.bi = b.y;
+    return z;
+  }
+  template <bool FIRST> __device__ __forceinline__ DownIn load_down(int s) const {
+    DownIn d;
+    d.ix = IDX(s);
+    const int ph = (unsigned)d.ix.z >> 28;
+    const double2 dd = ST(C_D, s); d.dr = dd.x; d.di = dd.y;
+    if (FIRST) { d.vr = src_r(ph); d.vi = src_i(ph); }
+    else { const double2 v = ST(C_V, s); d.vr = v.x; d.vi = v.y; }
+    const double2 pq = ST(C_S, s); d.p = pq.x; d.q = pq.y;
+    return d;
+  }
+  // J of slot `s` of the level whose messages sit in `buf` and whose first slot is `base`
+  template <bool LDSMSG> __device__ __forceinline__ void msg_j(const double* buf, int base, int s, double& jr, double& ji) const {
+    if (LDSMSG) { jr = buf[s - base]; ji = buf[cap + s - base]; }
+    else { const double2 j = ST(C_J, s); jr = j.x; ji = j.y; }
+  }
+  // D = Z-row times the currents of the node's conductors, for slot s of a level whose J are published.
+  // An absent sibling reads the slot's own J against a zero impedance.
+  template <bool LDSMSG> __device__ __forceinline__ void drop_of(const double* buf, int base, int s, const ZRow& z, int sa, int sb,
+                                                                 double& ar, double& ai) const {
+    double jr, ji, xr, xi, yr, yi;
+    msg_j<LDSMSG>(buf, base, s, jr, ji);
+    msg_j<LDSMSG>(buf, base, sa >= 0 ? sa : s, xr, xi);
+    msg_j<LDSMSG>(buf, base, sb >= 0 ? sb : s, yr, yi);
+    ar = z.dr * jr - z.di * ji; ai = z.dr * ji + z.di * jr;
+    ar += z.ar * xr - z.ai * xi; ai += z.ar * xi + z.ai * xr;
+    ar += z.br * yr - z.bi * yi; ai += z.br * yi + z.bi * yr;
+  }
+  // own injection current + same-phase children -> J of a slot (children in `dn`, whose level starts at s1)
+  template <bool LDSMSG, bool FIRST>
+  __device__ __forceinline__ void line_current(const UpIn& u, const double* dn, int s1, bool at_source, double& lmax, double& psrc,
+                                               double& jr, double& ji) const {
+    const int ph = (unsigned)u.ix.z >> 28, cc = u.ix.z & 0xffff;
+    if (FIRST) {
+      const double dP = fabs(u.p), dQ = fabs(u.q);
+      lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
+    }
+    const double rd = 1.0 / (u.vr * u.vr + u.vi * u.vi);
+    jr = -(u.p * u.vr + u.q * u.vi) * rd; ji = -(u.p * u.vi - u.q * u.vr) * rd;
+    for (int ch = u.ix.y; ch < u.ix.y + cc; ++ch) { double cr, ci; msg_j<LDSMSG>(dn, s1, ch, cr, ci); jr += cr; ji += ci; }
+    if (at_source) psrc += src_r(ph) * jr + src_i(ph) * ji;     // the source's share of sum P_calc
+  }
+
+  // ---- backward sweep: J up through the levels, D = Z J to HBM; returns max |S_spec| (FIRST) and the source's P
+  template <bool LDSMSG, int PF, bool FIRST> __device__ __forceinline__ void backward(double& lmax, double& psrc) const {
+    UpIn uq[PF];             // rows of the next PF levels, requested ahead (uq[0] = the level processed next)
+    ZRow zc = {};            // Z row of this thread's first slot in the level processed last (l + 1)
+    int zsa = -1, zsb = -1;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) uq[k] = load_up<FIRST>(clamp_to(lvl[L - 1 - k] + off(L - 1 - k), lvl[L - k]));
+    int w[PF + 3];           // w[j] = lvl[l - PF + j]: the prefetched level .. the level being finished
+#pragma unroll
+    for (int j = 0; j < PF + 3; ++j) w[j] = lvl[L - 1 - PF + j];
     for (int l = L - 1; l >= 1; --l) {
-      const int t0 = lvl[l], t1 = lvl[l + 1];
-      double* up = gs3_msg + (size_t)(l & 1) * 6 * cap;
-      const double* dn = gs3_msg + (size_t)((l + 1) & 1) * 6 * cap;
-      UpIn u = un;
-      if (l > 1) { const int t = lvl[l - 1] + tid; if (t < t0) un = load_up(t); }
-      for (int t = t0 + tid; t < t1; t += nth) {
-        if (t != t0 + tid) u = load_up(t);
-        // own injection current first: V, P, Q are dead before the impedance rows arrive
-        double jr[3], ji[3];
-        for (int ph = 0; ph < 3; ++ph) {
-          jr[ph] = 0.0; ji[ph] = 0.0;
-          if ((u.ix.w >> ph) & 1) {
-            if (first) {
-              const double dP = fabs(u.p[ph]), dQ = fabs(u.q[ph]);
-              lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
-            }
-            const double rd = 1.0 / (u.vr[ph] * u.vr[ph] + u.vi[ph] * u.vi[ph]);
-            jr[ph] = -(u.p[ph] * u.vr[ph] + u.q[ph] * u.vi[ph]) * rd;
-            ji[ph] = -(u.p[ph] * u.vi[ph] - u.q[ph] * u.vr[ph]) * rd;
-          }
+      const int s0 = w[PF], s1 = w[PF + 1], e1 = w[PF + 2];
+      const int wnext = lvl[l - PF - 1];
+      double* up = gs3_msg + (size_t)(l & 1) * 2 * cap;
+      const double* dn = gs3_msg + (size_t)((l + 1) & 1) * 2 * cap;
+      const UpIn u = uq[0];
+#pragma unroll
+      for (int k = 0; k + 1 < PF; ++k) uq[k] = uq[k + 1];
+      uq[PF - 1] = load_up<FIRST>(clamp_to(w[0] + off(l - PF), w[1]));
+      {                      // finish level l + 1: its J are all in `dn` now
+        const int s = s1 + off(l + 1);
+        double ar, ai;
+        if (s1 + wlo(l + 1) < e1) {
+          drop_of<LDSMSG>(dn, s1, min(s, e1 - 1), zc, zsa, zsb, ar, ai);
+          if (s < e1) ST(C_D, s) = make_double2(ar, ai);
         }
-        asm volatile("" ::: "memory");
-        double zr[9], zi[9];
-        for (int k = 0; k < 9; ++k) { zr[k] = ZT(T.zr, k, t); zi[k] = ZT(T.zi, k, t); }
-        for (int ch = u.ix.y; ch < u.ix.y + u.ix.z; ++ch)
-          for (int ph = 0; ph < 3; ++ph) {
-            if (LDSMSG) { jr[ph] += dn[ph * cap + (ch - t1)]; ji[ph] += dn[(3 + ph) * cap + (ch - t1)]; }
-            else { jr[ph] += ST(C_JR + ph, ch); ji[ph] += ST(C_JI + ph, ch); }
+        if (e1 - s1 > nth)
+          for (int s2 = s + nth; s2 < e1; s2 += nth) {
+            const int4 ix = IDX(s2); const int sb = SIBB(s2);
+            drop_of<LDSMSG>(dn, s1, s2, load_z(s2), ix.w, sb, ar, ai);
+            ST(C_D, s2) = make_double2(ar, ai);
           }
-        for (int ph = 0; ph < 3; ++ph) {
-          if (l == 1 && ((u.ix.w >> ph) & 1)) psrc += T.vsr[ph] * jr[ph] + T.vsi[ph] * ji[ph];     // the source's share of sum P_calc
-          if (LDSMSG) { up[ph * cap + (t - t0)] = jr[ph]; up[(3 + ph) * cap + (t - t0)] = ji[ph]; }
-          else { ST(C_JR + ph, t) = jr[ph]; ST(C_JI + ph, t) = ji[ph]; }
-        }
-        for (int r = 0; r < 3; ++r) {
-          double ar = 0.0, ai = 0.0;
-          for (int cc = 0; cc < 3; ++cc) {
-            ar += zr[3 * r + cc] * jr[cc] - zi[3 * r + cc] * ji[cc];
-            ai += zr[3 * r + cc] * ji[cc] + zi[3 * r + cc] * jr[cc];
-          }
-          ST(C_DR + r, t) = ar; ST(C_DI + r, t) = ai;
-        }
       }
+      {
+        const int s = s0 + off(l);
+        double jr, ji;
+        zsa = -1; zsb = -1;
+        if (s0 + wlo(l) < s1) {
+          line_current<LDSMSG, FIRST>(u, dn, s1, l == 1 && s < s1, lmax, psrc, jr, ji);
+          if (s < s1) {
+            if (LDSMSG) { up[s - s0] = jr; up[cap + s - s0] = ji; }
+            else ST(C_J, s) = make_double2(jr, ji);
+            zsa = u.ix.w; zsb = u.sb;
+          }
+        }
+        if (s1 - s0 > nth)
+          for (int s2 = s + nth; s2 < s1; s2 += nth) {
+            line_current<LDSMSG, FIRST>(load_up<FIRST>(s2), dn, s1, l == 1, lmax, psrc, jr, ji);
+            if (LDSMSG) { up[s2 - s0] = jr; up[cap + s2 - s0] = ji; }
+            else ST(C_J, s2) = make_double2(jr, ji);
+          }
+      }
+      zc = u.z;
+#pragma unroll
+      for (int j = PF + 2; j > 0; --j) w[j] = w[j - 1];
+      w[0] = wnext;
       level_barrier<LDSMSG>();
     }
-    if (first) {
+    {                        // finish level 1
+      const int s1 = lvl[1], e1 = lvl[2];
+      const double* dn = gs3_msg + (size_t)2 * cap;
+      double ar, ai;
+      for (int s = s1 + off(1); s < e1; s += nth) {
+        if (s == s1 + off(1)) drop_of<LDSMSG>(dn, s1, s, zc, zsa, zsb, ar, ai);
+        else { const int4 ix = IDX(s); const int sb = SIBB(s); drop_of<LDSMSG>(dn, s1, s, load_z(s), ix.w, sb, ar, ai); }
+        ST(C_D, s) = make_double2(ar, ai);
+      }
+      level_barrier<LDSMSG>();     // the forward sweep reuses level 1's buffer
+    }
+  }
+
+  template <bool LDSMSG>
+  __device__ __forceinline__ void new_voltage(const DownIn& d, const double* upr, int p0, int l, bool count, double& lmax, double& psum,
+                                              double& wr, double& wi) const {
+    const int ph = (unsigned)d.ix.z >> 28, ps = d.ix.x;
+    double pr, pi;
+    if (l == 1) { pr = src_r(ph); pi = src_i(ph); }
+    else if (LDSMSG) { pr = upr[ps - p0]; pi = upr[cap + ps - p0]; }
+    else { const double2 pv = ST(C_V, ps); pr = pv.x; pi = pv.y; }
+    wr = pr - d.dr; wi = pi - d.di;
+    const double rd = 1.0 / (d.vr * d.vr + d.vi * d.vi);
+    const double ior = (d.p * d.vr + d.q * d.vi) * rd, ioi = (d.p * d.vi - d.q * d.vr) * rd;
+    const double pc = wr * ior + wi * ioi, qc = wi * ior - wr * ioi;
+    const double dP = fabs(d.p - pc), dQ = fabs(d.q - qc);
+    if (count) {
+      lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
+      psum += pc;
+    }
+  }
+
+  // ---- forward sweep: V down through the levels, with the mismatch / sum of P_calc at the new voltages
+  template <bool LDSMSG, int PF, bool FIRST> __device__ __forceinline__ void forward(double& lmax, double& psum) const {
+    DownIn dq[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) dq[k] = load_down<FIRST>(clamp_to(lvl[1 + k] + off(1 + k), lvl[2 + k]));
+    int v[PF + 3];           // v[j] = lvl[l - 1 + j]: the parent level .. the end of the prefetched level
+#pragma unroll
+    for (int j = 0; j < PF + 3; ++j) v[j] = lvl[j];
+    for (int l = 1; l < L; ++l) {
+      const int p0 = v[0], s0 = v[1], s1 = v[2];
+      const int vnext = lvl[l + PF + 2];
+      double* dnw = gs3_msg + (size_t)(l & 1) * 2 * cap;
+      const double* upr = gs3_msg + (size_t)((l - 1) & 1) * 2 * cap;
+      const DownIn d = dq[0];
+#pragma unroll
+      for (int k = 0; k + 1 < PF; ++k) dq[k] = dq[k + 1];
+      dq[PF - 1] = load_down<FIRST>(clamp_to(v[PF + 1] + off(l + PF), v[PF + 2]));
+      const int s = s0 + off(l);
+      double wr, wi;
+      // a lane beyond the level holds a clamped copy of the last slot: valid arithmetic, nothing counted or stored
+      if (s0 + wlo(l) < s1) {
+        new_voltage<LDSMSG>(d, upr, p0, l, s < s1, lmax, psum, wr, wi);
+        if (s < s1) {
+          ST(C_V, s) = make_double2(wr, wi);
+          if (LDSMSG) { dnw[s - s0] = wr; dnw[cap + s - s0] = wi; }
+        }
+      }
+      if (s1 - s0 > nth)
+        for (int s2 = s + nth; s2 < s1; s2 += nth) {
+          new_voltage<LDSMSG>(load_down<FIRST>(s2), upr, p0, l, true, lmax, psum, wr, wi);
+          ST(C_V, s2) = make_double2(wr, wi);
+          if (LDSMSG) { dnw[s2 - s0] = wr; dnw[cap + s2 - s0] = wi; }
+        }
+#pragma unroll
+      for (int j = 0; j < PF + 2; ++j) v[j] = v[j + 1];
+      v[PF + 2] = vnext;
+      level_barrier<LDSMSG>();
+    }
+  }
+};
+
+template <bool LDSMSG, int PF>
+__device__ __forceinline__ void gs3_solve_body(const Topo3& T, double2* __restrict__ S, double tol, int max_it,
+                                               double* sh, double& losses, double& mm, int& it_out, int& conv_out) {
+  const int ns = T.ns, tid = threadIdx.x, nth = blockDim.x;
+  const Sweep3 sw = {T, S, ns, T.cap, T.n_levels, nth, nth >> 6, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63,
+                     (const GS3_CONST int32_t*)T.lvl_ptr + GS3_LVL_PAD};
+  int iters = max_it, conv = 0;
+  mm = INFINITY; losses = 0.0;
+  if (tid < 3) ST(C_V, tid) = make_double2(T.vsr[tid], T.vsi[tid]);     // the source's three conductors
+  for (int it = 0; it < max_it; ++it) {
+    double lmax = 0.0, psrc = 0.0;
+    if (it == 0) {
+      sw.backward<LDSMSG, PF, true>(lmax, psrc);
       mm = block_max(lmax, sh);
       losses = 0.0;
       if (!(mm < INFINITY) || mm < tol) {     // no sweep will follow: the answer is the flat start itself
-        for (int t = 1 + tid; t < n; t += nth) {
-          const int m = (*(const int4*)((const char*)T.idx + ((unsigned)t << 4))).w;
-          for (int ph = 0; ph < 3; ++ph) {
-            const bool on = (m >> ph) & 1;
-            ST(C_VR + ph, t) = on ? T.vsr[ph] : 0.0; ST(C_VI + ph, t) = on ? T.vsi[ph] : 0.0;
-          }
+        for (int s = 3 + tid; s < ns; s += nth) {
+          const int ph = (unsigned)IDX(s).z >> 28;
+          ST(C_V, s) = make_double2(sw.src_r(ph), sw.src_i(ph));
         }
         iters = 1; conv = mm < tol;
         break;
       }
+    } else {
+      sw.backward<LDSMSG, PF, false>(lmax, psrc);
     }
-
-    // ---- forward, with the mismatch / losses at the new voltages
     lmax = 0.0;
     double psum = psrc;
-    DownIn dnx = {};
-    { const int t = lvl[1] + tid; if (L > 1 && t < lvl[2]) dnx = load_down(t); }
-    for (int l = 1; l < L; ++l) {
-      const int t0 = lvl[l], t1 = lvl[l + 1], p0 = lvl[l - 1];
-      double* dnw = gs3_msg + (size_t)(l & 1) * 6 * cap;
-      const double* upr = gs3_msg + (size_t)((l - 1) & 1) * 6 * cap;
-      DownIn d = dnx;
-      if (l + 1 < L) { const int t = t1 + tid; if (t < lvl[l + 2]) dnx = load_down(t); }
-      for (int t = t0 + tid; t < t1; t += nth) {
-        if (t != t0 + tid) d = load_down(t);
-        const int m = d.ix.w, pt = d.ix.x;
-        for (int r = 0; r < 3; ++r) {
-          double pr, pi;
-          if (l == 1) { pr = T.vsr[r]; pi = T.vsi[r]; }
-          else if (LDSMSG) { pr = upr[r * cap + (pt - p0)]; pi = upr[(3 + r) * cap + (pt - p0)]; }
-          else { pr = ST(C_VR + r, pt); pi = ST(C_VI + r, pt); }
-          const bool on = (m >> r) & 1;
-          const double wr = on ? pr - d.dr[r] : 0.0, wi = on ? pi - d.di[r] : 0.0;
-          ST(C_VR + r, t) = wr; ST(C_VI + r, t) = wi;
-          if (LDSMSG) { dnw[r * cap + (t - t0)] = wr; dnw[(3 + r) * cap + (t - t0)] = wi; }
-          if (on) {
-            const double rd = 1.0 / (d.vr[r] * d.vr[r] + d.vi[r] * d.vi[r]);
-            const double ior = (d.p[r] * d.vr[r] + d.q[r] * d.vi[r]) * rd, ioi = (d.p[r] * d.vi[r] - d.q[r] * d.vr[r]) * rd;
-            const double pc = wr * ior + wi * ioi, qc = wi * ior - wr * ioi;
-            const double dP = fabs(d.p[r] - pc), dQ = fabs(d.q[r] - qc);
-            lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
-            psum += pc;
-          }
-        }
-      }
-      level_barrier<LDSMSG>();
-    }
+    if (it == 0) sw.forward<LDSMSG, PF, true>(lmax, psum);
+    else sw.forward<LDSMSG, PF, false>(lmax, psum);
     if (it + 1 < max_it) {        // what the backward sweep of iteration it + 1 would find
       mm = block_max(lmax, sh);
       losses = block_sum(psum, sh);
@@ -240,14 +361,14 @@ __device__ __forceinline__ void gs3_solve_body(const Topo3& T, double* __restric
   conv_out = conv;
 }
 
-template <bool LDSMSG>
+template <bool LDSMSG, int PF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-gs3_k_solve(Topo3 T, double* __restrict__ state, int B, double tol, int max_it, double* __restrict__ out_loss,
+gs3_k_solve(Topo3 T, double2* __restrict__ state, int B, double tol, int max_it, double* __restrict__ out_loss,
             double* __restrict__ out_mm, int32_t* __restrict__ out_it, uint8_t* __restrict__ out_conv) {
   __shared__ double sh[8];
   const int b = blockIdx.x;
   double losses, mm; int it, conv;
-  gs3_solve_body<LDSMSG>(T, state + (size_t)b * (LDSMSG ? C_COUNT : C_COUNT_NOLDS) * T.n, tol, max_it, sh, losses, mm, it, conv);
+  gs3_solve_body<LDSMSG, PF>(T, state + (size_t)b * (LDSMSG ? C_COUNT : C_COUNT_NOLDS) * T.ns, tol, max_it, sh, losses, mm, it, conv);
   if (threadIdx.x == 0) {
     out_loss[b] = losses;
     out_mm[b] = mm;
@@ -256,29 +377,30 @@ gs3_k_solve(Topo3 T, double* __restrict__ state, int B, double tol, int max_it, 
   }
 }
 
-// P/Q [B][n][3] in caller node order -> state rows in level order
+// P/Q [B][n][3] in caller node order -> the P, Q rows of the slots
 extern "C" __global__ void __launch_bounds__(256)
-gs3_k_scatter_in(int n, int rows, const int32_t* __restrict__ node_of, const double* __restrict__ P, const double* __restrict__ Q,
-                 double* __restrict__ state) {
+gs3_k_scatter_in(int n, int ns, int rows, const int32_t* __restrict__ src_of, const double* __restrict__ P,
+                 const double* __restrict__ Q, double2* __restrict__ state) {
   const int b = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  double* S = state + (size_t)b * rows * n;
-  const size_t src = ((size_t)b * n + node_of[t]) * 3;
-  for (int ph = 0; ph < 3; ++ph) { ST(C_P + ph, t) = P[src + ph]; ST(C_Q + ph, t) = Q ? Q[src + ph] : 0.0; }
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  double2* S = state + (size_t)b * rows * ns;
+  const size_t src = (size_t)b * n * 3 + src_of[s];
+  ST(C_S, s) = make_double2(P[src], Q ? Q[src] : 0.0);
 }
 
-// V in level order -> [B][n][3] in caller node order
+// V rows of the slots -> [B][n][3] in caller node order (absent phases 0)
 extern "C" __global__ void __launch_bounds__(256)
-gs3_k_gather_out(int n, int rows, const int32_t* __restrict__ pos_of, const double* __restrict__ state, double* __restrict__ vre,
-                 double* __restrict__ vim) {
+gs3_k_gather_out(int n, int ns, int rows, const int32_t* __restrict__ slot_of, const double2* __restrict__ state,
+                 double* __restrict__ vre, double* __restrict__ vim) {
   const int b = blockIdx.y;
-  const int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= n) return;
-  const double* S = state + (size_t)b * rows * n;
-  const int t = pos_of[node];
-  const size_t dst = ((size_t)b * n + node) * 3;
-  for (int ph = 0; ph < 3; ++ph) { vre[dst + ph] = ST(C_VR + ph, t); vim[dst + ph] = ST(C_VI + ph, t); }
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 3 * n) return;
+  double2* S = const_cast<double2*>(state) + (size_t)b * rows * ns;
+  const int s = slot_of[e];
+  const size_t dst = (size_t)b * n * 3 + e;
+  const double2 v = s >= 0 ? ST(C_V, s) : make_double2(0.0, 0.0);
+  vre[dst] = v.x; vim[dst] = v.y;
 }
 
 thread_local std::string g3_error;
@@ -286,13 +408,14 @@ thread_local std::string g3_error;
 }  // namespace
 
 struct gs3_handle {
-  int device = 0, n = 0, B = 0, n_levels = 0, max_width = 0, max_it = 50, threads = 256, lds_bytes = 0, rows = C_COUNT;
+  int device = 0, n = 0, ns = 0, B = 0, n_levels = 0, max_width = 0, max_it = 50, threads = 256, lds_bytes = 0, rows = C_COUNT, prefetch = GS3_PREFETCH_LEVELS;
   double tol = 1e-6;
   hipStream_t stream = nullptr;
   Topo3 T{};
   std::vector<void*> allocs;
-  int32_t *d_node_of = nullptr, *d_pos_of = nullptr;
-  double *d_state = nullptr, *d_p = nullptr, *d_q = nullptr, *d_vre = nullptr, *d_vim = nullptr, *d_loss = nullptr, *d_mm = nullptr;
+  int32_t *d_src_of = nullptr, *d_slot_of = nullptr;
+  double2* d_state = nullptr;
+  double  *d_p = nullptr, *d_q = nullptr, *d_vre = nullptr, *d_vim = nullptr, *d_loss = nullptr, *d_mm = nullptr;
   int32_t* d_it = nullptr; uint8_t* d_conv = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0;
   mutable std::string err;
@@ -384,54 +507,81 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   while (lvl_ptr.size() >= 2 && lvl_ptr[lvl_ptr.size() - 1] == lvl_ptr[lvl_ptr.size() - 2]) lvl_ptr.pop_back();
   const int n_levels = (int)lvl_ptr.size() - 1;
 
+  // slots: the conductors of each level, phase-major
+  std::vector<int32_t> slot_of((size_t)3 * n, -1), src_of, slvl{0};
+  for (int l = 0; l < n_levels; ++l) {
+    for (int ph = 0; ph < 3; ++ph)
+      for (int tt = lvl_ptr[l]; tt < lvl_ptr[l + 1]; ++tt) {
+        const int node = node_of[tt];
+        if ((t->phases[node] >> ph) & 1) { slot_of[(size_t)node * 3 + ph] = (int)src_of.size(); src_of.push_back(node * 3 + ph); }
+      }
+    slvl.push_back((int)src_of.size());
+  }
+  const int ns = (int)src_of.size();
+
   gs3_handle* h = new gs3_handle();
-  h->device = device; h->n = n; h->B = batch; h->tol = tolerance; h->max_it = max_iterations; h->n_levels = n_levels;
-  for (int l = 0; l < n_levels; ++l) h->max_width = std::max(h->max_width, lvl_ptr[l + 1] - lvl_ptr[l]);
-  std::vector<int32_t> par(n, 0), cfirst(n, 0), ccount(n, 0), mask(n, 7);
-  std::vector<double> zr((size_t)9 * n, 0.0), zi((size_t)9 * n, 0.0);
-  for (int tt = 0; tt < n; ++tt) {
-    const int node = node_of[tt];
-    mask[tt] = t->phases[node];
-    par[tt] = node == t->source ? 0 : pos_of[t->parent[node]];
-    ccount[tt] = (int)kids[node].size();
-    cfirst[tt] = ccount[tt] ? pos_of[kids[node][0]] : 0;
+  h->device = device; h->n = n; h->ns = ns; h->B = batch; h->tol = tolerance; h->max_it = max_iterations; h->n_levels = n_levels;
+  for (int l = 0; l < n_levels; ++l) h->max_width = std::max(h->max_width, slvl[l + 1] - slvl[l]);
+  std::vector<int4> idx(ns, make_int4(0, 0, 0, -1));
+  std::vector<int32_t> sibb(ns, -1);
+  std::vector<double2> z((size_t)3 * ns, make_double2(0.0, 0.0));
+  for (int sl = 0; sl < ns; ++sl) {
+    const int node = src_of[sl] / 3, ph = src_of[sl] % 3, mask = t->phases[node];
+    const int oa = ph == 0 ? 1 : 0, ob = ph == 2 ? 1 : 2;      // the other two phases, ascending
+    int cfirst = 0, ccount = 0;
+    for (int c : kids[node]) {       // children in level order; those carrying `ph` are consecutive slots
+      const int cs = slot_of[(size_t)c * 3 + ph];
+      if (cs < 0) continue;
+      if (!ccount) cfirst = cs;
+      else if (cs != cfirst + ccount) { delete h; return fail3(nullptr, GS_E_TOPOLOGY, "children of node %d are not consecutive slots", node); }
+      ++ccount;
+    }
+    if (ccount > 0xffff) { delete h; return fail3(nullptr, GS_E_TOPOLOGY, "node %d has more than 65535 children", node); }
+    const int parent = node == t->source ? 0 : slot_of[(size_t)t->parent[node] * 3 + ph];
+    idx[sl] = make_int4(parent, cfirst, ccount | (ph << 28), slot_of[(size_t)node * 3 + oa]);
+    sibb[sl] = slot_of[(size_t)node * 3 + ob];
     if (node == t->source) continue;
     double a[9], bb[9], ya[9], yb[9];
     for (int q = 0; q < 9; ++q) {
-      const bool on = ((mask[tt] >> (q / 3)) & 1) && ((mask[tt] >> (q % 3)) & 1);
+      const bool on = ((mask >> (q / 3)) & 1) && ((mask >> (q % 3)) & 1);
       a[q] = on ? t->z_re[(size_t)node * 9 + q] : 0.0; bb[q] = on ? t->z_im[(size_t)node * 9 + q] : 0.0;
     }
-    masked_inverse(a, bb, mask[tt], ya, yb);     // validation only: the sweeps never need Y
-    for (int q = 0; q < 9; ++q) {
-      zr[(size_t)q * n + tt] = a[q]; zi[(size_t)q * n + tt] = bb[q];
-      if (!std::isfinite(ya[q]) || !std::isfinite(yb[q])) { delete h; return fail3(nullptr, GS_E_TOPOLOGY, "line into node %d has a singular impedance block", node); }
+    if (ph == __builtin_ctz(mask)) {      // once per node: the impedance block must be invertible (a physical line)
+      masked_inverse(a, bb, mask, ya, yb);
+      for (int q = 0; q < 9; ++q)
+        if (!std::isfinite(ya[q]) || !std::isfinite(yb[q])) { delete h; return fail3(nullptr, GS_E_TOPOLOGY, "line into node %d has a singular impedance block", node); }
     }
+    z[(size_t)Z_D * ns + sl] = make_double2(a[3 * ph + ph], bb[3 * ph + ph]);
+    z[(size_t)Z_A * ns + sl] = make_double2(a[3 * ph + oa], bb[3 * ph + oa]);
+    z[(size_t)Z_B * ns + sl] = make_double2(a[3 * ph + ob], bb[3 * ph + ob]);
   }
   auto bail = [&](int rc) { gs3_destroy(h); return rc; };
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail3(nullptr, GS_E_HIP, "device / stream setup failed"));
   Topo3& T = h->T;
-  T.n = n; T.n_levels = n_levels; T.cap = h->max_width;
+  T.n = n; T.ns = ns; T.n_levels = n_levels; T.cap = h->max_width;
   const double ang[3] = {0.0, -2.0 * M_PI / 3.0, 2.0 * M_PI / 3.0};
   for (int ph = 0; ph < 3; ++ph) { T.vsr[ph] = t->v_source[ph] * std::cos(ang[ph]); T.vsi[ph] = t->v_source[ph] * std::sin(ang[ph]); }
   int rc;
-  std::vector<int4> idx(n);
-  for (int tt = 0; tt < n; ++tt) idx[tt] = make_int4(par[tt], cfirst[tt], ccount[tt], mask[tt]);
-  if ((rc = upload3(h, &T.lvl_ptr, lvl_ptr)) || (rc = upload3(h, &T.idx, idx)) || (rc = upload3(h, &T.zr, zr)) || (rc = upload3(h, &T.zi, zi)))
+  std::vector<int32_t> slvl_pad(GS3_LVL_PAD, 0);
+  slvl_pad.insert(slvl_pad.end(), slvl.begin(), slvl.end());
+  slvl_pad.insert(slvl_pad.end(), GS3_LVL_PAD, ns);
+  if ((rc = upload3(h, &T.lvl_ptr, slvl_pad)) || (rc = upload3(h, &T.idx, idx)) || (rc = upload3(h, &T.sibb, sibb)) || (rc = upload3(h, &T.z, z)))
     return bail(rc);
   // level messages through LDS when two parities of the widest level fit beside three other resident workgroups
-  h->lds_bytes = 2 * 6 * h->max_width * (int)sizeof(double);
+  h->lds_bytes = 2 * 2 * h->max_width * (int)sizeof(double);
   if (h->lds_bytes > 38 * 1024 || getenv("GS3_NO_LDS")) h->lds_bytes = 0;
   h->rows = h->lds_bytes ? C_COUNT : C_COUNT_NOLDS;
-  { const int32_t* q = nullptr; if ((rc = upload3(h, &q, node_of))) return bail(rc); h->d_node_of = const_cast<int32_t*>(q); }
-  { const int32_t* q = nullptr; if ((rc = upload3(h, &q, pos_of))) return bail(rc); h->d_pos_of = const_cast<int32_t*>(q); }
+  { const int32_t* q = nullptr; if ((rc = upload3(h, &q, src_of))) return bail(rc); h->d_src_of = const_cast<int32_t*>(q); }
+  { const int32_t* q = nullptr; if ((rc = upload3(h, &q, slot_of))) return bail(rc); h->d_slot_of = const_cast<int32_t*>(q); }
+  if (const char* e = getenv("GS3_PREFETCH")) h->prefetch = std::max(1, std::min(3, atoi(e)));
   if (const char* e = getenv("GS3_THREADS")) h->threads = std::max(64, std::min(256, atoi(e) / 64 * 64));
   const size_t bn3 = (size_t)batch * n * 3;
-  if ((rc = alloc3(h, &h->d_state, (size_t)batch * h->rows * n)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
+  if ((rc = alloc3(h, &h->d_state, (size_t)batch * h->rows * ns)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
       (rc = alloc3(h, &h->d_vre, bn3)) || (rc = alloc3(h, &h->d_vim, bn3)) || (rc = alloc3(h, &h->d_loss, batch)) ||
       (rc = alloc3(h, &h->d_mm, batch)) || (rc = alloc3(h, &h->d_it, batch)) || (rc = alloc3(h, &h->d_conv, batch)))
     return bail(rc);
-  if (hipMemset(h->d_state, 0, (size_t)batch * h->rows * n * sizeof(double)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
+  if (hipMemset(h->d_state, 0, (size_t)batch * h->rows * ns * sizeof(double2)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
   *out = h;
   return GS_OK;
 }
@@ -452,8 +602,8 @@ int gs3_upload_injections(gs3_handle* h, const double* P, const double* Q) {
   const size_t bytes = (size_t)h->B * h->n * 3 * sizeof(double);
   HIP3(h, hipMemcpyAsync(h->d_p, P, bytes, hipMemcpyHostToDevice, h->stream));
   if (Q) HIP3(h, hipMemcpyAsync(h->d_q, Q, bytes, hipMemcpyHostToDevice, h->stream));
-  dim3 grid((h->n + 255) / 256, h->B);
-  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->rows, h->d_node_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
+  dim3 grid((h->ns + 255) / 256, h->B);
+  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->ns, h->rows, h->d_src_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
   HIP3(h, hipGetLastError());
   HIP3(h, hipStreamSynchronize(h->stream));
   return GS_OK;
@@ -469,10 +619,10 @@ int gs3_solve_device(gs3_handle* h) {
   }
   auto& e = h->ev[h->ev_used++];
   HIP3(h, hipEventRecord(e.first, h->stream));
-  if (h->lds_bytes)
-    hipLaunchKernelGGL(gs3_k_solve<true>, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
-  else
-    hipLaunchKernelGGL(gs3_k_solve<false>, dim3(h->B), dim3(h->threads), 0, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
+  typedef void (*solve_fn)(Topo3, double2*, int, double, int, double*, double*, int32_t*, uint8_t*);
+  static const solve_fn with_lds[3] = {gs3_k_solve<true, 1>, gs3_k_solve<true, 2>, gs3_k_solve<true, 3>};
+  const solve_fn fn = h->lds_bytes ? with_lds[h->prefetch - 1] : gs3_k_solve<false, 1>;
+  hipLaunchKernelGGL(fn, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
   HIP3(h, hipGetLastError());
   HIP3(h, hipEventRecord(e.second, h->stream));
   return GS_OK;
@@ -483,8 +633,8 @@ int gs3_download_solution(gs3_handle* h, const gs3_solution_view* out) {
   HIP3(h, hipSetDevice(h->device));
   const size_t bn3 = (size_t)h->B * h->n * 3;
   if (out->v_re || out->v_im) {
-    dim3 grid((h->n + 255) / 256, h->B);
-    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->rows, h->d_pos_of, h->d_state, h->d_vre, h->d_vim);
+    dim3 grid((3 * h->n + 255) / 256, h->B);
+    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->ns, h->rows, h->d_slot_of, h->d_state, h->d_vre, h->d_vim);
     HIP3(h, hipGetLastError());
     if (out->v_re) HIP3(h, hipMemcpyAsync(out->v_re, h->d_vre, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (out->v_im) HIP3(h, hipMemcpyAsync(out->v_im, h->d_vim, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -526,8 +676,8 @@ int gs3_timing_read(gs3_handle* h, double* total_ms, int64_t* launches) {
 
 int gs3_describe(const gs3_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail3(nullptr, GS_E_INVALID, "bad arguments");
-  snprintf(buf, buflen, "{\"kernel\": \"fbs3\", \"n\": %d, \"levels\": %d, \"max_level_width\": %d, \"batch\": %d, \"lds_messages\": %d, \"state_bytes\": %zu}",
-           h->n, h->n_levels, h->max_width, h->B, h->lds_bytes, (size_t)h->B * h->rows * h->n * sizeof(double));
+  snprintf(buf, buflen, "{\"kernel\": \"fbs3\", \"n\": %d, \"conductors\": %d, \"levels\": %d, \"max_level_width\": %d, \"batch\": %d, \"lds_messages\": %d, \"state_bytes\": %zu}",
+           h->n, h->ns, h->n_levels, h->max_width, h->B, h->lds_bytes, (size_t)h->B * h->rows * h->ns * sizeof(double2));
   return GS_OK;
 }
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Memory-path PMC passes for one bench config (one counter set per run; --pmc never combined with other traces):
+#   BENCH_ARGS="--workload ieee8500_3ph_b1024" TAG=c5 tools/pmc_memory_path.sh
+R=$GRAFT_REPO_ROOT
+TAG=${TAG:-mem}
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM" \
+           "TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TOTAL_CACHE_ACCESSES TCP_PENDING_STALL_CYCLES" \
+           "TCP_TCC_READ_REQ_LATENCY TCP_TCP_LATENCY TCP_TOTAL_READ TCP_TOTAL_WRITE" \
+           "TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ" \
+           "TCC_EA0_RDREQ_DRAM TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" \
+           "TCC_EA0_RDREQ_LEVEL TCC_EA0_WRREQ_LEVEL TCC_TAG_STALL TCC_BUSY" \
+           "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TD_TD_BUSY" \
+           "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_REQUEST GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/${TAG}_pmcm_$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $R/gpurun_out/${TAG}_pmcm_$i.log 2>&1 || { tail -3 $R/gpurun_out/${TAG}_pmcm_$i.log; }
+done
