@@ -340,11 +340,12 @@ class Handle:
     def timing_enable(self, on: bool = True) -> None:
         self._check(self._lib.gs_timing_enable(self._h, 1 if on else 0))
 
-    STAMP_NAMES = ["prologue", "init", "mismatch", "bottom_up", "flag", "top_down", "final_mismatch", "epilogue"]
+    STAMP_NAMES = ["prologue_inject", "init", "mismatch", "bottom_up", "flag", "top_down", "final_mismatch", "epilogue_pack",
+                   "prologue_scalars_rng", "spare", "epi_buses", "epi_lines", "epi_reduce", "epi_scalars"]
 
     def debug_stamps(self) -> dict:
-        buf = (C.c_uint64 * 8)()
-        self._check(self._lib.gs_debug_stamps(self._h, buf, 8))
+        buf = (C.c_uint64 * 16)()
+        self._check(self._lib.gs_debug_stamps(self._h, buf, 16))
         return {n: int(buf[k]) for k, n in enumerate(self.STAMP_NAMES)}
 
     def timing_read(self) -> dict:

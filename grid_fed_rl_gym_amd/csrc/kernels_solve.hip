@@ -68,7 +68,8 @@ struct Ctx {
 // Diagnostic phase stamps (gs_debug_stamps): block 0 / wave 0 / lane 0 adds the cycles since its
 // previous stamp to slot `k`.  Off (one scalar branch) unless the host armed a buffer; the values
 // go to that buffer only and feed nothing.
-enum { ST_PROLOGUE = 0, ST_INIT, ST_MISMATCH, ST_BOTTOM_UP, ST_FLAG, ST_TOP_DOWN, ST_FINAL_MISMATCH, ST_EPILOGUE, ST_COUNT };
+enum { ST_PROLOGUE = 0, ST_INIT, ST_MISMATCH, ST_BOTTOM_UP, ST_FLAG, ST_TOP_DOWN, ST_FINAL_MISMATCH, ST_EPILOGUE,
+       ST_PRO_SCALAR, ST_PRO_SPARE, ST_EPI_BUSES, ST_EPI_LINES, ST_EPI_REDUCE, ST_EPI_SCALARS, ST_COUNT };   // ST_PROLOGUE = injections, ST_EPILOGUE = observation pack
 __device__ __forceinline__ void stamp(Ctx& c, int k) {
   if (c.stamps == nullptr) return;
   const unsigned long long now = __builtin_readcyclecounter();
@@ -932,6 +933,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
       vflags |= (v < E.v_min) ? 2 : 0;
     }
   }
+  stamp(c, ST_EPI_BUSES);
   for (int k = c.wave; k < T.m; k += c.W) {
     const int i = cld(T.lfrom, k), j = cld(T.lto, k);
     const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k);
@@ -947,6 +949,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
       over += (ld > 0.8) ? 1 : 0;
     }
   }
+  stamp(c, ST_EPI_LINES);
   double* post = gs_dyn + c.lane;                               // post[k][wave][lane]
   int* posti = (int*)(gs_dyn + GS_EPI_DOUBLES) + c.lane;        // posti[k][wave][lane]
 #define POST(k, w) post[((k) * GS_MAX_WAVES + (w)) * GS_LANES]
@@ -957,6 +960,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
     POSTI(0, c.wave) = over; POSTI(1, c.wave) = vflags;
   }
   __syncthreads();
+  stamp(c, ST_EPI_REDUCE);
   if (c.wave != 0) return;
   double losses = POST(0, 0);
   for (int w = 1; w < c.W; ++w) losses += POST(0, w);
@@ -1013,6 +1017,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
   ROW(R.VMAX) = vmax; ROW(R.VMIN) = vmin;
   ROW(R.VFLAGS + 0) = (double)vhigh; ROW(R.VFLAGS + 1) = (double)vlow;
   ROW(R.VFLAGS + 2) = (double)fhigh; ROW(R.VFLAGS + 3) = (double)flow_;
+  stamp(c, ST_EPI_SCALARS);
 }
 
 template <int ENV, int WRAP_VA>
@@ -1080,6 +1085,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
     for (int l = l0; l < T.n_loads; l += ls) ROW(R.LOADP + l) = load_power(T, E, l, seed, inst, snew, prof);
   }
   __syncthreads();
+  stamp(c, ST_PRO_SCALAR);
   {
     const GS_CONST GsInjRec* recs = (const GS_CONST GsInjRec*)T.winj;
     const int k1 = cld(T.wi_ptr, c.wave + 1);
