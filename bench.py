@@ -262,6 +262,23 @@ def main():
         m = dict(solver=solver, elapsed=elapsed, timing=timing, desc=desc,
                  converged_fraction=float(out["power_flow_converged"].mean()),
                  mean_iterations=float(out["iterations"].mean()))
+        if rank == 0 and solver == args.solver:
+            # SafetyChecker + SafetyMonitor + quality gate on the device state, outside the timed step
+            try:
+                from grid_fed_rl_gym_amd.safety import PostStepChecks
+                ck = PostStepChecks(env)
+                for _ in range(3):
+                    ck.run()
+                h.synchronize(); ck.timing_read()
+                for _ in range(20):
+                    ck.run()
+                ms, cnt = ck.timing_read()
+                byts = B * ((fs.n + 3 * fs.m + 5) + fs.n) * 8 + B * (fs.n + fs.m)      # rows read, previous voltages written, masks written
+                m["post_step_checks"] = {"kernel": "gs_k_checks", "avg_launch_us": 1e3 * ms / max(cnt, 1), "bytes_per_launch": byts,
+                                         "GB_per_s": byts / (ms / max(cnt, 1) * 1e-3) / 1e9 if ms > 0 else None}
+                ck.close()
+            except Exception as e:                                 # never let the side measurement break the bench line
+                m["post_step_checks"] = {"error": str(e)}
         if use_gather:
             h.comm_destroy()
         env.close()
@@ -343,6 +360,8 @@ def main():
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in main_m["timing"].items()},
             "converged_fraction": main_m["converged_fraction"],
         }
+        if "post_step_checks" in main_m:
+            result["post_step_checks"] = main_m["post_step_checks"]
         if other is not None:
             o_sps, o_ms = summarize(other)
             result["also"] = {"solver": other["solver"], "kernel": "gs_k_step_" + kernel_names[other["desc"]["kernel"]],

@@ -18,6 +18,7 @@ from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoup
 from .env import BatchedGridEnvironment, VectorizedEnvironment, Box
 from .rollout import collect_random_data, GridDataset
 from .sharding import ShardedGridEnvironment, shard_range
+from .safety import BatchedSafetyChecker, BatchedSafetyMonitor, PostStepChecks, device_quality_score
 from .unbalanced import UnbalancedPowerFlow, UnbalancedFeederSpec, UnbalancedSolution, unbalanced_from_single_phase, ieee8500_like
 
 __all__ = [
@@ -25,6 +26,7 @@ __all__ = [
     "BatchedForwardBackwardSweepSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
     "injections_from_dicts", "BatchedGridEnvironment", "VectorizedEnvironment", "Box",
     "collect_random_data", "GridDataset", "ShardedGridEnvironment", "shard_range",
+    "BatchedSafetyChecker", "BatchedSafetyMonitor", "PostStepChecks", "device_quality_score",
     "UnbalancedPowerFlow", "UnbalancedFeederSpec", "UnbalancedSolution", "unbalanced_from_single_phase", "ieee8500_like",
     "Bus", "Line", "Load", "PowerFlowSolution", "BatchedPowerFlowSolution", "PowerFlowError",
     "InvalidActionError", "FeederSpec", "flatten_feeder", "flatten_network", "to_objects",

@@ -94,6 +94,7 @@ SYMBOLS = [
     ("gs_timing_enable", C.c_int, [_H, C.c_int32]),
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
+    ("gs_debug_write_rows", C.c_int, [_H, C.c_int32, _dp]),
 ]
 # the gs3_* entry points (three-phase solver) are bound in unbalanced.py
 
@@ -195,8 +196,22 @@ class Handle:
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
+            for child in list(getattr(self, "_children", [])):     # objects bound to this handle (safety.PostStepChecks) go first
+                child.close()
             self._lib.gs_destroy(self._h)
             self._h = _H()
+
+    def last_error(self) -> str:
+        return self._lib.gs_last_error(self._h).decode()
+
+    def _adopt(self, child) -> None:
+        if not hasattr(self, "_children"):
+            self._children = []
+        self._children.append(child)
+
+    def _release(self, child) -> None:
+        if child in getattr(self, "_children", []):
+            self._children.remove(child)
 
     def __del__(self):
         try:
@@ -347,6 +362,16 @@ class Handle:
         buf = (C.c_uint64 * 16)()
         self._check(self._lib.gs_debug_stamps(self._h, buf, 16))
         return {n: int(buf[k]) for k, n in enumerate(self.STAMP_NAMES)}
+
+    ROW_FAMILIES = {"VM": 0, "LOAD": 1, "ENVLOAD": 2, "FLOW": 3, "FREQ": 4, "CONV": 5, "ITERS": 6, "MAXMIS": 7}
+
+    def debug_write_rows(self, rows: dict) -> None:
+        """Test aid (gs_debug_write_rows): overwrite families of device rows with [B, width] arrays; None entries are skipped."""
+        for name, val in rows.items():
+            if val is None:
+                continue
+            a = np.ascontiguousarray(np.asarray(val, dtype=np.float64).reshape(self.B, -1))
+            self._check(self._lib.gs_debug_write_rows(self._h, self.ROW_FAMILIES[name], a.ctypes.data_as(_dp)))
 
     def timing_read(self) -> dict:
         ms = (C.c_double * 5)()

@@ -828,4 +828,162 @@ int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches) {
   return GS_OK;
 }
 
+
+int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
+  if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  const GsRows& R = h->R;
+  const int row0[GS_ROWS_COUNT] = {R.VM, R.LOAD, R.ENVLOAD, R.FLOW, R.FREQ, R.CONV, R.ITERS, R.MAXMIS};
+  const int width[GS_ROWS_COUNT] = {h->n, h->m, h->m, h->m, 1, 1, 1, 1};
+  const int C = width[which];
+  if (C <= 0) return GS_OK;
+  if ((size_t)h->B * C > h->in_doubles) return fail(h, GS_E_INVALID, "staging buffer too small");
+  std::vector<int32_t> map(C);
+  for (int k = 0; k < C; ++k) map[k] = row0[which] + k;
+  int32_t* dmap = nullptr;
+  HIPCHK(h, hipMalloc((void**)&dmap, C * sizeof(int32_t)));
+  int rc = GS_OK;
+  if (hipMemcpyAsync(dmap, map.data(), C * sizeof(int32_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail(h, GS_E_HIP, "map upload failed");
+  if (!rc) rc = unpack_from_host(h, dmap, C, values);
+  const hipError_t e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dmap);
+  if (!rc && e != hipSuccess) rc = fail(h, GS_E_HIP, "row write failed");
+  return rc;
+}
+
+// ---- post-step checks -------------------------------------------------------------------------------
+struct gs_checks {
+  gs_handle* h = nullptr;
+  GsChecksCfg C{};
+  double* prev = nullptr; int32_t* state = nullptr; int32_t* out_i = nullptr; double* out_f = nullptr;
+  uint8_t *bus_mask = nullptr, *line_mask = nullptr; double* freq = nullptr; bool use_freq = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0;
+};
+
+int gs_checks_create(gs_handle* h, const gs_checks_config* cfg, gs_checks** out) {
+  if (!h || !cfg || !out) return fail(h, GS_E_INVALID, "handle / config / out is NULL");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(gs_checks_config)) return fail(h, GS_E_INVALID, "gs_checks_config.struct_size mismatch");
+  if (!(cfg->timestep > 0.0)) return fail(h, GS_E_INVALID, "timestep must be positive");
+  if (cfg->loading_source != 0 && cfg->loading_source != 1) return fail(h, GS_E_INVALID, "loading_source must be 0 or 1");
+  HIPCHK(h, hipSetDevice(h->device));
+  gs_checks* c = new gs_checks();
+  c->h = h;
+  GsChecksCfg& C = c->C;
+  C.c_vlo = cfg->voltage_limits[0]; C.c_vhi = cfg->voltage_limits[1]; C.c_flo = cfg->frequency_limits[0]; C.c_fhi = cfg->frequency_limits[1];
+  C.c_load = cfg->line_loading_limit; C.c_rocv = cfg->rate_voltage; C.c_rocf = cfg->rate_frequency; C.dt = cfg->timestep;
+  C.m_vlo = cfg->mon_voltage_limits[0]; C.m_vhi = cfg->mon_voltage_limits[1]; C.m_flo = cfg->mon_frequency_limits[0]; C.m_fhi = cfg->mon_frequency_limits[1];
+  C.m_load = cfg->mon_line_loading_limit; C.m_evlo = cfg->mon_emergency_voltage[0]; C.m_evhi = cfg->mon_emergency_voltage[1];
+  C.m_eflo = cfg->mon_emergency_frequency[0]; C.m_efhi = cfg->mon_emergency_frequency[1];
+  C.q_tol = cfg->quality_tolerance;
+  C.n = h->n; C.m = h->m; C.rows_total = h->R.total;
+  C.row_vm = h->R.VM; C.row_qload = h->R.LOAD; C.row_cload = cfg->loading_source ? h->R.ENVLOAD : h->R.LOAD; C.row_flow = h->R.FLOW;
+  C.row_freq = h->R.FREQ; C.row_conv = h->R.CONV; C.row_iters = h->R.ITERS; C.row_maxmis = h->R.MAXMIS;
+  const size_t Bp = h->Bp;
+  bool ok = hipMalloc((void**)&c->prev, (size_t)h->groups * (h->n + 1) * GS_LANES * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&c->state, 3 * Bp * sizeof(int32_t)) == hipSuccess &&
+            hipMalloc((void**)&c->out_i, (size_t)GS_CI_COUNT * Bp * sizeof(int32_t)) == hipSuccess &&
+            hipMalloc((void**)&c->out_f, (size_t)GS_CF_COUNT * Bp * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&c->bus_mask, std::max<size_t>(1, (size_t)h->groups * h->n * GS_LANES)) == hipSuccess &&
+            hipMalloc((void**)&c->line_mask, std::max<size_t>(1, (size_t)h->groups * h->m * GS_LANES)) == hipSuccess &&
+            hipMalloc((void**)&c->freq, Bp * sizeof(double)) == hipSuccess;
+  ok = ok && hipMemset(c->prev, 0, (size_t)h->groups * (h->n + 1) * GS_LANES * sizeof(double)) == hipSuccess &&
+       hipMemset(c->state, 0, 3 * Bp * sizeof(int32_t)) == hipSuccess && hipMemset(c->out_i, 0, (size_t)GS_CI_COUNT * Bp * sizeof(int32_t)) == hipSuccess &&
+       hipMemset(c->out_f, 0, (size_t)GS_CF_COUNT * Bp * sizeof(double)) == hipSuccess;
+  if (!ok) { gs_checks_destroy(c); return fail(h, GS_E_NOMEM, "device allocation for the checks failed"); }
+  *out = c;
+  return GS_OK;
+}
+
+void gs_checks_destroy(gs_checks* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->h->device);
+  (void)hipStreamSynchronize(c->h->stream);
+  for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (void* p : {(void*)c->prev, (void*)c->state, (void*)c->out_i, (void*)c->out_f, (void*)c->bus_mask, (void*)c->line_mask, (void*)c->freq})
+    if (p) (void)hipFree(p);
+  delete c;
+}
+
+int gs_checks_set_frequency(gs_checks* c, const double* f) {
+  if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
+  gs_handle* h = c->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  c->use_freq = f != nullptr;
+  if (f) { HIPCHK(h, hipMemcpyAsync(c->freq, f, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+  return GS_OK;
+}
+
+int gs_checks_run(gs_checks* c) {
+  if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
+  gs_handle* h = c->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (c->ev_used == c->ev.size()) {
+    hipEvent_t a, b2;
+    HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b2));
+    c->ev.emplace_back(a, b2);
+  }
+  auto& e = c->ev[c->ev_used++];
+  HIPCHK(h, hipEventRecord(e.first, h->stream));
+  hipLaunchKernelGGL(gs_k_checks, dim3(h->groups), dim3(1024), 0, h->stream, c->C, h->slab, c->use_freq ? c->freq : (const double*)nullptr,
+                     c->prev, c->state, c->out_i, c->out_f, c->bus_mask, c->line_mask, h->B, h->Bp);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(e.second, h->stream));
+  return GS_OK;
+}
+
+int gs_checks_download(gs_checks* c, const gs_checks_view* out) {
+  if (!c || !out) return fail(c ? c->h : nullptr, GS_E_INVALID, "checks object / view is NULL");
+  gs_handle* h = c->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t Bp = h->Bp, B = h->B;
+  std::vector<int32_t> ti; std::vector<double> tf; std::vector<uint8_t> tb, tl;
+  if (out->ints) { ti.resize((size_t)GS_CI_COUNT * Bp); HIPCHK(h, hipMemcpyAsync(ti.data(), c->out_i, ti.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)); }
+  if (out->reals) { tf.resize((size_t)GS_CF_COUNT * Bp); HIPCHK(h, hipMemcpyAsync(tf.data(), c->out_f, tf.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+  if (out->bus_mask && h->n) { tb.resize((size_t)h->groups * h->n * GS_LANES); HIPCHK(h, hipMemcpyAsync(tb.data(), c->bus_mask, tb.size(), hipMemcpyDeviceToHost, h->stream)); }
+  if (out->line_mask && h->m) { tl.resize((size_t)h->groups * h->m * GS_LANES); HIPCHK(h, hipMemcpyAsync(tl.data(), c->line_mask, tl.size(), hipMemcpyDeviceToHost, h->stream)); }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (out->ints) for (int k = 0; k < GS_CI_COUNT; ++k) memcpy(out->ints + (size_t)k * B, ti.data() + (size_t)k * Bp, B * sizeof(int32_t));
+  if (out->reals) for (int k = 0; k < GS_CF_COUNT; ++k) memcpy(out->reals + (size_t)k * B, tf.data() + (size_t)k * Bp, B * sizeof(double));
+  auto untile = [&](const std::vector<uint8_t>& t, uint8_t* dst, int width) {     // [group][row][lane] -> [b][row]
+    for (size_t b = 0; b < B; ++b) {
+      const size_t g = b / GS_LANES, lane = b % GS_LANES;
+      for (int r = 0; r < width; ++r) dst[b * width + r] = t[(g * width + r) * GS_LANES + lane];
+    }
+  };
+  if (out->bus_mask && h->n) untile(tb, out->bus_mask, h->n);
+  if (out->line_mask && h->m) untile(tl, out->line_mask, h->m);
+  return GS_OK;
+}
+
+int gs_checks_reset(gs_checks* c, const uint8_t* mask) {
+  if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
+  gs_handle* h = c->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  uint8_t* dmask = nullptr;
+  if (mask) {
+    HIPCHK(h, hipMalloc((void**)&dmask, h->B));
+    if (hipMemcpyAsync(dmask, mask, h->B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { (void)hipFree(dmask); return fail(h, GS_E_HIP, "mask upload failed"); }
+  }
+  hipLaunchKernelGGL(gs_k_checks_reset, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, c->state, (const uint8_t*)dmask, h->B, h->Bp);
+  const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
+  if (dmask) (void)hipFree(dmask);
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(h, GS_E_HIP, "checks reset failed");
+  return GS_OK;
+}
+
+int gs_checks_timing_read(gs_checks* c, double* total_ms, int64_t* launches) {
+  if (!c || !total_ms || !launches) return fail(c ? c->h : nullptr, GS_E_INVALID, "bad arguments");
+  gs_handle* h = c->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *total_ms = 0.0; *launches = 0;
+  for (size_t k = 0; k < c->ev_used; ++k) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[k].first, c->ev[k].second) == hipSuccess) { *total_ms += ms; *launches += 1; }
+  }
+  c->ev_used = 0;
+  return GS_OK;
+}
+
 }  // extern "C"

@@ -194,3 +194,13 @@ struct GsEnvCfg {
   int32_t episode_length, stochastic_loads, weather_variation, pad;
   int64_t first_instance;
 };
+
+// ---- post-step checks (kernels_checks.hip) ----
+struct GsChecksCfg {
+  double c_vlo, c_vhi, c_flo, c_fhi, c_load, c_rocv, c_rocf, dt;                       // SafetyChecker
+  double m_vlo, m_vhi, m_flo, m_fhi, m_load, m_evlo, m_evhi, m_eflo, m_efhi;           // SafetyMonitor
+  double q_tol;                                                                          // quality gate
+  int32_t n, m, rows_total;
+  int32_t row_vm, row_cload, row_qload, row_flow, row_freq, row_conv, row_iters, row_maxmis;
+  int32_t pad;
+};

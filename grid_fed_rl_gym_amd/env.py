@@ -182,6 +182,20 @@ class BatchedGridEnvironment:
     def state_column(self, name: str) -> int:
         return self.STATE_FIELDS.index(name)
 
+    def state_layout(self) -> Dict[str, Any]:
+        """Column index / slice of every field of the ``get_state()`` blob (layout: gs_get_state in include/gridstep.h)."""
+        sp = self.spec
+        lay: Dict[str, Any] = {name: k for k, name in enumerate(self.STATE_FIELDS)}
+        o = len(self.STATE_FIELDS)
+        for name, width in (("soc", sp.n_bats), ("battery_power", sp.n_bats), ("curtailment", sp.n_gens), ("vm", sp.n), ("va", sp.n),
+                            ("line_flow", sp.m), ("line_loading", sp.m)):
+            lay[name] = slice(o, o + width); o += width
+        return lay
+
+    def last_solution(self) -> Dict[str, np.ndarray]:
+        """The load-flow solution of the last step as it stands on the device (PowerFlowSolution fields, batched)."""
+        return self._h.download_solution()
+
     @property
     def handle(self) -> "_lib.Handle":
         return self._h

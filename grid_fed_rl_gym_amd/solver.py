@@ -78,6 +78,10 @@ class _BatchedSolverBase:
                                 acceleration_factor=float(self.acceleration_factor),
                                 waves_per_group=int(self.waves_per_group))
 
+    def handle_for(self, spec: FeederSpec, batch: int) -> "_lib.Handle":
+        """The native handle that serves (spec, batch): what the device-side checks (safety.py) bind to."""
+        return self._handle(spec, batch)
+
     def _handle(self, spec: FeederSpec, batch: int) -> "_lib.Handle":
         key = (spec.sha256(), int(batch), self.tolerance, self.max_iterations, self.acceleration_factor,
                self.jacobian, self.zero_z, self.linear_solver, self.device, self.waves_per_group)

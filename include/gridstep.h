@@ -205,6 +205,67 @@ int gs_timing_enable(gs_handle* h, int32_t on);
 int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n);
 /* total_ms[GS_K_COUNT], launches[GS_K_COUNT] accumulated since the last call; resets them */
 int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches);
+/* test aid: overwrite one family of device rows with values[B][width] (width = n, m or 1), so that kernels
+ * reading the device state (the post-step checks below) can be driven with fixture data */
+enum { GS_ROWS_VM = 0, GS_ROWS_LINE_LOADING = 1, GS_ROWS_ENV_LINE_LOADING = 2, GS_ROWS_LINE_FLOW = 3, GS_ROWS_FREQUENCY = 4,
+       GS_ROWS_CONVERGED = 5, GS_ROWS_ITERATIONS = 6, GS_ROWS_MAX_MISMATCH = 7, GS_ROWS_COUNT = 8 };
+int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values);
+
+/* ======================================================================================
+ * Post-step checks on the state a step / solve left on the device.
+ * Replaces, batched and without a host round trip of voltages and loadings:
+ *   SafetyChecker.check_constraints / is_safe / get_violation_severity   utils/safety.py:114-203
+ *   SafetyMonitor.check_constraints                                      utils/safety.py:313-394
+ *   AdvancedRobustPowerFlowSolver._assess_solution_quality               environments/robust_power_flow.py:615-657
+ * A gs_checks object is bound to one gs_handle (it reads that handle's device state and runs on
+ * its stream) and carries what the reference classes carry between calls: the previous voltages
+ * and frequency (rate-of-change limits), the consecutive-violation counter and the sticky
+ * emergency mode.  thermal_data is not modelled, so severity never reaches GS_SEVERITY_CRITICAL.
+ * ====================================================================================== */
+enum {  /* rows of gs_checks_view.ints, each [B]; C_ = SafetyChecker, M_ = SafetyMonitor */
+  GS_CI_C_NLOW = 0, GS_CI_C_NHIGH, GS_CI_C_FLOW, GS_CI_C_FHIGH, GS_CI_C_NOVER, GS_CI_C_VRATE, GS_CI_C_FRATE, GS_CI_C_TOTAL,
+  GS_CI_C_SEVERITY,   /* 0 safe, 1 low, 2 medium, 3 high, 4 critical (safety.py:188-203) */
+  GS_CI_M_NHIGH, GS_CI_M_NLOW, GS_CI_M_NEMERG, GS_CI_M_FHIGH, GS_CI_M_FLOW, GS_CI_M_FEMERG, GS_CI_M_NOVER, GS_CI_M_TOTAL,
+  GS_CI_M_ACTION,     /* emergency_action_required */
+  GS_CI_M_CONSEC, GS_CI_M_EMODE, GS_CI_COUNT
+};
+enum { GS_CF_VRATE = 0, GS_CF_FRATE, GS_CF_QUALITY, GS_CF_COUNT };   /* rows of gs_checks_view.reals, each [B] */
+enum {  /* bits of gs_checks_view.bus_mask[b][i] / line_mask[b][k] */
+  GS_BM_C_LOW = 1, GS_BM_C_HIGH = 2, GS_BM_M_LOW = 4, GS_BM_M_HIGH = 8, GS_BM_M_EMERGENCY = 16,
+  GS_LM_C_OVERLOAD = 1, GS_LM_M_OVERLOAD = 2
+};
+
+typedef struct gs_checks_config {
+  int32_t struct_size;             /* = sizeof(gs_checks_config) */
+  int32_t loading_source;          /* 0: |S|/rating of the load-flow solution (PowerFlowSolution.line_loadings);
+                                      1: the environment's |P|/rating (Line.update_state, base.py:261-264) */
+  double voltage_limits[2], frequency_limits[2], line_loading_limit;      /* SafetyChecker.__init__, safety.py:100-112 */
+  double rate_voltage, rate_frequency, timestep;
+  double mon_voltage_limits[2], mon_frequency_limits[2], mon_line_loading_limit;   /* SafetyMonitor.__init__, :296-311 */
+  double mon_emergency_voltage[2], mon_emergency_frequency[2];
+  double quality_tolerance;        /* the solver tolerance `_assess_solution_quality` compares max_mismatch with */
+} gs_checks_config;
+
+typedef struct gs_checks_view {    /* host buffers, any may be NULL */
+  int32_t* ints;                   /* [GS_CI_COUNT][B] */
+  double* reals;                   /* [GS_CF_COUNT][B] */
+  uint8_t* bus_mask;               /* [B][n] */
+  uint8_t* line_mask;              /* [B][m] */
+} gs_checks_view;
+
+typedef struct gs_checks gs_checks;
+
+int gs_checks_create(gs_handle* h, const gs_checks_config* cfg, gs_checks** out);
+void gs_checks_destroy(gs_checks* c);
+/* frequency per instance for handles without an environment (solver-only); NULL = back to the handle's own */
+int gs_checks_set_frequency(gs_checks* c, const double* frequency_hz);
+/* one check_constraints call per instance on the handle's current device state (asynchronous) */
+int gs_checks_run(gs_checks* c);
+int gs_checks_download(gs_checks* c, const gs_checks_view* out);
+/* forget previous state, counters and emergency mode of the masked instances (NULL = all): a freshly
+ * constructed SafetyChecker() / SafetyMonitor() */
+int gs_checks_reset(gs_checks* c, const uint8_t* mask);
+int gs_checks_timing_read(gs_checks* c, double* total_ms, int64_t* launches);
 
 /* ======================================================================================
  * Three-phase unbalanced radial load flow (BASELINE.json config 5).  NEW functionality: the

@@ -24,7 +24,8 @@ def test_every_declared_symbol_is_exported_and_bound():
     declared = _header_functions()
     assert len(declared) >= 25
     from grid_fed_rl_gym_amd.unbalanced import GS3_SYMBOLS
-    bound = {name for name, _, _ in _lib.SYMBOLS} | {name for name, _, _ in GS3_SYMBOLS}
+    from grid_fed_rl_gym_amd.safety import CHECKS_SYMBOLS
+    bound = {name for name, _, _ in _lib.SYMBOLS} | {name for name, _, _ in GS3_SYMBOLS} | {name for name, _, _ in CHECKS_SYMBOLS}
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gridstep.h but not exported by libgridstep.so"
         assert name in bound, f"{name} declared in gridstep.h but not bound in _lib.SYMBOLS"

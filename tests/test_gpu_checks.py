@@ -1,0 +1,138 @@
+"""Device-side post-step checks (gs_checks_*, safety.py) against (1) the fixtures captured from the reference's
+SafetyChecker / SafetyMonitor / _assess_solution_quality and (2) the NumPy oracle on live environment state.
+Integer / boolean outputs must be identical; the two rate values and the quality score are the same IEEE
+operations on the same doubles, so they are compared exactly as well."""
+import os
+
+import numpy as np
+import pytest
+
+import grid_fed_rl_gym_amd as P
+from grid_fed_rl_gym_amd import _lib
+from grid_fed_rl_gym_amd.safety import PostStepChecks
+from oracle import checks_np as CK
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _inject(handle, vm, loading_env, loading_sol, flows, freq, conv=None, its=None, mm=None):
+    """Write rows of the device state through gs_set_state-independent paths: the checks read VM, LOAD, ENVLOAD, FLOW,
+    FREQ, CONV, ITERS, MAXMIS; the state vector (get_state / set_state) carries FREQ, Vm and the env loadings, the
+    solver-side rows come from a solve.  For fixtures we drive the rows directly with the debug row writer."""
+    handle.debug_write_rows(dict(VM=vm, ENVLOAD=loading_env, LOAD=loading_sol, FLOW=flows, FREQ=freq,
+                                 CONV=conv, ITERS=its, MAXMIS=mm))
+
+
+@pytest.mark.parametrize("name", ["default", "custom"])
+def test_device_checks_reproduce_reference_sequences(name):
+    d = np.load(os.path.join(GOLD, "checks_safety_seq.npz"))
+    v, f, ld = d["voltages"], d["frequency"], d["loadings"]
+    T, K, n = v.shape; m = ld.shape[2]
+    spec = P.simple_radial(n)                                   # n buses, n - 1 = m lines
+    assert spec.m == m
+    env = P.BatchedGridEnvironment(spec, num_envs=K, solver="fbs")
+    env.reset(seed=0)
+    if name == "default":
+        ck = PostStepChecks(env, timestep=float(d["default_dt"]))
+    else:
+        c, mo = d["custom_checker_limits"], d["custom_monitor_limits"]
+        ck = PostStepChecks(env, timestep=float(d["custom_dt"]),
+                            checker=dict(voltage_limits=(c[0], c[1]), frequency_limits=(c[2], c[3]), line_loading_limit=c[4],
+                                         rate_of_change_limits={"voltage": c[5], "frequency": c[6]}),
+                            monitor=dict(voltage_limits=(mo[0], mo[1]), frequency_limits=(mo[2], mo[3]), line_loading_limit=mo[4],
+                                         emergency_voltage_limits=(mo[5], mo[6]), emergency_frequency_limits=(mo[7], mo[8])))
+    g = lambda k: d[f"{name}_{k}"]
+    for t in range(T):
+        _inject(env.handle, v[t], ld[t], ld[t], np.zeros((K, m)), f[t])
+        ck.run()
+        o = ck.download(masks=True)
+        bm, lm = o["bus_mask"], o["line_mask"]
+        np.testing.assert_array_equal((bm & 1) != 0, g("c_mask_low")[t].astype(bool))
+        np.testing.assert_array_equal((bm & 2) != 0, g("c_mask_high")[t].astype(bool))
+        np.testing.assert_array_equal((bm & 4) != 0, g("m_mask_low")[t].astype(bool))
+        np.testing.assert_array_equal((bm & 8) != 0, g("m_mask_high")[t].astype(bool))
+        np.testing.assert_array_equal((lm & 1) != 0, g("c_mask_overload")[t].astype(bool))
+        np.testing.assert_array_equal((lm & 2) != 0, g("m_mask_overload")[t].astype(bool))
+        for mine, ref in (("c_n_voltage_low", "c_voltage_low"), ("c_n_voltage_high", "c_voltage_high"), ("c_frequency_low", "c_freq_low"),
+                          ("c_frequency_high", "c_freq_high"), ("c_n_line_overload", "c_line_overload"),
+                          ("c_voltage_rate_violation", "c_voltage_rate"), ("c_frequency_rate_violation", "c_freq_rate"),
+                          ("c_total", "c_total"), ("c_severity", "c_severity"), ("m_n_voltage_emergency", "m_emergency_count"),
+                          ("m_frequency_high", "m_freq_high"), ("m_frequency_low", "m_freq_low"), ("m_frequency_emergency", "m_freq_emergency"),
+                          ("m_total_violations", "m_total"), ("m_emergency_action_required", "m_action_required"),
+                          ("m_consecutive_violations", "m_consecutive"), ("m_emergency_mode", "m_emergency_mode")):
+            np.testing.assert_array_equal(o[mine].astype(np.int64), g(ref)[t], err_msg=f"{mine} t={t}")
+        vr = g("c_voltage_rate")[t].astype(bool); fr = g("c_freq_rate")[t].astype(bool)
+        np.testing.assert_array_equal(o["voltage_rate"][vr], g("c_voltage_rate_value")[t][vr])
+        np.testing.assert_array_equal(o["frequency_rate"][fr], g("c_freq_rate_value")[t][fr])
+    # reset = freshly constructed objects: no rate violations on the next call, counters cleared for the masked instances
+    mask = np.zeros(K, dtype=np.uint8); mask[::2] = 1
+    before = ck.download()
+    ck.reset(mask)
+    _inject(env.handle, v[0], ld[0], ld[0], np.zeros((K, m)), f[0])
+    ck.run(); o = ck.download()
+    assert not o["c_voltage_rate_violation"][::2].any() and not o["c_frequency_rate_violation"][::2].any()
+    assert (o["m_consecutive_violations"][::2] <= 1).all()
+    assert (o["m_emergency_mode"][1::2] >= before["m_emergency_mode"][1::2]).all()      # the others kept their sticky mode
+    ck.close(); env.close()
+
+
+def test_device_quality_gate_reproduces_reference():
+    d = np.load(os.path.join(GOLD, "checks_quality.npz"))
+    Q, nb = d["bus_voltages"].shape; nl = d["line_loadings"].shape[1]
+    spec = P.simple_radial(nb)
+    assert spec.m == nl
+    env = P.BatchedGridEnvironment(spec, num_envs=Q, solver="fbs")
+    env.reset(seed=0)
+    ck = PostStepChecks(env, quality_tolerance=float(d["tolerance"]), loading="solution")
+    _inject(env.handle, d["bus_voltages"], np.zeros((Q, nl)), d["line_loadings"], d["line_flows"], np.full(Q, 60.0),
+            conv=d["converged"].astype(float), its=d["iterations"].astype(float), mm=d["max_mismatch"])
+    ck.run()
+    np.testing.assert_array_equal(ck.download()["quality"], d["quality"])
+    ck.close(); env.close()
+
+
+def test_checks_on_live_environment_state_match_oracle():
+    spec = P.ieee123_like(); B = 192
+    env = P.BatchedGridEnvironment(spec, num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True)
+    env.reset(seed=3)
+    rng = np.random.default_rng(0)
+    env.step(rng.uniform(-1, 1, (B, spec.action_dim)))
+    lay = env.state_layout()
+    st = env.get_state()
+    vlo, vem, vhi = np.quantile(st[:, lay["vm"]], [0.2, 0.02, 0.97])       # limits that cut through the live voltages / loadings
+    llim, llim2 = np.quantile(st[:, lay["line_loading"]], [0.97, 0.9])
+    chk = P.BatchedSafetyChecker(env, voltage_limits=(vlo, vhi), rate_of_change_limits={"voltage": 1e-3, "frequency": 1e-4}, line_loading_limit=llim)
+    mon = P.BatchedSafetyMonitor(env, voltage_limits=(vlo, vhi), emergency_voltage_limits=(vem, 1.2), line_loading_limit=llim2)
+    ccfg = CK.CheckerConfig((vlo, vhi), (59.5, 60.5), llim, 1e-3, 1e-4)
+    mcfg = CK.MonitorConfig((vlo, vhi), (59.0, 61.0), llim2, (vem, 1.2), (57.0, 63.0))
+    cs, ms = CK.CheckerState(), CK.MonitorState()
+    hit = set()
+    for t in range(6):
+        env.step(rng.uniform(-1, 1, (B, spec.action_dim)))
+        c = chk.check_constraints(masks=True); mo = mon.check_constraints(masks=True)
+        st = env.get_state()
+        vm = st[:, lay["vm"]]; envload = st[:, lay["line_loading"]]; freq = st[:, lay["frequency"]]
+        oc = CK.checker_step(ccfg, cs, vm, freq, envload, 1.0); om = CK.monitor_step(mcfg, ms, vm, freq, envload)
+        for k in ("n_voltage_low", "n_voltage_high", "frequency_low", "frequency_high", "n_line_overload", "voltage_rate_violation",
+                  "frequency_rate_violation", "total", "severity"):
+            np.testing.assert_array_equal(np.asarray(c[k]).astype(np.int64), np.asarray(oc[k]).astype(np.int64), err_msg=f"{k} t={t}")
+        np.testing.assert_array_equal(c["voltage_low"], oc["voltage_low"]); np.testing.assert_array_equal(c["line_overload"], oc["line_overload"])
+        if t > 0:
+            np.testing.assert_array_equal(c["voltage_rate"], oc["voltage_rate"]); np.testing.assert_array_equal(c["frequency_rate"], oc["frequency_rate"])
+        for k in ("n_voltage_high", "n_voltage_low", "n_voltage_emergency", "frequency_high", "frequency_low", "frequency_emergency",
+                  "n_line_overload", "total_violations", "emergency_action_required", "consecutive_violations", "emergency_mode"):
+            np.testing.assert_array_equal(np.asarray(mo[k]).astype(np.int64), np.asarray(om[k]).astype(np.int64), err_msg=f"{k} t={t}")
+        np.testing.assert_array_equal(mo["voltage_emergency"], (vm > 1.2) | (vm < vem))
+        hit |= set(np.asarray(c["severity"]).tolist())
+    assert hit and c["n_voltage_low"].max() > 0 and c["n_line_overload"].max() > 0 and mo["consecutive_violations"].max() == 6
+    rebuilt = chk.violations(5, vm[5], freq[5], envload[5])
+    assert len(rebuilt["voltage"]) == int(c["n_voltage_low"][5] + c["n_voltage_high"][5])
+    assert len(rebuilt["line_loading"]) == int(c["n_line_overload"][5])
+    # quality gate on the solver's own solution
+    q = P.device_quality_score(env, tolerance=1e-6)
+    sol = env.last_solution()
+    np.testing.assert_array_equal(q, CK.quality(sol["converged"], sol["iterations"], sol["max_mismatch"], sol["bus_voltages"],
+                                                sol["line_loadings"], sol["line_flows"], 1e-6))
+    assert (q > 0.7).all()                       # converged, in-band voltages, tiny loadings: the chain would accept them
+    chk.close(); mon.close(); env.close()
