@@ -18,6 +18,8 @@ from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoup
 from .env import BatchedGridEnvironment, VectorizedEnvironment, Box
 from .rollout import collect_random_data, GridDataset
 from .sharding import ShardedGridEnvironment, shard_range
+from .multi_agent import AgentConfig, BatchedMultiAgentWrapper
+from .feeders import feeder_from_dict, feeder_to_dict, network_dict_normalized
 from .safety import BatchedSafetyChecker, BatchedSafetyMonitor, PostStepChecks, device_quality_score
 from .unbalanced import UnbalancedPowerFlow, UnbalancedFeederSpec, UnbalancedSolution, unbalanced_from_single_phase, ieee8500_like
 
@@ -26,6 +28,7 @@ __all__ = [
     "BatchedForwardBackwardSweepSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
     "injections_from_dicts", "BatchedGridEnvironment", "VectorizedEnvironment", "Box",
     "collect_random_data", "GridDataset", "ShardedGridEnvironment", "shard_range",
+    "AgentConfig", "BatchedMultiAgentWrapper", "feeder_from_dict", "feeder_to_dict", "network_dict_normalized",
     "BatchedSafetyChecker", "BatchedSafetyMonitor", "PostStepChecks", "device_quality_score",
     "UnbalancedPowerFlow", "UnbalancedFeederSpec", "UnbalancedSolution", "unbalanced_from_single_phase", "ieee8500_like",
     "Bus", "Line", "Load", "PowerFlowSolution", "BatchedPowerFlowSolution", "PowerFlowError",

@@ -10,6 +10,7 @@ feeders (the shipped ones are not: SURVEY.md fact F5).
 from __future__ import annotations
 
 import hashlib
+import json
 from dataclasses import dataclass, field
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -364,3 +365,81 @@ def random_meshed(n: int, extra_lines: int, seed: int = 0) -> FeederSpec:
         bus_type=np.array([SLACK] + [PQ] * (n - 1), dtype=np.uint8), v_set=np.ones(n),
         frm=_i32(frm), to=_i32(to), r=_f64(r), x=_f64(x), rating=np.full(m, 5e6),
         load_bus=_i32(lb), load_base=rng.uniform(10e3, 200e3, n - 1), load_pf=np.full(n - 1, 0.95))
+
+
+# ----------------------------------------------------------------------------------------
+# dictionary (JSON) network format: CustomFeeder.from_dict / to_dict, feeders/base.py:170-253
+# ----------------------------------------------------------------------------------------
+_FEEDER_PARAMETERS = {"base_voltage": 12.47, "base_power": 10.0, "frequency": 60.0}     # FeederParameters defaults, base.py:18-27
+
+
+def network_dict_normalized(network_dict: Dict[str, Any], name: str = "Custom",
+                            parameters: Optional[Dict[str, float]] = None) -> Dict[str, Any]:
+    """What ``CustomFeeder(name).from_dict(d); .to_dict()`` returns: the same schema with every optional key filled
+    in the way the reference fills it (voltage_level = base_voltage[kV] * 1000, type "pq", base_voltage 1.0,
+    rating 1e6, power_factor 0.95; generator entries verbatim)."""
+    par = dict(_FEEDER_PARAMETERS); par.update(parameters or network_dict.get("parameters", {}) or {})
+    return {
+        "name": name,
+        "parameters": {k: par[k] for k in ("base_voltage", "base_power", "frequency")},
+        "buses": [{"id": b["id"], "voltage_level": b.get("voltage_level", par["base_voltage"] * 1000), "type": b.get("type", "pq"),
+                   "base_voltage": b.get("base_voltage", 1.0)} for b in network_dict.get("buses", [])],
+        "lines": [{"id": l["id"], "from_bus": l["from_bus"], "to_bus": l["to_bus"], "resistance": l["resistance"],
+                   "reactance": l["reactance"], "rating": l.get("rating", 1e6)} for l in network_dict.get("lines", [])],
+        "loads": [{"id": d["id"], "bus": d["bus"], "power": d["power"], "power_factor": d.get("power_factor", 0.95)}
+                  for d in network_dict.get("loads", [])],
+        "generators": [dict(g) for g in network_dict.get("generators", [])],
+    }
+
+
+def feeder_from_dict(network_dict: Dict[str, Any], name: Optional[str] = None) -> FeederSpec:
+    """FeederSpec from the reference's dictionary network format (``CustomFeeder.from_dict``, base.py:170-213).
+    The normalised dictionary is kept on the spec (``spec.source_dict``) so that ``feeder_to_dict`` round-trips ids,
+    voltage levels and generator entries the flat arrays do not carry."""
+    d = network_dict_normalized(network_dict, name or network_dict.get("name", "Custom"))
+
+    class _F:        # BaseFeeder-shaped view for flatten_feeder
+        pass
+    f = _F()
+    f.name = d["name"]
+    f.parameters = type("P", (), {"base_power": d["parameters"]["base_power"]})()
+    f.buses = [Bus(b["id"], bus_type=b["type"]) for b in d["buses"]]
+    f.lines = [Line(l["id"], l["from_bus"], l["to_bus"], l["resistance"], l["reactance"], l["rating"]) for l in d["lines"]]
+    f.loads = [Load(q["id"], q["bus"], q["power"], q["power_factor"]) for q in d["loads"]]
+    f.generators = {g["id"]: g for g in d["generators"]}
+    spec = flatten_feeder(f, name=d["name"])
+    spec.source_dict = d
+    return spec
+
+
+def feeder_to_dict(spec: FeederSpec) -> Dict[str, Any]:
+    """The reference's ``to_dict`` schema (base.py:215-253) for any FeederSpec.  A spec that came from
+    ``feeder_from_dict`` returns its normalised source; others get generated line / load ids (``line_k``,
+    ``load_k``) and their renewable / storage units as generator entries ``flatten_feeder`` reads back."""
+    src = getattr(spec, "source_dict", None)
+    if src is not None:
+        return json.loads(json.dumps(src))
+    names = {PQ: "pq", PV: "pv", SLACK: "slack"}
+    gens: List[Dict[str, Any]] = []
+    for g in range(spec.n_gens):
+        bus = spec.bus_ids[int(spec.gen_bus[g])]
+        if int(spec.gen_kind[g]) == GEN_SOLAR:
+            gens.append({"id": f"solar_{g}", "type": "solar", "bus": bus, "capacity": float(spec.gen_cap[g]),
+                         "efficiency": float(spec.gen_p0[g]), "panel_area": float(spec.gen_p1[g])})
+        else:
+            gens.append({"id": f"wind_{g}", "type": "wind", "bus": bus, "capacity": float(spec.gen_cap[g]), "cut_in_speed": float(spec.gen_p0[g]),
+                         "rated_speed": float(spec.gen_p1[g]), "cut_out_speed": float(spec.gen_p2[g])})
+    for q in range(spec.n_bats):
+        gens.append({"id": f"battery_{q}", "type": "battery", "bus": spec.bus_ids[int(spec.bat_bus[q])], "capacity": float(spec.bat_cap[q]),
+                     "power_rating": float(spec.bat_rating[q]), "efficiency": float(spec.bat_eff[q])})
+    par = dict(_FEEDER_PARAMETERS); par["base_power"] = spec.base_power_va / 1e6
+    return {
+        "name": spec.name, "parameters": par,
+        "buses": [{"id": bid, "voltage_level": par["base_voltage"] * 1000, "type": names[int(spec.bus_type[i])], "base_voltage": 1.0}
+                  for i, bid in enumerate(spec.bus_ids)],
+        "lines": [{"id": f"line_{k}", "from_bus": spec.bus_ids[int(spec.frm[k])], "to_bus": spec.bus_ids[int(spec.to[k])],
+                   "resistance": float(spec.r[k]), "reactance": float(spec.x[k]), "rating": float(spec.rating[k])} for k in range(spec.m)],
+        "loads": [{"id": f"load_{l}", "bus": spec.bus_ids[int(spec.load_bus[l])], "power": float(spec.load_base[l]),
+                   "power_factor": float(spec.load_pf[l])} for l in range(spec.n_loads)],
+        "generators": gens,
+    }
