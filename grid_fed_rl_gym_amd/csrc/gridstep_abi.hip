@@ -82,6 +82,8 @@ struct gs_handle {
   double* slab = nullptr;
   double* d_in = nullptr; size_t in_doubles = 0;
   double* d_out = nullptr; size_t out_doubles = 0;
+  double* d_obs = nullptr;            // [B][obs_dim], owned by the environment path: written whole at reset, its changing columns by every step
+  int obs_skip0 = 0, obs_skip1 = 0;   // the block of per-instance constants inside an observation
   double* d_actions = nullptr; int n_action_batches = 0;
   double* d_cst = nullptr;
   int32_t *map_obs = nullptr, *map_vm = nullptr, *map_va = nullptr, *map_flow = nullptr, *map_load = nullptr,
@@ -225,7 +227,8 @@ int step_kernels(gs_handle* h, const double* d_actions) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
     dim3 grid(h->groups), block(64 * h->W);
-    GsPackArgs pa{h->map_obs, h->d_cst, h->d_out, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, h->dyn_lds / (64 * 65 * sizeof(double))))};
+    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, h->dyn_lds / (64 * 65 * sizeof(double)))),
+                  h->obs_skip0, h->obs_skip1};
 #define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa)
     if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
     else if (h->solve_kernel == 4) GS_STEP(gs_k_step_nr_tree_lds);
@@ -541,6 +544,15 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   for (int i = 0; i < n; ++i) mst.push_back(R.VA + i);
   for (int k = 0; k < m; ++k) mst.push_back(R.FLOW + k);
   for (int k = 0; k < m; ++k) mst.push_back(R.ENVLOAD + k);
+  {   // the constants of an observation form one block (the static load powers); the step kernel skips it
+    int c0 = 0;
+    while (c0 < (int)mo.size() && mo[c0] >= 0) ++c0;
+    int c1 = c0;
+    while (c1 < (int)mo.size() && mo[c1] < 0) ++c1;
+    bool one_block = true;
+    for (int c = c1; c < (int)mo.size(); ++c) one_block = one_block && mo[c] >= 0;
+    if (one_block && !getenv("GS_PACK_ALL_COLUMNS")) { h->obs_skip0 = c0; h->obs_skip1 = c1; }
+  }
   if ((int)mo.size() != h->obs_dim || (int)mst.size() != h->state_dim)
     return bail(fail(nullptr, GS_E_INVALID, "internal: layout map size mismatch"));
   { const double* q = nullptr; if ((rc = dev_upload(h, &q, cst))) return bail(rc); h->d_cst = const_cast<double*>(q); }
@@ -561,7 +573,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   if (hipMemset(h->slab, 0, slab_doubles * sizeof(double)) != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipMemset(slab) failed"));
   const size_t widest = std::max<size_t>({(size_t)h->obs_dim, (size_t)h->state_dim, (size_t)n, (size_t)m, (size_t)h->action_dim, 1});
   h->in_doubles = (size_t)h->B * widest; h->out_doubles = (size_t)h->B * widest;
-  if ((rc = dev_alloc(h, &h->d_in, h->in_doubles)) || (rc = dev_alloc(h, &h->d_out, h->out_doubles))) return bail(rc);
+  if ((rc = dev_alloc(h, &h->d_in, h->in_doubles)) || (rc = dev_alloc(h, &h->d_out, h->out_doubles)) ||
+      (rc = dev_alloc(h, &h->d_obs, (size_t)h->Bp * h->obs_dim))) return bail(rc);
   if ((rc = dev_alloc(h, &h->sc_f, (size_t)SF_COUNT * h->Bp)) || (rc = dev_alloc(h, &h->sc_i, (size_t)SI_COUNT * h->Bp)) ||
       (rc = dev_alloc(h, &h->sc_u, (size_t)SU_COUNT * h->Bp)) || (rc = dev_alloc(h, &h->d_seeds, (size_t)h->B)) ||
       (rc = dev_alloc(h, &h->d_mask, (size_t)h->B)))
@@ -672,7 +685,9 @@ int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* o
                      seeds ? h->d_seeds : (const uint64_t*)nullptr, mask ? h->d_mask : (const uint8_t*)nullptr);
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;
-  if (obs_out) return pack_to_host(h, h->map_obs, h->obs_dim, obs_out);
+  int rc = launch_pack(h, h->map_obs, h->obs_dim, h->d_obs);       // every column, the constants included
+  if (rc) return rc;
+  if (obs_out) HIPCHK(h, hipMemcpyAsync(obs_out, h->d_obs, (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return GS_OK;
 }
@@ -682,7 +697,7 @@ int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* termina
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   HIPCHK(h, hipSetDevice(h->device));
   if (obs) {
-    HIPCHK(h, hipMemcpyAsync(obs, h->d_out, (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
   int rc = fetch_scalars(h);
   if (rc) return rc;
@@ -768,7 +783,7 @@ int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   if (!h->comm) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t count = (size_t)h->B * h->obs_dim;
-  int rc = g_rccl.AllGather(h->d_out, h->d_obs_full, count, /*ncclFloat64*/ 8, h->comm, h->stream);
+  int rc = g_rccl.AllGather(h->d_obs, h->d_obs_full, count, /*ncclFloat64*/ 8, h->comm, h->stream);
   if (rc != 0) return fail(h, GS_E_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
   if (obs_full_host) {
     HIPCHK(h, hipMemcpyAsync(obs_full_host, h->d_obs_full, count * h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -1034,16 +1034,19 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
   const int g = blockIdx.x;
   const int TG = A.tiles_per_pass;                     // 64-column tiles staged per pass (LDS permitting)
   const int span = 64 * TG;
-  for (int c0 = 0; c0 < A.obs_dim; c0 += span) {
+  // the step moves only the columns that can change: position j of that list is column j, or j shifted past the
+  // block of constants
+  const int gap = A.skip1 - A.skip0, n_dyn = A.obs_dim - gap;
+  for (int c0 = 0; c0 < n_dyn; c0 += span) {
     // gather: this wave's rows of the pass, four independent loads in flight at a time
     for (int j = c.wave; j < span; j += 4 * c.W) {
       double v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int cc = j + u * c.W, col = c0 + cc;
+        const int cc = j + u * c.W, jj = c0 + cc;
         v[u] = 0.0;
-        if (cc < span && col < A.obs_dim) {
-          const int s = cld(A.map, col);
+        if (cc < span && jj < n_dyn) {
+          const int s = cld(A.map, jj < A.skip0 ? jj : jj + gap);
           v[u] = (s >= 0) ? Sg[(size_t)s * GS_LANES + c.lane] : cld(A.cst, -s - 1);
         }
       }
@@ -1055,10 +1058,10 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
     }
     __syncthreads();
     for (int t = 0; t < TG; ++t) {
-      const int col = c0 + t * 64 + c.lane;
+      const int jj = c0 + t * 64 + c.lane, col = jj < A.skip0 ? jj : jj + gap;
       for (int r = c.wave; r < GS_LANES; r += c.W) {
         const int b = g * GS_LANES + r;
-        if (b < B && col < A.obs_dim) A.out[(size_t)b * A.obs_dim + col] = gs_dyn[t * (64 * 65) + c.lane * 65 + r];
+        if (b < B && jj < n_dyn) A.out[(size_t)b * A.obs_dim + col] = gs_dyn[t * (64 * 65) + c.lane * 65 + r];
       }
     }
     __syncthreads();
