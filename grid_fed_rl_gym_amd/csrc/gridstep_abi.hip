@@ -227,8 +227,9 @@ int step_kernels(gs_handle* h, const double* d_actions) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
     dim3 grid(h->groups), block(64 * h->W);
-    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, h->dyn_lds / (64 * 65 * sizeof(double)))),
+    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 40960) / (64 * 65 * sizeof(double)))), 0, 0,
                   h->obs_skip0, h->obs_skip1};
+    pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
 #define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa)
     if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
     else if (h->solve_kernel == 4) GS_STEP(gs_k_step_nr_tree_lds);
@@ -321,7 +322,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     if (h->solve_kernel == 0 && msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) h->solve_kernel = 4;
     if (h->solve_kernel == 4) h->dyn_lds = msg_bytes;
   } else { int rc = fail(nullptr, GS_E_INVALID, "unknown solver_kind %d", cfg->solver_kind); delete h; return rc; }
-  h->dyn_lds = std::max<size_t>(40960, h->dyn_lds);     // the epilogue's cross-wave partials need 40 KB
+  // the epilogue's cross-wave partials need 40 KB; the observation pack stages two or three 64-column tiles behind them
+  h->dyn_lds = std::max<size_t>(40960 + 2 * 64 * 65 * sizeof(double), h->dyn_lds);
 
   h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
   h->n = ht.n; h->m = ht.m; h->n_loads = topo->n_loads; h->n_gens = topo->n_gens; h->n_bats = topo->n_bats;

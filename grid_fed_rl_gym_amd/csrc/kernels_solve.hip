@@ -48,6 +48,7 @@ struct GsShared {
 extern __shared__ __attribute__((aligned(16))) double gs_dyn[];
 #define GS_MSG_DOUBLES 6
 #define GS_EPI_DOUBLES (4 * GS_MAX_WAVES * GS_LANES)   /* post[4][W][64] doubles, then posti[2][W][64] ints */
+#define GS_PACK_LDS_DOUBLES (GS_EPI_DOUBLES + GS_MAX_WAVES * GS_LANES)   /* the pack tiles start after both (40 KB) */
 
 // Barrier for waves that exchanged data through LDS only: wait for this wave's LDS traffic, then
 // rendezvous.  Unlike __syncthreads() it does not drain outstanding global loads/stores, so
@@ -900,12 +901,7 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
     double lmax;
     fbs_backward(c, k0, k1, &lmax, &psum);
   }
-  __syncthreads();
-  for (int i = c.wave; i < T.n; i += c.W) {
-    const double e = ROW(R.E + i), f = ROW(R.F + i);
-    ROW(R.VM + i) = sqrt(e * e + f * f);
-  }
-  __syncthreads();
+  __syncthreads();                                      // |V| and the angle are formed by the epilogue's bus loop
   return psum;
 }
 
@@ -921,12 +917,18 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
   int over = 0, vflags = 0;
   for (int i = c.wave; i < T.n; i += c.W) {
     if (!have_psum) lsum += ROW(R.PC + i);
-    {                                                       // np.angle: wrap theta to (-pi, pi]
+    double v;
+    if (WRAP_VA) {                                          // np.angle: wrap theta to (-pi, pi]
       const double va = ROW(R.VA + i);
-      ROW(R.VA + i) = WRAP_VA ? va - (2.0 * M_PI) * rint(va * (1.0 / (2.0 * M_PI))) : atan2(ROW(R.F + i), ROW(R.E + i));
+      ROW(R.VA + i) = va - (2.0 * M_PI) * rint(va * (1.0 / (2.0 * M_PI)));
+      v = ROW(R.VM + i);
+    } else {                                                // sweeps work on (e, f): polar form here, once
+      const double e = ROW(R.E + i), f = ROW(R.F + i);
+      ROW(R.VA + i) = atan2(f, e);
+      v = sqrt(e * e + f * f);
+      ROW(R.VM + i) = v;
     }
-    if (ENV) {
-      const double v = ROW(R.VM + i);                       // reward / flags, grid_env.py:790-792, base.py:156-159
+    if (ENV) {                                              // reward / flags, grid_env.py:790-792, base.py:156-159
       dev += fabs(v - 1.0);
       vmax = fmax(vmax, v); vmin = fmin(vmin, v);
       vflags |= (v > E.v_max) ? 1 : 0;
@@ -1029,21 +1031,28 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
 // Observation block of this group, batch-major, written straight from the step kernel: 64-column
 // tiles of slab rows are transposed through LDS so that both the row reads (512 B) and the
 // obs[b][c0..c0+63] writes (512 B) are coalesced.  Column order: grid_env.py:753-783.
+// The first pass starts while wave 0 is still in the scalar part of the epilogue: its columns (|V|, angle) were
+// final at the epilogue's reduction barrier, the tiles sit behind the partials wave 0 is reading, and the other
+// waves share out wave 0's rows of that pass.
 __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, int B) {
   const double* Sg = c.S - c.lane;                     // group base
+  double* tiles = gs_dyn + GS_PACK_LDS_DOUBLES;
   const int g = blockIdx.x;
   const int TG = A.tiles_per_pass;                     // 64-column tiles staged per pass (LDS permitting)
   const int span = 64 * TG;
   // the step moves only the columns that can change: position j of that list is column j, or j shifted past the
   // block of constants
   const int gap = A.skip1 - A.skip0, n_dyn = A.obs_dim - gap;
+  if (!A.early_pass0) __syncthreads();                 // small networks: the first pass already holds the frequency column
   for (int c0 = 0; c0 < n_dyn; c0 += span) {
     // gather: this wave's rows of the pass, four independent loads in flight at a time
-    for (int j = c.wave; j < span; j += 4 * c.W) {
+    const bool early = A.early_pass0 && c0 == 0 && c.W > 1;     // pass 0: waves 1 .. W-1 only
+    const int gw = early ? c.wave - 1 : c.wave, GW = early ? c.W - 1 : c.W;
+    for (int j = gw; j < span && gw >= 0; j += 4 * GW) {
       double v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int cc = j + u * c.W, jj = c0 + cc;
+        const int cc = j + u * GW, jj = c0 + cc;
         v[u] = 0.0;
         if (cc < span && jj < n_dyn) {
           const int s = cld(A.map, jj < A.skip0 ? jj : jj + gap);
@@ -1052,8 +1061,8 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int cc = j + u * c.W;
-        if (cc < span) gs_dyn[(cc >> 6) * (64 * 65) + (cc & 63) * 65 + c.lane] = v[u];
+        const int cc = j + u * GW;
+        if (cc < span) tiles[(cc >> 6) * (64 * 65) + (cc & 63) * 65 + c.lane] = v[u];
       }
     }
     __syncthreads();
@@ -1061,7 +1070,7 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
       const int jj = c0 + t * 64 + c.lane, col = jj < A.skip0 ? jj : jj + gap;
       for (int r = c.wave; r < GS_LANES; r += c.W) {
         const int b = g * GS_LANES + r;
-        if (b < B && jj < n_dyn) A.out[(size_t)b * A.obs_dim + col] = gs_dyn[t * (64 * 65) + c.lane * 65 + r];
+        if (b < B && jj < n_dyn) A.out[(size_t)b * A.obs_dim + col] = tiles[t * (64 * 65) + c.lane * 65 + r];
       }
     }
     __syncthreads();
@@ -1131,10 +1140,7 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds(c, C, st);
   else newton_loop<KIND>(c, C, st);
   epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS>(c, E, st, total_load, KIND == KIND_FBS_LDS, psum);   // FBS keeps no polar angle: atan2 there
-  if (ENV && PA.out != nullptr) {
-    __syncthreads();                                   // every row of the group's new state is visible
-    pack_observations(c, PA, B);
-  }
+  if (ENV && PA.out != nullptr) pack_observations(c, PA, B);     // rows of pass 0 visible since the epilogue's barrier
   stamp(c, ST_EPILOGUE);
 }
 
