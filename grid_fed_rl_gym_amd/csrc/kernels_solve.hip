@@ -849,15 +849,19 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
   *lmax_out = lmax; *psum_out = psum;
 }
 
+// FLAT_DONE: the flat start was already written (by the environment prologue's injection pass, which ends in a barrier)
+template <bool FLAT_DONE>
 __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrState& st) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double* msg = gs_dyn + c.lane;
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
-  for (int i = c.wave; i < T.n; i += c.W) {
-    ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
-    ROW(R.F + i) = 0.0;
+  if (!FLAT_DONE) {
+    for (int i = c.wave; i < T.n; i += c.W) {
+      ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+      ROW(R.F + i) = 0.0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
   bool stale = true;
   double psum = 0.0;
@@ -1078,6 +1082,8 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
 }
 
 // Everything of step() that precedes the load flow, spread over the W waves (grid_env.py:433-477).
+// FLAT_FBS: the injection pass also writes the sweep solver's flat start (e, f) of the buses it visits.
+template <bool FLAT_FBS>
 __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid) {
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   const uint64_t inst = (uint64_t)(E.first_instance + b);
@@ -1103,6 +1109,10 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
     const int k1 = cld(T.wi_ptr, c.wave + 1);
     for (int k = cld(T.wi_ptr, c.wave); k < k1; ++k) {
       const int i = recs[k].bus;
+      if (FLAT_FBS) {
+        ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+        ROW(R.F + i) = 0.0;
+      }
       if (recs[k].generic) { bus_injection(T, R, E, S, i); continue; }
       // same accumulation order as bus_injection: loads, then generators, then batteries
       double ls = 0.0, gs = 0.0;
@@ -1132,12 +1142,12 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   const bool valid = b < B;
   Ctx c{T, R, S, sh, lane, wave, W, C.stamps, 0ull, C.stamp_wave};
   if (C.stamps) c.tlast = __builtin_readcyclecounter();
-  if (ENV) prologue_env(c, E, actions, b, valid);
+  if (ENV) prologue_env<KIND == KIND_FBS_LDS>(c, E, actions, b, valid);
   stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
-  else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds(c, C, st);
+  else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds<ENV != 0>(c, C, st);
   else newton_loop<KIND>(c, C, st);
   epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS>(c, E, st, total_load, KIND == KIND_FBS_LDS, psum);   // FBS keeps no polar angle: atan2 there
   if (ENV && PA.out != nullptr) pack_observations(c, PA, B);     // rows of pass 0 visible since the epilogue's barrier
