@@ -50,6 +50,16 @@ __device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t instance, u
   return sqrt(-2.0 * log(u0)) * cos(2.0 * M_PI * u1);
 }
 
+// Both Box-Muller branches of one draw: z0 is rng_normal(draw), z1 the sine branch.  The load noise takes them in
+// pairs (load l: draw DRAW_LOAD0 + l / 2, branch l & 1), which halves the Philox / log / sqrt work of the prologue.
+__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw, double* z0, double* z1) {
+  double u0, u1, sn, cs;
+  rng_uniform_pair(seed, instance, step, draw, &u0, &u1);
+  const double r = sqrt(-2.0 * log(u0));
+  sincos(2.0 * M_PI * u1, &sn, &cs);
+  *z0 = r * cs; *z1 = r * sn;
+}
+
 enum { DRAW_IRRADIANCE = 0, DRAW_WIND = 1, DRAW_TEMP = 2, DRAW_CLOUD = 3, DRAW_LOAD0 = 16 };
 
 __device__ const double kDailyProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
@@ -122,13 +132,9 @@ __device__ __forceinline__ void env_actions_clock_weather(const GsTables& T, con
 }
 
 // realised power of load l (dynamics.py:54-75 when stochastic, base_power otherwise)
-__device__ __forceinline__ double load_power(const GsTables& T, const GsEnvCfg& E, int l, uint64_t seed, uint64_t inst,
-                                             uint32_t step, double prof) {
-  if (!E.stochastic_loads) return cld(T.load_base, l);
-  const double z = rng_normal(seed, inst, step, DRAW_LOAD0 + l);
+__device__ __forceinline__ double load_power_z(const GsTables& T, int l, double z, double prof) {
   return fmax(0.0, cld(T.load_base, l) * (prof * (1.0 + 0.1 * z)) * 1.0);
 }
-
 __device__ __forceinline__ double daily_profile(double time_s) {
   const double hour = fmod(time_s / 3600.0, 24.0);
   const int hi = (int)hour;

@@ -919,40 +919,66 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
   const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
   double lsum = have_psum ? psum : 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int over = 0, vflags = 0;
-  for (int i = c.wave; i < T.n; i += c.W) {
-    if (!have_psum) lsum += ROW(R.PC + i);
-    double v;
-    if (WRAP_VA) {                                          // np.angle: wrap theta to (-pi, pi]
-      const double va = ROW(R.VA + i);
-      ROW(R.VA + i) = va - (2.0 * M_PI) * rint(va * (1.0 / (2.0 * M_PI)));
-      v = ROW(R.VM + i);
-    } else {                                                // sweeps work on (e, f): polar form here, once
-      const double e = ROW(R.E + i), f = ROW(R.F + i);
-      ROW(R.VA + i) = atan2(f, e);
-      v = sqrt(e * e + f * f);
-      ROW(R.VM + i) = v;
+  // Both loops are a handful of rows per wave, each a round trip to L2 / Infinity Cache: four items per trip, their
+  // rows requested before any of the arithmetic (atan2, sqrt, divisions) starts.
+  for (int i0 = c.wave; i0 < T.n; i0 += 4 * c.W) {
+    double xa[4], xb[4], pcs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * c.W, T.n - 1);
+      xa[u] = WRAP_VA ? ROW(R.VA + i) : ROW(R.E + i);
+      xb[u] = WRAP_VA ? ROW(R.VM + i) : ROW(R.F + i);
+      pcs[u] = have_psum ? 0.0 : ROW(R.PC + i);
     }
-    if (ENV) {                                              // reward / flags, grid_env.py:790-792, base.py:156-159
-      dev += fabs(v - 1.0);
-      vmax = fmax(vmax, v); vmin = fmin(vmin, v);
-      vflags |= (v > E.v_max) ? 1 : 0;
-      vflags |= (v < E.v_min) ? 2 : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * c.W;
+      if (i >= T.n) break;
+      if (!have_psum) lsum += pcs[u];
+      double v;
+      if (WRAP_VA) {                                          // np.angle: wrap theta to (-pi, pi]
+        const double va = xa[u];
+        ROW(R.VA + i) = va - (2.0 * M_PI) * rint(va * (1.0 / (2.0 * M_PI)));
+        v = xb[u];
+      } else {                                                // sweeps work on (e, f): polar form here, once
+        const double e = xa[u], f = xb[u];
+        ROW(R.VA + i) = atan2(f, e);
+        v = sqrt(e * e + f * f);
+        ROW(R.VM + i) = v;
+      }
+      if (ENV) {                                              // reward / flags, grid_env.py:790-792, base.py:156-159
+        dev += fabs(v - 1.0);
+        vmax = fmax(vmax, v); vmin = fmin(vmin, v);
+        vflags |= (v > E.v_max) ? 1 : 0;
+        vflags |= (v < E.v_min) ? 2 : 0;
+      }
     }
   }
   stamp(c, ST_EPI_BUSES);
-  for (int k = c.wave; k < T.m; k += c.W) {
-    const int i = cld(T.lfrom, k), j = cld(T.lto, k);
-    const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k);
-    const double ei = ROW(R.E + i), fi = ROW(R.F + i);
-    const double dr = ei - ROW(R.E + j), di = fi - ROW(R.F + j);
-    const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
-    const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
-    ROW(R.FLOW + k) = sr;
-    ROW(R.LOAD + k) = (rating > 0.0) ? sqrt(sr * sr + si * si) / rating : 0.0;
-    if (ENV) {                                                        // Line.update_state, base.py:261-264
-      const double ld = (rating > 0.0) ? fabs(sr) / rating : 0.0;
-      ROW(R.ENVLOAD + k) = ld;
-      over += (ld > 0.8) ? 1 : 0;
+  for (int k0 = c.wave; k0 < T.m; k0 += 4 * c.W) {
+    double ei_[4], fi_[4], ej_[4], fj_[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = min(k0 + u * c.W, T.m - 1);
+      const int i = cld(T.lfrom, k), j = cld(T.lto, k);
+      ei_[u] = ROW(R.E + i); fi_[u] = ROW(R.F + i); ej_[u] = ROW(R.E + j); fj_[u] = ROW(R.F + j);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * c.W;
+      if (k >= T.m) break;
+      const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k);
+      const double ei = ei_[u], fi = fi_[u];
+      const double dr = ei - ej_[u], di = fi - fj_[u];
+      const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
+      const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
+      ROW(R.FLOW + k) = sr;
+      ROW(R.LOAD + k) = (rating > 0.0) ? sqrt(sr * sr + si * si) / rating : 0.0;
+      if (ENV) {                                                        // Line.update_state, base.py:261-264
+        const double ld = (rating > 0.0) ? fabs(sr) / rating : 0.0;
+        ROW(R.ENVLOAD + k) = ld;
+        over += (ld > 0.8) ? 1 : 0;
+      }
     }
   }
   stamp(c, ST_EPI_LINES);
@@ -1100,7 +1126,16 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
   if (c.W == 1 || c.wave > 0) {
     const int l0 = (c.W > 1) ? c.wave - 1 : 0, ls = (c.W > 1) ? c.W - 1 : 1;
     const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
-    for (int l = l0; l < T.n_loads; l += ls) ROW(R.LOADP + l) = load_power(T, E, l, seed, inst, snew, prof);
+    if (E.stochastic_loads) {                               // loads 2p and 2p + 1 share one Box-Muller draw
+      for (int p = l0; 2 * p < T.n_loads; p += ls) {
+        double z0, z1;
+        rng_normal_pair(seed, inst, snew, DRAW_LOAD0 + p, &z0, &z1);
+        ROW(R.LOADP + 2 * p) = load_power_z(T, 2 * p, z0, prof);
+        if (2 * p + 1 < T.n_loads) ROW(R.LOADP + 2 * p + 1) = load_power_z(T, 2 * p + 1, z1, prof);
+      }
+    } else {
+      for (int l = l0; l < T.n_loads; l += ls) ROW(R.LOADP + l) = cld(T.load_base, l);
+    }
   }
   __syncthreads();
   stamp(c, ST_PRO_SCALAR);

@@ -375,6 +375,12 @@ static double rng_normal(uint64_t seed, uint64_t inst, uint32_t step, uint32_t d
   double u0, u1; rng_pair(seed, inst, step, draw, &u0, &u1);
   return sqrt(-2.0 * log(u0)) * cos(2.0 * M_PI * u1);
 }
+/* both Box-Muller branches of one draw; load l takes draw 16 + l / 2, branch l & 1 */
+static double rng_normal_branch(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw, int sine) {
+  double u0, u1; rng_pair(seed, inst, step, draw, &u0, &u1);
+  const double r = sqrt(-2.0 * log(u0));
+  return sine ? r * sin(2.0 * M_PI * u1) : r * cos(2.0 * M_PI * u1);
+}
 
 static const double kProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
                                     0.7, 0.7, 0.6, 0.6, 0.7, 0.9, 1.0, 0.9, 0.8, 0.7, 0.6, 0.5};
@@ -487,7 +493,7 @@ int orc_env_step(const orc_net* t, const orc_cfg* c, int32_t B, const double* ac
         double hour = fmod(st[S_TIME] / 3600.0, 24.0); int hi = (int)hour; double frac = hour - hi;
         double prof = kProfile[hi] * (1.0 - frac) + kProfile[(hi + 1) % 24] * frac;
         for (int l = 0; l < t->n_loads; ++l)
-          loadp[l] = fmax(0.0, t->load_base[l] * (prof * (1.0 + 0.1 * rng_normal(seed, inst, (uint32_t)st[S_STEP], 16 + l))) * 1.0);
+          loadp[l] = fmax(0.0, t->load_base[l] * (prof * (1.0 + 0.1 * rng_normal_branch(seed, inst, (uint32_t)st[S_STEP], 16 + l / 2, l & 1))) * 1.0);
       }
       for (int i = 0; i < n; ++i) { ls[i] = 0.0; gs[i] = 0.0; }   /* grid_env.py:683-720 */
       for (int l = 0; l < t->n_loads; ++l) ls[t->load_bus[l]] += c->stochastic_loads ? loadp[l] : t->load_base[l];

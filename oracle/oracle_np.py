@@ -433,6 +433,13 @@ def rng_normal(seed: int, instance: int, step: int, draw: int) -> float:
     return math.sqrt(-2.0 * math.log(u0)) * math.cos(2.0 * math.pi * u1)
 
 
+def rng_normal_pair(seed: int, instance: int, step: int, draw: int) -> Tuple[float, float]:
+    """Both Box-Muller branches of one draw (cosine, sine); the load noise uses them in pairs."""
+    u0, u1 = rng_uniform_pair(seed, instance, step, draw)
+    r = math.sqrt(-2.0 * math.log(u0))
+    return r * math.cos(2.0 * math.pi * u1), r * math.sin(2.0 * math.pi * u1)
+
+
 # draw indices (per instance, per step)
 DRAW_IRRADIANCE, DRAW_WIND, DRAW_TEMP, DRAW_CLOUD, DRAW_LOAD0 = 0, 1, 2, 3, 16
 
@@ -583,7 +590,7 @@ def env_injections(spec: EnvSpec, st: EnvState) -> Tuple[np.ndarray, np.ndarray]
     gen_sum = np.zeros(spec.n)
     for l in range(spec.L):
         if spec.stochastic_loads:
-            z = rng_normal(st.seed, st.instance, st.step, DRAW_LOAD0 + l)
+            z = rng_normal_pair(st.seed, st.instance, st.step, DRAW_LOAD0 + l // 2)[l & 1]
             p, _ = load_profile_power(st.time, spec.load_base[l], noise=0.1 * z, power_factor=0.95)
         else:
             p = spec.load_base[l]
