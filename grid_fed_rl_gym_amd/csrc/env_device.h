@@ -65,12 +65,12 @@ enum { DRAW_IRRADIANCE = 0, DRAW_WIND = 1, DRAW_TEMP = 2, DRAW_CLOUD = 3, DRAW_L
 __device__ const double kDailyProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
                                              0.7, 0.7, 0.6, 0.6, 0.7, 0.9, 1.0, 0.9, 0.8, 0.7, 0.6, 0.5};
 
-__device__ __forceinline__ uint64_t lane_seed(double* S, const GsRows& R) {
+__device__ __forceinline__ uint64_t lane_seed(GsLaneRows S, const GsRows& R) {
   return ((uint64_t)(uint32_t)ROW(R.SEEDHI) << 32) | (uint64_t)(uint32_t)ROW(R.SEEDLO);
 }
 
 // grid_env.py:653-681
-__device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& E, double* S, uint64_t inst) {
+__device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& E, GsLaneRows S, uint64_t inst) {
   if (!E.weather_variation) return;
   const uint64_t seed = lane_seed(S, R);
   const uint32_t step = (uint32_t)ROW(R.STEP);
@@ -85,7 +85,7 @@ __device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& 
 }
 
 // dynamics.py:120-142 / 158-170
-__device__ __forceinline__ double renewable_power(const GsTables& T, const GsRows& R, double* S, int g) {
+__device__ __forceinline__ double renewable_power(const GsTables& T, const GsRows& R, GsLaneRows S, int g) {
   const double cap = cld(T.gen_cap, g), p0 = cld(T.gen_p0, g), p1 = cld(T.gen_p1, g), p2 = cld(T.gen_p2, g);
   if (cld(T.gen_kind, g) == 0) {
     const double hour = fmod(ROW(R.TIME) / 3600.0, 24.0);
@@ -104,7 +104,7 @@ __device__ __forceinline__ double renewable_power(const GsTables& T, const GsRow
 // before the injections are formed (grid_env.py:621-651, 470-474).  `act` points at this
 // instance's action row (batch-major [B][A]).
 __device__ __forceinline__ void env_actions_clock_weather(const GsTables& T, const GsRows& R, const GsEnvCfg& E,
-                                                          double* S, const double* __restrict__ act, uint64_t inst) {
+                                                          GsLaneRows S, const double* __restrict__ act, uint64_t inst) {
   const double dt = E.timestep;
   for (int q = 0; q < T.n_bats; ++q) {
     const double rating = cld(T.bat_rating, q), cap = cld(T.bat_cap, q), eff = cld(T.bat_eff, q);
@@ -144,7 +144,7 @@ __device__ __forceinline__ double daily_profile(double time_s) {
 
 // per-bus injection in the reference's accumulation order (grid_env.py:689-718), then
 // P_spec = (0 - loads) + generation (power_flow.py:112-121); Q_spec = 0 (power_flow.py:107)
-__device__ __forceinline__ void bus_injection(const GsTables& T, const GsRows& R, const GsEnvCfg& E, double* S, int i) {
+__device__ __forceinline__ void bus_injection(const GsTables& T, const GsRows& R, const GsEnvCfg& E, GsLaneRows S, int i) {
   double ls = 0.0, gs = 0.0;
   for (int p = cld(T.bl_ptr, i); p < cld(T.bl_ptr, i + 1); ++p) ls += ROW(R.LOADP + cld(T.bl_idx, p));
   for (int p = cld(T.bg_ptr, i); p < cld(T.bg_ptr, i + 1); ++p) {

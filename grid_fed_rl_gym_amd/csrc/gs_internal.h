@@ -24,6 +24,40 @@
 #define GS_CONST
 #endif
 
+#if defined(__HIPCC__)
+// A lane's view of its group's slab rows, through a buffer descriptor.  Row r of the lane is at
+// group base + r * 512 B + lane * 8 B; with the descriptor holding the group base, a wave-uniform row index goes into
+// the instruction's scalar offset and the lane offset is one constant VGPR:
+//     buffer_load_dwordx2 v, v_lane8, s[rsrc], s_rowoff offen
+// so an access costs no vector ALU work (a 64-bit pointer per lane costs a v_lshl_add_u64 each time).  Indexed like the
+// lane pointer it replaces, S[row * GS_LANES]; rows that differ between lanes (the dense solver's pivots) use
+// S.lane_row(row * GS_LANES).  Out-of-range offsets read 0 / are dropped by the hardware bounds check.
+typedef unsigned int gs_u32x2 __attribute__((ext_vector_type(2)));
+struct GsRowRef {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;
+  int soff;
+  __device__ __forceinline__ double get() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+  __device__ __forceinline__ void put(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gs_u32x2, v), r, voff, soff, 0); }
+  __device__ __forceinline__ operator double() const { return get(); }
+  __device__ __forceinline__ double operator=(double v) const { put(v); return v; }
+  __device__ __forceinline__ double operator=(const GsRowRef& o) const { const double v = o.get(); put(v); return v; }
+  __device__ __forceinline__ double operator+=(double v) const { const double x = get() + v; put(x); return x; }
+  __device__ __forceinline__ double operator-=(double v) const { const double x = get() - v; put(x); return x; }
+};
+struct GsLaneRows {
+  __amdgpu_buffer_rsrc_t r;
+  char* g;                   // group base (uniform)
+  unsigned lane8;
+  __device__ __forceinline__ GsRowRef operator[](size_t idx) const { return GsRowRef{r, lane8, (int)(idx << 3)}; }          // uniform row
+  __device__ __forceinline__ GsRowRef lane_row(size_t idx) const { return GsRowRef{r, lane8 + (unsigned)(idx << 3), 0}; }   // per-lane row
+};
+__device__ __forceinline__ GsLaneRows gs_lane_rows(double* slab, int group, int rows_total, int lane) {
+  char* g = (char*)(slab + (size_t)group * rows_total * GS_LANES);
+  return GsLaneRows{__builtin_amdgcn_make_buffer_rsrc(g, 0, rows_total * GS_LANES * (int)sizeof(double), 0x00020000), g, (unsigned)lane << 3};
+}
+#endif
+
 // One forest work item (a bus, in the order ONE wave meets it in the sweeps) with everything the
 // sweep needs that does not depend on the instance: read as one contiguous scalar load, and the
 // next record of the wave is the next 96 bytes (prefetched one item ahead).

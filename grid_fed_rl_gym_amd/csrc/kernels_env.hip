@@ -16,7 +16,7 @@ gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int 
                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x * GS_LANES + lane;
-  double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
+  const GsLaneRows S = gs_lane_rows(slab, blockIdx.x, R.total, lane);
   if (b >= B) return;
   if (mask && !mask[b]) return;
   const uint64_t seed = seeds ? seeds[b] : 0ull;

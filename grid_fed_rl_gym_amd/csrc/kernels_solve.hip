@@ -58,7 +58,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct Ctx {
   const GsTables& T;
   const GsRows& R;
-  double* S;
+  GsLaneRows S;
   GsShared& sh;
   int lane, wave, W;
   unsigned long long* stamps;
@@ -96,7 +96,7 @@ __device__ __forceinline__ int wg_or(Ctx& c, int par, int v) {
 
 // ---- flat start (power_flow.py:103, 128-136) ---------------------------------------------
 __device__ __forceinline__ void flat_start(Ctx& c) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   for (int i = c.wave; i < T.n; i += c.W) {
     const double vm = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
     ROW(R.VM + i) = vm;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void flat_start(Ctx& c) {
 
 // ---- polar -> rectangular ------------------------------------------------------------------
 __device__ __forceinline__ void to_rect(Ctx& c) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   for (int i = c.wave; i < T.n; i += c.W) {
     const double vm = ROW(R.VM + i), va = ROW(R.VA + i);
     double s, cs;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void to_rect(Ctx& c) {
 // the right-hand side itself), 2 = also the mismatch rows R0/R1 (the other linear solves)
 template <int STORE>
 __device__ __forceinline__ double mismatch_rows(Ctx& c) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double lmax = 0.0;
   const int k0 = cld(T.wb_ptr, c.wave), k1 = cld(T.wb_ptr, c.wave + 1);
   const GS_CONST GsBusRec* recs = (const GS_CONST GsBusRec*)T.wbus;
@@ -188,7 +188,7 @@ __device__ __forceinline__ Blk diag_from(const GsTables& T, int i, int exact, do
 }
 
 __device__ __forceinline__ Blk diag_block(Ctx& c, int i, int exact) {
-  const GsRows& R = c.R; double* S = c.S;
+  const GsRows& R = c.R; GsLaneRows S = c.S;
   return diag_from(c.T, i, exact, ROW(R.VM + i), ROW(R.PC + i), ROW(R.QC + i));
 }
 
@@ -210,7 +210,7 @@ __device__ __forceinline__ Blk offdiag_from(const GsTables& T, int i, int j, dou
 }
 
 __device__ __forceinline__ Blk offdiag_block(Ctx& c, int i, int j, double g, double b) {
-  const GsRows& R = c.R; double* S = c.S;
+  const GsRows& R = c.R; GsLaneRows S = c.S;
   return offdiag_from(c.T, i, j, g, b, ROW(R.E + i), ROW(R.F + i), ROW(R.E + j), ROW(R.F + j), ROW(R.VM + j));
 }
 
@@ -234,17 +234,17 @@ __device__ __forceinline__ Blk inv2(const Blk& d, int* sing) {
   return z;
 }
 
-__device__ __forceinline__ Blk load_blk(double* S, int row) {
+__device__ __forceinline__ Blk load_blk(GsLaneRows S, int row) {
   Blk b; b.a00 = ROW(row); b.a01 = ROW(row + 1); b.a10 = ROW(row + 2); b.a11 = ROW(row + 3); return b;
 }
-__device__ __forceinline__ void store_blk(double* S, int row, const Blk& b) {
+__device__ __forceinline__ void store_blk(GsLaneRows S, int row, const Blk& b) {
   ROW(row) = b.a00; ROW(row + 1) = b.a01; ROW(row + 2) = b.a10; ROW(row + 3) = b.a11;
 }
 
 // ---- apply the Newton step to bus i (power_flow.py:315-327); keeps Vm >= 0 like the
 // reference's abs/angle round trip does
 __device__ __forceinline__ void apply_step(Ctx& c, int i, double alpha, bool upd) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   if (!upd) return;
   double vm = ROW(R.VM + i), va = ROW(R.VA + i);
   if (cld(T.th_free, i)) va += alpha * ROW(R.X0 + i);
@@ -280,7 +280,7 @@ enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3, KIND_TREE_LDS =
 //               T_i = D_i^-1 J_ip ; s_i = D_i^-1 r_i ; C_i = J_pi T_i ; q_i = J_pi s_i
 //   top-down:   x_i = s_i - T_i x_p
 __device__ __forceinline__ void linsolve_tree(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   int sing = 0;
   for (int lv = 0; lv < T.n_levels; ++lv) {
     const int t1 = cld(T.lvl_ptr, lv + 1);
@@ -361,7 +361,7 @@ __device__ __forceinline__ GsItemRec load_item(const GsTables& T, int k) {
 }
 
 __device__ __forceinline__ BuOperands fetch_bu(Ctx& c, const GsItemRec& r) {
-  const GsRows& R = c.R; double* S = c.S;
+  const GsRows& R = c.R; GsLaneRows S = c.S;
   BuOperands o;
   const int i = r.bus, pj = r.parent >= 0 ? r.parent : r.bus;
   o.vm = ROW(R.VM + i); o.rvm = ROW(R.RVM + i); o.pc = ROW(R.PC + i); o.qc = ROW(R.QC + i);
@@ -372,7 +372,7 @@ __device__ __forceinline__ BuOperands fetch_bu(Ctx& c, const GsItemRec& r) {
 }
 
 __device__ __forceinline__ TdOperands fetch_td(Ctx& c, const GsItemRec& r) {
-  const GsRows& R = c.R; double* S = c.S;
+  const GsRows& R = c.R; GsLaneRows S = c.S;
   TdOperands o;
   const int i = r.bus;
   o.t00 = ROW(R.TB + 4 * i); o.t01 = ROW(R.TB + 4 * i + 1);
@@ -399,7 +399,7 @@ __device__ __forceinline__ Blk edge_block(double g, double b, double ei, double 
 }
 
 __device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double* msg = gs_dyn + c.lane;                       // slot s, component k at msg[(s * 6 + k) * 64]
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
   const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
@@ -535,7 +535,7 @@ __device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, N
 // neighbours and every (i, j) block its elimination touches; fill blocks own slots.  Waves split
 // the pair updates of a pivot; pivots are sequential (one barrier each).
 __device__ __forceinline__ void linsolve_lu(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   for (int t = c.wave; t < T.lu_n_piv; t += c.W) {
     const int i = cld(T.lu_piv_bus, t);
     store_blk(S, R.LUD + 4 * i, diag_block(c, i, C.jacobian_exact));
@@ -607,10 +607,10 @@ __device__ __forceinline__ void linsolve_lu(Ctx& c, const GsSolveCfg& C, NrState
 // so matrix rows are reached through a per-lane permutation (a gather: each lane reads its own
 // row at its own lane slot).  This path exists for parity with the as-coded Jacobian, whose 2x2
 // diagonal blocks can be exactly singular; it is not the fast path.
-#define DA_AT(prow, cc) S[((size_t)R.DA + (size_t)(prow) * N + (size_t)(cc)) * GS_LANES]
+#define DA_AT(prow, cc) S.lane_row(((size_t)R.DA + (size_t)(prow) * N + (size_t)(cc)) * GS_LANES)     /* prow differs between lanes */
 
 __device__ __forceinline__ void linsolve_dense(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   const int N = T.dn_N;
   for (int q = c.wave; q < N * N; q += c.W) ROW(R.DA + q) = 0.0;
   for (int q = c.wave; q < N; q += c.W) ROW(R.DPERM + q) = (double)q;
@@ -642,20 +642,20 @@ __device__ __forceinline__ void linsolve_dense(Ctx& c, const GsSolveCfg& C, NrSt
       }
       if (!(best > 0.0)) sing = 1;
       const double pk = ROW(R.DPERM + k);
-      const double pb = S[(size_t)(R.DPERM + bi) * GS_LANES];
-      S[(size_t)(R.DPERM + bi) * GS_LANES] = pk;
+      const double pb = S.lane_row((size_t)(R.DPERM + bi) * GS_LANES);
+      S.lane_row((size_t)(R.DPERM + bi) * GS_LANES) = pk;
       ROW(R.DPERM + k) = pb;
     }
     __syncthreads();
     const int pk = (int)ROW(R.DPERM + k);
     const double akk = DA_AT(pk, k);
-    const double bk = S[(size_t)(R.DB + pk) * GS_LANES];
+    const double bk = S.lane_row((size_t)(R.DB + pk) * GS_LANES);
     for (int i = k + 1 + c.wave; i < N; i += c.W) {
       const int pi = (int)ROW(R.DPERM + i);
       const double l = DA_AT(pi, k) / akk;
       if (__any(l != 0.0)) {
         for (int cc = k + 1; cc < N; ++cc) DA_AT(pi, cc) -= l * DA_AT(pk, cc);
-        S[(size_t)(R.DB + pi) * GS_LANES] -= l * bk;
+        S.lane_row((size_t)(R.DB + pi) * GS_LANES) -= l * bk;
       }
     }
     __syncthreads();
@@ -666,7 +666,7 @@ __device__ __forceinline__ void linsolve_dense(Ctx& c, const GsSolveCfg& C, NrSt
   if (c.wave == 0) {
     for (int k = N - 1; k >= 0; --k) {
       const int pk = (int)ROW(R.DPERM + k);
-      double s = S[(size_t)(R.DB + pk) * GS_LANES];
+      double s = S.lane_row((size_t)(R.DB + pk) * GS_LANES);
       for (int cc = k + 1; cc < N; ++cc) s -= DA_AT(pk, cc) * ROW(R.DX + cc);
       ROW(R.DX + k) = s / DA_AT(pk, k);
     }
@@ -728,7 +728,7 @@ __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState
 //   forward:   V_i = V_parent - J_i / y_i
 // =============================================================================================
 __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& st) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   for (int i = c.wave; i < T.n; i += c.W) {
     ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
     ROW(R.F + i) = 0.0;
@@ -794,7 +794,7 @@ __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& s
 struct FbsOperands { double e, f, p, q, ep, fp; };
 
 __device__ __forceinline__ FbsOperands fetch_fbs(Ctx& c, const GsItemRec& r) {
-  const GsRows& R = c.R; double* S = c.S;
+  const GsRows& R = c.R; GsLaneRows S = c.S;
   FbsOperands o;
   o.e = ROW(R.E + r.bus); o.f = ROW(R.F + r.bus); o.p = ROW(R.P + r.bus); o.q = ROW(R.Q + r.bus);
   o.ep = ROW(R.E + r.parent); o.fp = ROW(R.F + r.parent);
@@ -802,7 +802,7 @@ __device__ __forceinline__ FbsOperands fetch_fbs(Ctx& c, const GsItemRec& r) {
 }
 
 __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lmax_out, double* psum_out) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double* msg = gs_dyn + c.lane;
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
   double lmax = 0.0, psum = 0.0;
@@ -852,7 +852,7 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
 // FLAT_DONE: the flat start was already written (by the environment prologue's injection pass, which ends in a barrier)
 template <bool FLAT_DONE>
 __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrState& st) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double* msg = gs_dyn + c.lane;
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
   if (!FLAT_DONE) {
@@ -916,7 +916,7 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
 template <int ENV, int WRAP_VA>
 __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
                                          double psum) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double lsum = have_psum ? psum : 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int over = 0, vflags = 0;
   // Both loops are a handful of rows per wave, each a round trip to L2 / Infinity Cache: four items per trip, their
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
 // final at the epilogue's reduction barrier, the tiles sit behind the partials wave 0 is reading, and the other
 // waves share out wave 0's rows of that pass.
 __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, int B) {
-  const double* Sg = c.S - c.lane;                     // group base
+  const double* Sg = (const double*)c.S.g;             // group base
   double* tiles = gs_dyn + GS_PACK_LDS_DOUBLES;
   const int g = blockIdx.x;
   const int TG = A.tiles_per_pass;                     // 64-column tiles staged per pass (LDS permitting)
@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
 // FLAT_FBS: the injection pass also writes the sweep solver's flat start (e, f) of the buses it visits.
 template <bool FLAT_FBS>
 __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid) {
-  const GsTables& T = c.T; const GsRows& R = c.R; double* S = c.S;
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   const uint64_t inst = (uint64_t)(E.first_instance + b);
   // every wave derives the new clock from the old rows, then wave 0 alone advances the scalar
   // state (actions, clock, weather, renewables) while the other waves draw the load powers
@@ -1172,7 +1172,7 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int W = blockDim.x >> 6;
-  double* S = slab + (size_t)blockIdx.x * R.total * GS_LANES + lane;
+  const GsLaneRows S = gs_lane_rows(slab, blockIdx.x, R.total, lane);
   const int b = blockIdx.x * GS_LANES + lane;
   const bool valid = b < B;
   Ctx c{T, R, S, sh, lane, wave, W, C.stamps, 0ull, C.stamp_wave};
