@@ -805,7 +805,7 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double* msg = gs_dyn + c.lane;
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
-  double lmax = 0.0, psum = 0.0;
+  double lmax = 0.0, psum = 0.0, bad = 0.0;
   int lv = 0;
   GsItemRec rn{};
   FbsOperands on{};
@@ -835,7 +835,8 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
     const double icr = kr - skr, ici = ki - ski;
     const double pc = o.e * icr + o.f * ici, qc = o.f * icr - o.e * ici;
     const double dP = o.p - pc, dQ = o.q - qc;
-    lmax = fmax(lmax, fmax(finite_or_inf(fabs(dP)), finite_or_inf(fabs(dQ))));
+    lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));         // fmax drops a NaN; `bad` (x * 0 is NaN for NaN / inf) keeps it
+    bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
     psum += pc;
     if (r.flags & 16) psum -= o.ep * kr + o.fp * ki;    // the slack's share: Re(V_s conj(-K_root))
     // branch current for the next forward sweep: J_i = -conj(S_spec / V_i) + sum J_c
@@ -846,6 +847,7 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
   }
   while (lv < T.n_levels) { lds_barrier(); ++lv; }
 #undef MSG
+  if (bad != bad) lmax = INFINITY;                         // a non-finite mismatch anywhere in this wave's items
   *lmax_out = lmax; *psum_out = psum;
 }
 
@@ -1142,23 +1144,37 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
   {
     const GS_CONST GsInjRec* recs = (const GS_CONST GsInjRec*)T.winj;
     const int k1 = cld(T.wi_ptr, c.wave + 1);
-    for (int k = cld(T.wi_ptr, c.wave); k < k1; ++k) {
-      const int i = recs[k].bus;
-      if (FLAT_FBS) {
-        ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
-        ROW(R.F + i) = 0.0;
+    // four buses per trip, their load rows requested before any division or store: a bus is otherwise one
+    // round trip to L2 after another (most buses carry one load and nothing else)
+    for (int k0 = cld(T.wi_ptr, c.wave); k0 < k1; k0 += 4) {
+      double lp0[4], lp1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = min(k0 + u, k1 - 1);
+        lp0[u] = ROW(R.LOADP + (recs[k].nl > 0 ? recs[k].l0 : 0));
+        lp1[u] = ROW(R.LOADP + (recs[k].nl > 1 ? recs[k].l1 : 0));
       }
-      if (recs[k].generic) { bus_injection(T, R, E, S, i); continue; }
-      // same accumulation order as bus_injection: loads, then generators, then batteries
-      double ls = 0.0, gs = 0.0;
-      if (recs[k].nl > 0) ls += ROW(R.LOADP + recs[k].l0);
-      if (recs[k].nl > 1) ls += ROW(R.LOADP + recs[k].l1);
-      if (recs[k].ng > 0) gs += ROW(R.GENP + recs[k].g0) * ROW(R.CURT + recs[k].g0);
-      if (recs[k].ng > 1) gs += ROW(R.GENP + recs[k].g1) * ROW(R.CURT + recs[k].g1);
-      if (recs[k].nb > 0) { const double bp = ROW(R.BATP + recs[k].b0); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
-      if (recs[k].nb > 1) { const double bp = ROW(R.BATP + recs[k].b1); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
-      ROW(R.P + i) = (0.0 - ls / E.power_base) + gs / E.power_base;
-      ROW(R.Q + i) = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u;
+        if (k >= k1) break;
+        const int i = recs[k].bus;
+        if (FLAT_FBS) {
+          ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+          ROW(R.F + i) = 0.0;
+        }
+        if (recs[k].generic) { bus_injection(T, R, E, S, i); continue; }
+        // same accumulation order as bus_injection: loads, then generators, then batteries
+        double ls = 0.0, gs = 0.0;
+        if (recs[k].nl > 0) ls += lp0[u];
+        if (recs[k].nl > 1) ls += lp1[u];
+        if (recs[k].ng > 0) gs += ROW(R.GENP + recs[k].g0) * ROW(R.CURT + recs[k].g0);
+        if (recs[k].ng > 1) gs += ROW(R.GENP + recs[k].g1) * ROW(R.CURT + recs[k].g1);
+        if (recs[k].nb > 0) { const double bp = ROW(R.BATP + recs[k].b0); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+        if (recs[k].nb > 1) { const double bp = ROW(R.BATP + recs[k].b1); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+        ROW(R.P + i) = (0.0 - ls / E.power_base) + gs / E.power_base;
+        ROW(R.Q + i) = 0.0;
+      }
     }
   }
   __syncthreads();
