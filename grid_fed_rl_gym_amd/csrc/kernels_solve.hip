@@ -851,6 +851,52 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
   *lmax_out = lmax; *psum_out = psum;
 }
 
+// Backward sweep without the mismatch: J_i = -conj(S_spec / V_i) + sum J_c, up through LDS and into the J rows.
+struct FbsLightOperands { double e, f, p, q; };
+__device__ __forceinline__ FbsLightOperands fetch_fbs_light(Ctx& c, int bus) {
+  const GsRows& R = c.R; GsLaneRows S = c.S;
+  return FbsLightOperands{ROW(R.E + bus), ROW(R.F + bus), ROW(R.P + bus), ROW(R.Q + bus)};
+}
+
+__device__ __forceinline__ void fbs_backward_light(Ctx& c, int k0, int k1) {
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
+  double* msg = gs_dyn + c.lane;
+#define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
+  int lv = 0;
+  GsItemRec rn{};
+  FbsLightOperands on{};
+  if (k0 < k1) { rn = load_item(T, k0); on = fetch_fbs_light(c, rn.bus); }
+  for (int k = k0; k < k1; ++k) {
+    const GsItemRec r = rn;
+    const FbsLightOperands o = on;
+    if (k + 1 < k1) { rn = load_item(T, k + 1); on = fetch_fbs_light(c, rn.bus); }
+    // own injection current first: it does not depend on the children, so the division overlaps the wait for them
+    const double rd = 1.0 / (o.e * o.e + o.f * o.f);
+    double jr = -(o.p * o.e + o.q * o.f) * rd, ji = (o.q * o.e - o.p * o.f) * rd;
+    while (lv < r.level) { lds_barrier(); ++lv; }
+    const int nch = r.n_children;
+#pragma unroll
+    for (int u = 0; u < GS_ITEM_CHILDREN; ++u) {
+      if (u < nch) { const int slot = r.child_slot[u]; jr += MSG(slot, 0); ji += MSG(slot, 1); }
+    }
+    for (int u = GS_ITEM_CHILDREN; u < nch; ++u) {
+      const int slot = cld(T.ovf_slot, r.ovf0 + u - GS_ITEM_CHILDREN);
+      jr += MSG(slot, 0); ji += MSG(slot, 1);
+    }
+    MSG(r.slot, 0) = jr; MSG(r.slot, 1) = ji;
+    ROW(R.JR + r.bus) = jr; ROW(R.JI + r.bus) = ji;
+  }
+  while (lv < T.n_levels) { lds_barrier(); ++lv; }
+#undef MSG
+}
+
+// The sweep solver.  The first backward sweep is the full one above (mismatch at the flat start from K = y dV, which
+// is not zero when the slack's set point is not 1).  After that the mismatch is evaluated on the way DOWN: a forward
+// sweep leaves V_i - V_parent = -z_i J_i exactly, so the current the new voltages draw at bus i is the injection
+// current conj(S_spec / V_old) the backward sweep used, and S_spec - V_new conj(I_old) is what the next backward
+// sweep of the textbook loop would report -- one sweep earlier, and the later backward sweeps carry J only.
+// Iteration counts, mismatch and losses are those of the textbook loop (oracle: fbs_solve); an instance that has
+// converged keeps its rows, its mismatch and its loss sum.
 // FLAT_DONE: the flat start was already written (by the environment prologue's injection pass, which ends in a barrier)
 template <bool FLAT_DONE>
 __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrState& st) {
@@ -865,49 +911,64 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
     __syncthreads();
   }
   const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
-  bool stale = true;
   double psum = 0.0;
-  for (int it = 0; it < C.max_iterations; ++it) {
+  {
     double lmax;
-    if (it == 0) stamp(c, ST_INIT);
+    stamp(c, ST_INIT);
     fbs_backward(c, k0, k1, &lmax, &psum);
     stamp(c, ST_BOTTOM_UP);
-    const double mm = wg_max(c, it & 1, lmax);          // full barrier: also drains the J rows
+    const double mm = wg_max(c, 0, lmax);              // full barrier: also drains the J rows
     stamp(c, ST_FLAG);
-    nr_check(st, mm, it, C.tolerance);
-    stale = false;
-    if (__all(st.done)) break;
+    nr_check(st, mm, 0, C.tolerance);
+  }
+  for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
     const bool upd = !st.done;
-    {  // forward sweep: V_i = V_parent - z_i J_i
+    double lmax = 0.0, pnew = 0.0, bad = 0.0;
+    {  // forward sweep: V_i = V_parent - z_i J_i, and the mismatch / sum of P_calc at the new voltages
       int lv = T.n_levels - 1;
       GsItemRec rn{};
       double jr = 0, ji = 0;
-      if (k0 < k1) { rn = load_item(T, k1 - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); }
+      FbsLightOperands on{};
+      if (k0 < k1) { rn = load_item(T, k1 - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); on = fetch_fbs_light(c, rn.bus); }
       for (int k = k1 - 1; k >= k0; --k) {
         const GsItemRec r = rn;
         const double cjr = jr, cji = ji;
-        if (k - 1 >= k0) { rn = load_item(T, k - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); }
+        const FbsLightOperands o = on;
+        if (k - 1 >= k0) { rn = load_item(T, k - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); on = fetch_fbs_light(c, rn.bus); }
+        // the current this bus drew in the backward sweep, I_old = conj(S_spec / V_old): independent of the parent
+        const double rd = 1.0 / (o.e * o.e + o.f * o.f);
+        const double icr = (o.p * o.e + o.q * o.f) * rd, ici = (o.p * o.f - o.q * o.e) * rd;
         while (lv > r.level) { lds_barrier(); --lv; }
+        const bool root = r.flags & 16;                 // parent is the slack bus: its voltage is the set point, never updated
         double ep, fp;
-        if (r.flags & 16) { ep = ROW(R.E + r.parent); fp = ROW(R.F + r.parent); }     // parent is the slack bus
+        if (root) { ep = cld(T.v_set, r.parent); fp = 0.0; }
         else { ep = MSG(r.parent_slot, 0); fp = MSG(r.parent_slot, 1); }
-        double en = ep - (cjr * r.g - cji * r.b), fn = fp - (cjr * r.b + cji * r.g);
-        if (!upd) { en = ROW(R.E + r.bus); fn = ROW(R.F + r.bus); }
+        const double en = ep - (cjr * r.g - cji * r.b), fn = fp - (cjr * r.b + cji * r.g);
         MSG(r.slot, 0) = en; MSG(r.slot, 1) = fn;
         if (upd) { ROW(R.E + r.bus) = en; ROW(R.F + r.bus) = fn; }
+        // S_calc = V_new conj(I_old); mismatch (power_flow.py:150-168)
+        const double pc = en * icr + fn * ici, qc = fn * icr - en * ici;
+        const double dP = o.p - pc, dQ = o.q - qc;
+        lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
+        pnew += pc;
+        if (root) pnew += ep * cjr;                      // the slack's share: Re(V_s conj(J_root)), V_s real
       }
       while (lv >= 0) { lds_barrier(); --lv; }
     }
-    __syncthreads();
+    if (bad != bad) lmax = INFINITY;
     stamp(c, ST_TOP_DOWN);
-    stale = true;
+    if (upd) psum = pnew;                                // losses at the voltages just stored
+    if (it + 1 >= C.max_iterations) { __syncthreads(); break; }   // iteration cap: mismatch / count stay the last backward sweep's
+    const double mm = wg_max(c, (it + 1) & 1, lmax);     // full barrier
+    stamp(c, ST_FLAG);
+    nr_check(st, mm, it + 1, C.tolerance);
+    if (__all(st.done)) break;
+    fbs_backward_light(c, k0, k1);
+    __syncthreads();                                     // the J rows are read back by the forward sweep
+    stamp(c, ST_BOTTOM_UP);
   }
 #undef MSG
-  if (stale) {                                          // iteration cap: losses at the final V
-    double lmax;
-    fbs_backward(c, k0, k1, &lmax, &psum);
-  }
-  __syncthreads();                                      // |V| and the angle are formed by the epilogue's bus loop
   return psum;
 }
 
