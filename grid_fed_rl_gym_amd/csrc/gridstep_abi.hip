@@ -358,22 +358,24 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   GsRows& R = h->R;
   int r = 0;
   auto take = [&](int count) { int at = r; r += count; return at; };
+  auto take_even = [&](int count) { r = (r + 1) & ~1; return take(count); };          // blocks whose entries pair up
+  auto take_pair = [&](GsFam2& a, GsFam2& b2, int count) { r = (r + 1) & ~1; a.base = r; b2.base = r + 1; r += 2 * count; };
   const int n = h->n, m = h->m;
-  R.P = take(n); R.Q = take(n); R.VM = take(n); R.VA = take(n); R.FLOW = take(m); R.LOAD = take(m);
+  take_pair(R.P, R.Q, n); take_pair(R.VM, R.VA, n); take_pair(R.FLOW, R.ENVLOAD, m); R.LOAD = take(m);
   R.LOSSES = take(1); R.MAXMIS = take(1); R.ITERS = take(1); R.CONV = take(1); R.STATUS = take(1);
   // scratch rows are allocated only for the kernel that uses them: the slab is what the step
   // streams through L2 / Infinity Cache, so every unused row costs residency
   const int sk = h->solve_kernel;
   const bool k_tree = sk == 0, k_lu = sk == 1, k_fbs = sk == 2 || sk == 5, k_dense = sk == 3, k_tree_lds = sk == 4;
   const bool k_rhs = k_tree || k_lu || k_dense;
-  R.E = take(n); R.F = take(n); R.PC = take(n); R.QC = take(n);
-  R.R0 = take(k_rhs ? n : 0); R.R1 = take(k_rhs ? n : 0);
-  R.X0 = take(k_rhs ? n : 0); R.X1 = take(k_rhs ? n : 0); R.RVM = take(n);
-  R.SV = take(k_tree || k_tree_lds ? 2 * n : 0); R.QV = take(k_tree ? 2 * n : 0);
-  R.TB = take(k_tree || k_tree_lds ? 4 * n : 0); R.CB = take(k_tree ? 4 * n : 0);
-  R.JR = take(k_fbs ? n : 0); R.JI = take(k_fbs ? n : 0);
-  R.LU = take(h->solve_kernel == 1 ? 4 * ht.lu_n_slots : 0);
-  R.LUD = take(h->solve_kernel == 1 ? 4 * n : 0);
+  take_pair(R.E, R.F, n); take_pair(R.PC, R.QC, n);
+  take_pair(R.R0, R.R1, k_rhs ? n : 0); take_pair(R.X0, R.X1, k_rhs ? n : 0);
+  R.RVM = take(n);
+  R.SV = take_even(k_tree || k_tree_lds ? 2 * n : 0); R.QV = take_even(k_tree ? 2 * n : 0);
+  R.TB = take_even(k_tree || k_tree_lds ? 4 * n : 0); R.CB = take_even(k_tree ? 4 * n : 0);
+  take_pair(R.JR, R.JI, k_fbs ? n : 0);
+  R.LU = take_even(h->solve_kernel == 1 ? 4 * ht.lu_n_slots : 0);
+  R.LUD = take_even(h->solve_kernel == 1 ? 4 * n : 0);
   const int dnN = ht.dn_N;
   R.DA = take(h->solve_kernel == 3 ? dnN * dnN : 0);
   R.DB = take(h->solve_kernel == 3 ? dnN : 0); R.DX = take(h->solve_kernel == 3 ? dnN : 0);
@@ -381,10 +383,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   R.TIME = take(1); R.STEP = take(1); R.VIOL = take(1); R.TOTLOSS = take(1); R.EPREW = take(1); R.FREQ = take(1);
   R.IRR = take(1); R.WIND = take(1); R.TEMP = take(1); R.CLOUD = take(1); R.SEEDLO = take(1); R.SEEDHI = take(1);
   R.SOC = take(h->n_bats); R.BATP = take(h->n_bats); R.CURT = take(h->n_gens); R.GENP = take(h->n_gens);
-  R.ENVLOAD = take(m);
   R.REWARD = take(1); R.TERM = take(1); R.TRUNC = take(1); R.VMAX = take(1); R.VMIN = take(1); R.VFLAGS = take(4);
   R.ACT = take(h->action_dim); R.LOADP = take(h->n_loads);
-  R.total = r;
+  R.total = (r + 1) & ~1;        // rows are stored in pairs (GS_ELEM)
 
   // ---- per-wave work lists of the forest sweeps (records in the order each wave meets them) ----
   std::vector<GsItemRec> witems;
@@ -639,7 +640,7 @@ int gs_upload_injections(gs_handle* h, const double* P_spec, const double* Q_spe
     rc = unpack_from_host(h, h->map_q, h->n, Q_spec);
     if (rc) return rc;
   } else {
-    hipLaunchKernelGGL(gs_k_fill_rows, dim3(h->groups), dim3(64), 0, h->stream, h->R.Q, h->n, h->R.total, h->slab, 0.0);
+    hipLaunchKernelGGL(gs_k_fill_rows, dim3(h->groups), dim3(64), 0, h->stream, h->R.Q.base, 2, h->n, h->R.total, h->slab, 0.0);
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -850,13 +851,14 @@ int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
   if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
   const GsRows& R = h->R;
-  const int row0[GS_ROWS_COUNT] = {R.VM, R.LOAD, R.ENVLOAD, R.FLOW, R.FREQ, R.CONV, R.ITERS, R.MAXMIS};
+  const int row0[GS_ROWS_COUNT] = {R.VM.base, R.LOAD, R.ENVLOAD.base, R.FLOW.base, R.FREQ, R.CONV, R.ITERS, R.MAXMIS};
+  const int stride[GS_ROWS_COUNT] = {2, 1, 2, 2, 1, 1, 1, 1};
   const int width[GS_ROWS_COUNT] = {h->n, h->m, h->m, h->m, 1, 1, 1, 1};
   const int C = width[which];
   if (C <= 0) return GS_OK;
   if ((size_t)h->B * C > h->in_doubles) return fail(h, GS_E_INVALID, "staging buffer too small");
   std::vector<int32_t> map(C);
-  for (int k = 0; k < C; ++k) map[k] = row0[which] + k;
+  for (int k = 0; k < C; ++k) map[k] = row0[which] + stride[which] * k;
   int32_t* dmap = nullptr;
   HIPCHK(h, hipMalloc((void**)&dmap, C * sizeof(int32_t)));
   int rc = GS_OK;
@@ -894,7 +896,8 @@ int gs_checks_create(gs_handle* h, const gs_checks_config* cfg, gs_checks** out)
   C.m_eflo = cfg->mon_emergency_frequency[0]; C.m_efhi = cfg->mon_emergency_frequency[1];
   C.q_tol = cfg->quality_tolerance;
   C.n = h->n; C.m = h->m; C.rows_total = h->R.total;
-  C.row_vm = h->R.VM; C.row_qload = h->R.LOAD; C.row_cload = cfg->loading_source ? h->R.ENVLOAD : h->R.LOAD; C.row_flow = h->R.FLOW;
+  C.row_vm = h->R.VM.base; C.row_qload = h->R.LOAD; C.row_flow = h->R.FLOW.base;
+  C.row_cload = cfg->loading_source ? h->R.ENVLOAD.base : h->R.LOAD; C.stride_cload = cfg->loading_source ? 2 : 1;
   C.row_freq = h->R.FREQ; C.row_conv = h->R.CONV; C.row_iters = h->R.ITERS; C.row_maxmis = h->R.MAXMIS;
   const size_t Bp = h->Bp;
   bool ok = hipMalloc((void**)&c->prev, (size_t)h->groups * (h->n + 1) * GS_LANES * sizeof(double)) == hipSuccess &&

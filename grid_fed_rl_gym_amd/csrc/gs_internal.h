@@ -14,6 +14,12 @@
 #include <stdint.h>
 
 #define GS_LANES 64
+// Slab layout inside a 64-instance group: rows come in PAIRS that share 1 KB, lane-interleaved --
+//   double index of (row, lane) = (row / 2) * 128 + lane * 2 + (row % 2)
+// so two logically adjacent rows (e and f of a bus, P and Q, J re and im, |V| and angle ...) are ONE 16-byte access per
+// lane.  The kernels are bound by the number of vector memory instructions, not by their bytes (splitting every 8-byte
+// load in two: +23 % / +38 % step time), which is what the pairing halves.  The row count of a group is kept even.
+#define GS_ELEM(row, lane) ((((size_t)(row) >> 1) << 7) + ((size_t)(lane) << 1) + ((size_t)(row) & 1))
 #define GS_MAX_WAVES 16
 #define GS_ELL_K 4        // Ybus rows are stored in chunks of 4 entries (padded with exact zeros)
 
@@ -45,16 +51,36 @@ struct GsRowRef {
   __device__ __forceinline__ double operator+=(double v) const { const double x = get() + v; put(x); return x; }
   __device__ __forceinline__ double operator-=(double v) const { const double x = get() - v; put(x); return x; }
 };
+typedef unsigned int gs_u32x4 __attribute__((ext_vector_type(4)));
+struct GsPairRef {          // an (even row, odd row) pair of one lane: 16 bytes, one instruction
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;
+  int soff;
+  __device__ __forceinline__ double2 get() const { return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+  __device__ __forceinline__ void put(double2 v) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gs_u32x4, v), r, voff, soff, 0); }
+  __device__ __forceinline__ operator double2() const { return get(); }
+  __device__ __forceinline__ void operator=(double2 v) const { put(v); }
+};
 struct GsLaneRows {
   __amdgpu_buffer_rsrc_t r;
   char* g;                   // group base (uniform)
-  unsigned lane8;
-  __device__ __forceinline__ GsRowRef operator[](size_t idx) const { return GsRowRef{r, lane8, (int)(idx << 3)}; }          // uniform row
-  __device__ __forceinline__ GsRowRef lane_row(size_t idx) const { return GsRowRef{r, lane8 + (unsigned)(idx << 3), 0}; }   // per-lane row
+  unsigned lane16;
+  // idx = row * GS_LANES, as for the lane pointer this replaces
+  __device__ __forceinline__ GsRowRef operator[](size_t idx) const {                      // uniform row
+    const unsigned row = (unsigned)(idx >> 6);
+    return GsRowRef{r, lane16, (int)(((row >> 1) << 10) | ((row & 1) << 3))};
+  }
+  __device__ __forceinline__ GsPairRef pair(size_t idx) const {                           // uniform EVEN row and its odd partner
+    return GsPairRef{r, lane16, (int)((unsigned)(idx >> 7) << 10)};
+  }
+  __device__ __forceinline__ GsRowRef lane_row(size_t idx) const {                        // per-lane row
+    const unsigned row = (unsigned)(idx >> 6);
+    return GsRowRef{r, lane16 + (((row >> 1) << 10) | ((row & 1) << 3)), 0};
+  }
 };
 __device__ __forceinline__ GsLaneRows gs_lane_rows(double* slab, int group, int rows_total, int lane) {
   char* g = (char*)(slab + (size_t)group * rows_total * GS_LANES);
-  return GsLaneRows{__builtin_amdgcn_make_buffer_rsrc(g, 0, rows_total * GS_LANES * (int)sizeof(double), 0x00020000), g, (unsigned)lane << 3};
+  return GsLaneRows{__builtin_amdgcn_make_buffer_rsrc(g, 0, rows_total * GS_LANES * (int)sizeof(double), 0x00020000), g, (unsigned)lane << 4};
 }
 #endif
 
@@ -176,24 +202,36 @@ struct GsTables {
 };
 
 // Row offsets into the per-group slab (units: rows of 64 doubles).
+// A row family whose element i sits at base + 2 i: two such families with bases (even, even + 1) interleave, so that
+// their elements i share one 16-byte slot per lane (GS_ELEM).  `R.E + i` keeps reading as before.
+struct GsFam2 {
+  int32_t base;
+#if defined(__HIPCC__)
+  __host__ __device__
+#endif
+  int operator+(int i) const { return base + 2 * i; }
+};
+
 struct GsRows {
   int32_t total;
-  // solver inputs / outputs
-  int32_t P, Q;              // [n] specified injections
-  int32_t VM, VA;            // [n] polar state (solution)
-  int32_t FLOW, LOAD;        // [m] line P flow, |S|/rating
+  // solver inputs / outputs.  Paired (interleaved) families: (P, Q), (VM, VA), (FLOW, ENVLOAD), (E, F), (PC, QC),
+  // (R0, R1), (X0, X1), (JR, JI)
+  GsFam2 P, Q;               // [n] specified injections
+  GsFam2 VM, VA;             // [n] polar state (solution)
+  GsFam2 FLOW;               // [m] line P flow (paired with ENVLOAD)
+  int32_t LOAD;              // [m] |S|/rating
   int32_t LOSSES, MAXMIS, ITERS, CONV, STATUS;   // scalars (stored as doubles)
   // solver scratch
-  int32_t E, F;              // [n] rectangular voltage
-  int32_t PC, QC;            // [n] calculated injections
-  int32_t R0, R1;            // [n] mismatch (rhs)
-  int32_t X0, X1;            // [n] Newton step
+  GsFam2 E, F;               // [n] rectangular voltage
+  GsFam2 PC, QC;             // [n] calculated injections
+  GsFam2 R0, R1;             // [n] mismatch (rhs)
+  GsFam2 X0, X1;             // [n] Newton step
   int32_t RVM;               // [n] 1 / Vm (kept by the LDS forest solve)
-  int32_t SV;                // [2n] inv(D) r
+  int32_t SV;                // [2n] inv(D) r          (the [2n] / [4n] blocks start on even rows: a bus's entries pair up)
   int32_t QV;                // [2n] child -> parent rhs contribution
   int32_t TB;                // [4n] inv(D) U
   int32_t CB;                // [4n] child -> parent diagonal contribution
-  int32_t JR, JI;            // [n] FBS branch currents
+  GsFam2 JR, JI;             // [n] FBS branch currents
   int32_t LU;                // [4 * lu_n_slots] off-diagonal blocks
   int32_t LUD;               // [4n] diagonal blocks
   int32_t DA;                // [N*N] dense Jacobian (dense kernel only)
@@ -202,7 +240,7 @@ struct GsRows {
   int32_t TIME, STEP, VIOL, TOTLOSS, EPREW, FREQ, IRR, WIND, TEMP, CLOUD, SEEDLO, SEEDHI;
   int32_t SOC, BATP;         // [n_bats]
   int32_t CURT, GENP;        // [n_gens] curtailment factor, uncurtailed renewable power
-  int32_t ENVLOAD;           // [m] |flow|/rating (base.py:261-264)
+  GsFam2 ENVLOAD;            // [m] |flow|/rating (base.py:261-264), paired with FLOW
   // env outputs
   int32_t REWARD, TERM, TRUNC, VMAX, VMIN, VFLAGS /* [4] */;
   int32_t ACT;               // [action_dim] unpacked actions
@@ -238,6 +276,6 @@ struct GsChecksCfg {
   double m_vlo, m_vhi, m_flo, m_fhi, m_load, m_evlo, m_evhi, m_eflo, m_efhi;           // SafetyMonitor
   double q_tol;                                                                          // quality gate
   int32_t n, m, rows_total;
-  int32_t row_vm, row_cload, row_qload, row_flow, row_freq, row_conv, row_iters, row_maxmis;
-  int32_t pad;
+  int32_t row_vm, row_cload, row_qload, row_flow, row_freq, row_conv, row_iters, row_maxmis;   // row_vm, row_flow: stride 2
+  int32_t stride_cload;
 };

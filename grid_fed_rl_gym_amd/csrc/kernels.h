@@ -22,7 +22,7 @@ __global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restr
                           const double* __restrict__ slab, double* __restrict__ out, int B);
 __global__ void gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,
                             const double* __restrict__ in, int B);
-__global__ void gs_k_fill_rows(int row0, int count, int rows_total, double* __restrict__ slab, double value);
+__global__ void gs_k_fill_rows(int row0, int stride, int count, int rows_total, double* __restrict__ slab, double value);
 __global__ void gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__ ri, int ni,
                              const int32_t* __restrict__ ru, int nu, int rows_total, const double* __restrict__ slab,
                              double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp);

@@ -24,9 +24,9 @@ gs_k_checks(GsChecksCfg C, const double* __restrict__ slab, const double* __rest
   __shared__ double pd[4][CK_WAVES][GS_LANES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x;
   const int b = g * GS_LANES + lane;
-  const double* S = slab + (size_t)g * C.rows_total * GS_LANES + lane;
+  const double* S = slab + (size_t)g * C.rows_total * GS_LANES;
   double* P = prev + (size_t)g * (C.n + 1) * GS_LANES + lane;
-#define ROWS(r) S[(size_t)(r) * GS_LANES]
+#define ROWS(r) S[GS_ELEM((r), lane)]
   int c_nlow = 0, c_nhigh = 0, m_nhigh = 0, m_nlow = 0, m_nem = 0, c_nover = 0, m_nover = 0, flags = 0;   // flags: 1 rate NaN, 2 v non-finite, 4 flow non-finite, 8 quality loading NaN
   double dvmax = 0.0, vmin = INFINITY, vmax = -INFINITY, qlmax = -INFINITY;
   // four rows per trip, all loads first: a group's rows come from HBM / Infinity Cache and a wave has only
@@ -36,7 +36,7 @@ gs_k_checks(GsChecksCfg C, const double* __restrict__ slab, const double* __rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = min(i0 + u * CK_WAVES, C.n - 1);
-      vv[u] = ROWS(C.row_vm + i); pp[u] = P[(size_t)i * GS_LANES];
+      vv[u] = ROWS(C.row_vm + 2 * i); pp[u] = P[(size_t)i * GS_LANES];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -61,7 +61,7 @@ gs_k_checks(GsChecksCfg C, const double* __restrict__ slab, const double* __rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int k = min(k0 + u * CK_WAVES, C.m - 1);
-      l1[u] = ROWS(C.row_cload + k); l2[u] = ROWS(C.row_qload + k); l3[u] = ROWS(C.row_flow + k);
+      l1[u] = ROWS(C.row_cload + C.stride_cload * k); l2[u] = ROWS(C.row_qload + k); l3[u] = ROWS(C.row_flow + 2 * k);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

@@ -26,7 +26,7 @@ gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C
     const int c = c0 + cc;
     if (c < C) {
       const int s = src[c];
-      tile[cc * TILE_PAD + lane] = (s >= 0) ? S[(size_t)s * GS_LANES + lane] : cst[-s - 1];
+      tile[cc * TILE_PAD + lane] = (s >= 0) ? S[GS_ELEM(s, lane)] : cst[-s - 1];
     }
   }
   __syncthreads();
@@ -56,15 +56,15 @@ gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __re
   __syncthreads();
   for (int cc = wave; cc < TILE_C; cc += 4) {
     const int cx = c0 + cc;
-    if (cx < C) S[(size_t)dst[cx] * GS_LANES + lane] = tile[cc * TILE_PAD + lane];
+    if (cx < C) S[GS_ELEM(dst[cx], lane)] = tile[cc * TILE_PAD + lane];
   }
 }
 
-// Fill `count` slab rows starting at `row0` with a constant (Q_spec = 0 when the caller passes NULL).
+// Fill `count` slab rows row0, row0 + stride, ... with a constant (Q_spec = 0 when the caller passes NULL).
 extern "C" __global__ void __launch_bounds__(64)
-gs_k_fill_rows(int row0, int count, int rows_total, double* __restrict__ slab, double value) {
-  double* S = slab + (size_t)blockIdx.x * rows_total * GS_LANES + threadIdx.x;
-  for (int r = 0; r < count; ++r) S[(size_t)(row0 + r) * GS_LANES] = value;
+gs_k_fill_rows(int row0, int stride, int count, int rows_total, double* __restrict__ slab, double value) {
+  double* S = slab + (size_t)blockIdx.x * rows_total * GS_LANES;
+  for (int r = 0; r < count; ++r) S[GS_ELEM(row0 + stride * r, threadIdx.x)] = value;
 }
 
 // Per-instance scalars -> typed contiguous [B] arrays (already lane-contiguous in the slab).
@@ -75,8 +75,9 @@ gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__
              const int32_t* __restrict__ ru, int nu, int rows_total, const double* __restrict__ slab,
              double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp) {
   const int b = blockIdx.x * GS_LANES + threadIdx.x;
-  const double* S = slab + (size_t)blockIdx.x * rows_total * GS_LANES + threadIdx.x;
-  for (int k = 0; k < nf; ++k) of[(size_t)k * Bp + b] = S[(size_t)rf[k] * GS_LANES];
-  for (int k = 0; k < ni; ++k) oi[(size_t)k * Bp + b] = (int32_t)S[(size_t)ri[k] * GS_LANES];
-  for (int k = 0; k < nu; ++k) ou[(size_t)k * Bp + b] = (S[(size_t)ru[k] * GS_LANES] != 0.0) ? 1 : 0;
+  const double* S = slab + (size_t)blockIdx.x * rows_total * GS_LANES;
+  const int ln = threadIdx.x;
+  for (int k = 0; k < nf; ++k) of[(size_t)k * Bp + b] = S[GS_ELEM(rf[k], ln)];
+  for (int k = 0; k < ni; ++k) oi[(size_t)k * Bp + b] = (int32_t)S[GS_ELEM(ri[k], ln)];
+  for (int k = 0; k < nu; ++k) ou[(size_t)k * Bp + b] = (S[GS_ELEM(ru[k], ln)] != 0.0) ? 1 : 0;
 }

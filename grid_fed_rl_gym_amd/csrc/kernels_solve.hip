@@ -30,6 +30,7 @@
 #include "gs_internal.h"
 
 #define ROW(r) S[(size_t)(r) * GS_LANES]
+#define ROW2(r) S.pair((size_t)(r) * GS_LANES)        /* (row r, row r + 1) of the lane as one double2; r even */
 #include "env_device.h"
 
 __device__ __forceinline__ double finite_or_inf(double v) { return (fabs(v) < INFINITY) ? v : INFINITY; }
@@ -99,10 +100,8 @@ __device__ __forceinline__ void flat_start(Ctx& c) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   for (int i = c.wave; i < T.n; i += c.W) {
     const double vm = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
-    ROW(R.VM + i) = vm;
-    ROW(R.VA + i) = 0.0;
-    ROW(R.E + i) = vm;          // vm * cos(0), vm * sin(0): exact
-    ROW(R.F + i) = 0.0;
+    ROW2(R.VM + i) = make_double2(vm, 0.0);
+    ROW2(R.E + i) = make_double2(vm, 0.0);          // vm * cos(0), vm * sin(0): exact
     ROW(R.RVM + i) = 1.0 / vm;
   }
 }
@@ -111,11 +110,10 @@ __device__ __forceinline__ void flat_start(Ctx& c) {
 __device__ __forceinline__ void to_rect(Ctx& c) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   for (int i = c.wave; i < T.n; i += c.W) {
-    const double vm = ROW(R.VM + i), va = ROW(R.VA + i);
+    const double2 v = ROW2(R.VM + i);
     double s, cs;
-    sincos(va, &s, &cs);
-    ROW(R.E + i) = vm * cs;
-    ROW(R.F + i) = vm * s;
+    sincos(v.y, &s, &cs);
+    ROW2(R.E + i) = make_double2(v.x * cs, v.x * s);
   }
 }
 
@@ -141,11 +139,13 @@ __device__ __forceinline__ double mismatch_rows(Ctx& c) {
   double P = 0.0, Q = 0.0;
   for (int q = k0; q < k1; ++q) {
     const int i = hb, fl = hf;
-    const double ei = ROW(R.E + i), fi = ROW(R.F + i);
+    const double2 vi = ROW2(R.E + i);
+    const double ei = vi.x, fi = vi.y;
     double ej[GS_ELL_K], fj[GS_ELL_K];
 #pragma unroll
-    for (int k = 0; k < GS_ELL_K; ++k) { ej[k] = ROW(R.E + hc[k]); fj[k] = ROW(R.F + hc[k]); }
-    const double ps = ROW(R.P + i), qs = ROW(R.Q + i);
+    for (int k = 0; k < GS_ELL_K; ++k) { const double2 vj = ROW2(R.E + hc[k]); ej[k] = vj.x; fj[k] = vj.y; }
+    const double2 sp = ROW2(R.P + i);
+    const double ps = sp.x, qs = sp.y;
     if (q + 1 < k1) {
       hb = recs[q + 1].bus; hf = recs[q + 1].flags;
 #pragma unroll
@@ -161,11 +161,11 @@ __device__ __forceinline__ double mismatch_rows(Ctx& c) {
       Q += g * bb - b * a;
     }
     if (fl & 4) continue;                              // the row continues in the next record
-    ROW(R.PC + i) = P;
-    if (STORE >= 1) ROW(R.QC + i) = Q;
+    if (STORE >= 1) ROW2(R.PC + i) = make_double2(P, Q);
+    else ROW(R.PC + i) = P;
     const double dP = (fl & 1) ? (ps - P) : 0.0;
     const double dQ = (fl & 2) ? (qs - Q) : 0.0;
-    if (STORE >= 2) { ROW(R.R0 + i) = dP; ROW(R.R1 + i) = dQ; }
+    if (STORE >= 2) ROW2(R.R0 + i) = make_double2(dP, dQ);
     lmax = fmax(lmax, fmax(finite_or_inf(fabs(dP)), finite_or_inf(fabs(dQ))));
   }
   return lmax;
@@ -235,10 +235,11 @@ __device__ __forceinline__ Blk inv2(const Blk& d, int* sing) {
 }
 
 __device__ __forceinline__ Blk load_blk(GsLaneRows S, int row) {
-  Blk b; b.a00 = ROW(row); b.a01 = ROW(row + 1); b.a10 = ROW(row + 2); b.a11 = ROW(row + 3); return b;
+  const double2 lo = ROW2(row), hi = ROW2(row + 2);     // blocks start on even rows
+  Blk b; b.a00 = lo.x; b.a01 = lo.y; b.a10 = hi.x; b.a11 = hi.y; return b;
 }
 __device__ __forceinline__ void store_blk(GsLaneRows S, int row, const Blk& b) {
-  ROW(row) = b.a00; ROW(row + 1) = b.a01; ROW(row + 2) = b.a10; ROW(row + 3) = b.a11;
+  ROW2(row) = make_double2(b.a00, b.a01); ROW2(row + 2) = make_double2(b.a10, b.a11);
 }
 
 // ---- apply the Newton step to bus i (power_flow.py:315-327); keeps Vm >= 0 like the
@@ -364,10 +365,11 @@ __device__ __forceinline__ BuOperands fetch_bu(Ctx& c, const GsItemRec& r) {
   const GsRows& R = c.R; GsLaneRows S = c.S;
   BuOperands o;
   const int i = r.bus, pj = r.parent >= 0 ? r.parent : r.bus;
-  o.vm = ROW(R.VM + i); o.rvm = ROW(R.RVM + i); o.pc = ROW(R.PC + i); o.qc = ROW(R.QC + i);
-  o.r0 = ROW(R.P + i); o.r1 = ROW(R.Q + i);          // specified injections; the mismatch is formed in the sweep
-  o.ei = ROW(R.E + i); o.fi = ROW(R.F + i);
-  o.ep = ROW(R.E + pj); o.fp = ROW(R.F + pj); o.rvmp = ROW(R.RVM + pj);
+  const double2 sc = ROW2(R.PC + i), sp = ROW2(R.P + i), vi = ROW2(R.E + i), vp = ROW2(R.E + pj);
+  o.vm = ROW(R.VM + i); o.rvm = ROW(R.RVM + i); o.pc = sc.x; o.qc = sc.y;
+  o.r0 = sp.x; o.r1 = sp.y;                          // specified injections; the mismatch is formed in the sweep
+  o.ei = vi.x; o.fi = vi.y;
+  o.ep = vp.x; o.fp = vp.y; o.rvmp = ROW(R.RVM + pj);
   return o;
 }
 
@@ -375,11 +377,11 @@ __device__ __forceinline__ TdOperands fetch_td(Ctx& c, const GsItemRec& r) {
   const GsRows& R = c.R; GsLaneRows S = c.S;
   TdOperands o;
   const int i = r.bus;
-  o.t00 = ROW(R.TB + 4 * i); o.t01 = ROW(R.TB + 4 * i + 1);
-  o.t10 = ROW(R.TB + 4 * i + 2); o.t11 = ROW(R.TB + 4 * i + 3);
-  o.s0 = ROW(R.SV + 2 * i); o.s1 = ROW(R.SV + 2 * i + 1);
-  o.vm = ROW(R.VM + i); o.va = ROW(R.VA + i); o.rvm = ROW(R.RVM + i);
-  o.e = ROW(R.E + i); o.f = ROW(R.F + i);
+  const double2 t0 = ROW2(R.TB + 4 * i), t1 = ROW2(R.TB + 4 * i + 2), sv = ROW2(R.SV + 2 * i), vp = ROW2(R.VM + i), vr = ROW2(R.E + i);
+  o.t00 = t0.x; o.t01 = t0.y; o.t10 = t1.x; o.t11 = t1.y;
+  o.s0 = sv.x; o.s1 = sv.y;
+  o.vm = vp.x; o.va = vp.y; o.rvm = ROW(R.RVM + i);
+  o.e = vr.x; o.f = vr.y;
   return o;
 }
 
@@ -444,7 +446,7 @@ __device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, N
       }
       const Blk inv = inv2(d, &sing);
       const double s0 = inv.a00 * r0 + inv.a01 * r1, s1 = inv.a10 * r0 + inv.a11 * r1;
-      ROW(R.SV + 2 * i) = s0; ROW(R.SV + 2 * i + 1) = s1;
+      ROW2(R.SV + 2 * i) = make_double2(s0, s1);
       if (r.parent >= 0) {
         const double rvmp = o.rvmp;
         const Blk u = edge_block(r.g, r.b, o.ei, o.fi, o.ep, o.fp, rvmp, thi, vfi, thp, vfp);    // J(i, p)
@@ -519,8 +521,8 @@ __device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, N
           en = ratio * (o.e * cs - o.f * sn);
           fn = ratio * (o.e * sn + o.f * cs);
         }
-        ROW(R.VM + i) = vm; ROW(R.VA + i) = va; ROW(R.RVM + i) = 1.0 / vm;
-        ROW(R.E + i) = en; ROW(R.F + i) = fn;
+        ROW2(R.VM + i) = make_double2(vm, va); ROW(R.RVM + i) = 1.0 / vm;
+        ROW2(R.E + i) = make_double2(en, fn);
       }
     }
     while (lv >= 0) { lds_barrier(); --lv; }
@@ -796,8 +798,9 @@ struct FbsOperands { double e, f, p, q, ep, fp; };
 __device__ __forceinline__ FbsOperands fetch_fbs(Ctx& c, const GsItemRec& r) {
   const GsRows& R = c.R; GsLaneRows S = c.S;
   FbsOperands o;
-  o.e = ROW(R.E + r.bus); o.f = ROW(R.F + r.bus); o.p = ROW(R.P + r.bus); o.q = ROW(R.Q + r.bus);
-  o.ep = ROW(R.E + r.parent); o.fp = ROW(R.F + r.parent);
+  const double2 v = ROW2(R.E + r.bus), sp = ROW2(R.P + r.bus), vp = ROW2(R.E + r.parent);
+  o.e = v.x; o.f = v.y; o.p = sp.x; o.q = sp.y;
+  o.ep = vp.x; o.fp = vp.y;
   return o;
 }
 
@@ -843,7 +846,7 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
     const double rd = 1.0 / (o.e * o.e + o.f * o.f);
     const double jr = sjr - (o.p * o.e + o.q * o.f) * rd, ji = sji + (o.q * o.e - o.p * o.f) * rd;
     MSG(r.slot, 0) = jr; MSG(r.slot, 1) = ji; MSG(r.slot, 2) = kr; MSG(r.slot, 3) = ki;
-    ROW(R.JR + r.bus) = jr; ROW(R.JI + r.bus) = ji;
+    ROW2(R.JR + r.bus) = make_double2(jr, ji);
   }
   while (lv < T.n_levels) { lds_barrier(); ++lv; }
 #undef MSG
@@ -855,7 +858,8 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
 struct FbsLightOperands { double e, f, p, q; };
 __device__ __forceinline__ FbsLightOperands fetch_fbs_light(Ctx& c, int bus) {
   const GsRows& R = c.R; GsLaneRows S = c.S;
-  return FbsLightOperands{ROW(R.E + bus), ROW(R.F + bus), ROW(R.P + bus), ROW(R.Q + bus)};
+  const double2 v = ROW2(R.E + bus), sp = ROW2(R.P + bus);
+  return FbsLightOperands{v.x, v.y, sp.x, sp.y};
 }
 
 __device__ __forceinline__ void fbs_backward_light(Ctx& c, int k0, int k1) {
@@ -884,7 +888,7 @@ __device__ __forceinline__ void fbs_backward_light(Ctx& c, int k0, int k1) {
       jr += MSG(slot, 0); ji += MSG(slot, 1);
     }
     MSG(r.slot, 0) = jr; MSG(r.slot, 1) = ji;
-    ROW(R.JR + r.bus) = jr; ROW(R.JI + r.bus) = ji;
+    ROW2(R.JR + r.bus) = make_double2(jr, ji);
   }
   while (lv < T.n_levels) { lds_barrier(); ++lv; }
 #undef MSG
@@ -904,10 +908,7 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
   double* msg = gs_dyn + c.lane;
 #define MSG(slot, k) msg[((size_t)(slot) * GS_MSG_DOUBLES + (k)) * GS_LANES]
   if (!FLAT_DONE) {
-    for (int i = c.wave; i < T.n; i += c.W) {
-      ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
-      ROW(R.F + i) = 0.0;
-    }
+    for (int i = c.wave; i < T.n; i += c.W) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
     __syncthreads();
   }
   const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
@@ -929,12 +930,12 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
       GsItemRec rn{};
       double jr = 0, ji = 0;
       FbsLightOperands on{};
-      if (k0 < k1) { rn = load_item(T, k1 - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); on = fetch_fbs_light(c, rn.bus); }
+      if (k0 < k1) { rn = load_item(T, k1 - 1); const double2 j = ROW2(R.JR + rn.bus); jr = j.x; ji = j.y; on = fetch_fbs_light(c, rn.bus); }
       for (int k = k1 - 1; k >= k0; --k) {
         const GsItemRec r = rn;
         const double cjr = jr, cji = ji;
         const FbsLightOperands o = on;
-        if (k - 1 >= k0) { rn = load_item(T, k - 1); jr = ROW(R.JR + rn.bus); ji = ROW(R.JI + rn.bus); on = fetch_fbs_light(c, rn.bus); }
+        if (k - 1 >= k0) { rn = load_item(T, k - 1); const double2 j = ROW2(R.JR + rn.bus); jr = j.x; ji = j.y; on = fetch_fbs_light(c, rn.bus); }
         // the current this bus drew in the backward sweep, I_old = conj(S_spec / V_old): independent of the parent
         const double rd = 1.0 / (o.e * o.e + o.f * o.f);
         const double icr = (o.p * o.e + o.q * o.f) * rd, ici = (o.p * o.f - o.q * o.e) * rd;
@@ -945,7 +946,7 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
         else { ep = MSG(r.parent_slot, 0); fp = MSG(r.parent_slot, 1); }
         const double en = ep - (cjr * r.g - cji * r.b), fn = fp - (cjr * r.b + cji * r.g);
         MSG(r.slot, 0) = en; MSG(r.slot, 1) = fn;
-        if (upd) { ROW(R.E + r.bus) = en; ROW(R.F + r.bus) = fn; }
+        if (upd) ROW2(R.E + r.bus) = make_double2(en, fn);
         // S_calc = V_new conj(I_old); mismatch (power_flow.py:150-168)
         const double pc = en * icr + fn * ici, qc = fn * icr - en * ici;
         const double dP = o.p - pc, dQ = o.q - qc;
@@ -989,8 +990,9 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = min(i0 + u * c.W, T.n - 1);
-      xa[u] = WRAP_VA ? ROW(R.VA + i) : ROW(R.E + i);
-      xb[u] = WRAP_VA ? ROW(R.VM + i) : ROW(R.F + i);
+      const double2 x = WRAP_VA ? (double2)ROW2(R.VM + i) : (double2)ROW2(R.E + i);      // (|V|, angle) or (e, f)
+      xa[u] = WRAP_VA ? x.y : x.x;
+      xb[u] = WRAP_VA ? x.x : x.y;
       pcs[u] = have_psum ? 0.0 : ROW(R.PC + i);
     }
 #pragma unroll
@@ -1005,9 +1007,8 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
         v = xb[u];
       } else {                                                // sweeps work on (e, f): polar form here, once
         const double e = xa[u], f = xb[u];
-        ROW(R.VA + i) = atan2(f, e);
         v = sqrt(e * e + f * f);
-        ROW(R.VM + i) = v;
+        ROW2(R.VM + i) = make_double2(v, atan2(f, e));
       }
       if (ENV) {                                              // reward / flags, grid_env.py:790-792, base.py:156-159
         dev += fabs(v - 1.0);
@@ -1024,7 +1025,8 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
     for (int u = 0; u < 4; ++u) {
       const int k = min(k0 + u * c.W, T.m - 1);
       const int i = cld(T.lfrom, k), j = cld(T.lto, k);
-      ei_[u] = ROW(R.E + i); fi_[u] = ROW(R.F + i); ej_[u] = ROW(R.E + j); fj_[u] = ROW(R.F + j);
+      const double2 vi = ROW2(R.E + i), vj = ROW2(R.E + j);
+      ei_[u] = vi.x; fi_[u] = vi.y; ej_[u] = vj.x; fj_[u] = vj.y;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1035,12 +1037,13 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
       const double dr = ei - ej_[u], di = fi - fj_[u];
       const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
       const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
-      ROW(R.FLOW + k) = sr;
       ROW(R.LOAD + k) = (rating > 0.0) ? sqrt(sr * sr + si * si) / rating : 0.0;
       if (ENV) {                                                        // Line.update_state, base.py:261-264
         const double ld = (rating > 0.0) ? fabs(sr) / rating : 0.0;
-        ROW(R.ENVLOAD + k) = ld;
+        ROW2(R.FLOW + k) = make_double2(sr, ld);
         over += (ld > 0.8) ? 1 : 0;
+      } else {
+        ROW(R.FLOW + k) = sr;
       }
     }
   }
@@ -1149,7 +1152,7 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
         v[u] = 0.0;
         if (cc < span && jj < n_dyn) {
           const int s = cld(A.map, jj < A.skip0 ? jj : jj + gap);
-          v[u] = (s >= 0) ? Sg[(size_t)s * GS_LANES + c.lane] : cld(A.cst, -s - 1);
+          v[u] = (s >= 0) ? Sg[GS_ELEM(s, c.lane)] : cld(A.cst, -s - 1);
         }
       }
 #pragma unroll
@@ -1220,10 +1223,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         const int k = k0 + u;
         if (k >= k1) break;
         const int i = recs[k].bus;
-        if (FLAT_FBS) {
-          ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
-          ROW(R.F + i) = 0.0;
-        }
+        if (FLAT_FBS) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
         if (recs[k].generic) { bus_injection(T, R, E, S, i); continue; }
         // same accumulation order as bus_injection: loads, then generators, then batteries
         double ls = 0.0, gs = 0.0;
@@ -1233,8 +1233,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         if (recs[k].ng > 1) gs += ROW(R.GENP + recs[k].g1) * ROW(R.CURT + recs[k].g1);
         if (recs[k].nb > 0) { const double bp = ROW(R.BATP + recs[k].b0); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
         if (recs[k].nb > 1) { const double bp = ROW(R.BATP + recs[k].b1); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
-        ROW(R.P + i) = (0.0 - ls / E.power_base) + gs / E.power_base;
-        ROW(R.Q + i) = 0.0;
+        ROW2(R.P + i) = make_double2((0.0 - ls / E.power_base) + gs / E.power_base, 0.0);
       }
     }
   }
