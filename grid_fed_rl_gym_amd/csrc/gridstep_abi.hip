@@ -229,6 +229,7 @@ int step_kernels(gs_handle* h, const double* d_actions) {
     dim3 grid(h->groups), block(64 * h->W);
     GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 40960) / (64 * 65 * sizeof(double)))), 0, 0,
                   h->obs_skip0, h->obs_skip1};
+    pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
 #define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa)
     if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
@@ -384,7 +385,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   R.IRR = take(1); R.WIND = take(1); R.TEMP = take(1); R.CLOUD = take(1); R.SEEDLO = take(1); R.SEEDHI = take(1);
   R.SOC = take(h->n_bats); R.BATP = take(h->n_bats); R.CURT = take(h->n_gens); R.GENP = take(h->n_gens);
   R.REWARD = take(1); R.TERM = take(1); R.TRUNC = take(1); R.VMAX = take(1); R.VMIN = take(1); R.VFLAGS = take(4);
-  R.ACT = take(h->action_dim); R.LOADP = take(h->n_loads);
+  R.ACT = take(h->action_dim); R.LOADP = take_even(h->n_loads + 1);   // written in pairs by the load-noise draws
   R.total = (r + 1) & ~1;        // rows are stored in pairs (GS_ELEM)
 
   // ---- per-wave work lists of the forest sweeps (records in the order each wave meets them) ----

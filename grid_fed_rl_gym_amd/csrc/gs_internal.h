@@ -252,7 +252,8 @@ struct GsPackArgs {
   const double* cst;
   double* out;             // [B][obs_dim]
   int32_t obs_dim, tiles_per_pass;   // 64-column tiles staged in LDS per pass
-  int32_t early_pass0, pad;          // 1: no column of the first pass is written by the epilogue's scalar part
+  int32_t early_pass0, pair_ok;      // early_pass0: no column of the first pass is written by the epilogue's scalar part;
+                                     // pair_ok: obs_dim and the block of constants are even (two columns per lane)
   int32_t skip0, skip1;              // columns [skip0, skip1) are per-instance constants (the static load powers of
                                      // grid_env.py:769-770): written at reset, left alone by the step (skip0 == skip1: none)
 };

@@ -1130,7 +1130,7 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
 // The first pass starts while wave 0 is still in the scalar part of the epilogue: its columns (|V|, angle) were
 // final at the epilogue's reduction barrier, the tiles sit behind the partials wave 0 is reading, and the other
 // waves share out wave 0's rows of that pass.
-__device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, int B) {
+__device__ __forceinline__ void pack_observations_by_column(Ctx& c, const GsPackArgs& A, int B) {
   const double* Sg = (const double*)c.S.g;             // group base
   double* tiles = gs_dyn + GS_PACK_LDS_DOUBLES;
   const int g = blockIdx.x;
@@ -1173,6 +1173,63 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
   }
 }
 
+// The same with two columns per lane on both sides: the observation lists (|V|, angle) per bus and (flow, loading) per
+// line, which are row pairs of the slab (one 16-byte load), and an instance's columns 2L, 2L+1 are one 16-byte store.
+// Needs an even obs_dim and an even block of constants (every row of `out` and every column pair 16-byte aligned).
+__device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, int B) {
+  if (!A.pair_ok) { pack_observations_by_column(c, A, B); return; }
+  const double* Sg = (const double*)c.S.g;             // group base
+  double* tiles = gs_dyn + GS_PACK_LDS_DOUBLES;
+  const int g = blockIdx.x;
+  const int TG = A.tiles_per_pass & ~1;                // whole 128-column spans
+  const int span = 64 * TG, hspan = span >> 1;
+  const int gap = A.skip1 - A.skip0, n_dyn = A.obs_dim - gap;
+  if (!A.early_pass0) __syncthreads();
+  for (int c0 = 0; c0 < n_dyn; c0 += span) {
+    const bool early = A.early_pass0 && c0 == 0 && c.W > 1;     // pass 0: waves 1 .. W-1 only
+    const int gw = early ? c.wave - 1 : c.wave, GW = early ? c.W - 1 : c.W;
+    for (int j = gw; j < hspan && gw >= 0; j += 4 * GW) {
+      double2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = j + u * GW, jj = c0 + 2 * pp;            // columns jj, jj + 1 of the changing list
+        v[u] = make_double2(0.0, 0.0);
+        if (pp < hspan && jj < n_dyn) {
+          const int s0 = cld(A.map, jj < A.skip0 ? jj : jj + gap);
+          const int s1 = (jj + 1 < n_dyn) ? cld(A.map, jj + 1 < A.skip0 ? jj + 1 : jj + 1 + gap) : s0;
+          if (s0 >= 0 && !(s0 & 1) && s1 == s0 + 1) v[u] = *(const double2*)&Sg[GS_ELEM(s0, c.lane)];
+          else {
+            v[u].x = (s0 >= 0) ? Sg[GS_ELEM(s0, c.lane)] : cld(A.cst, -s0 - 1);
+            v[u].y = (s1 >= 0) ? Sg[GS_ELEM(s1, c.lane)] : cld(A.cst, -s1 - 1);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = 2 * (j + u * GW);
+        if (cc < span) {
+          tiles[(cc >> 6) * (64 * 65) + (cc & 63) * 65 + c.lane] = v[u].x;
+          tiles[(cc >> 6) * (64 * 65) + ((cc & 63) + 1) * 65 + c.lane] = v[u].y;
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = 0; t < TG; t += 2) {                  // a 128-column span: lane L carries columns 2L and 2L + 1
+      const int cc = t * 64 + 2 * c.lane, jj = c0 + cc;
+      const int col0 = jj < A.skip0 ? jj : jj + gap, col1 = jj + 1 < A.skip0 ? jj + 1 : jj + 1 + gap;
+      const double* tp = tiles + (cc >> 6) * (64 * 65) + (cc & 63) * 65;
+      for (int r = c.wave; r < GS_LANES; r += c.W) {
+        const int b = g * GS_LANES + r;
+        if (b >= B || jj >= n_dyn) continue;
+        double* o = A.out + (size_t)b * A.obs_dim;
+        if (jj + 1 < n_dyn && col1 == col0 + 1) *(double2*)(o + col0) = make_double2(tp[r], tp[65 + r]);
+        else { o[col0] = tp[r]; if (jj + 1 < n_dyn) o[col1] = tp[65 + r]; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Everything of step() that precedes the load flow, spread over the W waves (grid_env.py:433-477).
 // FLAT_FBS: the injection pass also writes the sweep solver's flat start (e, f) of the buses it visits.
 template <bool FLAT_FBS>
@@ -1196,8 +1253,9 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
       for (int p = l0; 2 * p < T.n_loads; p += ls) {
         double z0, z1;
         rng_normal_pair(seed, inst, snew, DRAW_LOAD0 + p, &z0, &z1);
-        ROW(R.LOADP + 2 * p) = load_power_z(T, 2 * p, z0, prof);
-        if (2 * p + 1 < T.n_loads) ROW(R.LOADP + 2 * p + 1) = load_power_z(T, 2 * p + 1, z1, prof);
+        const double lp0 = load_power_z(T, 2 * p, z0, prof);
+        if (2 * p + 1 < T.n_loads) ROW2(R.LOADP + 2 * p) = make_double2(lp0, load_power_z(T, 2 * p + 1, z1, prof));   // LOADP starts on an even row
+        else ROW(R.LOADP + 2 * p) = lp0;
       }
     } else {
       for (int l = l0; l < T.n_loads; l += ls) ROW(R.LOADP + l) = cld(T.load_base, l);
