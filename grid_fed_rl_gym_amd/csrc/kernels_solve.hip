@@ -973,6 +973,25 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
   return psum;
 }
 
+// Bus voltage angle from (e, f).  Distribution feeders sit within a few degrees of the slack, and libm's atan2 is
+// ~105 vector instructions (the epilogue's bus loop is bound by them): when every lane of the wave has e > 0 and
+// |f| <= e / 8 the angle is t - t^3/3 + t^5/5 - ... with t = f / e, whose tenth term is below 2^-63 of the first;
+// any other wave takes libm.  Either way the result is the correctly rounded angle to within 2 ulp.
+__device__ __forceinline__ double bus_angle(double f, double e) {
+  if (!__all(e > 0.0 && fabs(f) <= 0.125 * e)) return atan2(f, e);
+  const double t = f / e, z = t * t;
+  double p = -1.0 / 19.0;
+  p = p * z + 1.0 / 17.0;
+  p = p * z - 1.0 / 15.0;
+  p = p * z + 1.0 / 13.0;
+  p = p * z - 1.0 / 11.0;
+  p = p * z + 1.0 / 9.0;
+  p = p * z - 1.0 / 7.0;
+  p = p * z + 1.0 / 5.0;
+  p = p * z - 1.0 / 3.0;
+  return t + t * z * p;
+}
+
 // =============================================================================================
 // Epilogue: line flows (power_flow.py:340-356), losses (:198-200), wrapped angles, scalars; with
 // ENV also everything of step() that follows the load flow (grid_env.py:553-617).
@@ -1008,7 +1027,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
       } else {                                                // sweeps work on (e, f): polar form here, once
         const double e = xa[u], f = xb[u];
         v = sqrt(e * e + f * f);
-        ROW2(R.VM + i) = make_double2(v, atan2(f, e));
+        ROW2(R.VM + i) = make_double2(v, bus_angle(f, e));
       }
       if (ENV) {                                              // reward / flags, grid_env.py:790-792, base.py:156-159
         dev += fabs(v - 1.0);
@@ -1274,7 +1293,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
       for (int u = 0; u < 4; ++u) {
         const int k = min(k0 + u, k1 - 1);
         lp0[u] = ROW(R.LOADP + (recs[k].nl > 0 ? recs[k].l0 : 0));
-        lp1[u] = ROW(R.LOADP + (recs[k].nl > 1 ? recs[k].l1 : 0));
+        lp1[u] = recs[k].nl > 1 ? (double)ROW(R.LOADP + recs[k].l1) : 0.0;      // rare: most buses carry one load
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
