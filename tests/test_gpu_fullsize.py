@@ -1,0 +1,119 @@
+"""BASELINE.json's configurations at FULL size, checked through properties that do not need a CPU solve of the
+whole batch: the power-flow equations re-evaluated with the oracle's Ybus on the device's answer, the loss
+identity, the observation layout, independence of an instance's result from the batch it runs in (the property
+the multi-GPU sharding rests on), and monotonicity in the loading.  Complements the oracle-parity tests, which run
+at sizes the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+import grid_fed_rl_gym_amd as P
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_solution_against_power_flow_equations(spec, sol, P_spec, tol):
+    """S = V conj(Y V) with the oracle's Ybus (pinned by fixture G1/G2) for every instance at once."""
+    Y = O.admittance_matrix(spec.n, spec.frm, spec.to, spec.r, spec.x, "open")
+    V = sol["bus_voltages"] * np.exp(1j * sol["bus_angles"])
+    S = V * np.conj(V @ Y.T)
+    slack, pv, pq = O.classify(spec.bus_type)
+    ns = [i for i in range(spec.n) if i != slack]
+    dP = np.abs(P_spec[:, ns] - S.real[:, ns]).max(axis=1)
+    dQ = np.abs(S.imag[:, pq]).max(axis=1) if len(pq) else np.zeros(len(V))
+    conv = sol["converged"].astype(bool)
+    assert conv.all()
+    assert (np.maximum(dP, dQ)[conv] < 10 * tol).all()                     # the solver stopped at max mismatch < tol
+    np.testing.assert_allclose(sol["losses"], S.real.sum(axis=1), rtol=0, atol=1e-9)       # power_flow.py:198-200
+    assert (sol["losses"] > 0).all()
+    return dP
+
+
+@pytest.mark.parametrize("maker,B,solver", [(lambda: P.ieee123_like(), 8192, "fbs"),       # BASELINE config 3 (headline)
+                                             (lambda: P.ieee13_like("epsilon"), 4096, "nr")])   # config 2
+def test_full_size_environment_step_properties(maker, B, solver):
+    spec = maker()
+    kw = dict(solver=solver, stochastic_loads=True, weather_variation=True, jacobian="exact")
+    env = P.BatchedGridEnvironment(spec, num_envs=B, **kw)
+    seeds = np.arange(B, dtype=np.uint64) * 7919 + 5
+    env.reset(seed=seeds)
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, (3, B, spec.action_dim))
+    for t in range(3):
+        obs, rew, term, trunc, info = env.step(acts[t])
+    assert info["power_flow_converged"].all() and np.isfinite(obs).all() and np.isfinite(rew).all()
+    sol = env.last_solution()
+    # the injections the step solved for, rebuilt from the state: P_spec = what the solution's mismatch refers to
+    V = sol["bus_voltages"] * np.exp(1j * sol["bus_angles"])
+    Y = O.admittance_matrix(spec.n, spec.frm, spec.to, spec.r, spec.x, "open")
+    S = V * np.conj(V @ Y.T)
+    np.testing.assert_allclose(sol["losses"], S.real.sum(axis=1), rtol=0, atol=1e-9)
+    assert (sol["max_mismatch"] < 1e-6).all() and (sol["losses"] > 0).all()
+    # observation layout (grid_env.py:753-783): [Vm_i, Va_i] per bus, then [flow_k, |flow_k| / rating] per line, frequency
+    np.testing.assert_array_equal(obs[:, 0:2 * spec.n:2], sol["bus_voltages"])
+    np.testing.assert_array_equal(obs[:, 1:2 * spec.n:2], sol["bus_angles"])
+    np.testing.assert_array_equal(obs[:, 2 * spec.n:2 * spec.n + 2 * spec.m:2], sol["line_flows"])
+    st = env.get_state(); lay = env.state_layout()
+    np.testing.assert_array_equal(obs[:, 2 * spec.n + 2 * spec.m], st[:, lay["frequency"]])
+    # an instance's trajectory does not depend on the batch around it: one of them alone, and the last shard of a 32-way split
+    # the counter-based generator is keyed by the GLOBAL instance number (first_instance), the seeds travel with it
+    pick = np.sort(rng.choice(B, 64, replace=False))
+    for first in (int(pick[0]),):
+        one = P.BatchedGridEnvironment(spec, num_envs=1, first_instance=first, **kw)
+        one.reset(seed=seeds[first:first + 1])
+        for t in range(3):
+            o1, r1, *_ = one.step(acts[t, first:first + 1])
+        np.testing.assert_array_equal(o1[0], obs[first])
+        np.testing.assert_array_equal(r1[0], rew[first])
+        one.close()
+    blk = P.BatchedGridEnvironment(spec, num_envs=256, first_instance=B - 256, **kw)       # the last shard of a 32-way split
+    blk.reset(seed=seeds[B - 256:])
+    for t in range(3):
+        ob, rb, *_ = blk.step(acts[t, B - 256:])
+    np.testing.assert_array_equal(ob, obs[B - 256:])
+    np.testing.assert_array_equal(rb, rew[B - 256:])
+    blk.close(); env.close()
+
+
+def test_full_size_newton_raphson_batch_satisfies_the_power_flow_equations():
+    spec = P.ieee123_like(); B = 8192
+    rng = np.random.default_rng(3)
+    base = np.zeros(spec.n)
+    np.add.at(base, spec.load_bus, -spec.load_base / spec.base_power_va)
+    lam = rng.uniform(0.5, 1.5, B)
+    Pb = lam[:, None] * base[None, :]
+    for solver in (P.BatchedNewtonRaphsonSolver(tolerance=1e-8, max_iterations=30, jacobian="exact"),
+                   P.BatchedForwardBackwardSweepSolver(tolerance=1e-8, max_iterations=100)):
+        sol = solver.solve_batch(spec, Pb)
+        d = dict(bus_voltages=sol.bus_voltages, bus_angles=sol.bus_angles, converged=sol.converged, losses=sol.losses)
+        _check_solution_against_power_flow_equations(spec, d, Pb, 1e-8)
+        # heavier loading -> lower minimum voltage and higher losses, instance by instance
+        order = np.argsort(lam)
+        assert (np.diff(sol.bus_voltages.min(axis=1)[order]) <= 1e-12).all()
+        assert (np.diff(sol.losses[order]) >= -1e-12).all()
+        solver.close()
+
+
+def test_full_size_three_phase_batch_properties():
+    """BASELINE config 5: 8500 nodes, three-phase, B = 1024."""
+    from grid_fed_rl_gym_amd.unbalanced import UnbalancedPowerFlow, ieee8500_like
+    from oracle import oracle3_np as O3
+    spec, Pn, Qn = ieee8500_like()
+    B = 1024
+    lam = np.random.default_rng(1234).uniform(0.5, 1.5, B)
+    s = UnbalancedPowerFlow(tolerance=1e-6, max_iterations=100)
+    sol = s.solve_batch(spec, lam[:, None, None] * Pn[None], lam[:, None, None] * Qn[None])
+    assert sol.converged.all() and sol.iterations.min() >= 3 and sol.iterations.max() <= 6
+    vmag = np.abs(sol.voltages)
+    present = vmag[0] > 0
+    assert (vmag[:, ~present] == 0).all()                                  # absent phases stay exactly zero
+    vmin = np.where(present[None], vmag, np.inf).min(axis=(1, 2))
+    order = np.argsort(lam)
+    assert (np.diff(vmin[order]) <= 1e-9).all() and (np.diff(sol.losses[order]) >= -1e-9).all()     # monotone in the loading
+    for b in (0, 511, 1023):                                               # the unbalanced power-flow equations, independent assembly
+        res, _ = O3.residual(spec.parent, spec.phases, spec.z, 0, sol.voltages[b], lam[b] * Pn, lam[b] * Qn)
+        assert res < 5e-6
+    # the same instances in a different batch give the same answer bit for bit
+    sub = s.solve_batch(spec, lam[100:164, None, None] * Pn[None], lam[100:164, None, None] * Qn[None])
+    np.testing.assert_array_equal(sub.voltages, sol.voltages[100:164])
+    s.close()
