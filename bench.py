@@ -313,6 +313,9 @@ def main():
                 "sample": f"{b} instances x 3 steps of the workload", "gpu_tolerance": kw["tolerance"]}
 
     main_m = measure(args.solver, want_gather)
+    # N > 1: the same steps again without the observation exchange, so that the line shows what the all-gather costs
+    # (it is bound by xGMI, not by the step: see DESIGN.md section 6)
+    nogather_m = measure(args.solver, False) if want_gather else None
     other = None
     if world == 1 and not args.no_secondary:
         other = measure("nr" if args.solver == "fbs" else "fbs", False)
@@ -362,6 +365,15 @@ def main():
         }
         if "post_step_checks" in main_m:
             result["post_step_checks"] = main_m["post_step_checks"]
+        if nogather_m is not None:
+            ng_sps, _ = summarize(nogather_m)
+            ms_with, ms_without = 1e3 * main_m["elapsed"] / args.steps, 1e3 * nogather_m["elapsed"] / args.steps
+            obs_bytes = B * fs.obs_dim * 8
+            result["obs_allgather"] = {
+                "ms_per_step": ms_with - ms_without, "bytes_sent_per_rank_per_step": obs_bytes,
+                "bytes_received_per_rank_per_step": (world - 1) * obs_bytes,
+                "algbw_GB_per_s": world * obs_bytes / max(ms_with - ms_without, 1e-9) / 1e6,
+                "without_it": {"value": ng_sps, "unit": "env_steps/s", "ms_per_step": ms_without}}
         if other is not None:
             o_sps, o_ms = summarize(other)
             result["also"] = {"solver": other["solver"], "kernel": "gs_k_step_" + kernel_names[other["desc"]["kernel"]],

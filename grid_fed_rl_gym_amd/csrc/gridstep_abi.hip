@@ -82,7 +82,10 @@ struct gs_handle {
   double* slab = nullptr;
   double* d_in = nullptr; size_t in_doubles = 0;
   double* d_out = nullptr; size_t out_doubles = 0;
-  double* d_obs = nullptr;            // [B][obs_dim], owned by the environment path: written whole at reset, its changing columns by every step
+  // [B][obs_dim] x 2, owned by the environment path: both written whole at reset, the changing columns of the other one by
+  // every step -- so that the all-gather of step k (on its own stream) can run while step k + 1 computes
+  double* d_obs2[2] = {nullptr, nullptr}; int obs_cur = 0;
+  hipStream_t comm_stream = nullptr; hipEvent_t ev_step = nullptr, ev_gather[2] = {nullptr, nullptr}; bool gather_pending[2] = {false, false};
   int obs_skip0 = 0, obs_skip1 = 0;   // the block of per-instance constants inside an observation
   double* d_actions = nullptr; int n_action_batches = 0;
   double* d_cst = nullptr;
@@ -227,7 +230,10 @@ int step_kernels(gs_handle* h, const double* d_actions) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
     dim3 grid(h->groups), block(64 * h->W);
-    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 40960) / (64 * 65 * sizeof(double)))), 0, 0,
+    const int next = h->obs_cur ^ 1;
+    if (h->gather_pending[next]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[next], 0)); h->gather_pending[next] = false; }
+    h->obs_cur = next;
+    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs2[next], h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 40960) / (64 * 65 * sizeof(double)))), 0, 0,
                   h->obs_skip0, h->obs_skip1};
     pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
@@ -578,7 +584,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   const size_t widest = std::max<size_t>({(size_t)h->obs_dim, (size_t)h->state_dim, (size_t)n, (size_t)m, (size_t)h->action_dim, 1});
   h->in_doubles = (size_t)h->B * widest; h->out_doubles = (size_t)h->B * widest;
   if ((rc = dev_alloc(h, &h->d_in, h->in_doubles)) || (rc = dev_alloc(h, &h->d_out, h->out_doubles)) ||
-      (rc = dev_alloc(h, &h->d_obs, (size_t)h->Bp * h->obs_dim))) return bail(rc);
+      (rc = dev_alloc(h, &h->d_obs2[0], (size_t)h->Bp * h->obs_dim)) || (rc = dev_alloc(h, &h->d_obs2[1], (size_t)h->Bp * h->obs_dim))) return bail(rc);
   if ((rc = dev_alloc(h, &h->sc_f, (size_t)SF_COUNT * h->Bp)) || (rc = dev_alloc(h, &h->sc_i, (size_t)SI_COUNT * h->Bp)) ||
       (rc = dev_alloc(h, &h->sc_u, (size_t)SU_COUNT * h->Bp)) || (rc = dev_alloc(h, &h->d_seeds, (size_t)h->B)) ||
       (rc = dev_alloc(h, &h->d_mask, (size_t)h->B)))
@@ -593,7 +599,11 @@ void gs_destroy(gs_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  if (h->ev_step) (void)hipEventDestroy(h->ev_step);
+  for (int k = 0; k < 2; ++k) if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   for (auto& t : h->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->d_actions) (void)hipFree(h->d_actions);
@@ -627,6 +637,7 @@ int gs_synchronize(gs_handle* h) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   return GS_OK;
 }
 
@@ -689,9 +700,12 @@ int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* o
                      seeds ? h->d_seeds : (const uint64_t*)nullptr, mask ? h->d_mask : (const uint8_t*)nullptr);
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;
-  int rc = launch_pack(h, h->map_obs, h->obs_dim, h->d_obs);       // every column, the constants included
+  if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));       // no gather may still be reading an observation buffer
+  h->gather_pending[0] = h->gather_pending[1] = false; h->obs_cur = 0;
+  int rc = launch_pack(h, h->map_obs, h->obs_dim, h->d_obs2[0]);   // every column, the constants included
   if (rc) return rc;
-  if (obs_out) HIPCHK(h, hipMemcpyAsync(obs_out, h->d_obs, (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_obs2[1], h->d_obs2[0], (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (obs_out) HIPCHK(h, hipMemcpyAsync(obs_out, h->d_obs2[0], (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return GS_OK;
 }
@@ -701,7 +715,7 @@ int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* termina
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   HIPCHK(h, hipSetDevice(h->device));
   if (obs) {
-    HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(obs, h->d_obs2[h->obs_cur], (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
   int rc = fetch_scalars(h);
   if (rc) return rc;
@@ -779,6 +793,11 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
   if (rc != 0) return fail(h, GS_E_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
   h->rank = rank; h->world = world_size;
   HIPCHK(h, hipMalloc((void**)&h->d_obs_full, (size_t)world_size * h->B * h->obs_dim * sizeof(double)));
+  if (!h->comm_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather[k], hipEventDisableTiming));
+  }
   return GS_OK;
 }
 
@@ -787,17 +806,26 @@ int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   if (!h->comm) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t count = (size_t)h->B * h->obs_dim;
-  int rc = g_rccl.AllGather(h->d_obs, h->d_obs_full, count, /*ncclFloat64*/ 8, h->comm, h->stream);
+  // on its own stream, behind the step that produced the current observation buffer; the step after the next one
+  // (which reuses that buffer) waits for ev_gather -- so a gather overlaps exactly one step
+  const int cur = h->obs_cur;
+  HIPCHK(h, hipEventRecord(h->ev_step, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step, 0));
+  int rc = g_rccl.AllGather(h->d_obs2[cur], h->d_obs_full, count, /*ncclFloat64*/ 8, h->comm, h->comm_stream);
   if (rc != 0) return fail(h, GS_E_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+  HIPCHK(h, hipEventRecord(h->ev_gather[cur], h->comm_stream));
+  h->gather_pending[cur] = true;
   if (obs_full_host) {
-    HIPCHK(h, hipMemcpyAsync(obs_full_host, h->d_obs_full, count * h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(obs_full_host, h->d_obs_full, count * h->world * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   }
   return GS_OK;
 }
 
 int gs_comm_destroy(gs_handle* h) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  h->gather_pending[0] = h->gather_pending[1] = false;
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   if (h->d_obs_full) { (void)hipFree(h->d_obs_full); h->d_obs_full = nullptr; }
   return GS_OK;
