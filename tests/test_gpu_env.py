@@ -201,3 +201,22 @@ def test_handles_with_different_lds_footprints_coexist():
     o2 = big.step(np.zeros((4, big.action_dim)))[0]
     assert np.array_equal(o1, o2)
     big.close(); small.close()
+
+
+@pytest.mark.parametrize("solver", ["nr", "fbs"])
+def test_repeated_steps_never_lose_a_cross_wave_write(solver):
+    """Stress for memory-ordering slips between the waves of a group (a flat start or an injection written by one wave
+    and read by another a barrier later): an instance whose first Newton iteration sees stale rows reports SINGULAR /
+    stays at the flat start, which this catches within a few dozen launches."""
+    fs = P.ieee123_like(); B = 66
+    rng = np.random.default_rng(5678)
+    actions = rng.uniform(-1, 1, (3, B, fs.action_dim))
+    for rep in range(25):
+        env = P.BatchedGridEnvironment(fs, num_envs=B, stochastic_loads=False, weather_variation=False, solver=solver,
+                                       jacobian="exact", tolerance=1e-9, max_iterations=100)
+        env.reset(seed=np.arange(B, dtype=np.uint64))
+        for t in range(3):
+            obs, rew, term, trunc, info = env.step(actions[t])
+            assert info["power_flow_converged"].all(), (rep, t, np.unique(info["status"]))
+            assert not ((obs[:, 2] == 1.0) & (obs[:, 3] == 0.0)).any(), (rep, t)      # bus 1 never sits at 1.0 / 0 under load
+        env.close()
