@@ -47,7 +47,7 @@ class gs_config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("solver_kind", C.c_int32), ("jacobian_mode", C.c_int32),
                 ("zero_z_mode", C.c_int32), ("linear_solver", C.c_int32), ("max_iterations", C.c_int32),
                 ("episode_length", C.c_int32), ("stochastic_loads", C.c_int32), ("weather_variation", C.c_int32),
-                ("waves_per_group", C.c_int32), ("reserved0", C.c_int32),
+                ("waves_per_group", C.c_int32), ("fbs_warm_start", C.c_int32),
                 ("tolerance", C.c_double), ("acceleration_factor", C.c_double), ("timestep", C.c_double),
                 ("v_min", C.c_double), ("v_max", C.c_double), ("f_min", C.c_double), ("f_max", C.c_double),
                 ("safety_penalty", C.c_double), ("inertia_H", C.c_double), ("damping_D", C.c_double),
@@ -140,7 +140,7 @@ def make_config(**kw) -> gs_config:
     cfg = gs_config()
     cfg.struct_size = C.sizeof(gs_config)
     d = dict(solver_kind=0, jacobian_mode=0, zero_z_mode=0, linear_solver=0, max_iterations=50,
-             episode_length=86400, stochastic_loads=0, weather_variation=0, waves_per_group=0, reserved0=0,
+             episode_length=86400, stochastic_loads=0, weather_variation=0, waves_per_group=0, fbs_warm_start=0,
              tolerance=1e-6, acceleration_factor=1.0, timestep=1.0, v_min=0.95, v_max=1.05, f_min=59.5,
              f_max=60.5, safety_penalty=100.0, inertia_H=5.0, damping_D=1.0, f_nominal=60.0, power_base=1.0)
     for k, v in kw.items():

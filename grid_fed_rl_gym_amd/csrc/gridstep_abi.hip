@@ -525,7 +525,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   GsEnvCfg& E = h->EC;
   E.timestep = cfg->timestep; E.v_min = cfg->v_min; E.v_max = cfg->v_max; E.f_min = cfg->f_min; E.f_max = cfg->f_max;
   E.safety_penalty = cfg->safety_penalty; E.H = cfg->inertia_H; E.D = cfg->damping_D; E.f0 = cfg->f_nominal;
-  E.power_base = cfg->power_base; E.episode_length = cfg->episode_length; E.stochastic_loads = cfg->stochastic_loads;
+  E.power_base = cfg->power_base; E.episode_length = cfg->episode_length; E.stochastic_loads = cfg->stochastic_loads; E.fbs_warm_start = cfg->fbs_warm_start;
   E.weather_variation = cfg->weather_variation; E.first_instance = first_instance;
   // sum(load.active_power) in list order, starting from 0 like python's sum() (grid_env.py:744)
   h->total_load = 0.0;
@@ -767,6 +767,9 @@ int gs_set_state(gs_handle* h, const double* state) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = unpack_from_host(h, h->map_state, h->state_dim, state);
   if (rc) return rc;
+  // the rectangular voltages follow the checkpointed polar ones (what a warm-started sweep solver resumes from)
+  hipLaunchKernelGGL(gs_k_polar_to_rect, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->slab, h->B);
+  HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->was_reset = true;
   return GS_OK;

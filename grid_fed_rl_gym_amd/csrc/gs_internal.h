@@ -267,7 +267,7 @@ struct GsSolveCfg {
 
 struct GsEnvCfg {
   double timestep, v_min, v_max, f_min, f_max, safety_penalty, H, D, f0, power_base;
-  int32_t episode_length, stochastic_loads, weather_variation, pad;
+  int32_t episode_length, stochastic_loads, weather_variation, fbs_warm_start;
   int64_t first_instance;
 };
 

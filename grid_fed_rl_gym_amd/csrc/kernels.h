@@ -18,6 +18,7 @@ GS_DECLARE_KERNELS(fbs)
 GS_DECLARE_KERNELS(fbs_lds)
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);
+__global__ void gs_k_polar_to_rect(GsTables T, GsRows R, double* __restrict__ slab, int B);
 __global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C, int rows_total,
                           const double* __restrict__ slab, double* __restrict__ out, int B);
 __global__ void gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,

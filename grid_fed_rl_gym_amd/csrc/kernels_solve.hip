@@ -1300,7 +1300,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         const int k = k0 + u;
         if (k >= k1) break;
         const int i = recs[k].bus;
-        if (FLAT_FBS) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
+        if (FLAT_FBS && !E.fbs_warm_start) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
         if (recs[k].generic) { bus_injection(T, R, E, S, i); continue; }
         // same accumulation order as bus_injection: loads, then generators, then batteries
         double ls = 0.0, gs = 0.0;

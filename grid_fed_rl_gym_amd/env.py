@@ -65,7 +65,7 @@ class BatchedGridEnvironment:
                  safety_penalty: float = 100.0, *, solver: str = "nr", jacobian: str = "exact", zero_z: str = "open",
                  tolerance: float = 1e-6, max_iterations: int = 50, acceleration_factor: float = 1.0,
                  linear_solver: str = "auto", power_base: Optional[float] = None, device: int = 0,
-                 first_instance: int = 0, waves_per_group: int = 0, **kwargs: Any) -> None:
+                 first_instance: int = 0, waves_per_group: int = 0, warm_start: bool = False, **kwargs: Any) -> None:
         spec = feeder if isinstance(feeder, FeederSpec) else flatten_feeder(feeder)
         if renewable_sources is not None:
             keep = [g for g in range(spec.n_gens)
@@ -102,7 +102,7 @@ class BatchedGridEnvironment:
                                timestep=self.timestep, v_min=float(voltage_limits[0]), v_max=float(voltage_limits[1]),
                                f_min=float(frequency_limits[0]), f_max=float(frequency_limits[1]),
                                safety_penalty=self.safety_penalty, power_base=self.power_base,
-                               waves_per_group=int(waves_per_group))
+                               waves_per_group=int(waves_per_group), fbs_warm_start=int(bool(warm_start) and solver == "fbs"))
         self._h = _lib.Handle(spec, cfg, self.num_envs, device, first_instance)
         self.obs_dim, self.action_dim, self.state_dim = self._h.obs_dim, self._h.action_dim, self._h.state_dim
         big = np.finfo(np.float64).max

@@ -97,7 +97,9 @@ typedef struct gs_config {
   int32_t stochastic_loads;       /* grid_env.py:166 (Philox stream) */
   int32_t weather_variation;      /* grid_env.py:168 */
   int32_t waves_per_group;        /* 0 = auto; 1,2,4,8,16: waves cooperating on one 64-instance group */
-  int32_t reserved0;
+  int32_t fbs_warm_start;         /* 0 (default): every step solves from the flat start, as the reference's solve() does
+                                     (power_flow.py:125-134); 1: the sweep solver starts from the previous step's voltages --
+                                     same tolerance, fewer sweeps; an option, never the measured headline */
   double tolerance;               /* power_flow.py:81 (default 1e-6) */
   double acceleration_factor;     /* power_flow.py:83 (default 1.0) */
   double timestep;                /* grid_env.py:164 */

@@ -220,3 +220,39 @@ def test_repeated_steps_never_lose_a_cross_wave_write(solver):
             assert info["power_flow_converged"].all(), (rep, t, np.unique(info["status"]))
             assert not ((obs[:, 2] == 1.0) & (obs[:, 3] == 0.0)).any(), (rep, t)      # bus 1 never sits at 1.0 / 0 under load
         env.close()
+
+
+def test_warm_started_sweep_solver_agrees_with_the_cold_start():
+    """`warm_start=True` (option): the sweep solver resumes from the previous step's voltages.  Same tolerance, so the
+    trajectories agree to the solver tolerance; slightly fewer sweeps; checkpoints still resume (set_state rebuilds e, f)."""
+    fs = P.ieee123_like(); B = 96
+    kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True, tolerance=1e-9, max_iterations=100)
+    cold, warm = P.BatchedGridEnvironment(fs, **kw), P.BatchedGridEnvironment(fs, warm_start=True, **kw)
+    seeds = np.arange(B, dtype=np.uint64) + 17
+    cold.reset(seed=seeds); warm.reset(seed=seeds)
+    rng = np.random.default_rng(4)
+    its_c = its_w = 0
+    for t in range(6):
+        a = rng.uniform(-1, 1, (B, fs.action_dim))
+        oc, rc, *_, ic = cold.step(a)
+        ow, rw, *_, iw = warm.step(a)
+        assert ic["power_flow_converged"].all() and iw["power_flow_converged"].all()
+        assert np.max(np.abs(oc - ow) / np.maximum(1.0, np.abs(oc))) < 1e-7
+        its_c += ic["iterations"].sum(); its_w += iw["iterations"].sum()
+        if t == 0:
+            assert np.max(np.abs(oc - ow)) < 1e-15                 # the first step after reset starts flat either way
+        if t == 2:
+            snap = warm.get_state()
+    assert its_w < its_c                    # independent 10 % load noise every step leaves little to resume from: ~0.4 sweeps
+    resumed = P.BatchedGridEnvironment(fs, warm_start=True, **kw)
+    resumed.reset(seed=seeds); resumed.set_state(snap)
+    rng2 = np.random.default_rng(4)
+    for t in range(3): rng2.uniform(-1, 1, (B, fs.action_dim))
+    a3 = rng2.uniform(-1, 1, (B, fs.action_dim))
+    orr, *_ = resumed.step(a3)
+    w2 = P.BatchedGridEnvironment(fs, warm_start=True, **kw); w2.reset(seed=seeds)
+    rng3 = np.random.default_rng(4)
+    for t in range(4):
+        o4, *_ = w2.step(rng3.uniform(-1, 1, (B, fs.action_dim)))
+    assert np.max(np.abs(orr - o4) / np.maximum(1.0, np.abs(o4))) < 1e-7
+    for e in (cold, warm, resumed, w2): e.close()
