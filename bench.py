@@ -278,6 +278,20 @@ def main():
                 byts = B * ((fs.n + 3 * fs.m + 5) + fs.n) * 8 + B * (fs.n + fs.m)      # rows read, previous voltages written, masks written
                 m["post_step_checks"] = {"kernel": "gs_k_checks", "avg_launch_us": 1e3 * ms / max(cnt, 1), "bytes_per_launch": byts,
                                          "GB_per_s": byts / (ms / max(cnt, 1) * 1e-3) / 1e9 if ms > 0 else None}
+                # the same checks fused into the step kernel's epilogue (gs_checks_set_fused): cost = step time with - without
+                def loop(nsteps):
+                    for k in range(5):
+                        h.step_device(k % n_act)
+                    h.synchronize(); t1 = time.perf_counter()
+                    for k in range(nsteps):
+                        h.step_device(k % n_act)
+                    h.synchronize()
+                    return 1e6 * (time.perf_counter() - t1) / nsteps
+                plain_us = loop(30)
+                ck.set_fused(True)
+                fused_us = loop(30)
+                ck.set_fused(False)
+                m["post_step_checks"]["fused_into_step_us"] = fused_us - plain_us
                 ck.close()
             except Exception as e:                                 # never let the side measurement break the bench line
                 m["post_step_checks"] = {"error": str(e)}

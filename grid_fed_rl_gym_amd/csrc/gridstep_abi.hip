@@ -74,6 +74,7 @@ struct gs_handle {
   GsSolveCfg SC{};
   GsEnvCfg EC{};
   double total_load = 0.0;
+  struct gs_checks* fused = nullptr;      // checks evaluated inside the step kernel's epilogue (gs_checks_set_fused)
   int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs, 3 dense, 4 tree with LDS messages
   size_t dyn_lds = 0;
   unsigned long long* d_stamps = nullptr;
@@ -226,6 +227,8 @@ int launch_solve(gs_handle* h) {
   return GS_OK;
 }
 
+GsFusedChecks fused_checks_args(gs_handle* h);      // defined with gs_checks below
+
 int step_kernels(gs_handle* h, const double* d_actions) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
@@ -233,17 +236,27 @@ int step_kernels(gs_handle* h, const double* d_actions) {
     const int next = h->obs_cur ^ 1;
     if (h->gather_pending[next]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[next], 0)); h->gather_pending[next] = false; }
     h->obs_cur = next;
-    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs2[next], h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 40960) / (64 * 65 * sizeof(double)))), 0, 0,
+    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs2[next], h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 49152) / (64 * 65 * sizeof(double)))), 0, 0,
                   h->obs_skip0, h->obs_skip1};
     pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
-#define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa)
-    if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
-    else if (h->solve_kernel == 4) GS_STEP(gs_k_step_nr_tree_lds);
-    else if (h->solve_kernel == 1) GS_STEP(gs_k_step_nr_lu);
-    else if (h->solve_kernel == 3) GS_STEP(gs_k_step_nr_dense);
-    else if (h->solve_kernel == 5) GS_STEP(gs_k_step_fbs_lds);
-    else GS_STEP(gs_k_step_fbs);
+    const GsFusedChecks fc = fused_checks_args(h);
+#define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc)
+    if (fc.enabled) {
+      if (h->solve_kernel == 0) GS_STEP(gs_k_stepc_nr_tree);
+      else if (h->solve_kernel == 4) GS_STEP(gs_k_stepc_nr_tree_lds);
+      else if (h->solve_kernel == 1) GS_STEP(gs_k_stepc_nr_lu);
+      else if (h->solve_kernel == 3) GS_STEP(gs_k_stepc_nr_dense);
+      else if (h->solve_kernel == 5) GS_STEP(gs_k_stepc_fbs_lds);
+      else GS_STEP(gs_k_stepc_fbs);
+    } else {
+      if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
+      else if (h->solve_kernel == 4) GS_STEP(gs_k_step_nr_tree_lds);
+      else if (h->solve_kernel == 1) GS_STEP(gs_k_step_nr_lu);
+      else if (h->solve_kernel == 3) GS_STEP(gs_k_step_nr_dense);
+      else if (h->solve_kernel == 5) GS_STEP(gs_k_step_fbs_lds);
+      else GS_STEP(gs_k_step_fbs);
+    }
 #undef GS_STEP
     HIPCHK(h, hipGetLastError()); }
   return GS_OK;     // the observation block was written by the step kernel itself
@@ -329,8 +342,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     if (h->solve_kernel == 0 && msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) h->solve_kernel = 4;
     if (h->solve_kernel == 4) h->dyn_lds = msg_bytes;
   } else { int rc = fail(nullptr, GS_E_INVALID, "unknown solver_kind %d", cfg->solver_kind); delete h; return rc; }
-  // the epilogue's cross-wave partials need 40 KB; the observation pack stages two or three 64-column tiles behind them
-  h->dyn_lds = std::max<size_t>(40960 + 2 * 64 * 65 * sizeof(double), h->dyn_lds);
+  // the epilogue's cross-wave partials need 48 KB; the observation pack stages two or three 64-column tiles behind them
+  h->dyn_lds = std::max<size_t>(49152 + 2 * 64 * 65 * sizeof(double), h->dyn_lds);
 
   h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
   h->n = ht.n; h->m = ht.m; h->n_loads = topo->n_loads; h->n_gens = topo->n_gens; h->n_bats = topo->n_bats;
@@ -352,7 +365,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const void* fns[] = {(const void*)gs_k_nr_tree, (const void*)gs_k_step_nr_tree, (const void*)gs_k_nr_tree_lds,
                          (const void*)gs_k_step_nr_tree_lds, (const void*)gs_k_nr_lu, (const void*)gs_k_step_nr_lu,
                          (const void*)gs_k_nr_dense, (const void*)gs_k_step_nr_dense, (const void*)gs_k_fbs,
-                         (const void*)gs_k_step_fbs, (const void*)gs_k_fbs_lds, (const void*)gs_k_step_fbs_lds};
+                         (const void*)gs_k_step_fbs, (const void*)gs_k_fbs_lds, (const void*)gs_k_step_fbs_lds,
+                         (const void*)gs_k_stepc_nr_tree, (const void*)gs_k_stepc_nr_tree_lds, (const void*)gs_k_stepc_nr_lu,
+                         (const void*)gs_k_stepc_nr_dense, (const void*)gs_k_stepc_fbs, (const void*)gs_k_stepc_fbs_lds};
     // the attribute is per function, i.e. shared by every handle of the process: always raise it to
     // the most any handle may ask for (160 KB per workgroup minus the 24 KB static block)
     const int max_dyn = 160 * 1024 - 24576;
@@ -907,9 +922,36 @@ struct gs_checks {
   gs_handle* h = nullptr;
   GsChecksCfg C{};
   double* prev = nullptr; int32_t* state = nullptr; int32_t* out_i = nullptr; double* out_f = nullptr;
-  uint8_t *bus_mask = nullptr, *line_mask = nullptr; double* freq = nullptr; bool use_freq = false;
+  uint8_t *bus_mask = nullptr, *line_mask = nullptr; double* freq = nullptr; bool use_freq = false, want_masks = true;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0;
 };
+
+}  // extern "C"  (helpers below have C++ linkage)
+namespace {
+GsFusedChecks fused_checks_args(gs_handle* h) {
+  GsFusedChecks f{};
+  if (h->fused) {
+    gs_checks* c = h->fused;
+    f.C = c->C; f.prev = c->prev; f.state = c->state; f.out_i = c->out_i; f.out_f = c->out_f;
+    f.bus_mask = c->want_masks ? c->bus_mask : nullptr; f.line_mask = c->want_masks ? c->line_mask : nullptr;
+    f.enabled = 1; f.Bp = h->Bp;
+  }
+  return f;
+}
+}  // namespace
+extern "C" {
+
+int gs_checks_set_fused(gs_checks* c, int32_t on, int32_t want_masks) {
+  if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
+  gs_handle* h = c->h;
+  if (on && (h->n >= 65536 || h->m >= 65536)) return fail(h, GS_E_INVALID, "fused checks count in 16 bits: fewer than 65536 buses and lines");
+  if (on && h->fused && h->fused != c) return fail(h, GS_E_STATE, "another checks object is already fused into this handle's step");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  c->want_masks = want_masks != 0;
+  if (on) h->fused = c; else if (h->fused == c) h->fused = nullptr;
+  return GS_OK;
+}
 
 int gs_checks_create(gs_handle* h, const gs_checks_config* cfg, gs_checks** out) {
   if (!h || !cfg || !out) return fail(h, GS_E_INVALID, "handle / config / out is NULL");
@@ -949,6 +991,7 @@ int gs_checks_create(gs_handle* h, const gs_checks_config* cfg, gs_checks** out)
 
 void gs_checks_destroy(gs_checks* c) {
   if (!c) return;
+  if (c->h->fused == c) c->h->fused = nullptr;
   (void)hipSetDevice(c->h->device);
   (void)hipStreamSynchronize(c->h->stream);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

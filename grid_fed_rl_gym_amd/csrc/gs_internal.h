@@ -280,3 +280,12 @@ struct GsChecksCfg {
   int32_t row_vm, row_cload, row_qload, row_flow, row_freq, row_conv, row_iters, row_maxmis;   // row_vm, row_flow: stride 2
   int32_t stride_cload;
 };
+
+// The same checks evaluated inside the step kernel's epilogue (gs_checks_set_fused): its bus and line loops already
+// hold every value, so the safety checks of a step cost a few comparisons instead of a launch that re-reads the state.
+struct GsFusedChecks {
+  GsChecksCfg C;             // thresholds; stride_cload == 2: the environment's |P| / rating is what the limits apply to
+  double* prev; int32_t* state; int32_t* out_i; double* out_f; uint8_t* bus_mask; uint8_t* line_mask;
+  int32_t enabled, Bp;
+};
+

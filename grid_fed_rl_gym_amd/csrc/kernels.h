@@ -7,7 +7,11 @@
 #define GS_DECLARE_KERNELS(name)                                                                               \
   __global__ void gs_k_##name(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);           \
   __global__ void gs_k_step_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab,  \
-                                   int B, const double* __restrict__ actions, double total_load, GsPackArgs PA);
+                                   int B, const double* __restrict__ actions, double total_load, GsPackArgs PA,        \
+                                   GsFusedChecks FC);                                                          \
+  __global__ void gs_k_stepc_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, \
+                                    int B, const double* __restrict__ actions, double total_load, GsPackArgs PA,       \
+                                    GsFusedChecks FC);
 
 extern "C" {
 GS_DECLARE_KERNELS(nr_tree)

@@ -48,8 +48,8 @@ struct GsShared {
 // epilogue it is reused for the cross-wave partial results.
 extern __shared__ __attribute__((aligned(16))) double gs_dyn[];
 #define GS_MSG_DOUBLES 6
-#define GS_EPI_DOUBLES (4 * GS_MAX_WAVES * GS_LANES)   /* post[4][W][64] doubles, then posti[2][W][64] ints */
-#define GS_PACK_LDS_DOUBLES (GS_EPI_DOUBLES + GS_MAX_WAVES * GS_LANES)   /* the pack tiles start after both (40 KB) */
+#define GS_EPI_DOUBLES (4 * GS_MAX_WAVES * GS_LANES)   /* post[4][W][64] doubles, then posti[4][W][64] ints */
+#define GS_PACK_LDS_DOUBLES (GS_EPI_DOUBLES + 2 * GS_MAX_WAVES * GS_LANES)   /* the pack tiles start after post[4] and posti[4] (48 KB) */
 
 // Barrier for waves that exchanged data through LDS only: wait for this wave's LDS traffic, then
 // rendezvous.  Unlike __syncthreads() it does not drain outstanding global loads/stores, so
@@ -996,16 +996,22 @@ __device__ __forceinline__ double bus_angle(double f, double e) {
 // Epilogue: line flows (power_flow.py:340-356), losses (:198-200), wrapped angles, scalars; with
 // ENV also everything of step() that follows the load flow (grid_env.py:553-617).
 // =============================================================================================
-template <int ENV, int WRAP_VA>
+template <int ENV, int WRAP_VA, int CHK>
 __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
-                                         double psum) {
+                                         double psum, const GsFusedChecks& FC, int b) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double lsum = have_psum ? psum : 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int over = 0, vflags = 0;
+  // fused post-step checks (kernels_checks.hip is the stand-alone form; same arithmetic, same outputs)
+  const bool chk = ENV && CHK && FC.enabled;            // CHK = 0: the plain step kernels carry none of this
+  const GsChecksCfg& K = FC.C;
+  double* Pv = chk ? FC.prev + (size_t)blockIdx.x * (T.n + 1) * GS_LANES + c.lane : nullptr;
+  int k_nlow = 0, k_nhigh = 0, k_mhigh = 0, k_mlow = 0, k_mem = 0, k_cover = 0, k_mover = 0, k_vbad = 0, k_fbad = 0;
+  double k_dv = 0.0, k_ql = -INFINITY;
   // Both loops are a handful of rows per wave, each a round trip to L2 / Infinity Cache: four items per trip, their
   // rows requested before any of the arithmetic (atan2, sqrt, divisions) starts.
   for (int i0 = c.wave; i0 < T.n; i0 += 4 * c.W) {
-    double xa[4], xb[4], pcs[4];
+    double xa[4], xb[4], pcs[4], pvs[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = min(i0 + u * c.W, T.n - 1);
@@ -1013,6 +1019,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
       xa[u] = WRAP_VA ? x.y : x.x;
       xb[u] = WRAP_VA ? x.x : x.y;
       pcs[u] = have_psum ? 0.0 : ROW(R.PC + i);
+      if (chk) pvs[u] = Pv[(size_t)i * GS_LANES];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1035,6 +1042,17 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
         vflags |= (v > E.v_max) ? 1 : 0;
         vflags |= (v < E.v_min) ? 2 : 0;
       }
+      if (chk) {
+        const bool cl = v < K.c_vlo, ch = !cl && v > K.c_vhi;                // safety.py:129-137 (elif)
+        const bool mh = v > K.m_vhi, ml = v < K.m_vlo;                       // :333-337
+        const bool em = v > K.m_evhi || v < K.m_evlo;                        // :340-341
+        k_nlow += cl; k_nhigh += ch; k_mhigh += mh; k_mlow += ml; k_mem += em;
+        const double d = fabs(v - pvs[u]);                                   // :168 (np.max propagates NaN)
+        k_dv = (d != d || k_dv != k_dv) ? NAN : fmax(k_dv, d);
+        Pv[(size_t)i * GS_LANES] = v;                                        // :181-184
+        if (!(fabs(v) < INFINITY)) k_vbad = 1;                               // robust_power_flow.py:643-647
+        if (FC.bus_mask) FC.bus_mask[((size_t)blockIdx.x * T.n + i) * GS_LANES + c.lane] = (uint8_t)(cl | (ch << 1) | (ml << 2) | (mh << 3) | (em << 4));
+      }
     }
   }
   stamp(c, ST_EPI_BUSES);
@@ -1056,11 +1074,20 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
       const double dr = ei - ej_[u], di = fi - fj_[u];
       const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
       const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
-      ROW(R.LOAD + k) = (rating > 0.0) ? sqrt(sr * sr + si * si) / rating : 0.0;
+      const double ql = (rating > 0.0) ? sqrt(sr * sr + si * si) / rating : 0.0;
+      ROW(R.LOAD + k) = ql;
       if (ENV) {                                                        // Line.update_state, base.py:261-264
         const double ld = (rating > 0.0) ? fabs(sr) / rating : 0.0;
         ROW2(R.FLOW + k) = make_double2(sr, ld);
         over += (ld > 0.8) ? 1 : 0;
+        if (chk) {
+          const double cld_ = K.stride_cload == 2 ? ld : ql;             // which loading the limits apply to
+          const bool co = cld_ > K.c_load, mo = cld_ > K.m_load;         // safety.py:150-154, :364-365
+          k_cover += co; k_mover += mo;
+          k_ql = (ql != ql || k_ql != k_ql) ? NAN : fmax(k_ql, ql);
+          if (!(fabs(sr) < INFINITY)) k_fbad = 1;
+          if (FC.line_mask) FC.line_mask[((size_t)blockIdx.x * T.m + k) * GS_LANES + c.lane] = (uint8_t)(co | (mo << 1));
+        }
       } else {
         ROW(R.FLOW + k) = sr;
       }
@@ -1075,6 +1102,11 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
   if (ENV) {
     POST(1, c.wave) = dev; POST(2, c.wave) = vmax; POST(3, c.wave) = vmin;
     POSTI(0, c.wave) = over; POSTI(1, c.wave) = vflags;
+    if (chk) {          // counts are below 65536 (the host refuses to fuse otherwise): two per word, summed over the waves
+      POSTI(2, c.wave) = k_nlow | (k_nhigh << 16); POSTI(3, c.wave) = k_mhigh | (k_mlow << 16);
+      c.sh.flag[0][c.wave][c.lane] = k_mem | (k_cover << 16); c.sh.flag[1][c.wave][c.lane] = k_mover | (k_vbad << 16) | (k_fbad << 24);
+      c.sh.red[0][c.wave][c.lane] = k_dv; c.sh.red[1][c.wave][c.lane] = k_ql;      // the solver's reduction arrays are free by now
+    }
   }
   __syncthreads();
   stamp(c, ST_EPI_REDUCE);
@@ -1093,6 +1125,16 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
     dev += POST(1, w);
     vmax = fmax(vmax, POST(2, w)); vmin = fmin(vmin, POST(3, w));
     over += POSTI(0, w); vflags |= POSTI(1, w);
+  }
+  int kA = 0, kB = 0, kC = 0, kD = 0;
+  if (chk) {
+    k_dv = c.sh.red[0][0][c.lane]; k_ql = c.sh.red[1][0][c.lane];
+    for (int w = 0; w < c.W; ++w) {
+      kA += POSTI(2, w); kB += POSTI(3, w); kC += c.sh.flag[0][w][c.lane]; kD += c.sh.flag[1][w][c.lane];
+      const double dv = c.sh.red[0][w][c.lane], ql = c.sh.red[1][w][c.lane];
+      k_dv = (dv != dv || k_dv != k_dv) ? NAN : fmax(k_dv, dv);
+      k_ql = (ql != ql || k_ql != k_ql) ? NAN : fmax(k_ql, ql);
+    }
   }
 #undef POST
 #undef POSTI
@@ -1134,13 +1176,52 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
   ROW(R.VMAX) = vmax; ROW(R.VMIN) = vmin;
   ROW(R.VFLAGS + 0) = (double)vhigh; ROW(R.VFLAGS + 1) = (double)vlow;
   ROW(R.VFLAGS + 2) = (double)fhigh; ROW(R.VFLAGS + 3) = (double)flow_;
+  if (chk && b < (int)(FC.Bp) && Pv != nullptr) {
+    // same finalisation as gs_k_checks (kernels_checks.hip), on the values of this very step
+    const int c_nlow = kA & 0xffff, c_nhigh = kA >> 16, m_nhigh = kB & 0xffff, m_nlow = kB >> 16, m_nem = kC & 0xffff, c_nover = kC >> 16;
+    const int m_nover = kD & 0xffff, vbad = (kD >> 16) & 0xff, fbad = kD >> 24;
+    int32_t* has_prev = FC.state + b; int32_t* consec = FC.state + FC.Bp + b; int32_t* emode = FC.state + 2 * FC.Bp + b;
+#define OI(k) FC.out_i[(size_t)(k) * FC.Bp + b]
+#define OF(k) FC.out_f[(size_t)(k) * FC.Bp + b]
+    const int c_flow = f < K.c_flo, c_fhigh = !c_flow && f > K.c_fhi;        // safety.py:140-147
+    const double vrate = k_dv / K.dt;                                        // NaN stays NaN
+    const double frate = fabs(f - Pv[(size_t)T.n * GS_LANES]) / K.dt;        // :174
+    const int hp = *has_prev;
+    const int c_vr = hp && vrate > K.c_rocv, c_fr = hp && frate > K.c_rocf;
+    Pv[(size_t)T.n * GS_LANES] = f; *has_prev = 1;
+    const int c_total = c_nlow + c_nhigh + c_flow + c_fhigh + c_nover + c_vr + c_fr;
+    OI(GS_CI_C_NLOW) = c_nlow; OI(GS_CI_C_NHIGH) = c_nhigh; OI(GS_CI_C_FLOW) = c_flow; OI(GS_CI_C_FHIGH) = c_fhigh;
+    OI(GS_CI_C_NOVER) = c_nover; OI(GS_CI_C_VRATE) = c_vr; OI(GS_CI_C_FRATE) = c_fr; OI(GS_CI_C_TOTAL) = c_total;
+    OI(GS_CI_C_SEVERITY) = c_total > 5 ? 3 : (c_total > 2 ? 2 : (c_total > 0 ? 1 : 0));
+    OF(GS_CF_VRATE) = vrate; OF(GS_CF_FRATE) = frate;
+    const int m_fhigh = f > K.m_fhi, m_flow = !m_fhigh && f < K.m_flo, m_fem = f > K.m_efhi || f < K.m_eflo;
+    const int m_total = m_nhigh + m_nlow + m_nem + m_fhigh + m_flow + m_fem + m_nover;
+    const int cs = m_total > 0 ? *consec + 1 : 0;
+    const int trigger = (m_nem > 0) || m_fem || cs > 5 || m_total > 10;
+    const int mode = *emode | trigger;
+    *consec = cs; *emode = mode;
+    OI(GS_CI_M_NHIGH) = m_nhigh; OI(GS_CI_M_NLOW) = m_nlow; OI(GS_CI_M_NEMERG) = m_nem; OI(GS_CI_M_FHIGH) = m_fhigh; OI(GS_CI_M_FLOW) = m_flow;
+    OI(GS_CI_M_FEMERG) = m_fem; OI(GS_CI_M_NOVER) = m_nover; OI(GS_CI_M_TOTAL) = m_total; OI(GS_CI_M_ACTION) = trigger;
+    OI(GS_CI_M_CONSEC) = cs; OI(GS_CI_M_EMODE) = mode;
+    double q = 1.0;                                                          // robust_power_flow.py:615-657
+    if (vmin < 0.8 || vmax > 1.2) q *= 0.3;
+    else if (vmin < 0.9 || vmax > 1.1) q *= 0.7;
+    if (T.m > 0 && k_ql == k_ql) { if (k_ql > 2.0) q *= 0.2; else if (k_ql > 1.0) q *= 0.5; }
+    if (st.mm > K.q_tol * 100.0) q *= 0.6;
+    if (st.iters <= 5) q *= 1.1; else if (st.iters > 20) q *= 0.9;
+    q = fmin(q, 1.0);
+    if (!st.conv || vbad || fbad) q = 0.0;
+    OF(GS_CF_QUALITY) = q;
+#undef OI
+#undef OF
+  }
   stamp(c, ST_EPI_SCALARS);
 }
 
-template <int ENV, int WRAP_VA>
+template <int ENV, int WRAP_VA, int CHK>
 __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
-                                         double psum) {
-  epilogue_impl<ENV, WRAP_VA>(c, E, st, total_load, have_psum, psum);   // waves != 0 leave it after the reduction
+                                         double psum, const GsFusedChecks& FC, int b) {
+  epilogue_impl<ENV, WRAP_VA, CHK>(c, E, st, total_load, have_psum, psum, FC, b);   // waves != 0 leave it after the reduction
 }
 
 // Observation block of this group, batch-major, written straight from the step kernel: 64-column
@@ -1317,10 +1398,10 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
   __syncthreads();
 }
 
-template <int KIND, int ENV>
+template <int KIND, int ENV, int CHK>
 __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                           double* __restrict__ slab, int B, const double* __restrict__ actions,
-                                          double total_load, const GsPackArgs& PA) {
+                                          double total_load, const GsPackArgs& PA, const GsFusedChecks& FC) {
   __shared__ GsShared sh;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1337,7 +1418,7 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
   else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds<ENV != 0>(c, C, st);
   else newton_loop<KIND>(c, C, st);
-  epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS>(c, E, st, total_load, KIND == KIND_FBS_LDS, psum);   // FBS keeps no polar angle: atan2 there
+  epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS, CHK>(c, E, st, total_load, KIND == KIND_FBS_LDS, psum, FC, valid ? b : 0x7fffffff);   // FBS keeps no polar angle: atan2 there
   if (ENV && PA.out != nullptr) pack_observations(c, PA, B);     // rows of pass 0 visible since the epilogue's barrier
   stamp(c, ST_EPILOGUE);
 }
@@ -1347,12 +1428,18 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   gs_k_##name(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {                         \
     GsEnvCfg E{};                                                                                             \
     GsPackArgs PA{};                                                                                          \
-    main_body<KIND, 0>(T, R, C, E, slab, B, nullptr, 0.0, PA);                                                \
+    GsFusedChecks FC{};                                                                                       \
+    main_body<KIND, 0, 0>(T, R, C, E, slab, B, nullptr, 0.0, PA, FC);                                         \
   }                                                                                                           \
   extern "C" __global__ void __launch_bounds__(1024)                                                          \
   gs_k_step_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,          \
-                   const double* __restrict__ actions, double total_load, GsPackArgs PA) {                    \
-    main_body<KIND, 1>(T, R, C, E, slab, B, actions, total_load, PA);                                         \
+                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {  \
+    main_body<KIND, 1, 0>(T, R, C, E, slab, B, actions, total_load, PA, FC);                                  \
+  }                                                                                                           \
+  extern "C" __global__ void __launch_bounds__(1024)   /* the step with the post-step checks in its epilogue */ \
+  gs_k_stepc_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,         \
+                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) { \
+    main_body<KIND, 1, 1>(T, R, C, E, slab, B, actions, total_load, PA, FC);                                  \
   }
 
 GS_DEFINE_KERNELS(nr_tree, KIND_TREE)

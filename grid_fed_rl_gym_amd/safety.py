@@ -59,6 +59,7 @@ CHECKS_SYMBOLS = [
     ("gs_checks_download", C.c_int, [_CK, C.POINTER(gs_checks_view)]),
     ("gs_checks_reset", C.c_int, [_CK, _up]),
     ("gs_checks_timing_read", C.c_int, [_CK, _dp, C.POINTER(C.c_int64)]),
+    ("gs_checks_set_fused", C.c_int, [_CK, C.c_int32, C.c_int32]),
 ]
 _bound = False
 
@@ -86,7 +87,8 @@ class PostStepChecks:
     """One gs_checks object: SafetyChecker + SafetyMonitor + quality gate evaluated together on the device."""
 
     def __init__(self, source: Any, *, checker: Optional[Dict[str, Any]] = None, monitor: Optional[Dict[str, Any]] = None,
-                 quality_tolerance: float = 1e-6, loading: str = "environment", timestep: float = 1.0):
+                 quality_tolerance: float = 1e-6, loading: str = "environment", timestep: float = 1.0, fused: bool = False,
+                 fused_masks: bool = True):
         self._lib = _bind()
         self._handle = _native_handle(source)            # keeps the gs_handle alive for as long as the checks exist
         ck = dict(voltage_limits=(0.95, 1.05), frequency_limits=(59.5, 60.5), line_loading_limit=1.0,
@@ -115,6 +117,9 @@ class PostStepChecks:
             raise RuntimeError(f"gs_checks_create failed ({rc}): {self._handle.last_error()}")
         self.B, self.n, self.m = self._handle.B, self._handle.spec.n, self._handle.spec.m
         self._handle._adopt(self)                        # the handle closes its checks before itself
+        self.fused = False
+        if fused:
+            self.set_fused(True, fused_masks)
 
     def _check(self, rc: int) -> None:
         if rc != _lib.GS_OK:
@@ -138,8 +143,16 @@ class PostStepChecks:
         f = np.ascontiguousarray(np.broadcast_to(np.asarray(frequency_hz, dtype=np.float64), (self.B,)))
         self._check(self._lib.gs_checks_set_frequency(self._c, f.ctypes.data_as(_dp)))
 
+    def set_fused(self, on: bool = True, masks: bool = True) -> None:
+        """Evaluate the checks inside every later ``step()`` (the step kernel's epilogue already holds the voltages and
+        loadings): ``download()`` then returns the checks of the last step and ``run()`` must not be called as well."""
+        self._check(self._lib.gs_checks_set_fused(self._c, int(bool(on)), int(bool(masks))))
+        self.fused = bool(on)
+
     def run(self) -> None:
         """One check_constraints call per instance on the handle's current device state (asynchronous)."""
+        if self.fused:
+            raise RuntimeError("these checks are fused into step(): download() has the last step's result")
         self._check(self._lib.gs_checks_run(self._c))
 
     def download(self, masks: bool = False) -> Dict[str, np.ndarray]:

@@ -268,6 +268,11 @@ int gs_checks_download(gs_checks* c, const gs_checks_view* out);
  * constructed SafetyChecker() / SafetyMonitor() */
 int gs_checks_reset(gs_checks* c, const uint8_t* mask);
 int gs_checks_timing_read(gs_checks* c, double* total_ms, int64_t* launches);
+/* on != 0: every later gs_step / gs_step_device evaluates these checks inside its own kernel (the epilogue already holds
+ * the voltages and loadings), exactly as one gs_checks_run after the step would; gs_checks_download then returns the
+ * checks of the last step.  Do not call gs_checks_run as well (the stateful parts would advance twice).  One fused checks
+ * object per handle; the environment's |P| / rating or the solution's |S| / rating as configured. */
+int gs_checks_set_fused(gs_checks* c, int32_t on, int32_t want_masks);
 
 /* ======================================================================================
  * Three-phase unbalanced radial load flow (BASELINE.json config 5).  NEW functionality: the

@@ -136,3 +136,42 @@ def test_checks_on_live_environment_state_match_oracle():
                                                 sol["line_loadings"], sol["line_flows"], 1e-6))
     assert (q > 0.7).all()                       # converged, in-band voltages, tiny loadings: the chain would accept them
     chk.close(); mon.close(); env.close()
+
+
+@pytest.mark.parametrize("solver", ["fbs", "nr"])
+def test_checks_fused_into_the_step_equal_the_standalone_kernel(solver):
+    """gs_checks_set_fused: the same counts, flags, masks, rates and quality, step after step, including the stateful parts."""
+    spec = P.ieee123_like(); B = 130
+    kw = dict(num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True)
+    a, b = P.BatchedGridEnvironment(spec, **kw), P.BatchedGridEnvironment(spec, **kw)
+    seeds = np.arange(B, dtype=np.uint64) * 3 + 1
+    a.reset(seed=seeds); b.reset(seed=seeds)
+    rng = np.random.default_rng(0)
+    a.step(rng.uniform(-1, 1, (B, spec.action_dim)))
+    lay = a.state_layout(); st = a.get_state()
+    vlo, vem, vhi = np.quantile(st[:, lay["vm"]], [0.2, 0.02, 0.97])
+    llim = float(np.quantile(st[:, lay["line_loading"]], 0.95))
+    rng = np.random.default_rng(0)
+    a.reset(seed=seeds)
+    cfg = dict(checker=dict(voltage_limits=(vlo, vhi), line_loading_limit=llim, rate_of_change_limits={"voltage": 5e-4, "frequency": 1e-4}),
+               monitor=dict(voltage_limits=(vlo, vhi), emergency_voltage_limits=(vem, 1.2), line_loading_limit=llim))
+    for loading in ("environment", "solution"):
+        a.reset(seed=seeds); b.reset(seed=seeds)
+        sep = PostStepChecks(a, loading=loading, **cfg)
+        fus = PostStepChecks(b, loading=loading, fused=True, **cfg)
+        with pytest.raises(RuntimeError):
+            fus.run()
+        for t in range(7):
+            act = rng.uniform(-1, 1, (B, spec.action_dim))
+            oa, *_ = a.step(act); ob, *_ = b.step(act)
+            np.testing.assert_array_equal(oa, ob)
+            sep.run()
+            x, y = sep.download(masks=True), fus.download(masks=True)
+            for k in x:
+                np.testing.assert_array_equal(x[k], y[k], err_msg=f"{k} t={t} loading={loading}")
+        assert x["c_total"].max() > 0 and x["m_consecutive_violations"].max() == 7 and x["c_voltage_rate_violation"].any()
+        assert (x["quality"] > 0.7).all()
+        fus.set_fused(False)
+        b.step(act); fus.run()                                     # back to stand-alone use
+        sep.close(); fus.close()
+    a.close(); b.close()
