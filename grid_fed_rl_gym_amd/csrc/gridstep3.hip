@@ -38,8 +38,9 @@ namespace {
 struct Topo3 {
   int32_t n, ns, n_levels, cap;   // nodes, slots, levels, widest level in slots
   const int32_t* lvl_ptr;    // [PAD + n_levels + 1 + PAD] slot ranges, padded with empty levels; level 0 = the three source conductors
-  const int4* idx;           // [ns] {parent slot, first child slot, child count | phase << 28, sibling slot A}
-  const int32_t* sibb;       // [ns] sibling slot B (A / B = the lower / higher of the two other phases; -1 = absent)
+  const int4* idx;           // [ns] {first child slot, child count | phase << 28, sibling slot A, sibling slot B}: the backward sweep's
+                             //      (A / B = the lower / higher of the two other phases; -1 = absent)
+  const int32_t* par;        // [ns] parent slot | phase << 30: all the forward sweep needs (one 4-byte load)
   const double2* z;          // [3][ns] row of the upstream line's Z for this conductor: (re, im) x {own, A, B}
   double vsr[3], vsi[3];     // source voltage
 };
@@ -53,7 +54,7 @@ enum { Z_D = 0, Z_A, Z_B };
 #define ST(row, s) (*(double2*)((char*)(S + (size_t)(row) * ns) + ((unsigned)(s) << 4)))
 #define ZT(row, s) (*(const double2*)((const char*)(T.z + (size_t)(row) * ns) + ((unsigned)(s) << 4)))
 #define IDX(s) (*(const int4*)((const char*)T.idx + ((unsigned)(s) << 4)))
-#define SIBB(s) (*(const int32_t*)((const char*)T.sibb + ((unsigned)(s) << 2)))
+#define PAR(s) (*(const int32_t*)((const char*)T.par + ((unsigned)(s) << 2)))
 #define GS3_CONST __attribute__((address_space(4)))
 
 __device__ __forceinline__ double block_max(double v, double* sh) {
@@ -133,8 +134,8 @@ struct Sweep3 {
 
   template <bool FIRST> __device__ __forceinline__ UpIn load_up(int s) const {
     UpIn u;
-    u.ix = IDX(s); u.sb = SIBB(s);
-    const int ph = (unsigned)u.ix.z >> 28;
+    u.ix = IDX(s); u.sb = u.ix.w;
+    const int ph = (unsigned)u.ix.y >> 28;
     if (FIRST) { u.vr = src_r(ph); u.vi = src_i(ph); }
     else { const double2 v = ST(C_V, s); u.vr = v.x; u.vi = v.y; }
     const double2 pq = ST(C_S, s); u.p = pq.x; u.q = pq.y;
@@ -149,8 +150,8 @@ struct Sweep3 {
   }
   template <bool FIRST> __device__ __forceinline__ DownIn load_down(int s) const {
     DownIn d;
-    d.ix = IDX(s);
-    const int ph = (unsigned)d.ix.z >> 28;
+    d.ix = make_int4(PAR(s), 0, 0, 0);
+    const int ph = (unsigned)d.ix.x >> 30;
     const double2 dd = ST(C_D, s); d.dr = dd.x; d.di = dd.y;
     if (FIRST) { d.vr = src_r(ph); d.vi = src_i(ph); }
     else { const double2 v = ST(C_V, s); d.vr = v.x; d.vi = v.y; }
@@ -178,14 +179,14 @@ struct Sweep3 {
   template <bool LDSMSG, bool FIRST>
   __device__ __forceinline__ void line_current(const UpIn& u, const double* dn, int s1, bool at_source, double& lmax, double& psrc,
                                                double& jr, double& ji) const {
-    const int ph = (unsigned)u.ix.z >> 28, cc = u.ix.z & 0xffff;
+    const int ph = (unsigned)u.ix.y >> 28, cc = u.ix.y & 0xffff;
     if (FIRST) {
       const double dP = fabs(u.p), dQ = fabs(u.q);
       lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
     }
     const double rd = 1.0 / (u.vr * u.vr + u.vi * u.vi);
     jr = -(u.p * u.vr + u.q * u.vi) * rd; ji = -(u.p * u.vi - u.q * u.vr) * rd;
-    for (int ch = u.ix.y; ch < u.ix.y + cc; ++ch) { double cr, ci; msg_j<LDSMSG>(dn, s1, ch, cr, ci); jr += cr; ji += ci; }
+    for (int ch = u.ix.x; ch < u.ix.x + cc; ++ch) { double cr, ci; msg_j<LDSMSG>(dn, s1, ch, cr, ci); jr += cr; ji += ci; }
     if (at_source) psrc += src_r(ph) * jr + src_i(ph) * ji;     // the source's share of sum P_calc
   }
 
@@ -217,8 +218,8 @@ struct Sweep3 {
         }
         if (e1 - s1 > nth)
           for (int s2 = s + nth; s2 < e1; s2 += nth) {
-            const int4 ix = IDX(s2); const int sb = SIBB(s2);
-            drop_of<LDSMSG>(dn, s1, s2, load_z(s2), ix.w, sb, ar, ai);
+            const int4 ix = IDX(s2); const int sb = ix.w;
+            drop_of<LDSMSG>(dn, s1, s2, load_z(s2), ix.z, sb, ar, ai);
             ST(C_D, s2) = make_double2(ar, ai);
           }
       }
@@ -231,7 +232,7 @@ struct Sweep3 {
           if (s < s1) {
             if (LDSMSG) { up[s - s0] = jr; up[cap + s - s0] = ji; }
             else ST(C_J, s) = make_double2(jr, ji);
-            zsa = u.ix.w; zsb = u.sb;
+            zsa = u.ix.z; zsb = u.sb;
           }
         }
         if (s1 - s0 > nth)
@@ -253,7 +254,7 @@ struct Sweep3 {
       double ar, ai;
       for (int s = s1 + off(1); s < e1; s += nth) {
         if (s == s1 + off(1)) drop_of<LDSMSG>(dn, s1, s, zc, zsa, zsb, ar, ai);
-        else { const int4 ix = IDX(s); const int sb = SIBB(s); drop_of<LDSMSG>(dn, s1, s, load_z(s), ix.w, sb, ar, ai); }
+        else { const int4 ix = IDX(s); drop_of<LDSMSG>(dn, s1, s, load_z(s), ix.z, ix.w, ar, ai); }
         ST(C_D, s) = make_double2(ar, ai);
       }
       level_barrier<LDSMSG>();     // the forward sweep reuses level 1's buffer
@@ -263,7 +264,7 @@ struct Sweep3 {
   template <bool LDSMSG>
   __device__ __forceinline__ void new_voltage(const DownIn& d, const double* upr, int p0, int l, bool count, double& lmax, double& psum,
                                               double& wr, double& wi) const {
-    const int ph = (unsigned)d.ix.z >> 28, ps = d.ix.x;
+    const int ph = (unsigned)d.ix.x >> 30, ps = d.ix.x & 0x3fffffff;
     double pr, pi;
     if (l == 1) { pr = src_r(ph); pi = src_i(ph); }
     else if (LDSMSG) { pr = upr[ps - p0]; pi = upr[cap + ps - p0]; }
@@ -337,7 +338,7 @@ __device__ __forceinline__ void gs3_solve_body(const Topo3& T, double2* __restri
       losses = 0.0;
       if (!(mm < INFINITY) || mm < tol) {     // no sweep will follow: the answer is the flat start itself
         for (int s = 3 + tid; s < ns; s += nth) {
-          const int ph = (unsigned)IDX(s).z >> 28;
+          const int ph = (unsigned)IDX(s).y >> 28;
           ST(C_V, s) = make_double2(sw.src_r(ph), sw.src_i(ph));
         }
         iters = 1; conv = mm < tol;
@@ -523,7 +524,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   h->device = device; h->n = n; h->ns = ns; h->B = batch; h->tol = tolerance; h->max_it = max_iterations; h->n_levels = n_levels;
   for (int l = 0; l < n_levels; ++l) h->max_width = std::max(h->max_width, slvl[l + 1] - slvl[l]);
   std::vector<int4> idx(ns, make_int4(0, 0, 0, -1));
-  std::vector<int32_t> sibb(ns, -1);
+  std::vector<int32_t> par(ns, 0);
   std::vector<double2> z((size_t)3 * ns, make_double2(0.0, 0.0));
   for (int sl = 0; sl < ns; ++sl) {
     const int node = src_of[sl] / 3, ph = src_of[sl] % 3, mask = t->phases[node];
@@ -538,8 +539,8 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     }
     if (ccount > 0xffff) { delete h; return fail3(nullptr, GS_E_TOPOLOGY, "node %d has more than 65535 children", node); }
     const int parent = node == t->source ? 0 : slot_of[(size_t)t->parent[node] * 3 + ph];
-    idx[sl] = make_int4(parent, cfirst, ccount | (ph << 28), slot_of[(size_t)node * 3 + oa]);
-    sibb[sl] = slot_of[(size_t)node * 3 + ob];
+    idx[sl] = make_int4(cfirst, ccount | (ph << 28), slot_of[(size_t)node * 3 + oa], slot_of[(size_t)node * 3 + ob]);
+    par[sl] = parent | (ph << 30);
     if (node == t->source) continue;
     double a[9], bb[9], ya[9], yb[9];
     for (int q = 0; q < 9; ++q) {
@@ -566,7 +567,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   std::vector<int32_t> slvl_pad(GS3_LVL_PAD, 0);
   slvl_pad.insert(slvl_pad.end(), slvl.begin(), slvl.end());
   slvl_pad.insert(slvl_pad.end(), GS3_LVL_PAD, ns);
-  if ((rc = upload3(h, &T.lvl_ptr, slvl_pad)) || (rc = upload3(h, &T.idx, idx)) || (rc = upload3(h, &T.sibb, sibb)) || (rc = upload3(h, &T.z, z)))
+  if ((rc = upload3(h, &T.lvl_ptr, slvl_pad)) || (rc = upload3(h, &T.idx, idx)) || (rc = upload3(h, &T.par, par)) || (rc = upload3(h, &T.z, z)))
     return bail(rc);
   // level messages through LDS when two parities of the widest level fit beside three other resident workgroups
   h->lds_bytes = 2 * 2 * h->max_width * (int)sizeof(double);
