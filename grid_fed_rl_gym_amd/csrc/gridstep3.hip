@@ -37,6 +37,7 @@ namespace {
 
 struct Topo3 {
   int32_t n, ns, n_levels, cap;   // nodes, slots, levels, widest level in slots
+  const int32_t* lvl_mutual; // same padding: 1 where a level has a node with more than one phase (its mutual impedances are read)
   const int32_t* lvl_ptr;    // [PAD + n_levels + 1 + PAD] slot ranges, padded with empty levels; level 0 = the three source conductors
   const int4* idx;           // [ns] {first child slot, child count | phase << 28, sibling slot A, sibling slot B}: the backward sweep's
                              //      (A / B = the lower / higher of the two other phases; -1 = absent)
@@ -122,6 +123,7 @@ struct Sweep3 {
   double2* __restrict__ S;
   int ns, cap, L, nth, nw, wave, lane;   // nw wavefronts; wave is wave-uniform (an SGPR)
   const GS3_CONST int32_t* lvl;      // lvl[-PAD .. L + PAD]
+  const GS3_CONST int32_t* lmu;      // lvl_mutual, same indexing
 
   __device__ __forceinline__ double src_r(int ph) const { return ph == 0 ? T.vsr[0] : (ph == 1 ? T.vsr[1] : T.vsr[2]); }
   __device__ __forceinline__ double src_i(int ph) const { return ph == 0 ? T.vsi[0] : (ph == 1 ? T.vsi[1] : T.vsi[2]); }
@@ -132,14 +134,15 @@ struct Sweep3 {
   __device__ __forceinline__ int wlo(int l) const { return ((wave + l + 64) % nw) << 6; }     // l >= -GS3_LVL_PAD
   __device__ __forceinline__ int off(int l) const { return wlo(l) + lane; }
 
-  template <bool FIRST> __device__ __forceinline__ UpIn load_up(int s) const {
+  template <bool FIRST> __device__ __forceinline__ UpIn load_up(int s, bool mutual = true) const {
     UpIn u;
     u.ix = IDX(s); u.sb = u.ix.w;
     const int ph = (unsigned)u.ix.y >> 28;
     if (FIRST) { u.vr = src_r(ph); u.vi = src_i(ph); }
     else { const double2 v = ST(C_V, s); u.vr = v.x; u.vi = v.y; }
     const double2 pq = ST(C_S, s); u.p = pq.x; u.q = pq.y;
-    u.z = load_z(s);
+    if (mutual) u.z = load_z(s);                       // level-uniform: single-phase levels read the self impedance only
+    else { const double2 d = ZT(Z_D, s); u.z = ZRow{d.x, d.y, 0.0, 0.0, 0.0, 0.0}; }
     return u;
   }
   __device__ __forceinline__ ZRow load_z(int s) const {
@@ -196,19 +199,20 @@ struct Sweep3 {
     ZRow zc = {};            // Z row of this thread's first slot in the level processed last (l + 1)
     int zsa = -1, zsb = -1;
 #pragma unroll
-    for (int k = 0; k < PF; ++k) uq[k] = load_up<FIRST>(clamp_to(lvl[L - 1 - k] + off(L - 1 - k), lvl[L - k]));
+    for (int k = 0; k < PF; ++k) uq[k] = load_up<FIRST>(clamp_to(lvl[L - 1 - k] + off(L - 1 - k), lvl[L - k]), lmu[L - 1 - k] != 0);
+    int mu = lmu[L - 1 - PF];          // whether the level prefetched next carries mutual terms (read one step ahead, like w)
     int w[PF + 3];           // w[j] = lvl[l - PF + j]: the prefetched level .. the level being finished
 #pragma unroll
     for (int j = 0; j < PF + 3; ++j) w[j] = lvl[L - 1 - PF + j];
     for (int l = L - 1; l >= 1; --l) {
       const int s0 = w[PF], s1 = w[PF + 1], e1 = w[PF + 2];
-      const int wnext = lvl[l - PF - 1];
+      const int wnext = lvl[l - PF - 1], munext = lmu[l - PF - 1];
       double* up = gs3_msg + (size_t)(l & 1) * 2 * cap;
       const double* dn = gs3_msg + (size_t)((l + 1) & 1) * 2 * cap;
       const UpIn u = uq[0];
 #pragma unroll
       for (int k = 0; k + 1 < PF; ++k) uq[k] = uq[k + 1];
-      uq[PF - 1] = load_up<FIRST>(clamp_to(w[0] + off(l - PF), w[1]));
+      uq[PF - 1] = load_up<FIRST>(clamp_to(w[0] + off(l - PF), w[1]), mu != 0);
       {                      // finish level l + 1: its J are all in `dn` now
         const int s = s1 + off(l + 1);
         double ar, ai;
@@ -245,7 +249,7 @@ struct Sweep3 {
       zc = u.z;
 #pragma unroll
       for (int j = PF + 2; j > 0; --j) w[j] = w[j - 1];
-      w[0] = wnext;
+      w[0] = wnext; mu = munext;
       level_barrier<LDSMSG>();
     }
     {                        // finish level 1
@@ -326,7 +330,7 @@ __device__ __forceinline__ void gs3_solve_body(const Topo3& T, double2* __restri
                                                double* sh, double& losses, double& mm, int& it_out, int& conv_out) {
   const int ns = T.ns, tid = threadIdx.x, nth = blockDim.x;
   const Sweep3 sw = {T, S, ns, T.cap, T.n_levels, nth, nth >> 6, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63,
-                     (const GS3_CONST int32_t*)T.lvl_ptr + GS3_LVL_PAD};
+                     (const GS3_CONST int32_t*)T.lvl_ptr + GS3_LVL_PAD, (const GS3_CONST int32_t*)T.lvl_mutual + GS3_LVL_PAD};
   int iters = max_it, conv = 0;
   mm = INFINITY; losses = 0.0;
   if (tid < 3) ST(C_V, tid) = make_double2(T.vsr[tid], T.vsi[tid]);     // the source's three conductors
@@ -567,7 +571,11 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   std::vector<int32_t> slvl_pad(GS3_LVL_PAD, 0);
   slvl_pad.insert(slvl_pad.end(), slvl.begin(), slvl.end());
   slvl_pad.insert(slvl_pad.end(), GS3_LVL_PAD, ns);
-  if ((rc = upload3(h, &T.lvl_ptr, slvl_pad)) || (rc = upload3(h, &T.idx, idx)) || (rc = upload3(h, &T.par, par)) || (rc = upload3(h, &T.z, z)))
+  std::vector<int32_t> mutual_pad(slvl_pad.size(), 0);
+  for (int l = 0; l < n_levels; ++l)
+    for (int sl = slvl[l]; sl < slvl[l + 1]; ++sl)
+      if (idx[sl].z >= 0 || idx[sl].w >= 0) { mutual_pad[GS3_LVL_PAD + l] = 1; break; }
+  if ((rc = upload3(h, &T.lvl_mutual, mutual_pad)) || (rc = upload3(h, &T.lvl_ptr, slvl_pad)) || (rc = upload3(h, &T.idx, idx)) || (rc = upload3(h, &T.par, par)) || (rc = upload3(h, &T.z, z)))
     return bail(rc);
   // level messages through LDS when two parities of the widest level fit beside three other resident workgroups
   h->lds_bytes = 2 * 2 * h->max_width * (int)sizeof(double);
