@@ -206,7 +206,7 @@ def main():
     seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.uint64)
     want_gather = world > 1 and not args.no_allgather and n_dev >= world
     kernel_names = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
-                    "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds"}
+                    "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow"}
 
     def env_kwargs_of(solver):
         return dict(stochastic_loads=True, weather_variation=True, solver=solver, tolerance=args.tolerance,

@@ -75,7 +75,7 @@ struct gs_handle {
   GsEnvCfg EC{};
   double total_load = 0.0;
   struct gs_checks* fused = nullptr;      // checks evaluated inside the step kernel's epilogue (gs_checks_set_fused)
-  int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs, 3 dense, 4 tree with LDS messages
+  int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs, 3 dense, 4 tree with LDS messages, 5 fbs with LDS messages, 6 fbs as a dataflow over LDS
   size_t dyn_lds = 0;
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -221,6 +221,7 @@ int launch_solve(gs_handle* h) {
   else if (h->solve_kernel == 1) GS_SOLVE(gs_k_nr_lu);
   else if (h->solve_kernel == 3) GS_SOLVE(gs_k_nr_dense);
   else if (h->solve_kernel == 5) GS_SOLVE(gs_k_fbs_lds);
+  else if (h->solve_kernel == 6) GS_SOLVE(gs_k_fbs_flow);
   else GS_SOLVE(gs_k_fbs);
 #undef GS_SOLVE
   HIPCHK(h, hipGetLastError());
@@ -248,6 +249,7 @@ int step_kernels(gs_handle* h, const double* d_actions) {
       else if (h->solve_kernel == 1) GS_STEP(gs_k_stepc_nr_lu);
       else if (h->solve_kernel == 3) GS_STEP(gs_k_stepc_nr_dense);
       else if (h->solve_kernel == 5) GS_STEP(gs_k_stepc_fbs_lds);
+      else if (h->solve_kernel == 6) GS_STEP(gs_k_stepc_fbs_flow);
       else GS_STEP(gs_k_stepc_fbs);
     } else {
       if (h->solve_kernel == 0) GS_STEP(gs_k_step_nr_tree);
@@ -255,6 +257,7 @@ int step_kernels(gs_handle* h, const double* d_actions) {
       else if (h->solve_kernel == 1) GS_STEP(gs_k_step_nr_lu);
       else if (h->solve_kernel == 3) GS_STEP(gs_k_step_nr_dense);
       else if (h->solve_kernel == 5) GS_STEP(gs_k_step_fbs_lds);
+      else if (h->solve_kernel == 6) GS_STEP(gs_k_step_fbs_flow);
       else GS_STEP(gs_k_step_fbs);
     }
 #undef GS_STEP
@@ -324,11 +327,24 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
                                         h->topo);
   if (!why.empty()) { int rc = fail(nullptr, GS_E_INVALID, "topology: %s", why.c_str()); delete h; return rc; }
   const HostTopology& ht = h->topo;
+  h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
+  int W = cfg->waves_per_group;
+  if (const char* e = getenv("GS_WAVES")) W = atoi(e);
+  if (W <= 0) { W = 1; while (W < 16 && h->groups * W * 2 <= 2048) W *= 2; }
+  if (W > GS_MAX_WAVES) W = GS_MAX_WAVES;
+  h->W = W;
   if (cfg->solver_kind == GS_SOLVER_FBS) {
     if (!ht.fbs_ok) { int rc = fail(nullptr, GS_E_TOPOLOGY, "FBS: %s", ht.fbs_why.c_str()); delete h; return rc; }
     h->solve_kernel = 2;
     const size_t msg_bytes = (size_t)2 * ht.max_level_width * 6 * GS_LANES * sizeof(double);
     if (msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) { h->solve_kernel = 5; h->dyn_lds = msg_bytes; }
+    // dataflow sweeps: one 16-byte-per-lane message slot and one flag word per bus in LDS, at most 8 buses per wave
+    // (their state lives in registers); flat start only
+    const size_t flow_bytes = (size_t)ht.n * 2 * GS_LANES * sizeof(double) + (size_t)ht.n * sizeof(int32_t);
+    const int n_items = ht.is_forest ? ht.lvl_ptr[ht.n_levels] : 0;
+    if (h->solve_kernel == 5 && !cfg->fbs_warm_start && flow_bytes + 24576 <= 160 * 1024 && (n_items + W - 1) / W <= 8 &&
+        !getenv("GS_NO_FLOW")) {
+      h->solve_kernel = 6; h->dyn_lds = flow_bytes; }
   } else if (cfg->solver_kind == GS_SOLVER_NR) {
     if (cfg->linear_solver == GS_LINSOLVE_TREE && !ht.is_forest) {
       int rc = fail(nullptr, GS_E_TOPOLOGY, "tree elimination requested but the active network has loops"); delete h; return rc; }
@@ -345,17 +361,10 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   // the epilogue's cross-wave partials need 48 KB; the observation pack stages two or three 64-column tiles behind them
   h->dyn_lds = std::max<size_t>(49152 + 2 * 64 * 65 * sizeof(double), h->dyn_lds);
 
-  h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
   h->n = ht.n; h->m = ht.m; h->n_loads = topo->n_loads; h->n_gens = topo->n_gens; h->n_bats = topo->n_bats;
   h->obs_dim = 2 * h->n + 2 * h->m + 1 + 2 * h->n_loads + h->n_gens + 2 * h->n_bats;     // grid_env.py:307-314
   h->action_dim = h->n_bats + h->n_gens;                                                    // grid_env.py:351
   h->state_dim = 12 + 2 * h->n_bats + h->n_gens + 2 * h->n + 2 * h->m;
-  int W = cfg->waves_per_group;
-  if (const char* e = getenv("GS_WAVES")) W = atoi(e);
-  if (W <= 0) { W = 1; while (W < 16 && h->groups * W * 2 <= 2048) W *= 2; }
-  if (W > GS_MAX_WAVES) W = GS_MAX_WAVES;
-  h->W = W;
-
   auto bail = [&](int rc) { gs_destroy(h); return rc; };
   if (hipSetDevice(device) != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipSetDevice failed"));
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
@@ -367,7 +376,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
                          (const void*)gs_k_nr_dense, (const void*)gs_k_step_nr_dense, (const void*)gs_k_fbs,
                          (const void*)gs_k_step_fbs, (const void*)gs_k_fbs_lds, (const void*)gs_k_step_fbs_lds,
                          (const void*)gs_k_stepc_nr_tree, (const void*)gs_k_stepc_nr_tree_lds, (const void*)gs_k_stepc_nr_lu,
-                         (const void*)gs_k_stepc_nr_dense, (const void*)gs_k_stepc_fbs, (const void*)gs_k_stepc_fbs_lds};
+                         (const void*)gs_k_stepc_nr_dense, (const void*)gs_k_stepc_fbs, (const void*)gs_k_stepc_fbs_lds,
+                         (const void*)gs_k_fbs_flow, (const void*)gs_k_step_fbs_flow, (const void*)gs_k_stepc_fbs_flow};
     // the attribute is per function, i.e. shared by every handle of the process: always raise it to
     // the most any handle may ask for (160 KB per workgroup minus the 24 KB static block)
     const int max_dyn = 160 * 1024 - 24576;
@@ -388,7 +398,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   // scratch rows are allocated only for the kernel that uses them: the slab is what the step
   // streams through L2 / Infinity Cache, so every unused row costs residency
   const int sk = h->solve_kernel;
-  const bool k_tree = sk == 0, k_lu = sk == 1, k_fbs = sk == 2 || sk == 5, k_dense = sk == 3, k_tree_lds = sk == 4;
+  const bool k_tree = sk == 0, k_lu = sk == 1, k_fbs = sk == 2 || sk == 5 || sk == 6, k_dense = sk == 3, k_tree_lds = sk == 4;
   const bool k_rhs = k_tree || k_lu || k_dense;
   take_pair(R.E, R.F, n); take_pair(R.PC, R.QC, n);
   take_pair(R.R0, R.R1, k_rhs ? n : 0); take_pair(R.X0, R.X1, k_rhs ? n : 0);
@@ -414,10 +424,22 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   std::vector<int32_t> wl_ptr(h->W + 1, 0), ovf_slot;
   if (ht.is_forest) {
     const int maxw = ht.max_level_width;
+    const bool flow = h->solve_kernel == 6;      // messages by bus index, items dealt for equal item counts per wave
+    std::vector<int> owner(ht.lvl_ptr[ht.n_levels], 0);
+    {
+      std::vector<int> load(h->W, 0);
+      for (int lv = 0; lv < ht.n_levels; ++lv)
+        for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; ++t) {
+          int w = (t - ht.lvl_ptr[lv]) % h->W;
+          if (flow) { w = 0; for (int v = 1; v < h->W; ++v) if (load[v] < load[w]) w = v; }
+          owner[t] = w; ++load[w];
+        }
+    }
     for (int w = 0; w < h->W; ++w) {
       wl_ptr[w] = (int)witems.size();
       for (int lv = 0; lv < ht.n_levels; ++lv)
-        for (int t = ht.lvl_ptr[lv] + w; t < ht.lvl_ptr[lv + 1]; t += h->W) {
+        for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; ++t) {
+          if (owner[t] != w) continue;
           GsItemRec r{};
           const int i = ht.lvl_bus[t], p = ht.parent[i];
           r.bus = i; r.parent = p; r.level = lv;
@@ -429,12 +451,12 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
           r.ovf0 = (int)ovf_slot.size();
           for (int q = 0; q < r.n_children; ++q) {
             const int ch = ht.child_idx[ht.child_ptr[i] + q];
-            const int cs = ((lv - 1) & 1) * maxw + ht.lvl_pos[ch];
+            const int cs = flow ? ch : ((lv - 1) & 1) * maxw + ht.lvl_pos[ch];
             if (q < GS_ITEM_CHILDREN) r.child_slot[q] = cs; else ovf_slot.push_back(cs);
           }
           if (p >= 0) { r.g = ht.G[ht.parent_pos[i]]; r.b = ht.B[ht.parent_pos[i]]; }
           r.gd = ht.Gd[i]; r.bd = ht.Bd[i];
-          if (h->solve_kernel == 5) {       // FBS flavour: parent includes the slack, (g, b) := z = 1 / y
+          if (h->solve_kernel == 5 || flow) {       // FBS flavour: parent includes the slack, (g, b) := z = 1 / y
             const int fp = ht.fbs_parent[i], pos = ht.fbs_parent_pos[i];
             const double yr = -ht.G[pos], yi = -ht.B[pos], yd = yr * yr + yi * yi;
             r.g = yr / yd; r.b = -yi / yd;
@@ -637,7 +659,7 @@ int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_
 
 int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail(nullptr, GS_E_INVALID, "bad arguments");
-  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds", "fbs_lds"};
+  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds", "fbs_lds", "fbs_flow"};
   snprintf(buf, buflen,
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "

@@ -20,6 +20,7 @@ GS_DECLARE_KERNELS(nr_lu)
 GS_DECLARE_KERNELS(nr_dense)
 GS_DECLARE_KERNELS(fbs)
 GS_DECLARE_KERNELS(fbs_lds)
+GS_DECLARE_KERNELS(fbs_flow)
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);
 __global__ void gs_k_polar_to_rect(GsTables T, GsRows R, double* __restrict__ slab, int B);

@@ -269,7 +269,7 @@ __device__ __forceinline__ void nr_check(NrState& st, double mm, int it, double 
   }
 }
 
-enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3, KIND_TREE_LDS = 4, KIND_FBS_LDS = 5 };
+enum { KIND_TREE = 0, KIND_LU = 1, KIND_FBS = 2, KIND_DENSE = 3, KIND_TREE_LDS = 4, KIND_FBS_LDS = 5, KIND_FBS_FLOW = 6 };
 
 // =============================================================================================
 // Linear solves.  Each takes the mismatch in R0/R1 and the current E/F/VM/PC/QC rows, leaves the
@@ -973,6 +973,198 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
   return psum;
 }
 
+// ---- the sweep solver as a DATAFLOW over LDS: no level barriers -----------------------------------
+// A level barrier makes every wave wait for the slowest item of the level, and an item is one wave's serial
+// instruction stream (division, mismatch, record decode: ~1 k cycles) -- 11 levels x 6 sweeps of that are the
+// critical path of the barrier version above.  What a bus really waits for is ONE message: its parent's voltage on
+// the way down, its children's currents on the way up.  Here every bus owns a 16-byte-per-lane message slot in LDS
+// (so nothing is reused inside a sweep and no barrier is needed to protect a slot) plus a flag word; a producer
+// writes the message, then the sweep's epoch number into the flag; a consumer polls the flag, then reads the
+// message.  Everything else of an item (division, mismatch, row stores, the next record) runs after the flag is
+// posted, i.e. off the critical path, and the sweeps of one iteration flow into each other without a barrier.
+// Waves take their items in level order, so the item with the lowest level among those not yet done can always run:
+// no deadlock (all W waves of a workgroup are resident); the poll is bounded all the same.
+// Slot reuse is safe without barriers: V_i replaces J_i only after the parent consumed J_i (the parent's forward item
+// follows its backward item, and i's forward item waits for the parent's), J_i replaces V_i only after the children
+// consumed V_i (their backward items follow their forward items, and i's backward item waits for theirs).
+// Flat start only (every non-slack voltage is exactly 1, so no child sends a K): warm-started handles use fbs_lds.
+// The LDS executes the instructions of a compute unit in the order they were issued to it, so "message, then flag"
+// by the producer and "flag, then message" by the consumer need no s_waitcnt in between: the consumer asks for the
+// flag and -- speculatively -- the message in one round trip, and asks again when the flag was not there yet.
+// volatile keeps the compiler from reordering or merging the accesses.
+#define GS_FLOW_SPIN_CAP (1 << 18)
+typedef volatile __attribute__((address_space(3))) double* GsLdsD;
+typedef volatile __attribute__((address_space(3))) int* GsLdsI;
+__device__ __forceinline__ double2 flow_take(const double* m, const int* flag, int epoch) {
+  GsLdsD lm = (GsLdsD)m; GsLdsI lf = (GsLdsI)flag;
+  double2 v;
+  for (int spin = 0; spin < GS_FLOW_SPIN_CAP; ++spin) {
+    const int f = *lf;
+    v.x = lm[0]; v.y = lm[GS_LANES];
+    if (__builtin_amdgcn_readfirstlane(f) - epoch >= 0) break;
+  }
+  return v;
+}
+__device__ __forceinline__ void flow_give(Ctx& c, double* m, int* flag, int epoch, double x, double y) {
+  GsLdsD lm = (GsLdsD)m; GsLdsI lf = (GsLdsI)flag;
+  lm[0] = x; lm[GS_LANES] = y;
+  if (c.lane == 0) *lf = epoch;
+}
+
+// One iteration is three passes over a wave's own items, and only the two CHAIN passes wait for anybody:
+//   forward chain  (epoch 2t):   wait for the parent's V, V_i = V_parent - z_i J_i with J_i from the own slot, post V_i
+//   body           (no waits):   mismatch S_spec - V_new conj(I_old), the losses sum, I_new = conj(S_spec / V_new),
+//                                V_new into the E rows -- all the arithmetic
+//   [workgroup maximum of the mismatch = the only barrier of the iteration; convergence check]
+//   backward chain (epoch 2t+1): J_i = -I_new + sum of the children's J, post J_i
+// so the depth of the feeder is paid in LDS round trips (a few hundred cycles per level), not in whole items.
+// A wave owns at most GS_FLOW_ITEMS buses (the host selects this kernel only then), the passes are unrolled over
+// them, and S_spec and the injection current of each stay in REGISTERS for the whole solve: the iteration reads
+// no row at all (with one-item-ahead prefetch an item cost the latency of its row loads, ~1 k cycles), I_old of the
+// next mismatch is simply I_new of this one (one division per bus and iteration instead of two), and J never
+// leaves LDS.
+#define GS_FLOW_ITEMS 8
+template <bool FLAT_DONE>
+__device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrState& st) {
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
+  double* msg = gs_dyn + c.lane;
+  int* flags = (int*)(gs_dyn + (size_t)T.n * 2 * GS_LANES);
+  const GS_CONST GsItemRec* recs = (const GS_CONST GsItemRec*)T.witems;
+#define FMSG(bus, k) msg[((size_t)(bus) * 2 + (k)) * GS_LANES]
+  if (!FLAT_DONE) {
+    for (int i = c.wave; i < T.n; i += c.W) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
+    __syncthreads();
+  }
+  const int k0 = cld(T.wl_ptr, c.wave);
+  const int nit = min(cld(T.wl_ptr, c.wave + 1) - k0, GS_FLOW_ITEMS);
+  double P[GS_FLOW_ITEMS], Q[GS_FLOW_ITEMS], IR[GS_FLOW_ITEMS], II[GS_FLOW_ITEMS];
+#pragma unroll
+  for (int j = 0; j < GS_FLOW_ITEMS; ++j) {          // all S_spec rows of the wave in flight together
+    P[j] = 0.0; Q[j] = 0.0;
+    if (j < nit) { const double2 sp = ROW2(R.P + recs[k0 + j].bus); P[j] = sp.x; Q[j] = sp.y; }
+  }
+  double psum = 0.0;
+  int epoch = 1;
+  stamp(c, ST_INIT);
+  {  // first backward chain, at the flat start: V_i = 1 for every bus but the slack, so K_i = y_i (1 - V_parent) is
+     // non-zero for the children of the slack only and no bus receives a K from below; S_calc_i = V_i conj(K_i)
+    double lmax = 0.0, bad = 0.0;
+    GsItemRec rn{};
+    if (nit > 0) rn = load_item(T, k0);
+#pragma unroll
+    for (int j = 0; j < GS_FLOW_ITEMS; ++j) {
+      if (j < nit) {
+        const GsItemRec r = rn;
+        const double p = P[j], q = Q[j];
+        const bool root = r.flags & 16;
+        const double ep = root ? cld(T.v_set, r.parent) : 1.0;
+        const double dr = 1.0 - ep;
+        const double kr = r.gd * dr, ki = r.bd * dr;
+        const double pc = kr, qc = -ki;                      // V = 1: S_calc = conj(K)
+        const double dP = p - pc, dQ = q - qc;
+        lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
+        psum += pc;
+        if (root) psum -= ep * kr;                           // the slack's share: Re(V_s conj(-K_root))
+        IR[j] = p; II[j] = -q;                               // I = conj(S_spec / V) at V = 1
+        double jr = -p, ji = q;                              // J_i = -I_i + sum J_c
+        const int nch = r.n_children;
+#pragma unroll
+        for (int u = 0; u < GS_ITEM_CHILDREN; ++u) {
+          if (u < nch) { const int ch = r.child_slot[u]; const double2 jc = flow_take(&FMSG(ch, 0), flags + ch, epoch); jr += jc.x; ji += jc.y; }
+        }
+        for (int u = GS_ITEM_CHILDREN; u < nch; ++u) {
+          const int ch = cld(T.ovf_slot, r.ovf0 + u - GS_ITEM_CHILDREN);
+          const double2 jc = flow_take(&FMSG(ch, 0), flags + ch, epoch); jr += jc.x; ji += jc.y;
+        }
+        flow_give(c, &FMSG(r.bus, 0), flags + r.bus, epoch, jr, ji);
+        if (j + 1 < nit) rn = load_item(T, k0 + j + 1);
+      } else { IR[j] = 0.0; II[j] = 0.0; }
+    }
+    if (bad != bad) lmax = INFINITY;
+    stamp(c, ST_BOTTOM_UP);
+    const double mm = wg_max(c, 0, lmax);
+    stamp(c, ST_FLAG);
+    nr_check(st, mm, 0, C.tolerance);
+  }
+  for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
+    const bool upd = !st.done;
+    double lmax = 0.0, pnew = 0.0, bad = 0.0;
+    ++epoch;
+    {  // forward chain: V_i = V_parent - z_i J_i
+      GsItemRec rn{};
+      if (nit > 0) rn = load_item(T, k0 + nit - 1);
+#pragma unroll
+      for (int j = GS_FLOW_ITEMS - 1; j >= 0; --j) {
+        if (j < nit) {
+          const GsItemRec r = rn;
+          const double cjr = FMSG(r.bus, 0), cji = FMSG(r.bus, 1);                 // this wave's own backward item left it there
+          const double zr = cjr * r.g - cji * r.b, zi = cjr * r.b + cji * r.g;     // z J: known before the parent is
+          const bool root = r.flags & 16;                 // parent is the slack bus: its voltage is the set point, never updated
+          double ep, fp;
+          if (root) { ep = cld(T.v_set, r.parent); fp = 0.0; pnew += ep * cjr; }   // the slack's share of the losses sum: Re(V_s conj(J_root)), V_s real
+          else { const double2 vp = flow_take(&FMSG(r.parent, 0), flags + r.parent, epoch); ep = vp.x; fp = vp.y; }
+          flow_give(c, &FMSG(r.bus, 0), flags + r.bus, epoch, ep - zr, fp - zi);
+          if (j > 0) rn = load_item(T, k0 + j - 1);       // after the post: a scalar load in flight would turn every LDS wait of the poll into a wait for it
+        }
+      }
+    }
+    stamp(c, ST_TOP_DOWN);
+    // body: mismatch and sum of P_calc at the new voltages (power_flow.py:150-168), the next injection currents
+#pragma unroll
+    for (int j = 0; j < GS_FLOW_ITEMS; ++j) {
+      if (j < nit) {
+        const int bus = recs[k0 + j].bus;
+        const double en = FMSG(bus, 0), fn = FMSG(bus, 1);
+        if (upd) ROW2(R.E + bus) = make_double2(en, fn);
+        const double p = P[j], q = Q[j];
+        const double pc = en * IR[j] + fn * II[j], qc = fn * IR[j] - en * II[j];     // S_calc = V_new conj(I_old)
+        const double dP = p - pc, dQ = q - qc;
+        lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
+        pnew += pc;
+        const double rd = 1.0 / (en * en + fn * fn);
+        IR[j] = (p * en + q * fn) * rd; II[j] = (p * fn - q * en) * rd;              // I_new = conj(S_spec / V_new)
+      }
+    }
+    if (bad != bad) lmax = INFINITY;
+    stamp(c, ST_MISMATCH);
+    if (upd) psum = pnew;                                // losses at the voltages just stored
+    if (it + 1 >= C.max_iterations) break;               // iteration cap: mismatch / count stay the last check's
+    const double mm = wg_max(c, (it + 1) & 1, lmax);     // full barrier
+    stamp(c, ST_FLAG);
+    nr_check(st, mm, it + 1, C.tolerance);
+    if (__all(st.done)) break;
+    ++epoch;
+    {  // backward chain: J_i = -I_i + sum J_c
+      GsItemRec rn{};
+      if (nit > 0) rn = load_item(T, k0);
+#pragma unroll
+      for (int j = 0; j < GS_FLOW_ITEMS; ++j) {
+        if (j < nit) {
+          const GsItemRec r = rn;
+          double jr = -IR[j], ji = -II[j];
+          const int nch = r.n_children;
+#pragma unroll
+          for (int u = 0; u < GS_ITEM_CHILDREN; ++u) {
+            if (u < nch) { const int ch = r.child_slot[u]; const double2 jc = flow_take(&FMSG(ch, 0), flags + ch, epoch); jr += jc.x; ji += jc.y; }
+          }
+          for (int u = GS_ITEM_CHILDREN; u < nch; ++u) {
+            const int ch = cld(T.ovf_slot, r.ovf0 + u - GS_ITEM_CHILDREN);
+            const double2 jc = flow_take(&FMSG(ch, 0), flags + ch, epoch); jr += jc.x; ji += jc.y;
+          }
+          flow_give(c, &FMSG(r.bus, 0), flags + r.bus, epoch, jr, ji);
+          if (j + 1 < nit) rn = load_item(T, k0 + j + 1);
+        }
+      }
+    }
+    stamp(c, ST_BOTTOM_UP);
+  }
+  __syncthreads();          // the epilogue reuses the message block, and reads the E rows of other waves
+#undef FMSG
+  return psum;
+}
+
 // Bus voltage angle from (e, f).  Distribution feeders sit within a few degrees of the slack, and libm's atan2 is
 // ~105 vector instructions (the epilogue's bus loop is bound by them): when every lane of the wave has e > 0 and
 // |f| <= e / 8 the angle is t - t^3/3 + t^5/5 - ... with t = f / e, whose tenth term is below 2^-63 of the first;
@@ -1411,14 +1603,21 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   const bool valid = b < B;
   Ctx c{T, R, S, sh, lane, wave, W, C.stamps, 0ull, C.stamp_wave};
   if (C.stamps) c.tlast = __builtin_readcyclecounter();
-  if (ENV) prologue_env<KIND == KIND_FBS_LDS>(c, E, actions, b, valid);
+  if (KIND == KIND_FBS_FLOW) {     // message flags of the dataflow sweeps: epoch 0 = nothing posted (the prologue / flat start ends in a barrier)
+    int* flags = (int*)(gs_dyn + (size_t)T.n * 2 * GS_LANES);
+    for (int i = threadIdx.x; i < T.n; i += blockDim.x) flags[i] = 0;
+    if (!ENV) __syncthreads();
+  }
+  if (ENV) prologue_env<KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW>(c, E, actions, b, valid);
   stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
   else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds<ENV != 0>(c, C, st);
+  else if (KIND == KIND_FBS_FLOW) psum = fbs_loop_flow<ENV != 0>(c, C, st);
   else newton_loop<KIND>(c, C, st);
-  epilogue<ENV, KIND != KIND_FBS && KIND != KIND_FBS_LDS, CHK>(c, E, st, total_load, KIND == KIND_FBS_LDS, psum, FC, valid ? b : 0x7fffffff);   // FBS keeps no polar angle: atan2 there
+  constexpr bool kFbs = KIND == KIND_FBS || KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW;
+  epilogue<ENV, !kFbs, CHK>(c, E, st, total_load, KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW, psum, FC, valid ? b : 0x7fffffff);   // FBS keeps no polar angle: atan2 there
   if (ENV && PA.out != nullptr) pack_observations(c, PA, B);     // rows of pass 0 visible since the epilogue's barrier
   stamp(c, ST_EPILOGUE);
 }
@@ -1448,3 +1647,4 @@ GS_DEFINE_KERNELS(nr_lu, KIND_LU)
 GS_DEFINE_KERNELS(nr_dense, KIND_DENSE)
 GS_DEFINE_KERNELS(fbs, KIND_FBS)
 GS_DEFINE_KERNELS(fbs_lds, KIND_FBS_LDS)
+GS_DEFINE_KERNELS(fbs_flow, KIND_FBS_FLOW)

@@ -256,3 +256,52 @@ def test_warm_started_sweep_solver_agrees_with_the_cold_start():
         o4, *_ = w2.step(rng3.uniform(-1, 1, (B, fs.action_dim)))
     assert np.max(np.abs(orr - o4) / np.maximum(1.0, np.abs(o4))) < 1e-7
     for e in (cold, warm, resumed, w2): e.close()
+
+
+@pytest.mark.parametrize("maker,B", [(P.ieee123_like, 130), (lambda: P.ieee13_like("epsilon"), 70)])
+def test_dataflow_sweeps_agree_with_the_level_synchronous_kernel(maker, B, monkeypatch):
+    """`fbs_flow` (per-bus LDS slots + flags, register-resident bus state, no level barriers) against `fbs_lds` (level
+    barriers): same iteration counts per instance and the same trajectories to rounding (the two sum the children's
+    currents in a different order).  Several tolerances, so that at some of them the instances of one group stop at
+    different iterations and the frozen lanes are exercised."""
+    fs = maker()
+    seeds = np.arange(B, dtype=np.uint64) * 7 + 1
+    spread = 0
+    for tol in (1e-4, 3e-5, 1e-5, 3e-6, 1e-6, 1e-7, 1e-9):
+        kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True, tolerance=tol, max_iterations=50)
+        flow = P.BatchedGridEnvironment(fs, **kw)
+        monkeypatch.setenv("GS_NO_FLOW", "1")
+        sync = P.BatchedGridEnvironment(fs, **kw)
+        monkeypatch.delenv("GS_NO_FLOW")
+        assert flow.handle.describe()["kernel"] == "fbs_flow" and sync.handle.describe()["kernel"] == "fbs_lds"
+        flow.reset(seed=seeds); sync.reset(seed=seeds)
+        rng = np.random.default_rng(99)
+        for t in range(4):
+            a = rng.uniform(-1, 1, (B, fs.action_dim))
+            of, rf, tf, cf, inf_ = flow.step(a)
+            os_, rs, ts, cs, ins = sync.step(a)
+            assert inf_["power_flow_converged"].all() and ins["power_flow_converged"].all()
+            assert np.array_equal(inf_["iterations"], ins["iterations"]), tol
+            spread += len(np.unique(inf_["iterations"][:64])) > 1
+            assert np.max(np.abs(of - os_) / np.maximum(1.0, np.abs(os_))) < 1e-12, tol
+            assert np.allclose(rf, rs, rtol=1e-12, atol=1e-12)
+            assert np.array_equal(tf, ts) and np.array_equal(cf, cs)
+        flow.close(); sync.close()
+    assert spread > 0            # at some tolerance the first group mixes instances that stop one iteration apart
+
+
+def test_dataflow_kernel_falls_back_when_a_wave_would_own_too_many_buses(monkeypatch):
+    """The dataflow kernel keeps the state of at most 8 buses per wave in registers: with 4 waves per group the
+    123-bus feeder takes the level-synchronous kernel, and the results do not depend on which one ran."""
+    fs = P.ieee123_like(); B = 64
+    kw = dict(num_envs=B, solver="fbs", stochastic_loads=False, weather_variation=False, tolerance=1e-9, max_iterations=50)
+    a = np.random.default_rng(3).uniform(-1, 1, (B, fs.action_dim))
+    wide = P.BatchedGridEnvironment(fs, **kw)
+    monkeypatch.setenv("GS_WAVES", "4")
+    narrow = P.BatchedGridEnvironment(fs, **kw)
+    monkeypatch.delenv("GS_WAVES")
+    assert wide.handle.describe()["kernel"] == "fbs_flow" and narrow.handle.describe()["kernel"] == "fbs_lds"
+    wide.reset(seed=1); narrow.reset(seed=1)
+    ow = wide.step(a)[0]; on = narrow.step(a)[0]
+    assert np.max(np.abs(ow - on) / np.maximum(1.0, np.abs(on))) < 1e-12
+    wide.close(); narrow.close()
