@@ -1031,10 +1031,6 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
   int* flags = (int*)(gs_dyn + (size_t)T.n * 2 * GS_LANES);
   const GS_CONST GsItemRec* recs = (const GS_CONST GsItemRec*)T.witems;
 #define FMSG(bus, k) msg[((size_t)(bus) * 2 + (k)) * GS_LANES]
-  if (!FLAT_DONE) {
-    for (int i = c.wave; i < T.n; i += c.W) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
-    __syncthreads();
-  }
   const int k0 = cld(T.wl_ptr, c.wave);
   const int nit = min(cld(T.wl_ptr, c.wave + 1) - k0, GS_FLOW_ITEMS);
   double P[GS_FLOW_ITEMS], Q[GS_FLOW_ITEMS], IR[GS_FLOW_ITEMS], II[GS_FLOW_ITEMS];
@@ -1116,15 +1112,12 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
       if (j < nit) {
         const int bus = recs[k0 + j].bus;
         const double en = FMSG(bus, 0), fn = FMSG(bus, 1);
-        if (upd) ROW2(R.E + bus) = make_double2(en, fn);
         const double p = P[j], q = Q[j];
         const double pc = en * IR[j] + fn * II[j], qc = fn * IR[j] - en * II[j];     // S_calc = V_new conj(I_old)
         const double dP = p - pc, dQ = q - qc;
         lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
         bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
         pnew += pc;
-        const double rd = 1.0 / (en * en + fn * fn);
-        IR[j] = (p * en + q * fn) * rd; II[j] = (p * fn - q * en) * rd;              // I_new = conj(S_spec / V_new)
       }
     }
     if (bad != bad) lmax = INFINITY;
@@ -1136,6 +1129,18 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
     nr_check(st, mm, it + 1, C.tolerance);
     if (__all(st.done)) break;
     ++epoch;
+    // I_new = conj(S_spec / V_new) -- for the lanes that go on.  A lane that has just converged keeps the current that
+    // produced its voltages: its J and therefore its V repeat bit for bit in every later sweep of the group, so the
+    // slots hold every lane's final voltages whenever the group stops (the epilogue reads them there)
+#pragma unroll
+    for (int j = 0; j < GS_FLOW_ITEMS; ++j) {
+      if (j < nit) {
+        const int bus = recs[k0 + j].bus;
+        const double en = FMSG(bus, 0), fn = FMSG(bus, 1);
+        const double rd = 1.0 / (en * en + fn * fn);
+        if (!st.done) { IR[j] = (P[j] * en + Q[j] * fn) * rd; II[j] = (P[j] * fn - Q[j] * en) * rd; }
+      }
+    }
     {  // backward chain: J_i = -I_i + sum J_c
       GsItemRec rn{};
       if (nit > 0) rn = load_item(T, k0);
@@ -1160,7 +1165,7 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
     }
     stamp(c, ST_BOTTOM_UP);
   }
-  __syncthreads();          // the epilogue reuses the message block, and reads the E rows of other waves
+  __syncthreads();          // the epilogue reads the voltages of every bus from the slots
 #undef FMSG
   return psum;
 }
@@ -1188,10 +1193,25 @@ __device__ __forceinline__ double bus_angle(double f, double e) {
 // Epilogue: line flows (power_flow.py:340-356), losses (:198-200), wrapped angles, scalars; with
 // ENV also everything of step() that follows the load flow (grid_env.py:553-617).
 // =============================================================================================
-template <int ENV, int WRAP_VA, int CHK>
+// LDSV: the final (e, f) of every bus are in the per-bus LDS slots of the dataflow sweeps, not in the E rows.  A lane
+// that stopped at the very first check keeps the flat start (its slots went on iterating with the rest of the group).
+template <int LDSV>
+__device__ __forceinline__ double2 final_ef(Ctx& c, int i, bool flat_lane, bool any_flat) {
+  if (!LDSV) { const GsRows& R = c.R; GsLaneRows S = c.S; return ROW2(R.E + i); }
+  const double* m = gs_dyn + ((size_t)i * 2) * GS_LANES + c.lane;
+  double2 v = make_double2(m[0], m[GS_LANES]);
+  if (any_flat) {
+    const double fv = cld(c.T.fixed_v, i) ? cld(c.T.v_set, i) : 1.0;
+    if (flat_lane) v = make_double2(fv, 0.0);
+  }
+  return v;
+}
+
+template <int ENV, int WRAP_VA, int CHK, int LDSV>
 __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
                                          double psum, const GsFusedChecks& FC, int b) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
+  const bool flat_lane = LDSV && st.done && st.iters <= 1, any_flat = LDSV && __any(flat_lane);
   double lsum = have_psum ? psum : 0.0, dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int over = 0, vflags = 0;
   // fused post-step checks (kernels_checks.hip is the stand-alone form; same arithmetic, same outputs)
@@ -1207,7 +1227,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = min(i0 + u * c.W, T.n - 1);
-      const double2 x = WRAP_VA ? (double2)ROW2(R.VM + i) : (double2)ROW2(R.E + i);      // (|V|, angle) or (e, f)
+      const double2 x = WRAP_VA ? (double2)ROW2(R.VM + i) : final_ef<LDSV>(c, i, flat_lane, any_flat);      // (|V|, angle) or (e, f)
       xa[u] = WRAP_VA ? x.y : x.x;
       xb[u] = WRAP_VA ? x.x : x.y;
       pcs[u] = have_psum ? 0.0 : ROW(R.PC + i);
@@ -1254,7 +1274,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
     for (int u = 0; u < 4; ++u) {
       const int k = min(k0 + u * c.W, T.m - 1);
       const int i = cld(T.lfrom, k), j = cld(T.lto, k);
-      const double2 vi = ROW2(R.E + i), vj = ROW2(R.E + j);
+      const double2 vi = final_ef<LDSV>(c, i, flat_lane, any_flat), vj = final_ef<LDSV>(c, j, flat_lane, any_flat);
       ei_[u] = vi.x; fi_[u] = vi.y; ej_[u] = vj.x; fj_[u] = vj.y;
     }
 #pragma unroll
@@ -1286,6 +1306,7 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
     }
   }
   stamp(c, ST_EPI_LINES);
+  if (LDSV) __syncthreads();                                    // the partial results overlay the slots the loops read
   double* post = gs_dyn + c.lane;                               // post[k][wave][lane]
   int* posti = (int*)(gs_dyn + GS_EPI_DOUBLES) + c.lane;        // posti[k][wave][lane]
 #define POST(k, w) post[((k) * GS_MAX_WAVES + (w)) * GS_LANES]
@@ -1410,10 +1431,10 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
   stamp(c, ST_EPI_SCALARS);
 }
 
-template <int ENV, int WRAP_VA, int CHK>
+template <int ENV, int WRAP_VA, int CHK, int LDSV>
 __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrState& st, double total_load, bool have_psum,
                                          double psum, const GsFusedChecks& FC, int b) {
-  epilogue_impl<ENV, WRAP_VA, CHK>(c, E, st, total_load, have_psum, psum, FC, b);   // waves != 0 leave it after the reduction
+  epilogue_impl<ENV, WRAP_VA, CHK, LDSV>(c, E, st, total_load, have_psum, psum, FC, b);   // waves != 0 leave it after the reduction
 }
 
 // Observation block of this group, batch-major, written straight from the step kernel: 64-column
@@ -1603,12 +1624,18 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   const bool valid = b < B;
   Ctx c{T, R, S, sh, lane, wave, W, C.stamps, 0ull, C.stamp_wave};
   if (C.stamps) c.tlast = __builtin_readcyclecounter();
-  if (KIND == KIND_FBS_FLOW) {     // message flags of the dataflow sweeps: epoch 0 = nothing posted (the prologue / flat start ends in a barrier)
+  if (KIND == KIND_FBS_FLOW) {     // dataflow sweeps: flags at epoch 0 = nothing posted; a bus that is nobody's item (the slack, an
+    // islanded bus) keeps its flat-start voltage in its slot for good.  The prologue / the solver's first barrier publish both.
     int* flags = (int*)(gs_dyn + (size_t)T.n * 2 * GS_LANES);
     for (int i = threadIdx.x; i < T.n; i += blockDim.x) flags[i] = 0;
+    for (int i = wave; i < T.n; i += W)
+      if (cld(T.lvl_pos, i) < 0) {
+        gs_dyn[((size_t)i * 2) * GS_LANES + lane] = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+        gs_dyn[((size_t)i * 2 + 1) * GS_LANES + lane] = 0.0;
+      }
     if (!ENV) __syncthreads();
   }
-  if (ENV) prologue_env<KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW>(c, E, actions, b, valid);
+  if (ENV) prologue_env<KIND == KIND_FBS_LDS>(c, E, actions, b, valid);
   stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
@@ -1617,7 +1644,7 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   else if (KIND == KIND_FBS_FLOW) psum = fbs_loop_flow<ENV != 0>(c, C, st);
   else newton_loop<KIND>(c, C, st);
   constexpr bool kFbs = KIND == KIND_FBS || KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW;
-  epilogue<ENV, !kFbs, CHK>(c, E, st, total_load, KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW, psum, FC, valid ? b : 0x7fffffff);   // FBS keeps no polar angle: atan2 there
+  epilogue<ENV, !kFbs, CHK, KIND == KIND_FBS_FLOW>(c, E, st, total_load, KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW, psum, FC, valid ? b : 0x7fffffff);   // FBS keeps no polar angle: atan2 there
   if (ENV && PA.out != nullptr) pack_observations(c, PA, B);     // rows of pass 0 visible since the epilogue's barrier
   stamp(c, ST_EPILOGUE);
 }
