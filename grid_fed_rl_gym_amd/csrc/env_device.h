@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include "gs_internal.h"
+#include "fastmath.h"
 
 #ifndef ROW
 #define ROW(r) S[(size_t)(r) * GS_LANES]
@@ -19,6 +20,11 @@
 template <typename X>
 __device__ __forceinline__ X cld(const X* p, int i) {
   return ((const GS_CONST X*)p)[i];
+}
+
+// fmod(time / 3600, 24), exactly as libm's division and fmod give it (fastmath.h)
+__device__ __forceinline__ double hour_of_day(double time_s) {
+  return gs_fmod_pos(gs_div_by(time_s, 3600.0, 1.0 / 3600.0), 24.0, 1.0 / 24.0);
 }
 
 // ---- Philox4x32-10 (Salmon et al. 2011), key = seed, counter = (instance, step, draw, tag) ------
@@ -47,7 +53,9 @@ __device__ __forceinline__ void rng_uniform_pair(uint64_t seed, uint64_t instanc
 __device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw) {
   double u0, u1;
   rng_uniform_pair(seed, instance, step, draw, &u0, &u1);
-  return sqrt(-2.0 * log(u0)) * cos(2.0 * M_PI * u1);
+  double sn, cs;
+  gs_sincos_turns(u1, &sn, &cs);
+  return sqrt(-2.0 * gs_log01(u0)) * cs;
 }
 
 // Both Box-Muller branches of one draw: z0 is rng_normal(draw), z1 the sine branch.  The load noise takes them in
@@ -55,8 +63,8 @@ __device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t instance, u
 __device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw, double* z0, double* z1) {
   double u0, u1, sn, cs;
   rng_uniform_pair(seed, instance, step, draw, &u0, &u1);
-  const double r = sqrt(-2.0 * log(u0));
-  sincos(2.0 * M_PI * u1, &sn, &cs);
+  const double r = sqrt(-2.0 * gs_log01(u0));
+  gs_sincos_turns(u1, &sn, &cs);
   *z0 = r * cs; *z1 = r * sn;
 }
 
@@ -74,13 +82,16 @@ __device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& 
   if (!E.weather_variation) return;
   const uint64_t seed = lane_seed(S, R);
   const uint32_t step = (uint32_t)ROW(R.STEP);
-  const double hour = fmod(ROW(R.TIME) / 3600.0, 24.0);
-  const double base = (hour >= 6.0 && hour <= 18.0) ? 1000.0 * sin(M_PI * (hour - 6.0) / 12.0) : 0.0;
+  const double hour = hour_of_day(ROW(R.TIME));
+  double sn, cs;
+  gs_sincos_turns((hour - 6.0) * (1.0 / 24.0), &sn, &cs);       // sin(pi (hour - 6) / 12)
+  const double base = (hour >= 6.0 && hour <= 18.0) ? 1000.0 * sn : 0.0;
   double u, u_unused;
   rng_uniform_pair(seed, inst, step, DRAW_IRRADIANCE, &u, &u_unused);
   ROW(R.IRR) = base * (0.8 + 0.4 * u);
   ROW(R.WIND) = fmax(0.0, fmin(30.0, ROW(R.WIND) + 0.5 * rng_normal(seed, inst, step, DRAW_WIND)));
-  ROW(R.TEMP) = 25.0 + 10.0 * sin(2.0 * M_PI * (hour - 12.0) / 24.0) + 2.0 * rng_normal(seed, inst, step, DRAW_TEMP);
+  gs_sincos_turns((hour - 12.0) * (1.0 / 24.0), &sn, &cs);      // sin(2 pi (hour - 12) / 24)
+  ROW(R.TEMP) = 25.0 + 10.0 * sn + 2.0 * rng_normal(seed, inst, step, DRAW_TEMP);
   ROW(R.CLOUD) = fmax(0.0, fmin(1.0, ROW(R.CLOUD) + 0.1 * rng_normal(seed, inst, step, DRAW_CLOUD)));
 }
 
@@ -88,8 +99,10 @@ __device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& 
 __device__ __forceinline__ double renewable_power(const GsTables& T, const GsRows& R, GsLaneRows S, int g) {
   const double cap = cld(T.gen_cap, g), p0 = cld(T.gen_p0, g), p1 = cld(T.gen_p1, g), p2 = cld(T.gen_p2, g);
   if (cld(T.gen_kind, g) == 0) {
-    const double hour = fmod(ROW(R.TIME) / 3600.0, 24.0);
-    const double elev = (hour >= 6.0 && hour <= 18.0) ? sin(M_PI * (hour - 6.0) / 12.0) : 0.0;
+    const double hour = hour_of_day(ROW(R.TIME));
+    double sn, cs;
+    gs_sincos_turns((hour - 6.0) * (1.0 / 24.0), &sn, &cs);
+    const double elev = (hour >= 6.0 && hour <= 18.0) ? sn : 0.0;
     const double irr = 1000.0 * elev * (1.0 - 0.8 * ROW(R.CLOUD));
     const double tf = 1.0 - 0.004 * fmax(0.0, ROW(R.TEMP) - 25.0);
     return fmin(irr * p1 * p0 * tf, cap);
@@ -136,7 +149,7 @@ __device__ __forceinline__ double load_power_z(const GsTables& T, int l, double 
   return fmax(0.0, cld(T.load_base, l) * (prof * (1.0 + 0.1 * z)) * 1.0);
 }
 __device__ __forceinline__ double daily_profile(double time_s) {
-  const double hour = fmod(time_s / 3600.0, 24.0);
+  const double hour = hour_of_day(time_s);
   const int hi = (int)hour;
   const double frac = hour - (double)hi;
   return kDailyProfile[hi] * (1.0 - frac) + kDailyProfile[(hi + 1) % 24] * frac;
@@ -155,6 +168,6 @@ __device__ __forceinline__ void bus_injection(const GsTables& T, const GsRows& R
     const double bp = ROW(R.BATP + cld(T.bb_idx, p));
     if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp);
   }
-  ROW(R.P + i) = (0.0 - ls / E.power_base) + gs / E.power_base;
+  ROW(R.P + i) = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base);
   ROW(R.Q + i) = 0.0;
 }

@@ -92,7 +92,12 @@ extern __shared__ double gs3_msg[];   // [2 (level parity)][2 (re, im)][cap]: J 
 // level stay in flight across it.
 template <bool LDSMSG> __device__ __forceinline__ void level_barrier() {
   if (LDSMSG) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else __syncthreads();
+  else {      // J rows in HBM: written by one wave, read by another -- device-scope release / acquire around the rendezvous
+              // (a workgroup-scope __syncthreads() neither drains the stores nor refreshes the L1; see kernels_solve.hip)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
 }
 
 struct ZRow { double dr, di, ar, ai, br, bi; };               // a conductor's row of Z

@@ -545,7 +545,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   if ((rc = dev_upload(h, &T.witems, witems)) || (rc = dev_upload(h, &T.wl_ptr, wl_ptr)) || (rc = dev_upload(h, &T.ovf_slot, ovf_slot))) return bail(rc);
   T.max_level_width = ht.max_level_width;
   UP(fbs_parent, fbs_parent); UP(fbs_parent_pos, fbs_parent_pos);
-  UP(lfrom, lfrom); UP(lto, lto); UP(lyr, lyr); UP(lyi, lyi); UP(lrating, lrating);
+  UP(lfrom, lfrom); UP(lto, lto); UP(lyr, lyr); UP(lyi, lyi); UP(lrating, lrating); UP(lrating_inv, lrating_inv);
   UP(lu_piv_bus, lu_piv_bus); UP(lu_nb_ptr, lu_nb_ptr); UP(lu_nb_bus, lu_nb_bus); UP(lu_nb_kj, lu_nb_kj);
   UP(lu_nb_jk, lu_nb_jk); UP(lu_pair_ptr, lu_pair_ptr); UP(lu_pair_ik, lu_pair_ik); UP(lu_pair_kj, lu_pair_kj);
   UP(lu_pair_ij, lu_pair_ij); UP(lu_orig_slot, lu_orig_slot); UP(lu_orig_i, lu_orig_i); UP(lu_orig_j, lu_orig_j);
@@ -562,7 +562,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   GsEnvCfg& E = h->EC;
   E.timestep = cfg->timestep; E.v_min = cfg->v_min; E.v_max = cfg->v_max; E.f_min = cfg->f_min; E.f_max = cfg->f_max;
   E.safety_penalty = cfg->safety_penalty; E.H = cfg->inertia_H; E.D = cfg->damping_D; E.f0 = cfg->f_nominal;
-  E.power_base = cfg->power_base; E.episode_length = cfg->episode_length; E.stochastic_loads = cfg->stochastic_loads; E.fbs_warm_start = cfg->fbs_warm_start;
+  E.power_base = cfg->power_base; E.inv_power_base = 1.0 / cfg->power_base; E.episode_length = cfg->episode_length; E.stochastic_loads = cfg->stochastic_loads; E.fbs_warm_start = cfg->fbs_warm_start;
   E.weather_variation = cfg->weather_variation; E.first_instance = first_instance;
   // sum(load.active_power) in list order, starting from 0 like python's sum() (grid_env.py:744)
   h->total_load = 0.0;

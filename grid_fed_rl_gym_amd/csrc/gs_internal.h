@@ -38,12 +38,20 @@
 // so an access costs no vector ALU work (a 64-bit pointer per lane costs a v_lshl_add_u64 each time).  Indexed like the
 // lane pointer it replaces, S[row * GS_LANES]; rows that differ between lanes (the dense solver's pivots) use
 // S.lane_row(row * GS_LANES).  Out-of-range offsets read 0 / are dropped by the hardware bounds check.
+//
+// Row loads carry sc0: rows are how the waves of a group hand data to each other across a barrier, and a plain load may
+// be served from an L1 line that was filled around the time another wave's store went through (seen as 64-byte sectors
+// of stale data, rarely and timing-dependent).  sc0 loads are served from L2, which every store of the group has
+// reached in order.
+#ifndef GS_LOAD_AUX
+#define GS_LOAD_AUX 1
+#endif
 typedef unsigned int gs_u32x2 __attribute__((ext_vector_type(2)));
 struct GsRowRef {
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
   int soff;
-  __device__ __forceinline__ double get() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+  __device__ __forceinline__ double get() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, GS_LOAD_AUX)); }
   __device__ __forceinline__ void put(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gs_u32x2, v), r, voff, soff, 0); }
   __device__ __forceinline__ operator double() const { return get(); }
   __device__ __forceinline__ double operator=(double v) const { put(v); return v; }
@@ -56,7 +64,7 @@ struct GsPairRef {          // an (even row, odd row) pair of one lane: 16 bytes
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
   int soff;
-  __device__ __forceinline__ double2 get() const { return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+  __device__ __forceinline__ double2 get() const { return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, GS_LOAD_AUX)); }
   __device__ __forceinline__ void put(double2 v) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gs_u32x4, v), r, voff, soff, 0); }
   __device__ __forceinline__ operator double2() const { return get(); }
   __device__ __forceinline__ void operator=(double2 v) const { put(v); }
@@ -162,6 +170,7 @@ struct GsTables {
   const double* lyr;         // [m] series admittance, real
   const double* lyi;         // [m] imag
   const double* lrating;     // [m]
+  const double* lrating_inv; // [m] RN(1 / rating), 0 where the line has no rating (gs_div_by)
   // sparse block LU schedule (general / meshed networks)
   int32_t lu_n_piv, lu_n_slots, lu_n_orig, pad1;
   const int32_t* lu_piv_bus;     // [lu_n_piv] pivot bus, elimination order
@@ -266,7 +275,7 @@ struct GsSolveCfg {
 };
 
 struct GsEnvCfg {
-  double timestep, v_min, v_max, f_min, f_max, safety_penalty, H, D, f0, power_base;
+  double timestep, v_min, v_max, f_min, f_max, safety_penalty, H, D, f0, power_base, inv_power_base;
   int32_t episode_length, stochastic_loads, weather_variation, fbs_warm_start;
   int64_t first_instance;
 };

@@ -54,6 +54,15 @@ extern __shared__ __attribute__((aligned(16))) double gs_dyn[];
 // Barrier for waves that exchanged data through LDS only: wait for this wave's LDS traffic, then
 // rendezvous.  Unlike __syncthreads() it does not drain outstanding global loads/stores, so
 // prefetches issued before it stay in flight across it.
+// Barrier that publishes ROWS (global memory) between the waves of a group.  __syncthreads() is a workgroup-scope
+// release / acquire, for which the compiler emits no s_waitcnt vmcnt(0): it assumes that the vector memory operations of
+// one compute unit reach the cache in issue order.  Measured otherwise (rarely, in 64-byte sectors): a row stored by one
+// wave just before the barrier was still read old by another wave just after it.  So: drain this wave's stores before
+// the rendezvous; the loads behind it carry sc0 (gs_internal.h) and are served from L2.
+__device__ __forceinline__ void gs_rows_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef GS_EXP_PLAIN_SYNC
+#define __syncthreads() gs_rows_barrier()
+#endif
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct Ctx {
@@ -1281,15 +1290,15 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
     for (int u = 0; u < 4; ++u) {
       const int k = k0 + u * c.W;
       if (k >= T.m) break;
-      const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k);
+      const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k), rinv = cld(T.lrating_inv, k);
       const double ei = ei_[u], fi = fi_[u];
       const double dr = ei - ej_[u], di = fi - fj_[u];
       const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
       const double sr = ei * ir + fi * ii, si = fi * ir - ei * ii;      // S = Vi conj(I)
-      const double ql = (rating > 0.0) ? sqrt(sr * sr + si * si) / rating : 0.0;
+      const double ql = (rating > 0.0) ? gs_div_by(sqrt(sr * sr + si * si), rating, rinv) : 0.0;
       ROW(R.LOAD + k) = ql;
       if (ENV) {                                                        // Line.update_state, base.py:261-264
-        const double ld = (rating > 0.0) ? fabs(sr) / rating : 0.0;
+        const double ld = (rating > 0.0) ? gs_div_by(fabs(sr), rating, rinv) : 0.0;
         ROW2(R.FLOW + k) = make_double2(sr, ld);
         over += (ld > 0.8) ? 1 : 0;
         if (chk) {
@@ -1604,7 +1613,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         if (recs[k].ng > 1) gs += ROW(R.GENP + recs[k].g1) * ROW(R.CURT + recs[k].g1);
         if (recs[k].nb > 0) { const double bp = ROW(R.BATP + recs[k].b0); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
         if (recs[k].nb > 1) { const double bp = ROW(R.BATP + recs[k].b1); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
-        ROW2(R.P + i) = make_double2((0.0 - ls / E.power_base) + gs / E.power_base, 0.0);
+        ROW2(R.P + i) = make_double2((0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base), 0.0);
       }
     }
   }

@@ -48,6 +48,8 @@ std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want
   o.lfrom.assign(t.from_bus, t.from_bus + m);
   o.lto.assign(t.to_bus, t.to_bus + m);
   o.lrating.assign(t.rating, t.rating + m);
+  o.lrating_inv.assign(m, 0.0);
+  for (int k = 0; k < m; ++k) if (o.lrating[k] > 0.0) o.lrating_inv[k] = 1.0 / o.lrating[k];
   o.lyr.resize(m); o.lyi.resize(m);
   for (int k = 0; k < m; ++k) {
     if (o.lfrom[k] < 0 || o.lfrom[k] >= n || o.lto[k] < 0 || o.lto[k] >= n) return "line endpoint out of range";

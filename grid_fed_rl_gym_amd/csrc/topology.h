@@ -28,7 +28,7 @@ struct HostTopology {
   std::vector<int32_t> fbs_parent, fbs_parent_pos;
   // lines
   std::vector<int32_t> lfrom, lto;
-  std::vector<double> lyr, lyi, lrating;
+  std::vector<double> lyr, lyi, lrating, lrating_inv;
   // sparse block LU
   bool has_lu = false;
   int lu_n_piv = 0, lu_n_slots = 0, lu_n_orig = 0;
