@@ -33,8 +33,11 @@ struct U4 { uint32_t a, b, c, d; };
 __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low one: integer multiplies are
+    // quarter rate, and the forty of a Philox call were most of the load-noise phase
+    const uint64_t m0 = (uint64_t)0xD2511F53u * (uint64_t)c0, m1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0;
+    const uint32_t hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -78,11 +81,11 @@ __device__ __forceinline__ uint64_t lane_seed(GsLaneRows S, const GsRows& R) {
 }
 
 // grid_env.py:653-681
-__device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& E, GsLaneRows S, uint64_t inst) {
+// time_s / step: the clock AFTER this step's advance (the rows may be updated by another wave meanwhile)
+__device__ __forceinline__ void weather_update_at(const GsRows& R, const GsEnvCfg& E, GsLaneRows S, uint64_t inst, double time_s, uint32_t step) {
   if (!E.weather_variation) return;
   const uint64_t seed = lane_seed(S, R);
-  const uint32_t step = (uint32_t)ROW(R.STEP);
-  const double hour = hour_of_day(ROW(R.TIME));
+  const double hour = hour_of_day(time_s);
   double sn, cs;
   gs_sincos_turns((hour - 6.0) * (1.0 / 24.0), &sn, &cs);       // sin(pi (hour - 6) / 12)
   const double base = (hour >= 6.0 && hour <= 18.0) ? 1000.0 * sn : 0.0;
@@ -94,15 +97,21 @@ __device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& 
   ROW(R.TEMP) = 25.0 + 10.0 * sn + 2.0 * rng_normal(seed, inst, step, DRAW_TEMP);
   ROW(R.CLOUD) = fmax(0.0, fmin(1.0, ROW(R.CLOUD) + 0.1 * rng_normal(seed, inst, step, DRAW_CLOUD)));
 }
+__device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& E, GsLaneRows S, uint64_t inst) {
+  weather_update_at(R, E, S, inst, ROW(R.TIME), (uint32_t)ROW(R.STEP));
+}
 
 // dynamics.py:120-142 / 158-170
-__device__ __forceinline__ double renewable_power(const GsTables& T, const GsRows& R, GsLaneRows S, int g) {
+// sin of the solar elevation proxy of the reference's solar model: sin(pi (hour - 6) / 12) between 6 h and 18 h
+__device__ __forceinline__ double solar_elevation(double time_s) {
+  const double hour = hour_of_day(time_s);
+  double sn, cs;
+  gs_sincos_turns((hour - 6.0) * (1.0 / 24.0), &sn, &cs);
+  return (hour >= 6.0 && hour <= 18.0) ? sn : 0.0;
+}
+__device__ __forceinline__ double renewable_power_e(const GsTables& T, const GsRows& R, GsLaneRows S, int g, double elev) {
   const double cap = cld(T.gen_cap, g), p0 = cld(T.gen_p0, g), p1 = cld(T.gen_p1, g), p2 = cld(T.gen_p2, g);
   if (cld(T.gen_kind, g) == 0) {
-    const double hour = hour_of_day(ROW(R.TIME));
-    double sn, cs;
-    gs_sincos_turns((hour - 6.0) * (1.0 / 24.0), &sn, &cs);
-    const double elev = (hour >= 6.0 && hour <= 18.0) ? sn : 0.0;
     const double irr = 1000.0 * elev * (1.0 - 0.8 * ROW(R.CLOUD));
     const double tf = 1.0 - 0.004 * fmax(0.0, ROW(R.TEMP) - 25.0);
     return fmin(irr * p1 * p0 * tf, cap);
@@ -112,12 +121,15 @@ __device__ __forceinline__ double renewable_power(const GsTables& T, const GsRow
   if (w <= p1) { const double q = (w - p0) / (p1 - p0); return cap * (q * q * q); }
   return cap;
 }
+__device__ __forceinline__ double renewable_power(const GsTables& T, const GsRows& R, GsLaneRows S, int g) {
+  return renewable_power_e(T, R, S, g, solar_elevation(ROW(R.TIME)));
+}
 
 // _apply_actions + clock + weather for this lane: the part of step() that mutates scalar state
 // before the injections are formed (grid_env.py:621-651, 470-474).  `act` points at this
 // instance's action row (batch-major [B][A]).
-__device__ __forceinline__ void env_actions_clock_weather(const GsTables& T, const GsRows& R, const GsEnvCfg& E,
-                                                          GsLaneRows S, const double* __restrict__ act, uint64_t inst) {
+__device__ __forceinline__ void env_actions_clock(const GsTables& T, const GsRows& R, const GsEnvCfg& E,
+                                                  GsLaneRows S, const double* __restrict__ act) {
   const double dt = E.timestep;
   for (int q = 0; q < T.n_bats; ++q) {
     const double rating = cld(T.bat_rating, q), cap = cld(T.bat_cap, q), eff = cld(T.bat_eff, q);
@@ -141,7 +153,6 @@ __device__ __forceinline__ void env_actions_clock_weather(const GsTables& T, con
   for (int g = 0; g < T.n_gens; ++g) ROW(R.CURT + g) = (act[T.n_bats + g] + 1.0) / 2.0;
   ROW(R.TIME) = ROW(R.TIME) + dt;                    // grid_env.py:470-471
   ROW(R.STEP) = ROW(R.STEP) + 1.0;
-  weather_update(R, E, S, inst);
 }
 
 // realised power of load l (dynamics.py:54-75 when stochastic, base_power otherwise)

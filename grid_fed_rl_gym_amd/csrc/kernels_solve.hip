@@ -1279,18 +1279,26 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
   stamp(c, ST_EPI_BUSES);
   for (int k0 = c.wave; k0 < T.m; k0 += 4 * c.W) {
     double ei_[4], fi_[4], ej_[4], fj_[4];
+    // every scalar of the four lines first (one wait for all of them: a scalar load in flight makes each later LDS /
+    // scalar wait a wait for it), then the eight voltages, then the arithmetic
+    int li_[4], lj_[4];
+    double yr_[4], yi_[4], rt_[4], ri_[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int k = min(k0 + u * c.W, T.m - 1);
-      const int i = cld(T.lfrom, k), j = cld(T.lto, k);
-      const double2 vi = final_ef<LDSV>(c, i, flat_lane, any_flat), vj = final_ef<LDSV>(c, j, flat_lane, any_flat);
+      li_[u] = cld(T.lfrom, k); lj_[u] = cld(T.lto, k);
+      yr_[u] = cld(T.lyr, k); yi_[u] = cld(T.lyi, k); rt_[u] = cld(T.lrating, k); ri_[u] = cld(T.lrating_inv, k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double2 vi = final_ef<LDSV>(c, li_[u], flat_lane, any_flat), vj = final_ef<LDSV>(c, lj_[u], flat_lane, any_flat);
       ei_[u] = vi.x; fi_[u] = vi.y; ej_[u] = vj.x; fj_[u] = vj.y;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int k = k0 + u * c.W;
       if (k >= T.m) break;
-      const double yr = cld(T.lyr, k), yi = cld(T.lyi, k), rating = cld(T.lrating, k), rinv = cld(T.lrating_inv, k);
+      const double yr = yr_[u], yi = yi_[u], rating = rt_[u], rinv = ri_[u];
       const double ei = ei_[u], fi = fi_[u];
       const double dr = ei - ej_[u], di = fi - fj_[u];
       const double ir = yr * dr - yi * di, ii = yr * di + yi * dr;      // I = y (Vi - Vj)
@@ -1361,16 +1369,18 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
 #undef POST
 #undef POSTI
   const double dt = E.timestep;
-  const double totloss = ROW(R.TOTLOSS) + losses * dt / 3600.0;        // grid_env.py:739
-  ROW(R.TOTLOSS) = totloss;
+  // the rows of the scalar state, requested together (each is a round trip to L2; stores in between would serialise them)
+  const double totloss0 = ROW(R.TOTLOSS), f_old = ROW(R.FREQ), viol0 = ROW(R.VIOL), step0 = ROW(R.STEP), eprew0 = ROW(R.EPREW);
   double total_gen = 0.0, total_curt = 0.0;                            // grid_env.py:744-751, 807-816
   for (int g = 0; g < T.n_gens; ++g) {
     const double p = ROW(R.GENP + g);
     total_gen += p;
     total_curt += p * (1.0 - ROW(R.CURT + g));
   }
+  const double totloss = totloss0 + losses * dt / 3600.0;              // grid_env.py:739
+  ROW(R.TOTLOSS) = totloss;
   const double imbalance = (total_gen - total_load - losses * E.power_base) / 1e6;
-  double f = ROW(R.FREQ);                                              // dynamics.py:260-273
+  double f = f_old;                                                    // dynamics.py:260-273
   f += ((imbalance - E.D * (f - E.f0)) / (2.0 * E.H * E.f0)) * dt;
   f = fmax(55.0, fmin(65.0, f));
   ROW(R.FREQ) = f;
@@ -1385,16 +1395,16 @@ __device__ __forceinline__ void epilogue_impl(Ctx& c, const GsEnvCfg& E, const N
     reward += (soc >= 0.2 && soc <= 0.8) ? 1.0 : -5.0;
   }
   const int vhigh = vflags & 1, vlow = (vflags >> 1) & 1, fhigh = f > E.f_max, flow_ = f < E.f_min;
-  double viol = ROW(R.VIOL), trunc = 0.0;
+  double viol = viol0, trunc = 0.0;
   if (vhigh | vlow | fhigh | flow_) {
     viol += 1.0;
     if (viol > 10.0) { trunc = 1.0; reward -= E.safety_penalty; }     // grid_env.py:604-606
   }
   ROW(R.VIOL) = viol;
   ROW(R.TRUNC) = trunc;
-  ROW(R.TERM) = (ROW(R.STEP) >= (double)E.episode_length) ? 1.0 : 0.0;   // base.py:140-142
+  ROW(R.TERM) = (step0 >= (double)E.episode_length) ? 1.0 : 0.0;   // base.py:140-142
   ROW(R.REWARD) = reward;
-  ROW(R.EPREW) = ROW(R.EPREW) + reward;
+  ROW(R.EPREW) = eprew0 + reward;
   ROW(R.VMAX) = vmax; ROW(R.VMIN) = vmin;
   ROW(R.VFLAGS + 0) = (double)vhigh; ROW(R.VFLAGS + 1) = (double)vlow;
   ROW(R.VFLAGS + 2) = (double)fhigh; ROW(R.VFLAGS + 3) = (double)flow_;
@@ -1558,18 +1568,23 @@ template <bool FLAT_FBS>
 __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   const uint64_t inst = (uint64_t)(E.first_instance + b);
-  // every wave derives the new clock from the old rows, then wave 0 alone advances the scalar
-  // state (actions, clock, weather, renewables) while the other waves draw the load powers
-  const double tnew = ROW(R.TIME) + E.timestep;
+  // every wave derives the new clock from the old rows; then wave 0 applies the actions (batteries, curtailment) and
+  // advances the clock rows, wave 1 draws the weather and evaluates the renewables, and the other waves draw the load
+  // powers -- three chains that do not depend on each other (the scalar chain of one wave was the longest of them)
+  const double told = ROW(R.TIME), tnew = told + E.timestep;
   const uint32_t snew = (uint32_t)(ROW(R.STEP) + 1.0);
   const uint64_t seed = lane_seed(S, R);
   __syncthreads();
-  if (c.wave == 0) {
-    if (valid) env_actions_clock_weather(T, R, E, S, actions + (size_t)b * (T.n_bats + T.n_gens), inst);
-    for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power(T, R, S, g);
+  const int wave_b = c.W > 1 ? 1 : 0;               // who takes the weather chain
+  const int rng0 = c.W > 2 ? 2 : 0;                 // first wave of the load draws (every wave when there are only one or two)
+  if (c.wave == 0 && valid) env_actions_clock(T, R, E, S, actions + (size_t)b * (T.n_bats + T.n_gens));
+  if (c.wave == wave_b) {
+    if (valid) weather_update_at(R, E, S, inst, tnew, snew);
+    const double elev = solar_elevation(valid ? tnew : told);
+    for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power_e(T, R, S, g, elev);
   }
-  if (c.W == 1 || c.wave > 0) {
-    const int l0 = (c.W > 1) ? c.wave - 1 : 0, ls = (c.W > 1) ? c.W - 1 : 1;
+  if (c.wave >= rng0) {
+    const int l0 = c.wave - rng0, ls = c.W - rng0;
     const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
     if (E.stochastic_loads) {                               // loads 2p and 2p + 1 share one Box-Muller draw
       for (int p = l0; 2 * p < T.n_loads; p += ls) {
@@ -1583,6 +1598,7 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
       for (int l = l0; l < T.n_loads; l += ls) ROW(R.LOADP + l) = cld(T.load_base, l);
     }
   }
+  stamp(c, ST_PRO_SPARE);          // this wave's own share; ST_PRO_SCALAR is then the wait for the slowest wave
   __syncthreads();
   stamp(c, ST_PRO_SCALAR);
   {
