@@ -13,7 +13,7 @@ from .feeders import (FeederSpec, flatten_feeder, flatten_network, to_objects, r
                       random_meshed)
 
 from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoupledSolver,
-                     BatchedForwardBackwardSweepSolver, DistributionPowerFlow, parallel_power_flow_batch,
+                     BatchedForwardBackwardSweepSolver, BatchedRobustPowerFlowSolver, DistributionPowerFlow, parallel_power_flow_batch,
                      injections_from_dicts)
 from .env import BatchedGridEnvironment, VectorizedEnvironment, Box
 from .rollout import collect_random_data, GridDataset
@@ -25,7 +25,7 @@ from .unbalanced import UnbalancedPowerFlow, UnbalancedFeederSpec, UnbalancedSol
 
 __all__ = [
     "BatchedNewtonRaphsonSolver", "NewtonRaphsonSolver", "FastDecoupledSolver",
-    "BatchedForwardBackwardSweepSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
+    "BatchedForwardBackwardSweepSolver", "BatchedRobustPowerFlowSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
     "injections_from_dicts", "BatchedGridEnvironment", "VectorizedEnvironment", "Box",
     "collect_random_data", "GridDataset", "ShardedGridEnvironment", "shard_range",
     "AgentConfig", "BatchedMultiAgentWrapper", "feeder_from_dict", "feeder_to_dict", "network_dict_normalized",

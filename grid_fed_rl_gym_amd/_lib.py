@@ -95,6 +95,7 @@ SYMBOLS = [
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     ("gs_debug_write_rows", C.c_int, [_H, C.c_int32, _dp]),
+    ("gs_fallback_linear", C.c_int, [_H, _dp, _dp, _dp, _dp, _up, _up, C.POINTER(C.c_int32)]),
 ]
 # the gs3_* entry points (three-phase solver) are bound in unbalanced.py
 
@@ -254,6 +255,26 @@ class Handle:
         out, v = self._solution_buffers()
         self._check(self._lib.gs_solve(self._h, _ptr(P, _dp), _ptr(Q, _dp), C.byref(v)))
         return out
+
+    def fallback_linear(self, load_w=None, gen_w=None, total_load=None, total_gen=None, mask=None) -> np.ndarray:
+        """gs_fallback_linear: replace the solution of the masked (default: non-converged) instances by the reference's
+        linear approximation (robust_power_flow.py:336-398); returns the boolean [B] array of replaced instances.
+        Without load_w / gen_w the per-bus totals come from the environment state on the device."""
+        def arr(a, shape):
+            if a is None:
+                return None
+            a = _f64(a)
+            if a.shape != shape:
+                raise PowerFlowError(f"expected shape {shape}, got {a.shape}")
+            return a
+        lw, gw = arr(load_w, (self.B, self.n)), arr(gen_w, (self.B, self.n))
+        tl, tg = arr(total_load, (self.B,)), arr(total_gen, (self.B,))
+        mk = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8).reshape(self.B))
+        applied = np.zeros(self.B, dtype=np.uint8)
+        cnt = C.c_int32(0)
+        self._check(self._lib.gs_fallback_linear(self._h, _ptr(lw, _dp), _ptr(gw, _dp), _ptr(tl, _dp), _ptr(tg, _dp), _ptr(mk, _up),
+                                                 _ptr(applied, _up), C.byref(cnt)))
+        return applied.astype(bool)
 
     def upload_injections(self, P, Q=None) -> None:
         P, Q = self._pq(P, Q)

@@ -79,7 +79,8 @@ class PowerFlowSolution:
 @dataclass
 class BatchedPowerFlowSolution:
     """The same record with a leading batch axis on every field, plus per-instance status
-    (0 converged, 1 iteration cap, 2 singular Jacobian, 3 non-finite mismatch)."""
+    (0 converged, 1 iteration cap, 2 singular Jacobian, 3 non-finite mismatch, 4 replaced by the linear-approximation
+    fallback)."""
     converged: np.ndarray        # bool  [B]
     iterations: np.ndarray       # int32 [B]
     bus_voltages: np.ndarray     # f64   [B, n]

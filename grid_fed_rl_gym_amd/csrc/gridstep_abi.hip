@@ -95,6 +95,10 @@ struct gs_handle {
   int32_t *rows_f = nullptr, *rows_i = nullptr, *rows_u = nullptr;
   double* sc_f = nullptr; int32_t* sc_i = nullptr; uint8_t* sc_u = nullptr;
   uint64_t* d_seeds = nullptr; uint8_t* d_mask = nullptr;
+  // gs_fallback_linear: line reactances, dict-order bus lists and staging, created on first use
+  std::vector<double> line_x;
+  bool fb_ready = false; GsFallbackArgs FB{};
+  double *fb_load = nullptr, *fb_gen = nullptr, *fb_tl = nullptr, *fb_tg = nullptr; uint8_t* fb_mask = nullptr; int32_t* fb_applied = nullptr;
   std::vector<double> h_f; std::vector<int32_t> h_i; std::vector<uint8_t> h_u;
   // timing
   bool timing = false;
@@ -327,6 +331,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
                                         h->topo);
   if (!why.empty()) { int rc = fail(nullptr, GS_E_INVALID, "topology: %s", why.c_str()); delete h; return rc; }
   const HostTopology& ht = h->topo;
+  h->line_x.assign(topo->x, topo->x + topo->m);
   h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
   int W = cfg->waves_per_group;
   if (const char* e = getenv("GS_WAVES")) W = atoi(e);
@@ -937,6 +942,64 @@ int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
   (void)hipFree(dmap);
   if (!rc && e != hipSuccess) rc = fail(h, GS_E_HIP, "row write failed");
   return rc;
+}
+
+// ---- linear-approximation fallback ------------------------------------------------------------------
+int gs_fallback_linear(gs_handle* h, const double* load_w, const double* gen_w, const double* total_load,
+                       const double* total_gen, const uint8_t* mask, uint8_t* applied_out, int32_t* n_applied) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  if ((load_w == nullptr) != (gen_w == nullptr)) return fail(h, GS_E_INVALID, "load_w and gen_w go together");
+  if ((total_load == nullptr) != (total_gen == nullptr)) return fail(h, GS_E_INVALID, "total_load and total_gen go together");
+  if (!load_w && total_load) return fail(h, GS_E_INVALID, "totals without per-bus arrays: with the device state the sums are formed on the device");
+  if (!load_w && !h->was_reset) return fail(h, GS_E_STATE, "no environment state on the device: call gs_reset first or pass load_w / gen_w");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int B = h->B, n = h->n;
+  int rc = GS_OK;
+  if (!h->fb_ready) {
+    const HostTopology& ht = h->topo;
+    // the order in which _calculate_power_injections fills its dicts (grid_env.py:683-720): load buses by first
+    // appearance in the load list, then battery buses not seen before (a charging battery adds a load entry);
+    // generator buses likewise, then battery buses (a discharging battery adds a generation entry)
+    auto order_of = [&](const std::vector<int32_t>& ptr, const std::vector<int32_t>& idx, int count) {
+      std::vector<int32_t> bus_of(count, 0), out; std::vector<char> seen(n, 0);
+      for (int i = 0; i < n; ++i) for (int p = ptr[i]; p < ptr[i + 1]; ++p) bus_of[idx[p]] = i;
+      for (int d = 0; d < count; ++d) if (!seen[bus_of[d]]) { seen[bus_of[d]] = 1; out.push_back(bus_of[d]); }
+      std::vector<int32_t> bat_bus(h->n_bats, 0);
+      for (int i = 0; i < n; ++i) for (int p = ht.bb_ptr[i]; p < ht.bb_ptr[i + 1]; ++p) bat_bus[ht.bb_idx[p]] = i;
+      for (int q = 0; q < h->n_bats; ++q) if (!seen[bat_bus[q]]) { seen[bat_bus[q]] = 1; out.push_back(bat_bus[q]); }
+      return out; };
+    const std::vector<int32_t> lo = order_of(ht.bl_ptr, ht.bl_idx, h->n_loads), go = order_of(ht.bg_ptr, ht.bg_idx, h->n_gens);
+    if ((rc = dev_upload(h, &h->FB.load_order, lo)) || (rc = dev_upload(h, &h->FB.gen_order, go)) ||
+        (rc = dev_upload(h, &h->FB.line_x, h->line_x))) return rc;
+    h->FB.n_load_order = (int32_t)lo.size(); h->FB.n_gen_order = (int32_t)go.size();
+    if ((rc = dev_alloc(h, &h->fb_load, (size_t)B * n)) || (rc = dev_alloc(h, &h->fb_gen, (size_t)B * n)) ||
+        (rc = dev_alloc(h, &h->fb_tl, (size_t)B)) || (rc = dev_alloc(h, &h->fb_tg, (size_t)B)) ||
+        (rc = dev_alloc(h, &h->fb_mask, (size_t)B)) || (rc = dev_alloc(h, &h->fb_applied, (size_t)B))) return rc;
+    h->fb_ready = true;
+  }
+  GsFallbackArgs A = h->FB;
+  A.env_mode = load_w ? 0 : 1;
+  if (load_w) {
+    HIPCHK(h, hipMemcpyAsync(h->fb_load, load_w, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->fb_gen, gen_w, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    A.load_w = h->fb_load; A.gen_w = h->fb_gen;
+    if (total_load) {
+      HIPCHK(h, hipMemcpyAsync(h->fb_tl, total_load, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(h->fb_tg, total_gen, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      A.tot_load = h->fb_tl; A.tot_gen = h->fb_tg;
+    }
+  }
+  if (mask) { HIPCHK(h, hipMemcpyAsync(h->fb_mask, mask, (size_t)B, hipMemcpyHostToDevice, h->stream)); A.mask = h->fb_mask; }
+  A.applied = h->fb_applied;
+  hipLaunchKernelGGL(gs_k_fallback_linear, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, A, h->slab, B);
+  HIPCHK(h, hipGetLastError());
+  std::vector<int32_t> ap(B);
+  HIPCHK(h, hipMemcpyAsync(ap.data(), h->fb_applied, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int32_t cnt = 0;
+  for (int b = 0; b < B; ++b) { cnt += ap[b] != 0; if (applied_out) applied_out[b] = ap[b] != 0; }
+  if (n_applied) *n_applied = cnt;
+  return GS_OK;
 }
 
 // ---- post-step checks -------------------------------------------------------------------------------

@@ -92,6 +92,17 @@ __device__ __forceinline__ GsLaneRows gs_lane_rows(double* slab, int group, int 
 }
 #endif
 
+// gs_k_fallback_linear (kernels_fallback.hip)
+struct GsFallbackArgs {
+  const double* load_w; const double* gen_w;          // [B][n] batch-major, or NULL with env_mode
+  const double* tot_load; const double* tot_gen;      // [B] or NULL
+  const int32_t* load_order; const int32_t* gen_order;   // buses in the order the reference's dicts are filled (env_mode)
+  const double* line_x;                                // [m] line reactance
+  const uint8_t* mask;                                 // [B] or NULL = where CONV == 0
+  int32_t* applied;                                    // [B] out
+  int32_t n_load_order, n_gen_order, env_mode, pad;
+};
+
 // One forest work item (a bus, in the order ONE wave meets it in the sweeps) with everything the
 // sweep needs that does not depend on the instance: read as one contiguous scalar load, and the
 // next record of the wave is the next 96 bytes (prefetched one item ahead).

@@ -35,5 +35,6 @@ __global__ void gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32
 __global__ void gs_k_checks(GsChecksCfg C, const double* __restrict__ slab, const double* __restrict__ freq_override,
                             double* __restrict__ prev, int32_t* __restrict__ state, int32_t* __restrict__ out_i,
                             double* __restrict__ out_f, uint8_t* __restrict__ bus_mask, uint8_t* __restrict__ line_mask, int B, int Bp);
+__global__ void gs_k_fallback_linear(GsTables T, GsRows R, GsFallbackArgs A, double* __restrict__ slab, int B);
 __global__ void gs_k_checks_reset(int32_t* __restrict__ state, const uint8_t* __restrict__ mask, int B, int Bp);
 }

@@ -198,3 +198,81 @@ def parallel_power_flow_batch(solver: _BatchedSolverBase, network_configs: List[
         for row, i in enumerate(members):
             results[i] = sol[row]
     return results  # type: ignore[return-value]
+
+
+class BatchedRobustPowerFlowSolver:
+    """The accept / fall-back policy of the reference's ``AdvancedRobustPowerFlowSolver.solve``
+    (robust_power_flow.py:523-613) for a batch: the primary solver answers every instance, the quality gate
+    (``_assess_solution_quality``, :615-657) is evaluated on the device, and the instances it rejects (score <= 0.7)
+    get the reference's linear approximation (``LinearApproximationSolver``, :336-398) written over their rows by
+    ``gs_fallback_linear`` -- the other instances are not touched and nothing but the verdicts crosses the host boundary
+    in between.  What the reference's chain has in between (Gauss-Seidel as coded diverges, the "fast decoupled" class is
+    Newton-Raphson again) and behind (a constant-voltage guess) is not reproduced; caches, circuit breakers
+    and health scores are host bookkeeping outside the path.
+
+    ``solve_batch(network, loads_w, gens_w)`` takes the totals of the reference's two dicts per bus, ``[B, n]`` each, in
+    the reference's units (W); the net injection handed to the primary solver is ``(gens_w - loads_w) / power_base``.
+    Returns the solution with two more per-instance fields: ``method`` (0 primary, 1 linear approximation, -1 neither
+    passed the gate -- the reference raises PowerFlowError there) and ``quality``.
+    """
+
+    METHODS = {0: "newton_raphson", 1: "linear_approximation", -1: "failed"}
+
+    def __init__(self, primary: Optional[_BatchedSolverBase] = None, accept_quality: float = 0.7, power_base: float = 1.0,
+                 **primary_kwargs: Any) -> None:
+        self.primary = primary if primary is not None else BatchedNewtonRaphsonSolver(**primary_kwargs)
+        self.accept_quality = float(accept_quality)
+        self.power_base = float(power_base)
+
+    def close(self) -> None:
+        self.primary.close()
+
+    def solve_batch(self, network: Union[FeederSpec, Tuple[Sequence[Any], Sequence[Any]]], loads_w, gens_w,
+                    total_load=None, total_gen=None) -> BatchedPowerFlowSolution:
+        from .safety import PostStepChecks
+        spec = network if isinstance(network, FeederSpec) else _network_spec(*network)
+        L = np.ascontiguousarray(loads_w, dtype=np.float64); G = np.ascontiguousarray(gens_w, dtype=np.float64)
+        if L.ndim != 2 or L.shape[1] != spec.n or G.shape != L.shape:
+            raise PowerFlowError(f"loads_w / gens_w must have shape (B, {spec.n}), got {L.shape} / {G.shape}")
+        h = self.primary.handle_for(spec, L.shape[0])
+        h.upload_injections((G - L) / self.power_base)
+        h.solve_device()
+        gate = PostStepChecks(h, quality_tolerance=self.primary.tolerance, loading="solution")
+        try:
+            gate.run(); q0 = gate.download()["quality"]
+            rejected = ~(q0 > self.accept_quality)
+            method = np.zeros(L.shape[0], dtype=np.int32)
+            quality = q0.copy()
+            if rejected.any():
+                applied = h.fallback_linear(L, G, total_load, total_gen, mask=rejected)
+                gate.run(); q1 = gate.download()["quality"]
+                quality = np.where(applied, q1, q0)
+                method = np.where(applied, np.where(q1 > self.accept_quality, 1, -1), 0).astype(np.int32)
+        finally:
+            gate.close()
+        out = h.download_solution()
+        sol = BatchedPowerFlowSolution(converged=out["converged"].astype(bool), iterations=out["iterations"],
+                                       bus_voltages=out["bus_voltages"], bus_angles=out["bus_angles"],
+                                       line_flows=out["line_flows"], line_loadings=out["line_loadings"],
+                                       losses=out["losses"], max_mismatch=out["max_mismatch"], status=out["status"])
+        sol.method = method
+        sol.quality = quality
+        return sol
+
+    def solve(self, buses: List[Any], lines: List[Any], loads: Dict[Any, float], generation: Dict[Any, float]):
+        """The reference's signature; returns (solution, method_name) like ``SolverResult.solution / .method_used``.
+        Totals are summed in the dicts' own order, as the reference's linear solver does."""
+        spec = _network_spec(buses, lines)
+        idx = spec.bus_index()
+        L = np.zeros((1, spec.n)); G = np.zeros((1, spec.n))
+        for bus_id, p in loads.items():
+            if bus_id in idx:
+                L[0, idx[bus_id]] += p
+        for bus_id, p in generation.items():
+            if bus_id in idx:
+                G[0, idx[bus_id]] += p
+        tl = np.array([float(sum(loads.values())) if loads else 0.0]); tg = np.array([float(sum(generation.values())) if generation else 0.0])
+        sol = self.solve_batch(spec, L, G, tl, tg)
+        if sol.method[0] < 0:
+            raise PowerFlowError("All power flow solvers failed: neither the primary answer nor the linear approximation passed the quality gate")
+        return sol[0], self.METHODS[int(sol.method[0])]

@@ -49,7 +49,8 @@ enum { GS_SOLVER_NR = 0, GS_SOLVER_FBS = 1 };
  * because the as-coded diagonal blocks can be exactly singular (e.g. a leaf fed through r = x). */
 enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2, GS_LINSOLVE_DENSE_PIVOT = 3 };
 enum { GS_GEN_SOLAR = 0, GS_GEN_WIND = 1 };
-enum { GS_STATUS_OK = 0, GS_STATUS_MAX_ITER = 1, GS_STATUS_SINGULAR = 2, GS_STATUS_NAN = 3 };
+enum { GS_STATUS_OK = 0, GS_STATUS_MAX_ITER = 1, GS_STATUS_SINGULAR = 2, GS_STATUS_NAN = 3,
+       GS_STATUS_FALLBACK_LINEAR = 4 /* answer replaced by gs_fallback_linear; converged = 1 as the reference's linear solver reports */ };
 
 /* Network + devices, flattened.  Replaces the Bus/Line/Load object lists the reference
  * passes to solve() (environments/base.py:197-295, power_flow.py:38-46) and the feeder
@@ -168,6 +169,20 @@ int gs_solve(gs_handle* h, const double* P_spec, const double* Q_spec, const gs_
 int gs_upload_injections(gs_handle* h, const double* P_spec, const double* Q_spec);
 int gs_solve_device(gs_handle* h);
 int gs_download_solution(gs_handle* h, const gs_solution_view* out);
+
+/* ---- fallback for rejected load flows: LinearApproximationSolver.solve (robust_power_flow.py:336-398), the
+ * "linear_approximation" stage of AdvancedRobustPowerFlowSolver.solve (:523-613) ------------------------------
+ * Overwrites the solution rows (voltages, angles, flows, loadings, losses, converged = 1, iterations = 1,
+ * max_mismatch = 0, status = GS_STATUS_FALLBACK_LINEAR) of the instances selected by mask[B] (!= 0), or, with
+ * mask == NULL, of the instances whose last solve / step did not converge; every other instance keeps its rows.
+ * load_w / gen_w: [B][n] totals of the reference's `loads` / `generation` dicts per bus (0 = no entry), in the
+ * reference's units (W); both NULL = take them from the environment state on the device (load powers, curtailed
+ * renewables, battery powers: grid_env.py:683-720).  total_load / total_gen: [B] sums of the dict values in the
+ * caller's dict order, or NULL = summed over the buses in index order (host arrays) / in the order the
+ * reference's dicts are filled (device state).  applied_out: NULL or [B], 1 where the answer was replaced;
+ * n_applied: NULL or their count.  Follow with gs_download_solution / gs_checks_run / gs_download_step as usual. */
+int gs_fallback_linear(gs_handle* h, const double* load_w, const double* gen_w, const double* total_load,
+                       const double* total_gen, const uint8_t* mask, uint8_t* applied_out, int32_t* n_applied);
 
 /* ---- env plug point: GridEnvironment.reset/step (grid_env.py:360-408, 410-619) and their
  * batched form VectorizedEnvironment.reset/step (utils/parallel_environment.py:309-355) --- */
