@@ -478,7 +478,12 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   std::vector<int32_t> wi_ptr(h->W + 1, 0);
   for (int w = 0; w < h->W; ++w) {
     wi_ptr[w] = (int)winj.size();
-    for (int i = w; i < ht.n; i += h->W) {
+    // dataflow sweep kernel: a wave builds the injections of the buses it solves, in item order, straight into the
+    // solver's registers (a bus that is nobody's item -- the slack -- needs no injection there)
+    std::vector<int> mine;
+    if (h->solve_kernel == 6) for (int k = wl_ptr[w]; k < wl_ptr[w + 1]; ++k) mine.push_back(witems[k].bus);
+    else for (int i = w; i < ht.n; i += h->W) mine.push_back(i);
+    for (int i : mine) {
       GsInjRec r{};
       r.bus = i;
       r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];

@@ -1033,8 +1033,9 @@ __device__ __forceinline__ void flow_give(Ctx& c, double* m, int* flag, int epoc
 // next mismatch is simply I_new of this one (one division per bus and iteration instead of two), and J never
 // leaves LDS.
 #define GS_FLOW_ITEMS 8
-template <bool FLAT_DONE>
-__device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrState& st) {
+// HAVE_P: the environment prologue left S_spec = (Pin[j], 0) of the wave's buses in registers
+template <bool HAVE_P>
+__device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrState& st, const double* Pin) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   double* msg = gs_dyn + c.lane;
   int* flags = (int*)(gs_dyn + (size_t)T.n * 2 * GS_LANES);
@@ -1045,8 +1046,8 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
   double P[GS_FLOW_ITEMS], Q[GS_FLOW_ITEMS], IR[GS_FLOW_ITEMS], II[GS_FLOW_ITEMS];
 #pragma unroll
   for (int j = 0; j < GS_FLOW_ITEMS; ++j) {          // all S_spec rows of the wave in flight together
-    P[j] = 0.0; Q[j] = 0.0;
-    if (j < nit) { const double2 sp = ROW2(R.P + recs[k0 + j].bus); P[j] = sp.x; Q[j] = sp.y; }
+    P[j] = HAVE_P ? Pin[j] : 0.0; Q[j] = 0.0;
+    if (!HAVE_P && j < nit) { const double2 sp = ROW2(R.P + recs[k0 + j].bus); P[j] = sp.x; Q[j] = sp.y; }
   }
   double psum = 0.0;
   int epoch = 1;
@@ -1564,8 +1565,10 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
 
 // Everything of step() that precedes the load flow, spread over the W waves (grid_env.py:433-477).
 // FLAT_FBS: the injection pass also writes the sweep solver's flat start (e, f) of the buses it visits.
-template <bool FLAT_FBS>
-__device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid) {
+// FLOW_REGS: the wave's injection records are its solver items in item order (dataflow kernel), and P goes into the
+// solver's registers Pout[0 .. 7] instead of the P rows: no store, no reload, no barrier between the two.
+template <bool FLAT_FBS, bool FLOW_REGS>
+__device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid, double* Pout) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   const uint64_t inst = (uint64_t)(E.first_instance + b);
   // every wave derives the new clock from the old rows; then wave 0 applies the actions (batteries, curtailment) and
@@ -1606,7 +1609,8 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
     const int k1 = cld(T.wi_ptr, c.wave + 1);
     // four buses per trip, their load rows requested before any division or store: a bus is otherwise one
     // round trip to L2 after another (most buses carry one load and nothing else)
-    for (int k0 = cld(T.wi_ptr, c.wave); k0 < k1; k0 += 4) {
+    const int kbase = cld(T.wi_ptr, c.wave);
+    auto four_buses = [&](const int k0, const int slot0) {
       double lp0[4], lp1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1620,7 +1624,11 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         if (k >= k1) break;
         const int i = recs[k].bus;
         if (FLAT_FBS && !E.fbs_warm_start) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
-        if (recs[k].generic) { bus_injection(T, R, E, S, i); continue; }
+        if (recs[k].generic) {
+          bus_injection(T, R, E, S, i);
+          if (FLOW_REGS) Pout[slot0 + u] = ROW(R.P + i);
+          continue;
+        }
         // same accumulation order as bus_injection: loads, then generators, then batteries
         double ls = 0.0, gs = 0.0;
         if (recs[k].nl > 0) ls += lp0[u];
@@ -1629,11 +1637,15 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         if (recs[k].ng > 1) gs += ROW(R.GENP + recs[k].g1) * ROW(R.CURT + recs[k].g1);
         if (recs[k].nb > 0) { const double bp = ROW(R.BATP + recs[k].b0); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
         if (recs[k].nb > 1) { const double bp = ROW(R.BATP + recs[k].b1); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
-        ROW2(R.P + i) = make_double2((0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base), 0.0);
+        const double pinj = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base);
+        if (FLOW_REGS) Pout[slot0 + u] = pinj;
+        else ROW2(R.P + i) = make_double2(pinj, 0.0);
       }
-    }
+    };
+    if (FLOW_REGS) { four_buses(kbase, 0); if (kbase + 4 < k1) four_buses(kbase + 4, 4); }     // at most 8 buses per wave
+    else for (int k0 = kbase; k0 < k1; k0 += 4) four_buses(k0, 0);
   }
-  __syncthreads();
+  if (!FLOW_REGS) __syncthreads();          // FLOW_REGS: nothing of this pass is read by another wave
 }
 
 template <int KIND, int ENV, int CHK>
@@ -1660,13 +1672,14 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
       }
     if (!ENV) __syncthreads();
   }
-  if (ENV) prologue_env<KIND == KIND_FBS_LDS>(c, E, actions, b, valid);
+  double Pinj[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // KIND_FBS_FLOW + ENV: S_spec of the wave's own buses
+  if (ENV) prologue_env<KIND == KIND_FBS_LDS, KIND == KIND_FBS_FLOW>(c, E, actions, b, valid, Pinj);
   stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
   else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds<ENV != 0>(c, C, st);
-  else if (KIND == KIND_FBS_FLOW) psum = fbs_loop_flow<ENV != 0>(c, C, st);
+  else if (KIND == KIND_FBS_FLOW) psum = fbs_loop_flow<ENV != 0>(c, C, st, Pinj);
   else newton_loop<KIND>(c, C, st);
   constexpr bool kFbs = KIND == KIND_FBS || KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW;
   epilogue<ENV, !kFbs, CHK, KIND == KIND_FBS_FLOW>(c, E, st, total_load, KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW, psum, FC, valid ? b : 0x7fffffff);   // FBS keeps no polar angle: atan2 there
