@@ -24,6 +24,7 @@
 // clock -> weather -> renewables -> loads -> injections -> load flow -> line flows -> losses ->
 // grid state -> frequency -> reward -> flags.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 
 #include "../../include/gridstep.h"
@@ -1610,16 +1611,22 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
     // four buses per trip, their load rows requested before any division or store: a bus is otherwise one
     // round trip to L2 after another (most buses carry one load and nothing else)
     const int kbase = cld(T.wi_ptr, c.wave);
-    auto four_buses = [&](const int k0, const int slot0) {
-      double lp0[4], lp1[4];
+    // NB buses per trip, every row they need requested before any division or store: a bus is otherwise one round
+    // trip to L2 after another (most buses carry one load and nothing else; a generator or battery adds rows)
+    auto bus_batch = [&](auto nb_tag, const int k0, const int slot0) {
+      constexpr int NB = decltype(nb_tag)::value;
+      double lp0[NB], lp1[NB], gp0[NB], gc0[NB], bp0[NB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int k = min(k0 + u, k1 - 1);
         lp0[u] = ROW(R.LOADP + (recs[k].nl > 0 ? recs[k].l0 : 0));
         lp1[u] = recs[k].nl > 1 ? (double)ROW(R.LOADP + recs[k].l1) : 0.0;      // rare: most buses carry one load
+        gp0[u] = 0.0; gc0[u] = 0.0; bp0[u] = 0.0;
+        if (recs[k].ng > 0) { gp0[u] = ROW(R.GENP + recs[k].g0); gc0[u] = ROW(R.CURT + recs[k].g0); }
+        if (recs[k].nb > 0) bp0[u] = ROW(R.BATP + recs[k].b0);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int k = k0 + u;
         if (k >= k1) break;
         const int i = recs[k].bus;
@@ -1633,17 +1640,17 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         double ls = 0.0, gs = 0.0;
         if (recs[k].nl > 0) ls += lp0[u];
         if (recs[k].nl > 1) ls += lp1[u];
-        if (recs[k].ng > 0) gs += ROW(R.GENP + recs[k].g0) * ROW(R.CURT + recs[k].g0);
+        if (recs[k].ng > 0) gs += gp0[u] * gc0[u];
         if (recs[k].ng > 1) gs += ROW(R.GENP + recs[k].g1) * ROW(R.CURT + recs[k].g1);
-        if (recs[k].nb > 0) { const double bp = ROW(R.BATP + recs[k].b0); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+        if (recs[k].nb > 0) { const double bp = bp0[u]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
         if (recs[k].nb > 1) { const double bp = ROW(R.BATP + recs[k].b1); if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
         const double pinj = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base);
         if (FLOW_REGS) Pout[slot0 + u] = pinj;
         else ROW2(R.P + i) = make_double2(pinj, 0.0);
       }
     };
-    if (FLOW_REGS) { four_buses(kbase, 0); if (kbase + 4 < k1) four_buses(kbase + 4, 4); }     // at most 8 buses per wave
-    else for (int k0 = kbase; k0 < k1; k0 += 4) four_buses(k0, 0);
+    if (FLOW_REGS) bus_batch(std::integral_constant<int, 8>{}, kbase, 0);      // at most 8 buses per wave: one trip
+    else for (int k0 = kbase; k0 < k1; k0 += 4) bus_batch(std::integral_constant<int, 4>{}, k0, 0);
   }
   if (!FLOW_REGS) __syncthreads();          // FLOW_REGS: nothing of this pass is read by another wave
 }
