@@ -335,6 +335,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   h->B = batch; h->Bp = (batch + 63) / 64 * 64; h->groups = h->Bp / 64;
   int W = cfg->waves_per_group;
   if (const char* e = getenv("GS_WAVES")) W = atoi(e);
+  const bool auto_w = W <= 0;
   if (W <= 0) { W = 1; while (W < 16 && h->groups * W * 2 <= 2048) W *= 2; }
   if (W > GS_MAX_WAVES) W = GS_MAX_WAVES;
   h->W = W;
@@ -347,6 +348,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     // (their state lives in registers); flat start only
     const size_t flow_bytes = (size_t)ht.n * 2 * GS_LANES * sizeof(double) + (size_t)ht.n * sizeof(int32_t);
     const int n_items = ht.is_forest ? ht.lvl_ptr[ht.n_levels] : 0;
+    // its LDS footprint allows one group per CU whatever W is, so a batch of any size runs it with all 16 waves
+    if (auto_w && n_items > 8 * W && n_items <= 8 * GS_MAX_WAVES) { W = GS_MAX_WAVES; h->W = W; }
     if (h->solve_kernel == 5 && !cfg->fbs_warm_start && flow_bytes + 24576 <= 160 * 1024 && (n_items + W - 1) / W <= 8 &&
         !getenv("GS_NO_FLOW")) {
       h->solve_kernel = 6; h->dyn_lds = flow_bytes; }
