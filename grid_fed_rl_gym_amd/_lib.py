@@ -373,8 +373,9 @@ class Handle:
         self._check(self._lib.gs_comm_destroy(self._h))
 
     # -- measurement ----------------------------------------------------------------------
-    def timing_enable(self, on: bool = True) -> None:
-        self._check(self._lib.gs_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on: bool = True, span: bool = False) -> None:
+        """Per-launch HIP event pairs (on), or one pair around the whole region up to the next timing_read() (span)."""
+        self._check(self._lib.gs_timing_enable(self._h, (2 if span else 1) if on else 0))
 
     STAMP_NAMES = ["prologue_inject", "init", "mismatch", "bottom_up", "flag", "top_down", "final_mismatch", "epilogue_pack",
                    "prologue_scalars_rng", "spare", "epi_buses", "epi_lines", "epi_reduce", "epi_scalars"]

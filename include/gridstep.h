@@ -215,6 +215,9 @@ int gs_comm_destroy(gs_handle* h);
 
 /* ---- measurement: HIP-event timing of every kernel launched on the handle's stream ------ */
 enum { GS_K_UNPACK = 0, GS_K_ENV_PRE = 1, GS_K_SOLVE = 2, GS_K_ENV_POST = 3, GS_K_PACK = 4, GS_K_COUNT = 5 };
+/* on = 1: a HIP event pair around every launch (per-kernel totals; the events themselves cost a few us per launch);
+ * on = 2: ONE event pair around everything launched until the next gs_timing_read -- call that right after the last
+ * launch of the region; it returns the span as the time of the most-launched kernel, i.e. duration + gaps per launch */
 int gs_timing_enable(gs_handle* h, int32_t on);
 /* diagnostic build aid: the first call arms per-phase cycle counters inside the solver kernels
  * (block 0 / wave 0; phases: prologue, init, mismatch, bottom-up, flag, top-down, final mismatch,
