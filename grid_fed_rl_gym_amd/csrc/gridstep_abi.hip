@@ -361,7 +361,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const int n_items = ht.is_forest ? ht.lvl_ptr[ht.n_levels] : 0;
     // its LDS footprint allows one group per CU whatever W is, so a batch of any size runs it with all 16 waves
     if (auto_w && n_items > 8 * W && n_items <= 8 * GS_MAX_WAVES) { W = GS_MAX_WAVES; h->W = W; }
-    if (h->solve_kernel == 5 && !cfg->fbs_warm_start && flow_bytes + 24576 <= 160 * 1024 && (n_items + W - 1) / W <= 8 &&
+    if (!cfg->fbs_warm_start && flow_bytes + 24576 <= 160 * 1024 && (n_items + W - 1) / W <= 8 &&
         !getenv("GS_NO_FLOW")) {
       h->solve_kernel = 6; h->dyn_lds = flow_bytes; }
   } else if (cfg->solver_kind == GS_SOLVER_NR) {
