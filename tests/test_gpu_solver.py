@@ -213,3 +213,36 @@ def test_topology_errors():
         P.BatchedNewtonRaphsonSolver(linear_solver="tree").solve_batch(fs, np.zeros((1, 10)))
     with pytest.raises(P.PowerFlowError, match="shape"):
         P.BatchedNewtonRaphsonSolver().solve_batch(fs, np.zeros((1, 9)))
+
+
+def test_dataflow_sweeps_on_a_bus_with_many_children(monkeypatch):
+    """A bus with 13 children (more than the 8 child slots of an item record: the rest go through the overflow list)
+    and a zero-load batch instance (converges at the very first check): dataflow kernel = level-synchronous kernel =
+    Newton-Raphson."""
+    from grid_fed_rl_gym_amd.feeders import FeederSpec
+    n = 20
+    frm = [0] + [1] * 13 + [2, 15, 16, 3, 18]
+    to = list(range(1, n))
+    rng = np.random.default_rng(11)
+    spec = FeederSpec(name="star", bus_ids=list(range(n)), bus_type=np.array([2] + [0] * (n - 1), dtype=np.uint8), v_set=np.ones(n),
+                      frm=np.asarray(frm, dtype=np.int32), to=np.asarray(to, dtype=np.int32), r=rng.uniform(0.005, 0.02, n - 1),
+                      x=rng.uniform(0.005, 0.03, n - 1), rating=np.full(n - 1, 5e6))
+    B = 70
+    P_spec = -rng.uniform(0.0, 0.04, (B, n)); P_spec[:, 0] = 0.0
+    P_spec[3] = 0.0                                        # nothing to solve: stops at the flat start
+    flow = P.BatchedForwardBackwardSweepSolver(tolerance=1e-10, max_iterations=100)
+    a = flow.solve_batch(spec, P_spec)
+    assert flow.handle_for(spec, B).describe()["kernel"] == "fbs_flow"
+    monkeypatch.setenv("GS_NO_FLOW", "1")
+    sync = P.BatchedForwardBackwardSweepSolver(tolerance=1e-10, max_iterations=100)
+    b = sync.solve_batch(spec, P_spec)
+    monkeypatch.delenv("GS_NO_FLOW")
+    assert sync.handle_for(spec, B).describe()["kernel"] in ("fbs_lds", "fbs")
+    nr = P.BatchedNewtonRaphsonSolver(tolerance=1e-12, max_iterations=50).solve_batch(spec, P_spec)
+    assert a.converged.all() and b.converged.all() and nr.converged.all()
+    assert np.array_equal(a.iterations, b.iterations)
+    assert np.max(np.abs(a.bus_voltages - b.bus_voltages)) < 1e-13 and np.max(np.abs(a.bus_angles - b.bus_angles)) < 1e-13
+    assert np.max(np.abs(a.bus_voltages - nr.bus_voltages)) < 1e-9 and np.max(np.abs(a.bus_angles - nr.bus_angles)) < 1e-9
+    assert np.all(a.bus_voltages[3] == 1.0) and np.all(a.bus_angles[3] == 0.0) and np.all(a.line_flows[3] == 0.0)
+    np.testing.assert_allclose(a.line_flows, b.line_flows, rtol=1e-10, atol=1e-14)
+    flow.close(); sync.close()
