@@ -1649,8 +1649,33 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         else ROW2(R.P + i) = make_double2(pinj, 0.0);
       }
     };
-    if (FLOW_REGS) bus_batch(std::integral_constant<int, 8>{}, kbase, 0);      // at most 8 buses per wave: one trip
-    else for (int k0 = kbase; k0 < k1; k0 += 4) bus_batch(std::integral_constant<int, 4>{}, k0, 0);
+    if (FLOW_REGS) {
+      // At most 8 buses per wave, nearly all of them one or two loads and nothing else: a straight-line pass -- every
+      // record, then every load row (unconditionally: an absent load re-reads row l0 and is masked out), then the
+      // arithmetic; the few buses that carry a generator, a battery or more than two loads go through the general
+      // routine afterwards.  Same accumulation order as bus_injection (x + 0.0 = x for the load powers, which are >= 0).
+      int nl[8], l0[8], l1[8], special[8], bus[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const GS_CONST GsInjRec* q = recs + min(kbase + u, k1 - 1);
+        nl[u] = q->nl; l0[u] = nl[u] > 0 ? q->l0 : 0; l1[u] = nl[u] > 1 ? q->l1 : l0[u];
+        special[u] = q->generic | q->ng | q->nb; bus[u] = q->bus;
+      }
+      double lp0[8], lp1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { lp0[u] = ROW(R.LOADP + l0[u]); lp1[u] = ROW(R.LOADP + l1[u]); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double ls = (nl[u] > 0 ? lp0[u] : 0.0) + (nl[u] > 1 ? lp1[u] : 0.0);
+        Pout[u] = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(0.0, E.power_base, E.inv_power_base);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kbase + u < k1 && special[u]) { bus_injection(T, R, E, S, bus[u]); Pout[u] = ROW(R.P + bus[u]); }
+      }
+    } else {
+      for (int k0 = kbase; k0 < k1; k0 += 4) bus_batch(std::integral_constant<int, 4>{}, k0, 0);
+    }
   }
   if (!FLOW_REGS) __syncthreads();          // FLOW_REGS: nothing of this pass is read by another wave
 }
