@@ -53,25 +53,21 @@ __device__ __forceinline__ void rng_uniform_pair(uint64_t seed, uint64_t instanc
   *u1 = (double)(x1 >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
 }
 
-__device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw) {
-  double u0, u1;
-  rng_uniform_pair(seed, instance, step, draw, &u0, &u1);
+// Four standard normals from ONE Philox call: every 32-bit output word is a uniform (r + 1/2) 2^-32, words (0, 1) and
+// (2, 3) are one Box-Muller pair each (cosine, sine).  The load noise takes them four at a time (load l: draw
+// DRAW_LOAD0 + l / 4, component l & 3), the weather takes wind / temperature / cloud from one call: the integer
+// multiplies of Philox were half the vector work of the load-noise phase with one call per pair.
+__device__ __forceinline__ void rng_normal_quad(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw, double (&z)[4]) {
+  const U4 r = philox((uint32_t)instance, step, draw, 0x47535450u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const double u0 = ((double)r.a + 0.5) * (1.0 / 4294967296.0), u1 = ((double)r.b + 0.5) * (1.0 / 4294967296.0);
+  const double u2 = ((double)r.c + 0.5) * (1.0 / 4294967296.0), u3 = ((double)r.d + 0.5) * (1.0 / 4294967296.0);
+  const double ra = sqrt(-2.0 * gs_log01(u0)), rb = sqrt(-2.0 * gs_log01(u2));
   double sn, cs;
-  gs_sincos_turns(u1, &sn, &cs);
-  return sqrt(-2.0 * gs_log01(u0)) * cs;
+  gs_sincos_turns(u1, &sn, &cs); z[0] = ra * cs; z[1] = ra * sn;
+  gs_sincos_turns(u3, &sn, &cs); z[2] = rb * cs; z[3] = rb * sn;
 }
 
-// Both Box-Muller branches of one draw: z0 is rng_normal(draw), z1 the sine branch.  The load noise takes them in
-// pairs (load l: draw DRAW_LOAD0 + l / 2, branch l & 1), which halves the Philox / log / sqrt work of the prologue.
-__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t instance, uint32_t step, uint32_t draw, double* z0, double* z1) {
-  double u0, u1, sn, cs;
-  rng_uniform_pair(seed, instance, step, draw, &u0, &u1);
-  const double r = sqrt(-2.0 * gs_log01(u0));
-  gs_sincos_turns(u1, &sn, &cs);
-  *z0 = r * cs; *z1 = r * sn;
-}
-
-enum { DRAW_IRRADIANCE = 0, DRAW_WIND = 1, DRAW_TEMP = 2, DRAW_CLOUD = 3, DRAW_LOAD0 = 16 };
+enum { DRAW_IRRADIANCE = 0, DRAW_WEATHER = 1, DRAW_LOAD0 = 16 };
 
 __device__ const double kDailyProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
                                              0.7, 0.7, 0.6, 0.6, 0.7, 0.9, 1.0, 0.9, 0.8, 0.7, 0.6, 0.5};
@@ -92,10 +88,50 @@ __device__ __forceinline__ void weather_update_at(const GsRows& R, const GsEnvCf
   double u, u_unused;
   rng_uniform_pair(seed, inst, step, DRAW_IRRADIANCE, &u, &u_unused);
   ROW(R.IRR) = base * (0.8 + 0.4 * u);
-  ROW(R.WIND) = fmax(0.0, fmin(30.0, ROW(R.WIND) + 0.5 * rng_normal(seed, inst, step, DRAW_WIND)));
+  double z[4];
+  rng_normal_quad(seed, inst, step, DRAW_WEATHER, z);
+  ROW(R.WIND) = fmax(0.0, fmin(30.0, ROW(R.WIND) + 0.5 * z[0]));
   gs_sincos_turns((hour - 12.0) * (1.0 / 24.0), &sn, &cs);      // sin(2 pi (hour - 12) / 24)
-  ROW(R.TEMP) = 25.0 + 10.0 * sn + 2.0 * rng_normal(seed, inst, step, DRAW_TEMP);
-  ROW(R.CLOUD) = fmax(0.0, fmin(1.0, ROW(R.CLOUD) + 0.1 * rng_normal(seed, inst, step, DRAW_CLOUD)));
+  ROW(R.TEMP) = 25.0 + 10.0 * sn + 2.0 * z[1];
+  ROW(R.CLOUD) = fmax(0.0, fmin(1.0, ROW(R.CLOUD) + 0.1 * z[2]));
+}
+// The same update with the weather state handed on in registers: the three rows are requested together, updated where
+// `update` holds (a padded lane keeps its rows), and what the renewables need comes back without reading them again.
+struct GsWeather { double wind, temp, cloud; };
+__device__ __forceinline__ GsWeather weather_step(const GsRows& R, const GsEnvCfg& E, GsLaneRows S, uint64_t inst, double time_s, uint32_t step, bool update) {
+  GsWeather w;
+  w.wind = ROW(R.WIND); w.temp = ROW(R.TEMP); w.cloud = ROW(R.CLOUD);
+  if (!E.weather_variation) return w;
+  const uint64_t seed = lane_seed(S, R);
+  const double hour = hour_of_day(time_s);
+  double sn, cs;
+  gs_sincos_turns((hour - 6.0) * (1.0 / 24.0), &sn, &cs);       // sin(pi (hour - 6) / 12)
+  const double base = (hour >= 6.0 && hour <= 18.0) ? 1000.0 * sn : 0.0;
+  double u, u_unused;
+  rng_uniform_pair(seed, inst, step, DRAW_IRRADIANCE, &u, &u_unused);
+  const double irr = base * (0.8 + 0.4 * u);
+  double z[4];
+  rng_normal_quad(seed, inst, step, DRAW_WEATHER, z);
+  const double wind = fmax(0.0, fmin(30.0, w.wind + 0.5 * z[0]));
+  gs_sincos_turns((hour - 12.0) * (1.0 / 24.0), &sn, &cs);      // sin(2 pi (hour - 12) / 24)
+  const double temp = 25.0 + 10.0 * sn + 2.0 * z[1];
+  const double cloud = fmax(0.0, fmin(1.0, w.cloud + 0.1 * z[2]));
+  if (update) {
+    ROW(R.IRR) = irr; ROW(R.WIND) = wind; ROW(R.TEMP) = temp; ROW(R.CLOUD) = cloud;
+    w.wind = wind; w.temp = temp; w.cloud = cloud;
+  }
+  return w;
+}
+__device__ __forceinline__ double renewable_power_w(const GsTables& T, int g, double elev, const GsWeather& w) {
+  const double cap = cld(T.gen_cap, g), p0 = cld(T.gen_p0, g), p1 = cld(T.gen_p1, g), p2 = cld(T.gen_p2, g);
+  if (cld(T.gen_kind, g) == 0) {
+    const double irr = 1000.0 * elev * (1.0 - 0.8 * w.cloud);
+    const double tf = 1.0 - 0.004 * fmax(0.0, w.temp - 25.0);
+    return fmin(irr * p1 * p0 * tf, cap);
+  }
+  if (w.wind < p0 || w.wind > p2) return 0.0;
+  if (w.wind <= p1) { const double q = (w.wind - p0) / (p1 - p0); return cap * (q * q * q); }
+  return cap;
 }
 __device__ __forceinline__ void weather_update(const GsRows& R, const GsEnvCfg& E, GsLaneRows S, uint64_t inst) {
   weather_update_at(R, E, S, inst, ROW(R.TIME), (uint32_t)ROW(R.STEP));
@@ -131,7 +167,36 @@ __device__ __forceinline__ double renewable_power(const GsTables& T, const GsRow
 __device__ __forceinline__ void env_actions_clock(const GsTables& T, const GsRows& R, const GsEnvCfg& E,
                                                   GsLaneRows S, const double* __restrict__ act) {
   const double dt = E.timestep;
-  for (int q = 0; q < T.n_bats; ++q) {
+  // the action entries and state-of-charge rows of the first four batteries and the actions of the first eight
+  // generators are requested before anything is computed: each is otherwise a round trip of its own
+  double a_b[4], s_b[4], a_g[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a_b[q] = act[min(q, max(T.n_bats - 1, 0))]; s_b[q] = ROW(R.SOC + min(q, max(T.n_bats - 1, 0))); }
+#pragma unroll
+  for (int g = 0; g < 8; ++g) a_g[g] = act[T.n_bats + min(g, max(T.n_gens - 1, 0))];
+  const double t_old = ROW(R.TIME), k_old = ROW(R.STEP);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q >= T.n_bats) break;
+    const double rating = cld(T.bat_rating, q), cap = cld(T.bat_cap, q), eff = cld(T.bat_eff, q);
+    const double cmd = a_b[q] * rating;
+    double soc = s_b[q];
+    if (cmd > 0.0) {                                  // discharge, dynamics.py:206-220
+      const double p = fmin(cmd, rating);
+      const double e = fmin(p * dt / 3600.0, soc * cap * eff);
+      soc -= e / (cap * eff);
+      ROW(R.SOC + q) = soc;
+      ROW(R.BATP + q) = e * 3600.0 / dt;
+    } else if (cmd < 0.0) {                           // charge, dynamics.py:189-204
+      const double p = fmin(-cmd, rating);
+      const double max_e = (1.0 - soc) * cap;
+      const double e = fmin(p * dt / 3600.0, max_e / eff);
+      soc += e * eff / cap;
+      ROW(R.SOC + q) = soc;
+      ROW(R.BATP + q) = -(e * 3600.0 / dt);
+    }
+  }
+  for (int q = 4; q < T.n_bats; ++q) {
     const double rating = cld(T.bat_rating, q), cap = cld(T.bat_cap, q), eff = cld(T.bat_eff, q);
     const double cmd = act[q] * rating;
     double soc = ROW(R.SOC + q);
@@ -150,9 +215,11 @@ __device__ __forceinline__ void env_actions_clock(const GsTables& T, const GsRow
       ROW(R.BATP + q) = -(e * 3600.0 / dt);
     }
   }
-  for (int g = 0; g < T.n_gens; ++g) ROW(R.CURT + g) = (act[T.n_bats + g] + 1.0) / 2.0;
-  ROW(R.TIME) = ROW(R.TIME) + dt;                    // grid_env.py:470-471
-  ROW(R.STEP) = ROW(R.STEP) + 1.0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) { if (g >= T.n_gens) break; ROW(R.CURT + g) = (a_g[g] + 1.0) / 2.0; }
+  for (int g = 8; g < T.n_gens; ++g) ROW(R.CURT + g) = (act[T.n_bats + g] + 1.0) / 2.0;
+  ROW(R.TIME) = t_old + dt;                          // grid_env.py:470-471
+  ROW(R.STEP) = k_old + 1.0;
 }
 
 // realised power of load l (dynamics.py:54-75 when stochastic, base_power otherwise)

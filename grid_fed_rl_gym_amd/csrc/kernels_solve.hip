@@ -1583,20 +1583,26 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
   const int rng0 = c.W > 2 ? 2 : 0;                 // first wave of the load draws (every wave when there are only one or two)
   if (c.wave == 0 && valid) env_actions_clock(T, R, E, S, actions + (size_t)b * (T.n_bats + T.n_gens));
   if (c.wave == wave_b) {
-    if (valid) weather_update_at(R, E, S, inst, tnew, snew);
+    const GsWeather wx = weather_step(R, E, S, inst, tnew, snew, valid);
     const double elev = solar_elevation(valid ? tnew : told);
-    for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power_e(T, R, S, g, elev);
+    for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power_w(T, g, elev, wx);
   }
   if (c.wave >= rng0) {
     const int l0 = c.wave - rng0, ls = c.W - rng0;
     const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
-    if (E.stochastic_loads) {                               // loads 2p and 2p + 1 share one Box-Muller draw
-      for (int p = l0; 2 * p < T.n_loads; p += ls) {
-        double z0, z1;
-        rng_normal_pair(seed, inst, snew, DRAW_LOAD0 + p, &z0, &z1);
-        const double lp0 = load_power_z(T, 2 * p, z0, prof);
-        if (2 * p + 1 < T.n_loads) ROW2(R.LOADP + 2 * p) = make_double2(lp0, load_power_z(T, 2 * p + 1, z1, prof));   // LOADP starts on an even row
-        else ROW(R.LOADP + 2 * p) = lp0;
+    if (E.stochastic_loads) {                               // loads 4p .. 4p + 3 share one Philox call (two Box-Muller pairs)
+      for (int p = l0; 4 * p < T.n_loads; p += ls) {
+        double z[4];
+        rng_normal_quad(seed, inst, snew, DRAW_LOAD0 + p, z);
+        const int l = 4 * p;                                // LOADP starts on an even row: (l, l + 1) and (l + 2, l + 3) are row pairs
+        const double lp0 = load_power_z(T, l, z[0], prof);
+        if (l + 1 < T.n_loads) ROW2(R.LOADP + l) = make_double2(lp0, load_power_z(T, l + 1, z[1], prof));
+        else ROW(R.LOADP + l) = lp0;
+        if (l + 2 < T.n_loads) {
+          const double lp2 = load_power_z(T, l + 2, z[2], prof);
+          if (l + 3 < T.n_loads) ROW2(R.LOADP + l + 2) = make_double2(lp2, load_power_z(T, l + 3, z[3], prof));
+          else ROW(R.LOADP + l + 2) = lp2;
+        }
       }
     } else {
       for (int l = l0; l < T.n_loads; l += ls) ROW(R.LOADP + l) = cld(T.load_base, l);

@@ -371,15 +371,14 @@ static void rng_pair(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw,
   *u0 = (double)(x0 >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
   *u1 = (double)(x1 >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
 }
-static double rng_normal(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw) {
-  double u0, u1; rng_pair(seed, inst, step, draw, &u0, &u1);
-  return sqrt(-2.0 * log(u0)) * cos(2.0 * M_PI * u1);
-}
-/* both Box-Muller branches of one draw; load l takes draw 16 + l / 2, branch l & 1 */
-static double rng_normal_branch(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw, int sine) {
-  double u0, u1; rng_pair(seed, inst, step, draw, &u0, &u1);
-  const double r = sqrt(-2.0 * log(u0));
-  return sine ? r * sin(2.0 * M_PI * u1) : r * cos(2.0 * M_PI * u1);
+/* four normals from one Philox call: each 32-bit word is a uniform (r + 1/2) 2^-32, words (0, 1) and (2, 3) are one
+ * Box-Muller pair each (cosine, sine); load l takes draw 16 + l / 4, component l & 3 */
+static double rng_normal_quad(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw, int k) {
+  uint32_t r[4];
+  philox((uint32_t)inst, step, draw, 0x47535450u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const double ur = ((double)r[k & 2] + 0.5) * (1.0 / 4294967296.0), ua = ((double)r[(k & 2) + 1] + 0.5) * (1.0 / 4294967296.0);
+  const double rad = sqrt(-2.0 * log(ur));
+  return (k & 1) ? rad * sin(2.0 * M_PI * ua) : rad * cos(2.0 * M_PI * ua);
 }
 
 static const double kProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
@@ -411,9 +410,9 @@ static void weather(const orc_cfg* c, double* st, uint64_t inst) {   /* grid_env
   double base = (hour >= 6.0 && hour <= 18.0) ? 1000.0 * sin(M_PI * (hour - 6.0) / 12.0) : 0.0;
   double u, u2; rng_pair(seed, inst, step, 0, &u, &u2);
   st[S_IRR] = base * (0.8 + 0.4 * u);
-  st[S_WIND] = fmax(0.0, fmin(30.0, st[S_WIND] + 0.5 * rng_normal(seed, inst, step, 1)));
-  st[S_TEMP] = 25.0 + 10.0 * sin(2.0 * M_PI * (hour - 12.0) / 24.0) + 2.0 * rng_normal(seed, inst, step, 2);
-  st[S_CLOUD] = fmax(0.0, fmin(1.0, st[S_CLOUD] + 0.1 * rng_normal(seed, inst, step, 3)));
+  st[S_WIND] = fmax(0.0, fmin(30.0, st[S_WIND] + 0.5 * rng_normal_quad(seed, inst, step, 1, 0)));
+  st[S_TEMP] = 25.0 + 10.0 * sin(2.0 * M_PI * (hour - 12.0) / 24.0) + 2.0 * rng_normal_quad(seed, inst, step, 1, 1);
+  st[S_CLOUD] = fmax(0.0, fmin(1.0, st[S_CLOUD] + 0.1 * rng_normal_quad(seed, inst, step, 1, 2)));
 }
 
 int orc_state_dim(const orc_net* t) { return S_FIXED + 2 * t->n_bats + t->n_gens + 2 * t->n + 2 * t->m; }
@@ -493,7 +492,7 @@ int orc_env_step(const orc_net* t, const orc_cfg* c, int32_t B, const double* ac
         double hour = fmod(st[S_TIME] / 3600.0, 24.0); int hi = (int)hour; double frac = hour - hi;
         double prof = kProfile[hi] * (1.0 - frac) + kProfile[(hi + 1) % 24] * frac;
         for (int l = 0; l < t->n_loads; ++l)
-          loadp[l] = fmax(0.0, t->load_base[l] * (prof * (1.0 + 0.1 * rng_normal_branch(seed, inst, (uint32_t)st[S_STEP], 16 + l / 2, l & 1))) * 1.0);
+          loadp[l] = fmax(0.0, t->load_base[l] * (prof * (1.0 + 0.1 * rng_normal_quad(seed, inst, (uint32_t)st[S_STEP], 16 + l / 4, l & 3))) * 1.0);
       }
       for (int i = 0; i < n; ++i) { ls[i] = 0.0; gs[i] = 0.0; }   /* grid_env.py:683-720 */
       for (int l = 0; l < t->n_loads; ++l) ls[t->load_bus[l]] += c->stochastic_loads ? loadp[l] : t->load_base[l];

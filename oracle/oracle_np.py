@@ -427,21 +427,19 @@ def rng_uniform_pair(seed: int, instance: int, step: int, draw: int) -> Tuple[fl
     return u0, u1
 
 
-def rng_normal(seed: int, instance: int, step: int, draw: int) -> float:
-    """Standard normal by Box-Muller (cosine branch)."""
-    u0, u1 = rng_uniform_pair(seed, instance, step, draw)
-    return math.sqrt(-2.0 * math.log(u0)) * math.cos(2.0 * math.pi * u1)
-
-
-def rng_normal_pair(seed: int, instance: int, step: int, draw: int) -> Tuple[float, float]:
-    """Both Box-Muller branches of one draw (cosine, sine); the load noise uses them in pairs."""
-    u0, u1 = rng_uniform_pair(seed, instance, step, draw)
-    r = math.sqrt(-2.0 * math.log(u0))
-    return r * math.cos(2.0 * math.pi * u1), r * math.sin(2.0 * math.pi * u1)
+def rng_normal_quad(seed: int, instance: int, step: int, draw: int) -> Tuple[float, float, float, float]:
+    """Four standard normals from ONE Philox call: every 32-bit output word is a uniform (r + 1/2) 2^-32, words (0, 1)
+    and (2, 3) are one Box-Muller pair each (cosine, sine).  The load noise takes them four at a time (load l: draw
+    DRAW_LOAD0 + l // 4, component l & 3), the weather takes wind / temperature / cloud from one call."""
+    r = philox4x32((instance & _M32, step & _M32, draw & _M32, 0x47535450), (seed & _M32, (seed >> 32) & _M32))
+    u = [(x + 0.5) * (1.0 / 4294967296.0) for x in r]
+    ra, rb = math.sqrt(-2.0 * math.log(u[0])), math.sqrt(-2.0 * math.log(u[2]))
+    return (ra * math.cos(2.0 * math.pi * u[1]), ra * math.sin(2.0 * math.pi * u[1]),
+            rb * math.cos(2.0 * math.pi * u[3]), rb * math.sin(2.0 * math.pi * u[3]))
 
 
 # draw indices (per instance, per step)
-DRAW_IRRADIANCE, DRAW_WIND, DRAW_TEMP, DRAW_CLOUD, DRAW_LOAD0 = 0, 1, 2, 3, 16
+DRAW_IRRADIANCE, DRAW_WEATHER, DRAW_LOAD0 = 0, 1, 16
 
 
 # --------------------------------------------------------------------------------------
@@ -537,9 +535,10 @@ def _weather_update(spec: EnvSpec, st: EnvState) -> None:
     base = 1000 * math.sin(math.pi * (hour - 6) / 12) if 6 <= hour <= 18 else 0
     u, _ = rng_uniform_pair(st.seed, st.instance, st.step, DRAW_IRRADIANCE)
     st.irradiance = base * (0.8 + 0.4 * u)
-    st.wind = max(0, min(30, st.wind + 0.5 * rng_normal(st.seed, st.instance, st.step, DRAW_WIND)))
-    st.temp = 25 + 10 * math.sin(2 * math.pi * (hour - 12) / 24) + 2 * rng_normal(st.seed, st.instance, st.step, DRAW_TEMP)
-    st.cloud = max(0, min(1, st.cloud + 0.1 * rng_normal(st.seed, st.instance, st.step, DRAW_CLOUD)))
+    z = rng_normal_quad(st.seed, st.instance, st.step, DRAW_WEATHER)
+    st.wind = max(0, min(30, st.wind + 0.5 * z[0]))
+    st.temp = 25 + 10 * math.sin(2 * math.pi * (hour - 12) / 24) + 2 * z[1]
+    st.cloud = max(0, min(1, st.cloud + 0.1 * z[2]))
 
 
 def _renewable(spec: EnvSpec, st: EnvState, g: int) -> float:
@@ -590,7 +589,7 @@ def env_injections(spec: EnvSpec, st: EnvState) -> Tuple[np.ndarray, np.ndarray]
     gen_sum = np.zeros(spec.n)
     for l in range(spec.L):
         if spec.stochastic_loads:
-            z = rng_normal_pair(st.seed, st.instance, st.step, DRAW_LOAD0 + l // 2)[l & 1]
+            z = rng_normal_quad(st.seed, st.instance, st.step, DRAW_LOAD0 + l // 4)[l & 3]
             p, _ = load_profile_power(st.time, spec.load_base[l], noise=0.1 * z, power_factor=0.95)
         else:
             p = spec.load_base[l]
