@@ -1465,7 +1465,6 @@ __device__ __forceinline__ void epilogue(Ctx& c, const GsEnvCfg& E, const NrStat
 // final at the epilogue's reduction barrier, the tiles sit behind the partials wave 0 is reading, and the other
 // waves share out wave 0's rows of that pass.
 __device__ __forceinline__ void pack_observations_by_column(Ctx& c, const GsPackArgs& A, int B) {
-  const double* Sg = (const double*)c.S.g;             // group base
   double* tiles = gs_dyn + GS_PACK_LDS_DOUBLES;
   const int g = blockIdx.x;
   const int TG = A.tiles_per_pass;                     // 64-column tiles staged per pass (LDS permitting)
@@ -1486,7 +1485,7 @@ __device__ __forceinline__ void pack_observations_by_column(Ctx& c, const GsPack
         v[u] = 0.0;
         if (cc < span && jj < n_dyn) {
           const int s = cld(A.map, jj < A.skip0 ? jj : jj + gap);
-          v[u] = (s >= 0) ? Sg[GS_ELEM(s, c.lane)] : cld(A.cst, -s - 1);
+          v[u] = (s >= 0) ? (double)c.S[(size_t)s * GS_LANES] : cld(A.cst, -s - 1);      // rows of other waves: sc0 loads, like every row load
         }
       }
 #pragma unroll
@@ -1512,7 +1511,6 @@ __device__ __forceinline__ void pack_observations_by_column(Ctx& c, const GsPack
 // Needs an even obs_dim and an even block of constants (every row of `out` and every column pair 16-byte aligned).
 __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, int B) {
   if (!A.pair_ok) { pack_observations_by_column(c, A, B); return; }
-  const double* Sg = (const double*)c.S.g;             // group base
   double* tiles = gs_dyn + GS_PACK_LDS_DOUBLES;
   const int g = blockIdx.x;
   const int TG = A.tiles_per_pass & ~1;                // whole 128-column spans
@@ -1531,10 +1529,10 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
         if (pp < hspan && jj < n_dyn) {
           const int s0 = cld(A.map, jj < A.skip0 ? jj : jj + gap);
           const int s1 = (jj + 1 < n_dyn) ? cld(A.map, jj + 1 < A.skip0 ? jj + 1 : jj + 1 + gap) : s0;
-          if (s0 >= 0 && !(s0 & 1) && s1 == s0 + 1) v[u] = *(const double2*)&Sg[GS_ELEM(s0, c.lane)];
+          if (s0 >= 0 && !(s0 & 1) && s1 == s0 + 1) v[u] = (double2)c.S.pair((size_t)s0 * GS_LANES);      // rows of other waves: sc0 loads
           else {
-            v[u].x = (s0 >= 0) ? Sg[GS_ELEM(s0, c.lane)] : cld(A.cst, -s0 - 1);
-            v[u].y = (s1 >= 0) ? Sg[GS_ELEM(s1, c.lane)] : cld(A.cst, -s1 - 1);
+            v[u].x = (s0 >= 0) ? (double)c.S[(size_t)s0 * GS_LANES] : cld(A.cst, -s0 - 1);
+            v[u].y = (s1 >= 0) ? (double)c.S[(size_t)s1 * GS_LANES] : cld(A.cst, -s1 - 1);
           }
         }
       }
