@@ -65,7 +65,14 @@ struct GsPairRef {          // an (even row, odd row) pair of one lane: 16 bytes
   unsigned voff;
   int soff;
   __device__ __forceinline__ double2 get() const { return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, GS_LOAD_AUX)); }
-  __device__ __forceinline__ void put(double2 v) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gs_u32x4, v), r, voff, soff, 0); }
+  // A 16-byte store reads its data registers over several cycles after it issues; with the row offset in an SGPR the
+  // compiler's hazard recogniser assumes the hardware interlocks (the documented exemption) and lets the next VALU
+  // instruction overwrite them at once -- measured on gfx950: lanes 12-15 of every 16 then store the NEW contents
+  // (e.g. a zero being set up for something else).  The s_nop keeps the registers alive for a few cycles more.
+  __device__ __forceinline__ void put(double2 v) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gs_u32x4, v), r, voff, soff, 0);
+    asm volatile("s_nop 3" :: "v"(v.x), "v"(v.y));
+  }
   __device__ __forceinline__ operator double2() const { return get(); }
   __device__ __forceinline__ void operator=(double2 v) const { put(v); }
 };

@@ -696,10 +696,13 @@ __device__ __forceinline__ void linsolve_dense(Ctx& c, const GsSolveCfg& C, NrSt
 // Newton-Raphson driver (power_flow.py:143-193).  Returns with E/F/PC/QC describing the final V
 // (recomputed when the loop ended on the iteration cap, i.e. after an update).
 // =============================================================================================
-template <int KIND>
+// FLAT_DONE: the environment prologue's injection pass (which ends in a row barrier) wrote the flat start already
+template <int KIND, bool FLAT_DONE>
 __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState& st) {
-  flat_start(c);
-  __syncthreads();
+  if (!FLAT_DONE) {
+    flat_start(c);
+    __syncthreads();
+  }
   bool stale = true;
   for (int it = 0; it < C.max_iterations; ++it) {
     if (KIND != KIND_TREE_LDS && it > 0) {              // flat_start wrote E/F; the LDS forest solve refreshes them itself
@@ -1566,7 +1569,8 @@ __device__ __forceinline__ void pack_observations(Ctx& c, const GsPackArgs& A, i
 // FLAT_FBS: the injection pass also writes the sweep solver's flat start (e, f) of the buses it visits.
 // FLOW_REGS: the wave's injection records are its solver items in item order (dataflow kernel), and P goes into the
 // solver's registers Pout[0 .. 7] instead of the P rows: no store, no reload, no barrier between the two.
-template <bool FLAT_FBS, bool FLOW_REGS>
+// FLAT_NR: ... or the Newton solvers' flat start (|V|, angle, e, f, 1 / |V|: power_flow.py:103, 128-136)
+template <bool FLAT_FBS, bool FLOW_REGS, bool FLAT_NR>
 __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const double* __restrict__ actions, int b, bool valid, double* Pout) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   const uint64_t inst = (uint64_t)(E.first_instance + b);
@@ -1635,6 +1639,12 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
         if (k >= k1) break;
         const int i = recs[k].bus;
         if (FLAT_FBS && !E.fbs_warm_start) ROW2(R.E + i) = make_double2(cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0, 0.0);
+        if (FLAT_NR) {
+          const double vm = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0;
+          ROW2(R.VM + i) = make_double2(vm, 0.0);
+          ROW2(R.E + i) = make_double2(vm, 0.0);
+          ROW(R.RVM + i) = 1.0 / vm;
+        }
         if (recs[k].generic) {
           bus_injection(T, R, E, S, i);
           if (FLOW_REGS) Pout[slot0 + u] = ROW(R.P + i);
@@ -1709,14 +1719,15 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
     if (!ENV) __syncthreads();
   }
   double Pinj[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // KIND_FBS_FLOW + ENV: S_spec of the wave's own buses
-  if (ENV) prologue_env<KIND == KIND_FBS_LDS, KIND == KIND_FBS_FLOW>(c, E, actions, b, valid, Pinj);
+  constexpr bool kNewton = KIND == KIND_TREE || KIND == KIND_TREE_LDS || KIND == KIND_LU || KIND == KIND_DENSE;
+  if (ENV) prologue_env<KIND == KIND_FBS_LDS, KIND == KIND_FBS_FLOW, kNewton>(c, E, actions, b, valid, Pinj);
   stamp(c, ST_PROLOGUE);
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
   else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds<ENV != 0>(c, C, st);
   else if (KIND == KIND_FBS_FLOW) psum = fbs_loop_flow<ENV != 0>(c, C, st, Pinj);
-  else newton_loop<KIND>(c, C, st);
+  else newton_loop<KIND, ENV != 0>(c, C, st);
   constexpr bool kFbs = KIND == KIND_FBS || KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW;
   epilogue<ENV, !kFbs, CHK, KIND == KIND_FBS_FLOW>(c, E, st, total_load, KIND == KIND_FBS_LDS || KIND == KIND_FBS_FLOW, psum, FC, valid ? b : 0x7fffffff);   // FBS keeps no polar angle: atan2 there
   if (ENV && PA.out != nullptr) pack_observations(c, PA, B);     // rows of pass 0 visible since the epilogue's barrier
