@@ -39,10 +39,9 @@
 // lane pointer it replaces, S[row * GS_LANES]; rows that differ between lanes (the dense solver's pivots) use
 // S.lane_row(row * GS_LANES).  Out-of-range offsets read 0 / are dropped by the hardware bounds check.
 //
-// Row loads carry sc0: rows are how the waves of a group hand data to each other across a barrier, and a plain load may
-// be served from an L1 line that was filled around the time another wave's store went through (seen as 64-byte sectors
-// of stale data, rarely and timing-dependent).  sc0 loads are served from L2, which every store of the group has
-// reached in order.
+// Row loads carry sc0 (workgroup scope): rows are how the waves of a group hand data to each other across a barrier.
+// (Introduced while hunting "stale 64-byte sectors" that turned out to be the store-data hazard handled in
+// GsPairRef::put below; costs nothing measurable, kept.)
 #ifndef GS_LOAD_AUX
 #define GS_LOAD_AUX 1
 #endif

@@ -56,10 +56,10 @@ extern __shared__ __attribute__((aligned(16))) double gs_dyn[];
 // rendezvous.  Unlike __syncthreads() it does not drain outstanding global loads/stores, so
 // prefetches issued before it stay in flight across it.
 // Barrier that publishes ROWS (global memory) between the waves of a group.  __syncthreads() is a workgroup-scope
-// release / acquire, for which the compiler emits no s_waitcnt vmcnt(0): it assumes that the vector memory operations of
-// one compute unit reach the cache in issue order.  Measured otherwise (rarely, in 64-byte sectors): a row stored by one
-// wave just before the barrier was still read old by another wave just after it.  So: drain this wave's stores before
-// the rendezvous; the loads behind it carry sc0 (gs_internal.h) and are served from L2.
+// release / acquire, for which the compiler emits no s_waitcnt vmcnt(0) (the vector memory operations of one compute
+// unit reach its L1 in issue order); this one drains the wave's stores first all the same -- it costs nothing
+// measurable, and it took one suspect off the list while the cause of the corrupted row sectors was being found
+// (the store-data hazard of GsPairRef::put, gs_internal.h).
 __device__ __forceinline__ void gs_rows_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifndef GS_EXP_PLAIN_SYNC
 #define __syncthreads() gs_rows_barrier()
