@@ -313,8 +313,10 @@ def test_dataflow_kernel_falls_back_when_a_wave_would_own_too_many_buses(monkeyp
 @pytest.mark.parametrize("solver", ["nr", "fbs"])
 def test_two_builds_of_the_step_kernel_agree_bit_for_bit(solver):
     """The step kernel with the fused post-step checks is a second instantiation of the same code with different
-    timing.  Any cross-wave hand-off through rows that is not properly ordered (stores drained before the barrier,
-    loads served from L2 after it) shows up as a 64-byte sector of one kernel reading stale data: this caught one."""
+    register allocation and timing.  This comparison is what exposed the store-data hazard of the 16-byte row stores
+    (a VALU write to the data registers right behind a buffer_store_dwordx4 whose offset is in an SGPR: lanes 12-15 of
+    every 16 store the new register contents; GsPairRef::put in csrc/gs_internal.h): it showed up as a 64-byte sector
+    of one build holding different values."""
     from grid_fed_rl_gym_amd.safety import PostStepChecks
     spec = P.ieee123_like(); B = 130
     kw = dict(num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True)
