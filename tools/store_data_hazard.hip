@@ -5,6 +5,7 @@
 // MI355X, ROCm 7.2 (round 1):   wait states 0: 109632 of 16777216 slots wrong, all of them lanes 12-15 of every 16
 //                               wait states 1, 2, 4: 0 wrong
 // The compiler's hazard recogniser inserts that wait state for 16-byte stores EXCEPT when soffset is a register.
+// (The same experiment with buffer_store_dwordx2, 8 bytes per lane: 0 of 16777216 wrong -- only the wide store is affected.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
