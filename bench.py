@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/sec of the batched AC power-flow env.step() on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ieee123_b8192|ieee13_b4096]
-                    [--solver nr|fbs] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--workload ieee123_b8192|ieee13_b4096|ieee8500_3ph_b1024]
+                    [--solver nr|fbs] [--batch B] [--no-cpu-baseline] [--no-also]
 
 One "step" = one batched env.step(): actions -> batteries/curtailment -> weather -> injections
 -> AC load flow -> line flows -> frequency -> reward/flags -> observation block, for every
 instance of the batch, with the K action batches already resident in HBM.  The default
 workload is the configuration BASELINE.json's target is quoted on (configs[2]): the 123-bus radial
 feeder, 8192 instances per GPU, forward/backward-sweep load flow, reference defaults for stochastic
-loads and weather.  The same line also carries the Newton-Raphson measurement ("also"), the accuracy
-of the GPU voltages against the CPU oracle's Newton-Raphson, and the CPU baseline.
+loads and weather.  Protocol: W warm-up steps, then R regions of exactly K
+steps, each bracketed by a barrier + device synchronisation on both sides; per region the maximum
+over the ranks' clocks; `value` / `ms_per_step` are the MEDIAN region, p10 / p90 beside them.
+
+The same line carries (N = 1): the Newton-Raphson measurement and BASELINE configs 2 and 5 ("also",
+each with its own roofline), the device-resident rollout collector and the host-inclusive rate of
+plain env.step() ("rollout", "with_host_io"), the accuracy of the GPU voltages / angles / flows
+against the CPU oracle's Newton-Raphson, and the CPU baselines (all cores and one core).
 
 For N > 1 the driver launches one process per GPU (torch.distributed.run); each rank owns a
-contiguous block of instances (weak scaling, per-GPU batch fixed); the ranks are independent, so
-`value` has no collective in it.  The one exchange north_star names -- the RCCL all-gather of the
-observation block after each step -- is timed in a second pass and reported in the same line
-("with_obs_allgather"): it is bound by xGMI, not by the step.  torch is imported only for the
-rendezvous (gloo barrier + max-over-ranks), never for compute; libgridstep.so is loaded first
-so that the process uses one HIP runtime.
+contiguous block of instances (weak scaling, per-GPU batch fixed).  `value` is BASELINE config 4 as
+written: the sharded step WITH the RCCL all-gather of the observation blocks after every step
+(`config.obs_allgather_in_value`); the rate of the independent ranks without the exchange is
+reported beside it ("without_obs_allgather").  The ranks rendezvous through a directory of small
+files (grid_fed_rl_gym_amd/rendezvous.py): no torch anywhere in this process.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -38,10 +44,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor figure for MI355X FP64 vector
 
 WORKLOADS = {
-    "ieee123_b8192": dict(feeder="ieee123_like", batch=8192),
-    "ieee13_b4096": dict(feeder="ieee13_like", batch=4096),
-    "ieee8500_3ph_b1024": dict(feeder="ieee8500_like", batch=1024),      # BASELINE.json config 5 (solver only)
+    "ieee123_b8192": dict(feeder="ieee123_like", batch=8192, solver="fbs"),       # BASELINE.json config 3 (and 4 for N > 1)
+    "ieee13_b4096": dict(feeder="ieee13_like", batch=4096, solver="nr"),          # config 2
+    "ieee8500_3ph_b1024": dict(feeder="ieee8500_like", batch=1024, solver="fbs3"),  # config 5 (solver only)
 }
+KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
+                "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow", "fbs_flow2": "fbs_flow2",
+                "nr_flow2": "nr_flow2"}
 
 
 def make_feeder(name):
@@ -59,14 +68,39 @@ def algorithmic_flops_per_iteration(fs):
     return 180 * fs.n
 
 
-def cpu_baseline(fs, env_kwargs, budget_s=15.0):
+def host_description():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return {"cpu_model": model or platform.processor(), "nproc": os.cpu_count(), "cpus_available_to_this_process": avail}
+
+
+def traffic_of(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key, {}).get("solve_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def quantiles(xs):
+    a = np.sort(np.asarray(xs, dtype=float))
+    return float(np.median(a)), float(np.quantile(a, 0.1)), float(np.quantile(a, 0.9))
+
+
+def cpu_baseline(fs, env_kwargs, budget_s=15.0, threads=None):
     """The oracle timed on this box's host cores on a bounded sample of the same workload.
     Prefers the C/OpenMP port (oracle/liboracle_cpu.so) when it has been built, else the NumPy
     restatement on one core."""
     try:
         from oracle import oracle_c
         if oracle_c.available():
-            return oracle_c.bench_env_steps(fs, env_kwargs, budget_s)
+            return oracle_c.bench_env_steps(fs, env_kwargs, budget_s, threads=threads)
     except Exception as e:  # pragma: no cover - reported, not fatal
         print(f"[bench] C oracle unavailable ({e}); timing the NumPy oracle", file=sys.stderr)
     from oracle import oracle_np as O
@@ -89,12 +123,12 @@ def cpu_baseline(fs, env_kwargs, budget_s=15.0):
             "sample": f"NumPy oracle, {b} instances x 4 steps of the same workload in {dt:.1f} s"}
 
 
-def bench_unbalanced(args, device):
+def measure_unbalanced(args, device, with_cpu):
     """BASELINE.json config 5: 8500-node three-phase unbalanced FBS, batch 1024 -- load-flow solves/s.
     A "step" is one batched solve from a flat start; injections resident in HBM."""
     from grid_fed_rl_gym_amd.unbalanced import UnbalancedPowerFlow, ieee8500_like
     spec, Pn, Qn = ieee8500_like()
-    B = args.batch or WORKLOADS[args.workload]["batch"]
+    B = (args.batch if args.workload == "ieee8500_3ph_b1024" else 0) or WORKLOADS["ieee8500_3ph_b1024"]["batch"]
     lam = np.random.default_rng(1234).uniform(0.5, 1.5, B)
     Pb, Qb = lam[:, None, None] * Pn[None], lam[:, None, None] * Qn[None]
     s = UnbalancedPowerFlow(tolerance=args.tolerance, max_iterations=args.max_iterations or 100, device=device)
@@ -102,12 +136,16 @@ def bench_unbalanced(args, device):
     for _ in range(args.warmup):
         s.solve_device()
     s.synchronize(); s.timing_read()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s.solve_device()
-    s.synchronize()
-    elapsed = time.perf_counter() - t0
-    total_ms, launches = s.timing_read()
+    regions = []
+    total_ms = launches = 0
+    for _ in range(args.repeats):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s.solve_device()
+        s.synchronize()
+        regions.append(time.perf_counter() - t0)
+        ms, cnt = s.timing_read()
+        total_ms += ms; launches += cnt
     sol = s.download()
     desc = s.describe()
     avg_ms = total_ms / max(launches, 1)
@@ -118,32 +156,30 @@ def bench_unbalanced(args, device):
     alg_bytes = 4 * 16 * desc["conductors"] * mean_it * B
     survey_bytes = 4 * 48 * spec.n * mean_it * B
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    try:
-        if B == WORKLOADS[args.workload]["batch"]:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(f"{args.workload}:fbs3", {}).get("solve_bytes_per_launch")
-    except Exception:
-        traffic = None
-    result = {"metric": "three-phase load-flow solves/sec (batched feeders)", "value": B * args.steps / elapsed, "unit": "solves/s",
-              "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+    traffic = traffic_of("ieee8500_3ph_b1024:fbs3") if B == WORKLOADS["ieee8500_3ph_b1024"]["batch"] else None
+    med, p10, p90 = quantiles(regions)
+    result = {"metric": "three-phase load-flow solves/sec (batched feeders)", "value": B * args.steps / med, "unit": "solves/s",
+              "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats, "ms_per_step": 1e3 * med / args.steps,
+              "ms_per_step_p10_p90": [1e3 * p10 / args.steps, 1e3 * p90 / args.steps],
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
               "config": {"workload": f"{spec.name}, 3-phase unbalanced FBS, batch={B}, per-instance loading U(0.5,1.5), tolerance {args.tolerance:g}",
                          "n_nodes": spec.n, "phase_conductors": desc["conductors"], "tree_levels": desc["levels"],
                          "max_level_width": desc["max_level_width"],
-                         "batch_per_gpu": B, "kernel": "gs3_k_solve"},
+                         "batch_per_gpu": B, "kernel": "gs3_k_solve",
+                         "parity": "unpinned: the reference has no three-phase solver (README prose only)"},
               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": "gs3_k_solve", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                            "bytes_per_launch_at_3_conductors_per_node": survey_bytes, "mean_iterations": mean_it},
               "converged_fraction": float(sol.converged.mean()),
               "min_voltage_pu": float(np.abs(sol.voltages)[np.abs(sol.voltages) > 0].min())}
-    if not args.no_cpu_baseline:
+    if with_cpu:
         try:
             from oracle import oracle_c as OC
             threads = max(1, min(OC.lib().orc_max_threads(), len(os.sched_getaffinity(0)), 16))
             nb = 4 * threads
             t1 = time.perf_counter(); done = 0
             while time.perf_counter() - t1 < 10.0:
-                out = OC.solve3_batch(spec, Pb[:nb], Qb[:nb], tolerance=args.tolerance, threads=threads); done += nb
+                OC.solve3_batch(spec, Pb[:nb], Qb[:nb], tolerance=args.tolerance, threads=threads); done += nb
             dt = time.perf_counter() - t1
             ref = OC.solve3_batch(spec, Pb[:4], Qb[:4], tolerance=args.tolerance, threads=threads)
             result["accuracy"] = {"max_abs_dV_pu": float(np.max(np.abs(sol.voltages[:4] - ref["voltages"]))),
@@ -153,8 +189,8 @@ def bench_unbalanced(args, device):
         except Exception as e:
             result["cpu_baseline"] = None
             print(f"[bench] C oracle unavailable: {e}", file=sys.stderr)
-    print(json.dumps(result), flush=True)
     s.close()
+    return result
 
 
 def main():
@@ -162,10 +198,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each; median / p10 / p90 are reported")
     ap.add_argument("--workload", default="ieee123_b8192", choices=sorted(WORKLOADS))
-    ap.add_argument("--solver", default="fbs", choices=["nr", "fbs"],
-                    help="fbs = BASELINE.json config 3 (DistributionPowerFlow); nr = the reference's Newton-Raphson")
+    ap.add_argument("--solver", default="", choices=["", "nr", "fbs"],
+                    help="fbs = BASELINE.json config 3 (DistributionPowerFlow); nr = the reference's Newton-Raphson; default: the workload's")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second measurement with the other solver")
+    ap.add_argument("--no-also", action="store_true", help="skip BASELINE configs 2 and 5, the rollout and the host-inclusive measurements")
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per 64-instance group (0 = auto)")
     ap.add_argument("--tolerance", type=float, default=1e-6, help="ablation only; the headline uses 1e-6")
@@ -182,38 +220,34 @@ def main():
             print("[bench] --gpus > 1 needs `python -m torch.distributed.run --nproc-per-node N bench.py ...`", file=sys.stderr)
             sys.exit(2)
 
-    lib = _lib.load()                # HIP runtime of /opt/rocm first; torch (if any) comes after
+    lib = _lib.load()
     n_dev = max(lib.gs_device_count(), 1)
     device = local_rank % n_dev      # ranks share a device only when rehearsing N > 1 on a smaller box
-    dist = None
+    rz = None
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        from grid_fed_rl_gym_amd.rendezvous import FileRendezvous
+        rz = FileRendezvous(rank, world)
 
     if args.workload == "ieee8500_3ph_b1024":
         if world != 1:
             print("[bench] the 3-phase workload is a single-GPU measurement", file=sys.stderr)
             sys.exit(2)
-        bench_unbalanced(args, device)
+        print(json.dumps(measure_unbalanced(args, device, not args.no_cpu_baseline)), flush=True)
         return
     wl = WORKLOADS[args.workload]
-    fs = make_feeder(wl["feeder"])
-    B = args.batch or wl["batch"]
+    solver0 = args.solver or wl["solver"]
     n_act = 8
-    rng = np.random.default_rng(5678 + rank)
-    actions = rng.uniform(-1, 1, (n_act, B, fs.action_dim))
-    seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.uint64)
     want_gather = world > 1 and not args.no_allgather and n_dev >= world
-    kernel_names = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
-                    "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow"}
 
     def env_kwargs_of(solver):
         return dict(stochastic_loads=True, weather_variation=True, solver=solver, tolerance=args.tolerance,
                     max_iterations=args.max_iterations or (50 if solver == "nr" else 100))
 
-    def measure(solver, use_gather):
-        """W untimed + K timed batched steps of one solver; returns the measurement as a dict."""
+    def measure(fs, B, solver, use_gather, repeats, extras=False):
+        """W untimed + R x K timed batched steps of one solver; returns the measurement as a dict."""
+        rng = np.random.default_rng(5678 + rank)
+        actions = rng.uniform(-1, 1, (n_act, B, fs.action_dim))
+        seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.uint64)
         env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=device,
                                        first_instance=rank * B, waves_per_group=args.waves, **env_kwargs_of(solver))
         h = env.handle
@@ -224,12 +258,8 @@ def main():
         st[:, env.state_column("time")] = 11.5 * 3600.0          # midday: loads near peak, PV producing
         env.set_state(st)
         if use_gather:
-            import torch
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(_lib.Handle.comm_unique_id()), dtype=torch.uint8).clone()
-            dist.broadcast(uid, src=0)
-            h.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+            uid = rz.broadcast_bytes(_lib.Handle.comm_unique_id() if rank == 0 else None)
+            h.comm_init(uid, rank, world)
 
         def one_step(k):
             h.step_device(k % n_act)
@@ -238,72 +268,120 @@ def main():
 
         def barrier():
             h.synchronize()
-            if dist is not None:
-                dist.barrier()
+            if rz is not None:
+                rz.barrier()
 
         for k in range(args.warmup):
             one_step(k)
-        barrier()
-        # one HIP event pair on the kernel's stream around the K launches of the timed region (an event pair per launch
-        # puts two marker packets between consecutive kernels: +4..5 us per step)
-        h.timing_enable(True, span=True)
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            one_step(args.warmup + k)
-        timing = h.timing_read()                                # closing event behind the last launch; waits for it
-        h.synchronize()
-        if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        h.timing_enable(False)
-        if dist is not None:
-            import torch
-            t = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        regions, kernel_ms, kernel_launches = [], 0.0, 0
+        for r in range(repeats):
+            # one HIP event pair on the kernel's stream around the K launches of the region (an event pair per launch
+            # puts two marker packets between consecutive kernels: +4..5 us per step)
+            h.timing_enable(True, span=True)
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                one_step(args.warmup + k)
+            timing = h.timing_read()                            # closing event behind the last launch; waits for it
+            h.synchronize()
+            elapsed = time.perf_counter() - t0
+            h.timing_enable(False)
+            if rz is not None:
+                elapsed = rz.all_reduce_max(elapsed)
+            regions.append(elapsed)
+            kernel_ms += timing["solve"]["total_ms"]; kernel_launches += timing["solve"]["launches"]
         out = h.download_step(want_obs=False)                    # sanity of the timed work: every instance solved
-        m = dict(solver=solver, elapsed=elapsed, timing=timing, desc=desc,
+        m = dict(solver=solver, regions=regions, kernel_ms=kernel_ms, kernel_launches=kernel_launches, desc=desc, B=B, fs=fs,
                  converged_fraction=float(out["power_flow_converged"].mean()),
                  mean_iterations=float(out["iterations"].mean()))
-        if rank == 0 and solver == args.solver:
-            # SafetyChecker + SafetyMonitor + quality gate on the device state, outside the timed step
-            try:
-                from grid_fed_rl_gym_amd.safety import PostStepChecks
-                ck = PostStepChecks(env)
-                for _ in range(3):
-                    ck.run()
-                h.synchronize(); ck.timing_read()
-                for _ in range(20):
-                    ck.run()
-                ms, cnt = ck.timing_read()
-                byts = B * ((fs.n + 3 * fs.m + 5) + fs.n) * 8 + B * (fs.n + fs.m)      # rows read, previous voltages written, masks written
-                m["post_step_checks"] = {"kernel": "gs_k_checks", "avg_launch_us": 1e3 * ms / max(cnt, 1), "bytes_per_launch": byts,
-                                         "GB_per_s": byts / (ms / max(cnt, 1) * 1e-3) / 1e9 if ms > 0 else None}
-                # the same checks fused into the step kernel's epilogue (gs_checks_set_fused): cost = step time with - without
-                def loop(nsteps):
-                    for k in range(5):
-                        h.step_device(k % n_act)
-                    h.synchronize(); t1 = time.perf_counter()
-                    for k in range(nsteps):
-                        h.step_device(k % n_act)
-                    h.synchronize()
-                    return 1e6 * (time.perf_counter() - t1) / nsteps
-                plain_us = loop(30)
-                ck.set_fused(True)
-                fused_us = loop(30)
-                ck.set_fused(False)
-                m["post_step_checks"]["fused_into_step_us"] = fused_us - plain_us
-                ck.close()
-            except Exception as e:                                 # never let the side measurement break the bench line
-                m["post_step_checks"] = {"error": str(e)}
+        if extras and rank == 0:
+            m.update(side_measurements(env, fs, B, actions, solver))
         if use_gather:
             h.comm_destroy()
         env.close()
         return m
 
-    def accuracy(solver):
-        """max |V| error of the HIP path against the CPU oracle on a 64-instance, 3-step sample of the workload."""
+    def side_measurements(env, fs, B, actions, solver):
+        """Outside the timed regions: post-step checks, the rollout collector, plain env.step() with its host copies."""
+        h = env.handle
+        m = {}
+        # SURVEY 8(f) rows 2-3: SafetyChecker + SafetyMonitor + quality gate on the device state
+        try:
+            from grid_fed_rl_gym_amd.safety import PostStepChecks
+            ck = PostStepChecks(env)
+            ck.timing_enable(True)
+            for _ in range(3):
+                ck.run()
+            h.synchronize(); ck.timing_read()
+            for _ in range(20):
+                ck.run()
+            ms, cnt = ck.timing_read()
+            ck.timing_enable(False)
+            byts = B * ((fs.n + 3 * fs.m + 5) + fs.n) * 8 + B * (fs.n + fs.m)      # rows read, previous voltages written, masks written
+            m["post_step_checks"] = {"kernel": "gs_k_checks", "avg_launch_us": 1e3 * ms / max(cnt, 1), "bytes_per_launch": byts,
+                                     "GB_per_s": byts / (ms / max(cnt, 1) * 1e-3) / 1e9 if ms > 0 else None}
+
+            def loop(nsteps):
+                for k in range(5):
+                    h.step_device(k % n_act)
+                h.synchronize(); t1 = time.perf_counter()
+                for k in range(nsteps):
+                    h.step_device(k % n_act)
+                h.synchronize()
+                return 1e6 * (time.perf_counter() - t1) / nsteps
+            plain_us = loop(30)
+            ck.set_fused(True)
+            fused_us = loop(30)
+            ck.set_fused(False)
+            m["post_step_checks"]["fused_into_step_us"] = fused_us - plain_us
+            ck.close()
+        except Exception as e:                                 # never let a side measurement break the bench line
+            m["post_step_checks"] = {"error": str(e)}
+        if args.no_also:
+            return m
+        # SURVEY 8(f) row 1: the device-resident rollout collector (gs_rollout): T steps + bookkeeping + in-place resets,
+        # random actions drawn on the device, nothing on the host in between
+        try:
+            T = args.steps
+            h.rollout(T, "random", seed=1); h.synchronize()                       # allocation + warm-up
+            rates = []
+            for r in range(5):
+                t1 = time.perf_counter()
+                h.rollout(T, "random", seed=2 + r)
+                h.synchronize()
+                rates.append(B * T / (time.perf_counter() - t1))
+            med, p10, p90 = quantiles(rates)
+            t1 = time.perf_counter()
+            d = h.rollout_download()
+            dt_dl = time.perf_counter() - t1
+            nbytes = sum(v.nbytes for v in d.values() if isinstance(v, np.ndarray))
+            m["rollout"] = {"env_steps_per_s": med, "p10_p90": [p10, p90], "T": T, "policy": "random actions drawn on the device",
+                            "what": "gs_rollout: T fused steps, each writing its observation block into the next slot of obs_seq[T+1][B][obs_dim]; "
+                                    "reward / done bookkeeping and in-place resets by a second small kernel per step; no host copy",
+                            "finished_episodes": d["n_terminal"],
+                            "download_once_at_the_end": {"seconds": dt_dl, "bytes": nbytes, "GB_per_s": nbytes / dt_dl / 1e9}}
+        except Exception as e:
+            m["rollout"] = {"error": str(e)}
+        # what a caller of BatchedGridEnvironment.step() gets: actions from host memory in, the whole observation block and
+        # the info arrays out, every step (PCIe-bound; never `value`)
+        try:
+            env.step(actions[0]); env.step(actions[1])
+            ts = []
+            for k in range(10):
+                t1 = time.perf_counter()
+                env.step(actions[k % n_act])
+                ts.append(time.perf_counter() - t1)
+            med, p10, p90 = quantiles(ts)
+            m["with_host_io"] = {"env_steps_per_s": B / med, "ms_per_step": 1e3 * med, "ms_per_step_p10_p90": [1e3 * p10, 1e3 * p90],
+                                 "what_is_copied": f"per step: actions [B][{fs.action_dim}] f64 host->device ({B * fs.action_dim * 8} B), observations "
+                                                   f"[B][{fs.obs_dim}] f64 device->host ({B * fs.obs_dim * 8} B), reward / flags / info arrays (~{B * 70} B), "
+                                                   "pageable NumPy memory on the host side"}
+        except Exception as e:
+            m["with_host_io"] = {"error": str(e)}
+        return m
+
+    def accuracy(fs, solver):
+        """max |V|, angle and line-flow error of the HIP path against the CPU oracle on a 64-instance, 3-step sample of the workload."""
         try:
             from oracle import oracle_c as OC
             if not OC.available():
@@ -311,6 +389,8 @@ def main():
         except Exception:
             return None
         b = 64
+        rng = np.random.default_rng(5678 + rank)
+        actions = rng.uniform(-1, 1, (n_act, b, fs.action_dim))
         env = P.BatchedGridEnvironment(fs, num_envs=b, jacobian="exact", zero_z="open", device=device, **env_kwargs_of(solver))
         env.reset(seed=np.arange(b, dtype=np.uint64))
         st = env.get_state(); st[:, env.state_column("time")] = 11.5 * 3600.0; env.set_state(st)
@@ -320,101 +400,132 @@ def main():
         cfg = OC.config(solver="nr", jacobian="exact", max_iterations=50, tolerance=1e-10, stochastic_loads=True,
                         weather_variation=True, power_base=fs.base_power_va, threads=8)
         _, cst = OC.env_reset(net, cfg, b, np.arange(b, dtype=np.uint64)); cst[:, 0] = 11.5 * 3600.0
-        dv = da = 0.0
+        dv = da = df = 0.0
+        o_f = 2 * fs.n
         for k in range(3):
-            obs, *_ = env.step(actions[k, :b])
-            ref = OC.env_step(net, cfg, cst, actions[k, :b])["obs"]
+            obs, *_ = env.step(actions[k])
+            ref = OC.env_step(net, cfg, cst, actions[k])["obs"]
             dv = max(dv, float(np.max(np.abs(obs[:, 0:2 * fs.n:2] - ref[:, 0:2 * fs.n:2]))))
             da = max(da, float(np.max(np.abs(obs[:, 1:2 * fs.n:2] - ref[:, 1:2 * fs.n:2]))))
+            df = max(df, float(np.max(np.abs(obs[:, o_f:o_f + 2 * fs.m:2] - ref[:, o_f:o_f + 2 * fs.m:2]))))
         env.close()
-        return {"max_abs_dVm_pu": dv, "max_abs_dVa_rad": da, "against": "C oracle, Newton-Raphson (reference algorithm) converged to 1e-10",
+        return {"max_abs_dVm_pu": dv, "max_abs_dVa_rad": da, "max_abs_dflow_pu": df,
+                "against": "C oracle, Newton-Raphson (reference algorithm) converged to 1e-10",
                 "sample": f"{b} instances x 3 steps of the workload", "gpu_tolerance": kw["tolerance"]}
 
-    # `value` is the sharded step itself: the ranks' instances are independent, no collective is on the path.  For N > 1
-    # the same steps are then timed WITH north_star's observation all-gather after every step and reported beside it
-    # ("with_obs_allgather"); that exchange is bound by xGMI, not by the step.
-    main_m = measure(args.solver, False)
-    gather_m = measure(args.solver, True) if want_gather else None
+    def summarize(m, n_ranks):
+        med, p10, p90 = quantiles(m["regions"])
+        sps = [n_ranks * m["B"] * args.steps / t for t in m["regions"]]
+        s_med, s_p10, s_p90 = quantiles(sps)
+        return dict(value=s_med, value_p10_p90=[s_p10, s_p90], ms_per_step=1e3 * med / args.steps,
+                    ms_per_step_p10_p90=[1e3 * p10 / args.steps, 1e3 * p90 / args.steps],
+                    avg_launch_ms=m["kernel_ms"] / max(m["kernel_launches"], 1))
+
+    def roofline_of(m, s, workload_key):
+        fs, B = m["fs"], m["B"]
+        bytes_step = algorithmic_bytes_per_step(fs)
+        avg = s["avg_launch_ms"]
+        achieved = bytes_step * B / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        flops_it = algorithmic_flops_per_iteration(fs) if m["solver"] == "nr" else 30 * fs.n
+        tflops = flops_it * m["mean_iterations"] * B / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic_of(f"{workload_key}:{m['solver']}") if B == WORKLOADS[workload_key]["batch"] else None,
+                "kernel": "gs_k_step_" + KERNEL_NAMES.get(m["desc"]["kernel"], m["desc"]["kernel"]),
+                "avg_launch_ms": avg, "avg_launch_method": "one HIP event pair on the kernel's stream around the K launches of each timed region / K, mean over the regions",
+                "algorithmic_bytes_per_launch": bytes_step * B,
+                "fp64_valu": {"achieved_tflops": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                              "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "mean_iterations": m["mean_iterations"]}}
+
+    fs = make_feeder(wl["feeder"])
+    B = args.batch or wl["batch"]
+    main_m = measure(fs, B, solver0, False, args.repeats, extras=(world == 1))
+    gather_m = measure(fs, B, solver0, True, args.repeats) if want_gather else None
     other = None
     if world == 1 and not args.no_secondary:
-        other = measure("nr" if args.solver == "fbs" else "fbs", False)
+        other = measure(fs, B, "nr" if solver0 == "fbs" else "fbs", False, max(3, args.repeats // 2))
 
     if rank == 0:
-        def summarize(m):
-            steps_per_s = world * B * args.steps / m["elapsed"]
-            solve = m["timing"]["solve"]
-            avg_ms = solve["total_ms"] / max(solve["launches"], 1)
-            return steps_per_s, avg_ms
-
-        steps_per_s, avg_solve_ms = summarize(main_m)
+        plain = summarize(main_m, world)
+        head_m, head = (gather_m, summarize(gather_m, world)) if gather_m is not None else (main_m, plain)
         desc = main_m["desc"]
-        bytes_step = algorithmic_bytes_per_step(fs)
-        achieved_gbs = bytes_step * B / (avg_solve_ms * 1e-3) / 1e9 if avg_solve_ms > 0 else 0.0
-        flops_it = algorithmic_flops_per_iteration(fs) if args.solver == "nr" else 30 * fs.n
-        tflops = flops_it * main_m["mean_iterations"] * B / (avg_solve_ms * 1e-3) / 1e12 if avg_solve_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(f"{args.workload}:{args.solver}", {}).get("solve_bytes_per_launch")
-            except Exception:
-                traffic = None
         solver_text = {"nr": "Newton-Raphson (exact Jacobian)", "fbs": "forward/backward sweep (DistributionPowerFlow)"}
         result = {
-            "metric": "env steps/sec (batched feeders)", "value": steps_per_s, "unit": "env_steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * main_m["elapsed"] / args.steps, "higher_is_better": True, "scaling": "weak",
+            "metric": "env steps/sec (batched feeders)", "value": head["value"], "unit": "env_steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
+            "ms_per_step": head["ms_per_step"], "value_p10_p90": head["value_p10_p90"], "ms_per_step_p10_p90": head["ms_per_step_p10_p90"],
+            "statistic": "median over the timed regions of --steps steps each (max over ranks per region)",
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{fs.name}, batch={B} per GPU, {solver_text[args.solver]}, "
+            "config": {"workload": f"{fs.name}, batch={B} per GPU, {solver_text[solver0]}, "
                                    f"stochastic loads + weather, tolerance {args.tolerance:g}",
                        "feeder_sha256": fs.sha256(), "n_buses": fs.n, "n_lines": fs.m, "obs_dim": fs.obs_dim,
                        "action_dim": fs.action_dim, "batch_per_gpu": B, "global_batch": world * B,
-                       "solver": args.solver, "kernel": desc["kernel"], "waves_per_group": desc["waves_per_group"],
-                       "tree_levels": desc["levels"], "obs_allgather_in_value": False,
+                       "solver": solver0, "kernel": desc["kernel"], "waves_per_group": desc["waves_per_group"],
+                       "instances_per_workgroup": desc.get("instances_per_workgroup", 64), "workgroups": desc.get("workgroups", desc["groups"]),
+                       "tree_levels": desc["levels"], "obs_allgather_in_value": gather_m is not None,
                        "parallelism": f"batch-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gs_k_step_" + kernel_names[desc["kernel"]],
-                         "avg_launch_ms": avg_solve_ms, "avg_launch_method": "one HIP event pair on the kernel's stream around the K launches of the timed region / K",
-                         "algorithmic_bytes_per_launch": bytes_step * B,
-                         "fp64_valu": {"achieved_tflops": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
-                                       "mean_iterations": main_m["mean_iterations"]}},
-            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in main_m["timing"].items()},
-            "converged_fraction": main_m["converged_fraction"],
+            "roofline": roofline_of(main_m, plain, args.workload),
+            "converged_fraction": head_m["converged_fraction"],
+            "host": host_description(),
         }
-        if "post_step_checks" in main_m:
-            result["post_step_checks"] = main_m["post_step_checks"]
-        if gather_m is not None:
-            g_sps, _ = summarize(gather_m)
-            ms_with, ms_without = 1e3 * gather_m["elapsed"] / args.steps, 1e3 * main_m["elapsed"] / args.steps
-            obs_bytes = B * fs.obs_dim * 8
-            result["with_obs_allgather"] = {
-                "value": g_sps, "unit": "env_steps/s", "ms_per_step": ms_with,
-                "allgather_ms_per_step": ms_with - ms_without, "bytes_sent_per_rank_per_step": obs_bytes,
-                "bytes_received_per_rank_per_step": (world - 1) * obs_bytes,
-                "algbw_GB_per_s": world * obs_bytes / max(ms_with - ms_without, 1e-9) / 1e6,
-                "note": "RCCL all-gather of the observation block after every step, overlapped with the next step; xGMI-bound"}
+        for k in ("post_step_checks", "rollout", "with_host_io"):
+            if k in main_m:
+                result[k] = main_m[k]
+        if world > 1:
+            obs_bytes = B * (fs.obs_dim - 2 * fs.n_loads) * 8
+            result["without_obs_allgather"] = {"value": plain["value"], "unit": "env_steps/s", "ms_per_step": plain["ms_per_step"],
+                                               "value_p10_p90": plain["value_p10_p90"],
+                                               "note": "the same sharded steps with no exchange: the ranks are independent (a learner that consumes its own shard)"}
+            if gather_m is not None:
+                d_ms = head["ms_per_step"] - plain["ms_per_step"]
+                result["obs_allgather"] = {"allgather_ms_per_step": d_ms, "bytes_sent_per_rank_per_step": obs_bytes,
+                                           "bytes_received_per_rank_per_step": (world - 1) * obs_bytes,
+                                           "algbw_GB_per_s": world * obs_bytes / max(d_ms, 1e-9) / 1e6,
+                                           "note": "RCCL all-gather of the changing observation columns (the static load columns are rank-independent and never sent) "
+                                                   "after every step, on its own stream, overlapped with the next step; xGMI-bound"}
+            else:
+                result["obs_allgather"] = {"skipped": "fewer devices than ranks (rehearsal on a smaller box) or --no-allgather: value has no exchange in it"}
         if other is not None:
-            o_sps, o_ms = summarize(other)
-            result["also"] = {"solver": other["solver"], "kernel": "gs_k_step_" + kernel_names[other["desc"]["kernel"]],
-                              "value": o_sps, "unit": "env_steps/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
-                              "avg_launch_ms": o_ms, "mean_iterations": other["mean_iterations"],
-                              "converged_fraction": other["converged_fraction"]}
+            o = summarize(other, 1)
+            result["also"] = {"solver": other["solver"], "kernel": "gs_k_step_" + KERNEL_NAMES.get(other["desc"]["kernel"], other["desc"]["kernel"]),
+                              "value": o["value"], "unit": "env_steps/s", "ms_per_step": o["ms_per_step"], "value_p10_p90": o["value_p10_p90"],
+                              "avg_launch_ms": o["avg_launch_ms"], "mean_iterations": other["mean_iterations"],
+                              "converged_fraction": other["converged_fraction"], "roofline": roofline_of(other, o, args.workload)}
+        if world == 1 and not args.no_also and args.workload == "ieee123_b8192":
+            # BASELINE configs 2 and 5 in the same line, each with its own roofline
+            try:
+                w2 = WORKLOADS["ieee13_b4096"]
+                fs2 = make_feeder(w2["feeder"])
+                m2 = measure(fs2, w2["batch"], w2["solver"], False, max(3, args.repeats // 2))
+                s2 = summarize(m2, 1)
+                result["also_config2"] = {"workload": f"{fs2.name}, batch={w2['batch']}, Newton-Raphson (BASELINE config 2)", "value": s2["value"],
+                                          "unit": "env_steps/s", "ms_per_step": s2["ms_per_step"], "value_p10_p90": s2["value_p10_p90"],
+                                          "kernel": m2["desc"]["kernel"], "waves_per_group": m2["desc"]["waves_per_group"],
+                                          "workgroups": m2["desc"].get("workgroups", m2["desc"]["groups"]), "mean_iterations": m2["mean_iterations"],
+                                          "converged_fraction": m2["converged_fraction"], "roofline": roofline_of(m2, s2, "ieee13_b4096")}
+            except Exception as e:
+                result["also_config2"] = {"error": str(e)}
+            try:
+                sub = argparse.Namespace(**vars(args)); sub.workload = "ieee123_b8192"; sub.batch = 0; sub.steps = min(args.steps, 20); sub.repeats = 3
+                r5 = measure_unbalanced(sub, device, False)
+                result["also_config5"] = {k: r5[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "converged_fraction")}
+            except Exception as e:
+                result["also_config5"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            result["accuracy"] = accuracy(args.solver)
+            result["accuracy"] = accuracy(fs, solver0)
             # the reference's CPU path is dense Newton-Raphson: that port is THE baseline; the CPU port of
-            # the solver the GPU ran is reported next to it when it differs
-            result["cpu_baseline"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=12.0)
-            if args.solver != "nr":
-                result["cpu_baseline_same_solver"] = cpu_baseline(fs, env_kwargs_of(args.solver), budget_s=8.0)
+            # the solver the GPU ran is reported next to it when it differs; and the same on ONE core
+            result["cpu_baseline"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=10.0)
+            result["cpu_baseline_1core"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=6.0, threads=1)
+            if solver0 != "nr":
+                result["cpu_baseline_same_solver"] = cpu_baseline(fs, env_kwargs_of(solver0), budget_s=6.0)
+                result["cpu_baseline_same_solver_1core"] = cpu_baseline(fs, env_kwargs_of(solver0), budget_s=4.0, threads=1)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rz is not None:
+        rz.close()
 
 
 if __name__ == "__main__":

@@ -65,6 +65,19 @@ class gs_info_view(C.Structure):
                 ("episode_reward", _dp), ("iterations", _ip), ("status", _ip)]
 
 
+class gs_rollout_view(C.Structure):
+    _fields_ = [("observations", _dp), ("actions", _dp), ("rewards", _dp), ("next_observations", _dp), ("terminals", _up),
+                ("final_observation", _dp), ("n_terminal", _ip)]
+
+
+class gs_rollout_device(C.Structure):
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("obs_dim", C.c_int32), ("action_dim", C.c_int32),
+                ("obs_seq", C.c_void_p), ("actions", C.c_void_p), ("rewards", C.c_void_p), ("terminals", C.c_void_p),
+                ("n_terminal", C.c_int32), ("reserved", C.c_int32), ("terminal_index", C.c_void_p), ("terminal_obs", C.c_void_p)]
+
+
+POLICY = {"uploaded": 0, "random": 1}
+
 # every symbol include/gridstep.h declares: (name, restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = [
@@ -85,6 +98,9 @@ SYMBOLS = [
     ("gs_upload_actions", C.c_int, [_H, _dp, C.c_int32]),
     ("gs_step_device", C.c_int, [_H, C.c_int32]),
     ("gs_download_step", C.c_int, [_H, _dp, _dp, _up, _up, C.POINTER(gs_info_view)]),
+    ("gs_rollout", C.c_int, [_H, C.c_int32, C.c_int32, C.c_uint64, _dp]),
+    ("gs_rollout_download", C.c_int, [_H, C.POINTER(gs_rollout_view)]),
+    ("gs_rollout_device_view", C.c_int, [_H, C.POINTER(gs_rollout_device)]),
     ("gs_get_state", C.c_int, [_H, _dp]),
     ("gs_set_state", C.c_int, [_H, _dp]),
     ("gs_comm_unique_id", C.c_int, [_up]),
@@ -95,6 +111,7 @@ SYMBOLS = [
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     ("gs_debug_write_rows", C.c_int, [_H, C.c_int32, _dp]),
+    ("gs_debug_read_rows", C.c_int, [_H, C.c_int32, _dp]),
     ("gs_fallback_linear", C.c_int, [_H, _dp, _dp, _dp, _dp, _up, _up, C.POINTER(C.c_int32)]),
 ]
 # the gs3_* entry points (three-phase solver) are bound in unbalanced.py
@@ -338,6 +355,43 @@ class Handle:
                                                _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
         return out
 
+    # -- rollout collection ------------------------------------------------------------------
+    def rollout(self, T: int, policy: str = "random", seed: int = 0, actions=None) -> None:
+        """gs_rollout: T env steps back to back on the device (asynchronous).  policy "random": uniform actions in
+        (-1, 1) drawn on the device from ``seed``; "uploaded": ``actions`` [T, B, A]."""
+        a = None
+        if policy == "uploaded":
+            a = _f64(actions)
+            if a.shape != (int(T), self.B, self.action_dim):
+                raise PowerFlowError(f"actions shape {a.shape} != ({T}, {self.B}, {self.action_dim})")
+        self._check(self._lib.gs_rollout(self._h, int(T), POLICY[policy], C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _ptr(a, _dp)))
+        self._rollout_T = int(T)
+
+    def rollout_download(self, want=("observations", "actions", "rewards", "next_observations", "terminals")) -> dict:
+        """Host copies of the last rollout, [T, B, ...] each (gs_rollout_download); ``terminals`` is the raw uint8 flag
+        array (bit 0 terminated, bit 1 truncated)."""
+        T, B = self._rollout_T, self.B
+        out = {}
+        if "observations" in want: out["observations"] = np.empty((T, B, self.obs_dim))
+        if "actions" in want: out["actions"] = np.empty((T, B, self.action_dim))
+        if "rewards" in want: out["rewards"] = np.empty((T, B))
+        if "next_observations" in want: out["next_observations"] = np.empty((T, B, self.obs_dim))
+        if "terminals" in want: out["terminals"] = np.empty((T, B), dtype=np.uint8)
+        if "final_observation" in want: out["final_observation"] = np.empty((B, self.obs_dim))
+        n = C.c_int32(0)
+        v = gs_rollout_view(_ptr(out.get("observations"), _dp), _ptr(out.get("actions"), _dp), _ptr(out.get("rewards"), _dp),
+                            _ptr(out.get("next_observations"), _dp), _ptr(out.get("terminals"), _up),
+                            _ptr(out.get("final_observation"), _dp), C.pointer(n))
+        self._check(self._lib.gs_rollout_download(self._h, C.byref(v)))
+        out["n_terminal"] = int(n.value)
+        return out
+
+    def rollout_device_view(self) -> gs_rollout_device:
+        """Device pointers of the last rollout (gs_rollout_device_view) for a consumer that stays on the GPU."""
+        v = gs_rollout_device()
+        self._check(self._lib.gs_rollout_device_view(self._h, C.byref(v)))
+        return v
+
     def get_state(self) -> np.ndarray:
         st = np.empty((self.B, self.state_dim))
         self._check(self._lib.gs_get_state(self._h, _ptr(st, _dp)))
@@ -385,7 +439,15 @@ class Handle:
         self._check(self._lib.gs_debug_stamps(self._h, buf, 16))
         return {n: int(buf[k]) for k, n in enumerate(self.STAMP_NAMES)}
 
-    ROW_FAMILIES = {"VM": 0, "LOAD": 1, "ENVLOAD": 2, "FLOW": 3, "FREQ": 4, "CONV": 5, "ITERS": 6, "MAXMIS": 7}
+    ROW_FAMILIES = {"VM": 0, "LOAD": 1, "ENVLOAD": 2, "FLOW": 3, "FREQ": 4, "CONV": 5, "ITERS": 6, "MAXMIS": 7, "LOADP": 8}
+
+    def debug_read_rows(self, name: str) -> np.ndarray:
+        """Test aid (gs_debug_read_rows): one family of device rows as a [B, width] array."""
+        width = {"VM": self.n, "LOAD": self.m, "ENVLOAD": self.m, "FLOW": self.m, "LOADP": self.spec.n_loads}.get(name, 1)
+        out = np.empty((self.B, width))
+        if width:
+            self._check(self._lib.gs_debug_read_rows(self._h, self.ROW_FAMILIES[name], out.ctypes.data_as(_dp)))
+        return out
 
     def debug_write_rows(self, rows: dict) -> None:
         """Test aid (gs_debug_write_rows): overwrite families of device rows with [B, width] arrays; None entries are skipped."""

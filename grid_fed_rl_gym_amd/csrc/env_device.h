@@ -69,6 +69,17 @@ __device__ __forceinline__ void rng_normal_quad(uint64_t seed, uint64_t instance
 
 enum { DRAW_IRRADIANCE = 0, DRAW_WEATHER = 1, DRAW_LOAD0 = 16 };
 
+// Seed of an instance's NEXT episode when reset() is called without one (gs_reset with seeds == NULL, and the
+// automatic resets inside gs_rollout).  The reference's reset(seed=None) does not re-seed: its global `random` /
+// np.random streams simply run on (grid_env.py:366-369), so consecutive episodes see different noise.  Here the
+// stream is a pure function of (seed, instance, step, draw); "running on" = a new seed derived from the old one,
+// one Philox call with its own tag word.  reset(seed=k) stays exactly reproducible, and the seed is part of the
+// checkpoint, so a resumed run continues the same chain.
+__device__ __forceinline__ uint64_t next_episode_seed(uint64_t seed, uint64_t instance) {
+  const U4 r = philox((uint32_t)instance, (uint32_t)(instance >> 32), 0u, 0x52534544u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return ((uint64_t)r.b << 32) | (uint64_t)r.a;
+}
+
 __device__ const double kDailyProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
                                              0.7, 0.7, 0.6, 0.6, 0.7, 0.9, 1.0, 0.9, 0.8, 0.7, 0.6, 0.5};
 

@@ -58,6 +58,7 @@ bool load_rccl(std::string& why) {
 }
 
 struct TimedLaunch { int kid; hipEvent_t a, b; };
+constexpr size_t GS_CHECKS_MAX_EVENTS = 4096;
 
 }  // namespace
 
@@ -89,6 +90,14 @@ struct gs_handle {
   hipStream_t comm_stream = nullptr; hipEvent_t ev_step = nullptr, ev_gather[2] = {nullptr, nullptr}; bool gather_pending[2] = {false, false};
   int obs_skip0 = 0, obs_skip1 = 0;   // the block of per-instance constants inside an observation
   double* d_actions = nullptr; int n_action_batches = 0;
+  // gs_rollout: [T + 1][B][obs_dim] observation sequence, [T][B][A] actions, [T][B] rewards / done flags, and the side
+  // list of terminal observations (the rows the in-place resets replaced)
+  struct Rollout {
+    int T_cap = 0, T = 0, term_cap = 0; uint64_t calls = 0;
+    double* obs_seq = nullptr; double* act = nullptr; double* rew = nullptr; uint8_t* done = nullptr;
+    int32_t* term_count = nullptr; int32_t* term_idx = nullptr; double* term_obs = nullptr;
+    int32_t n_term = 0;
+  } ro;
   double* d_cst = nullptr;
   int32_t *map_obs = nullptr, *map_vm = nullptr, *map_va = nullptr, *map_flow = nullptr, *map_load = nullptr,
           *map_p = nullptr, *map_q = nullptr, *map_act = nullptr, *map_state = nullptr;
@@ -106,6 +115,7 @@ struct gs_handle {
   std::vector<TimedLaunch> timed; size_t timed_used = 0;
   // comm
   gs_ncclComm_t comm = nullptr; int rank = 0, world = 1; double* d_obs_full = nullptr;
+  double *d_gather_send = nullptr, *d_gather_recv = nullptr;     // compact observation blocks (changing columns only): [B][nd], [world * B][nd]
   mutable std::string err;
 };
 
@@ -245,14 +255,19 @@ int launch_solve(gs_handle* h) {
 
 GsFusedChecks fused_checks_args(gs_handle* h);      // defined with gs_checks below
 
-int step_kernels(gs_handle* h, const double* d_actions) {
+// obs_out: where the step writes the changing columns of its observation block ([B][obs_dim], constants already in
+// place); NULL = the other one of the handle's two observation buffers
+int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullptr) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
     dim3 grid(h->groups), block(64 * h->W);
-    const int next = h->obs_cur ^ 1;
-    if (h->gather_pending[next]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[next], 0)); h->gather_pending[next] = false; }
-    h->obs_cur = next;
-    GsPackArgs pa{h->map_obs, h->d_cst, h->d_obs2[next], h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 49152) / (64 * 65 * sizeof(double)))), 0, 0,
+    if (!obs_out) {
+      const int next = h->obs_cur ^ 1;
+      if (h->gather_pending[next]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[next], 0)); h->gather_pending[next] = false; }
+      h->obs_cur = next;
+      obs_out = h->d_obs2[next];
+    }
+    GsPackArgs pa{h->map_obs, h->d_cst, obs_out, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 49152) / (64 * 65 * sizeof(double)))), 0, 0,
                   h->obs_skip0, h->obs_skip1};
     pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
@@ -669,7 +684,12 @@ void gs_destroy(gs_handle* h) {
   if (h->span_a) { (void)hipEventDestroy(h->span_a); (void)hipEventDestroy(h->span_b); }
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->d_actions) (void)hipFree(h->d_actions);
+  for (void* p : {(void*)h->ro.obs_seq, (void*)h->ro.act, (void*)h->ro.rew, (void*)h->ro.done, (void*)h->ro.term_count,
+                  (void*)h->ro.term_idx, (void*)h->ro.term_obs})
+    if (p) (void)hipFree(p);
   if (h->d_obs_full) (void)hipFree(h->d_obs_full);
+  if (h->d_gather_send) (void)hipFree(h->d_gather_send);
+  if (h->d_gather_recv) (void)hipFree(h->d_gather_recv);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -817,6 +837,135 @@ int gs_step_device(gs_handle* h, int32_t k) {
   return step_kernels(h, h->d_actions + (size_t)k * h->B * h->action_dim);
 }
 
+
+// ---- device-resident rollout collection ---------------------------------------------------------------
+// T fused env steps back to back, nothing on the host in between (algorithms/base.py:268-298, batched).
+// Device layout (gs_rollout_device_view): obs_seq[T + 1][B][obs_dim] -- slot t is what step t started from, slot
+// t + 1 is written by step t's kernel itself (its observation output IS the next slot: no copy) --, act[T][B][A],
+// rew[T][B], done[T][B], and the side list of terminal observations (t, b, row) the in-place resets replaced.
+static int rollout_ensure(gs_handle* h, int T) {
+  gs_handle::Rollout& ro = h->ro;
+  if (T <= ro.T_cap) return GS_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (void* p : {(void*)ro.obs_seq, (void*)ro.act, (void*)ro.rew, (void*)ro.done, (void*)ro.term_idx, (void*)ro.term_obs})
+    if (p) (void)hipFree(p);
+  ro.obs_seq = nullptr; ro.act = nullptr; ro.rew = nullptr; ro.done = nullptr; ro.term_idx = nullptr; ro.term_obs = nullptr; ro.T_cap = 0;
+  const size_t B = h->B, D = h->obs_dim, A = std::max(h->action_dim, 1);
+  // an instance finishes at most once per min(episode_length, 11) steps (truncation needs more than 10 violating steps
+  // since its last reset, grid_env.py:604) plus once for an episode that was already under way
+  const int min_ep = std::max(1, std::min(h->cfg.episode_length, 11));
+  const size_t cap = B * ((size_t)T / min_ep + 1);
+  if (!ro.term_count) HIPCHK(h, hipMalloc((void**)&ro.term_count, sizeof(int32_t)));
+  if (hipMalloc((void**)&ro.obs_seq, (size_t)(T + 1) * B * D * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&ro.act, (size_t)T * B * A * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&ro.rew, (size_t)T * B * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&ro.done, (size_t)T * B) != hipSuccess ||
+      hipMalloc((void**)&ro.term_idx, cap * 2 * sizeof(int32_t)) != hipSuccess ||
+      hipMalloc((void**)&ro.term_obs, cap * D * sizeof(double)) != hipSuccess)
+    return fail(h, GS_E_NOMEM, "rollout buffers for T = %d (%.1f MB per step) do not fit", T, (double)B * D * 8e-6);
+  ro.T_cap = T; ro.term_cap = (int)std::min<size_t>(cap, 0x7fffffff);
+  // the constant columns of every slot, once: the step kernels write only the columns that change
+  const long long rows = (long long)(T + 1) * B;
+  const int w = h->obs_skip1 - h->obs_skip0;
+  if (w > 0) {
+    const long long total = rows * w;
+    hipLaunchKernelGGL(gs_k_fill_const_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, ro.obs_seq, rows,
+                       h->obs_dim, h->obs_skip0, h->obs_skip1, h->map_obs, h->d_cst);
+    HIPCHK(h, hipGetLastError());
+  }
+  return GS_OK;
+}
+
+int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, const double* actions) {
+  if (!h || T <= 0) return fail(h, GS_E_INVALID, "handle is NULL or T <= 0");
+  if (policy != GS_POLICY_UPLOADED && policy != GS_POLICY_RANDOM) return fail(h, GS_E_INVALID, "unknown policy %d", policy);
+  if (policy == GS_POLICY_UPLOADED && !actions && h->action_dim > 0) return fail(h, GS_E_INVALID, "GS_POLICY_UPLOADED needs actions[T][B][action_dim]");
+  if (!h->was_reset) return fail(h, GS_E_STATE, "gs_rollout before gs_reset");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = rollout_ensure(h, T);
+  if (rc) return rc;
+  gs_handle::Rollout& ro = h->ro;
+  const size_t B = h->B, D = h->obs_dim, A = h->action_dim;
+  ro.T = T; ro.n_term = -1;
+  HIPCHK(h, hipMemsetAsync(ro.term_count, 0, sizeof(int32_t), h->stream));
+  if (A > 0) {
+    if (policy == GS_POLICY_UPLOADED) {
+      HIPCHK(h, hipMemcpyAsync(ro.act, actions, (size_t)T * B * A * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {
+      const long long total = (long long)T * B * ((A + 3) / 4);
+      hipLaunchKernelGGL(gs_k_rollout_actions, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, ro.act, (int)T, (int)B, (int)A,
+                         policy_seed, h->EC.first_instance, 0u);
+      HIPCHK(h, hipGetLastError());
+    }
+  }
+  // slot 0 = the observation the environment stands at
+  HIPCHK(h, hipMemcpyAsync(ro.obs_seq, h->d_obs2[h->obs_cur], B * D * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  for (int t = 0; t < T; ++t) {
+    double* nxt = ro.obs_seq + (size_t)(t + 1) * B * D;
+    if ((rc = step_kernels(h, ro.act + (size_t)t * B * A, nxt))) return rc;
+    GsRolloutPostArgs pa{ro.rew, ro.done, nxt, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, h->B};
+    hipLaunchKernelGGL(gs_k_rollout_post, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, pa);
+    HIPCHK(h, hipGetLastError());
+  }
+  // the environment now stands at slot T: that is its current observation for gs_download_step / gs_allgather_obs
+  if (h->gather_pending[h->obs_cur]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[h->obs_cur], 0)); h->gather_pending[h->obs_cur] = false; }
+  HIPCHK(h, hipMemcpyAsync(h->d_obs2[h->obs_cur], ro.obs_seq + (size_t)T * B * D, B * D * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  ro.calls += 1;
+  return GS_OK;      // asynchronous: gs_synchronize / gs_rollout_download / gs_rollout_device_view wait for it
+}
+
+static int rollout_finish(gs_handle* h) {
+  gs_handle::Rollout& ro = h->ro;
+  if (ro.T <= 0) return fail(h, GS_E_STATE, "no rollout has been collected on this handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (ro.n_term < 0) {
+    int32_t n = 0;
+    HIPCHK(h, hipMemcpyAsync(&n, ro.term_count, sizeof n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n > ro.term_cap) return fail(h, GS_E_NOMEM, "internal: %d finished episodes exceed the terminal list (%d)", n, ro.term_cap);
+    ro.n_term = n;
+  }
+  return GS_OK;
+}
+
+int gs_rollout_device_view(gs_handle* h, gs_rollout_device* out) {
+  if (!h || !out) return fail(h, GS_E_INVALID, "handle / out is NULL");
+  int rc = rollout_finish(h);
+  if (rc) return rc;
+  const gs_handle::Rollout& ro = h->ro;
+  out->T = ro.T; out->B = h->B; out->obs_dim = h->obs_dim; out->action_dim = h->action_dim;
+  out->obs_seq = ro.obs_seq; out->actions = ro.act; out->rewards = ro.rew; out->terminals = ro.done;
+  out->n_terminal = ro.n_term; out->terminal_index = ro.term_idx; out->terminal_obs = ro.term_obs;
+  return GS_OK;
+}
+
+int gs_rollout_download(gs_handle* h, const gs_rollout_view* out) {
+  if (!h || !out) return fail(h, GS_E_INVALID, "handle / view is NULL");
+  int rc = rollout_finish(h);
+  if (rc) return rc;
+  const gs_handle::Rollout& ro = h->ro;
+  const size_t T = ro.T, B = h->B, D = h->obs_dim, A = h->action_dim, blk = B * D;
+  if (out->observations) HIPCHK(h, hipMemcpyAsync(out->observations, ro.obs_seq, T * blk * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out->next_observations) HIPCHK(h, hipMemcpyAsync(out->next_observations, ro.obs_seq + blk, T * blk * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out->final_observation) HIPCHK(h, hipMemcpyAsync(out->final_observation, ro.obs_seq + T * blk, blk * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out->actions && A) HIPCHK(h, hipMemcpyAsync(out->actions, ro.act, T * B * A * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out->rewards) HIPCHK(h, hipMemcpyAsync(out->rewards, ro.rew, T * B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out->terminals) HIPCHK(h, hipMemcpyAsync(out->terminals, ro.done, T * B, hipMemcpyDeviceToHost, h->stream));
+  std::vector<int32_t> idx((size_t)ro.n_term * 2);
+  std::vector<double> rows(out->next_observations ? (size_t)ro.n_term * D : 0);
+  if (ro.n_term && out->next_observations) {
+    HIPCHK(h, hipMemcpyAsync(idx.data(), ro.term_idx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(rows.data(), ro.term_obs, rows.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  // next_observations[t][b] of a finished transition is the terminal observation, not the fresh one in slot t + 1
+  if (out->next_observations)
+    for (int k = 0; k < ro.n_term; ++k)
+      memcpy(out->next_observations + ((size_t)idx[2 * k] * B + idx[2 * k + 1]) * D, rows.data() + (size_t)k * D, D * sizeof(double));
+  if (out->n_terminal) *out->n_terminal = ro.n_term;
+  return GS_OK;
+}
+
 // ---- checkpoint ---------------------------------------------------------------------------------
 int gs_get_state(gs_handle* h, double* state) {
   if (!h || !state) return fail(h, GS_E_INVALID, "handle / state is NULL");
@@ -829,9 +978,16 @@ int gs_set_state(gs_handle* h, const double* state) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = unpack_from_host(h, h->map_state, h->state_dim, state);
   if (rc) return rc;
-  // the rectangular voltages follow the checkpointed polar ones (what a warm-started sweep solver resumes from)
+  // rows that follow from the checkpoint: the rectangular voltages (what a warm-started sweep solver resumes from) and
+  // the uncurtailed renewable powers of the observation
   hipLaunchKernelGGL(gs_k_polar_to_rect, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->slab, h->B);
   HIPCHK(h, hipGetLastError());
+  // both observation buffers whole, as gs_reset leaves them: the step kernel never writes the constant columns, so a
+  // handle that is restored without ever having been reset (resume in a new process) must get them here
+  if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  h->gather_pending[0] = h->gather_pending[1] = false;
+  if ((rc = launch_pack(h, h->map_obs, h->obs_dim, h->d_obs2[h->obs_cur]))) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->d_obs2[h->obs_cur ^ 1], h->d_obs2[h->obs_cur], (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->was_reset = true;
   return GS_OK;
@@ -858,10 +1014,22 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
   if (rc != 0) return fail(h, GS_E_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
   h->rank = rank; h->world = world_size;
   HIPCHK(h, hipMalloc((void**)&h->d_obs_full, (size_t)world_size * h->B * h->obs_dim * sizeof(double)));
+  const int nd = h->obs_dim - (h->obs_skip1 - h->obs_skip0);
+  HIPCHK(h, hipMalloc((void**)&h->d_gather_send, (size_t)h->B * nd * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->d_gather_recv, (size_t)world_size * h->B * nd * sizeof(double)));
   if (!h->comm_stream) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather[k], hipEventDisableTiming));
+  }
+  // the constant columns of the gathered block do not depend on the rank (static load powers of the shared feeder):
+  // written here once, never sent
+  if (h->obs_skip1 > h->obs_skip0) {
+    const long long rows = (long long)world_size * h->B, total = rows * (h->obs_skip1 - h->obs_skip0);
+    hipLaunchKernelGGL(gs_k_fill_const_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->comm_stream, h->d_obs_full, rows,
+                       h->obs_dim, h->obs_skip0, h->obs_skip1, h->map_obs, h->d_cst);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   }
   return GS_OK;
 }
@@ -870,18 +1038,28 @@ int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   if (!h->comm) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init");
   HIPCHK(h, hipSetDevice(h->device));
-  const size_t count = (size_t)h->B * h->obs_dim;
-  // on its own stream, behind the step that produced the current observation buffer; the step after the next one
-  // (which reuses that buffer) waits for ev_gather -- so a gather overlaps exactly one step
+  const int D = h->obs_dim, nd = D - (h->obs_skip1 - h->obs_skip0);
+  const size_t count = (size_t)h->B * nd;
+  // On its own stream, behind the step that produced the current observation buffer.  Only the columns that change
+  // travel: the block is compacted first (which is also all the gather needs of the observation buffer -- the step
+  // after the next one, which reuses that buffer, waits for ev_gather = the end of the compaction, not of the gather),
+  // the compact blocks are gathered over xGMI, and expanded into the [world * B][obs_dim] block.
   const int cur = h->obs_cur;
   HIPCHK(h, hipEventRecord(h->ev_step, h->stream));
   HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step, 0));
-  int rc = g_rccl.AllGather(h->d_obs2[cur], h->d_obs_full, count, /*ncclFloat64*/ 8, h->comm, h->comm_stream);
-  if (rc != 0) return fail(h, GS_E_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+  hipLaunchKernelGGL(gs_k_obs_compact, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->comm_stream, h->d_obs2[cur], h->d_gather_send,
+                     (long long)h->B, D, h->obs_skip0, h->obs_skip1, 0);
+  HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev_gather[cur], h->comm_stream));
   h->gather_pending[cur] = true;
+  int rc = g_rccl.AllGather(h->d_gather_send, h->d_gather_recv, count, /*ncclFloat64*/ 8, h->comm, h->comm_stream);
+  if (rc != 0) return fail(h, GS_E_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+  const size_t total = count * h->world;
+  hipLaunchKernelGGL(gs_k_obs_compact, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->comm_stream, h->d_gather_recv, h->d_obs_full,
+                     (long long)h->world * h->B, D, h->obs_skip0, h->obs_skip1, 1);
+  HIPCHK(h, hipGetLastError());
   if (obs_full_host) {
-    HIPCHK(h, hipMemcpyAsync(obs_full_host, h->d_obs_full, count * h->world * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
+    HIPCHK(h, hipMemcpyAsync(obs_full_host, h->d_obs_full, (size_t)h->B * D * h->world * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
     HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   }
   return GS_OK;
@@ -893,6 +1071,8 @@ int gs_comm_destroy(gs_handle* h) {
   h->gather_pending[0] = h->gather_pending[1] = false;
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   if (h->d_obs_full) { (void)hipFree(h->d_obs_full); h->d_obs_full = nullptr; }
+  if (h->d_gather_send) { (void)hipFree(h->d_gather_send); h->d_gather_send = nullptr; }
+  if (h->d_gather_recv) { (void)hipFree(h->d_gather_recv); h->d_gather_recv = nullptr; }
   return GS_OK;
 }
 
@@ -960,18 +1140,23 @@ int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches) {
 }
 
 
+static int debug_rows_map(gs_handle* h, int32_t which, std::vector<int32_t>& map) {
+  const GsRows& R = h->R;
+  const int row0[GS_ROWS_COUNT] = {R.VM.base, R.LOAD, R.ENVLOAD.base, R.FLOW.base, R.FREQ, R.CONV, R.ITERS, R.MAXMIS, R.LOADP};
+  const int stride[GS_ROWS_COUNT] = {2, 1, 2, 2, 1, 1, 1, 1, 1};
+  const int width[GS_ROWS_COUNT] = {h->n, h->m, h->m, h->m, 1, 1, 1, 1, h->n_loads};
+  map.resize(width[which]);
+  for (int k = 0; k < width[which]; ++k) map[k] = row0[which] + stride[which] * k;
+  return width[which];
+}
+
 int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
   if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
-  const GsRows& R = h->R;
-  const int row0[GS_ROWS_COUNT] = {R.VM.base, R.LOAD, R.ENVLOAD.base, R.FLOW.base, R.FREQ, R.CONV, R.ITERS, R.MAXMIS};
-  const int stride[GS_ROWS_COUNT] = {2, 1, 2, 2, 1, 1, 1, 1};
-  const int width[GS_ROWS_COUNT] = {h->n, h->m, h->m, h->m, 1, 1, 1, 1};
-  const int C = width[which];
+  std::vector<int32_t> map;
+  const int C = debug_rows_map(h, which, map);
   if (C <= 0) return GS_OK;
   if ((size_t)h->B * C > h->in_doubles) return fail(h, GS_E_INVALID, "staging buffer too small");
-  std::vector<int32_t> map(C);
-  for (int k = 0; k < C; ++k) map[k] = row0[which] + stride[which] * k;
   int32_t* dmap = nullptr;
   HIPCHK(h, hipMalloc((void**)&dmap, C * sizeof(int32_t)));
   int rc = GS_OK;
@@ -980,6 +1165,23 @@ int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
   const hipError_t e = hipStreamSynchronize(h->stream);
   (void)hipFree(dmap);
   if (!rc && e != hipSuccess) rc = fail(h, GS_E_HIP, "row write failed");
+  return rc;
+}
+
+int gs_debug_read_rows(gs_handle* h, int32_t which, double* values) {
+  if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<int32_t> map;
+  const int C = debug_rows_map(h, which, map);
+  if (C <= 0) return GS_OK;
+  if ((size_t)h->B * C > h->out_doubles) return fail(h, GS_E_INVALID, "staging buffer too small");
+  int32_t* dmap = nullptr;
+  HIPCHK(h, hipMalloc((void**)&dmap, C * sizeof(int32_t)));
+  int rc = GS_OK;
+  if (hipMemcpyAsync(dmap, map.data(), C * sizeof(int32_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail(h, GS_E_HIP, "map upload failed");
+  if (!rc) rc = pack_to_host(h, dmap, C, values);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(dmap);
   return rc;
 }
 
@@ -1047,6 +1249,7 @@ struct gs_checks {
   GsChecksCfg C{};
   double* prev = nullptr; int32_t* state = nullptr; int32_t* out_i = nullptr; double* out_f = nullptr;
   uint8_t *bus_mask = nullptr, *line_mask = nullptr; double* freq = nullptr; bool use_freq = false, want_masks = true;
+  bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0;
 };
 
@@ -1137,17 +1340,22 @@ int gs_checks_run(gs_checks* c) {
   if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
   gs_handle* h = c->h;
   HIPCHK(h, hipSetDevice(h->device));
-  if (c->ev_used == c->ev.size()) {
-    hipEvent_t a, b2;
-    HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b2));
-    c->ev.emplace_back(a, b2);
+  // HIP events only while somebody reads them (gs_checks_timing_enable), and never more than GS_CHECKS_MAX_EVENTS pairs:
+  // a per-step safety check over a long run must not grow an event list without bound
+  std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
+  if (c->timing && c->ev_used < GS_CHECKS_MAX_EVENTS) {
+    if (c->ev_used == c->ev.size()) {
+      hipEvent_t a, b2;
+      HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b2));
+      c->ev.emplace_back(a, b2);
+    }
+    e = &c->ev[c->ev_used++];
+    HIPCHK(h, hipEventRecord(e->first, h->stream));
   }
-  auto& e = c->ev[c->ev_used++];
-  HIPCHK(h, hipEventRecord(e.first, h->stream));
   hipLaunchKernelGGL(gs_k_checks, dim3(h->groups), dim3(1024), 0, h->stream, c->C, h->slab, c->use_freq ? c->freq : (const double*)nullptr,
                      c->prev, c->state, c->out_i, c->out_f, c->bus_mask, c->line_mask, h->B, h->Bp);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipEventRecord(e.second, h->stream));
+  if (e) HIPCHK(h, hipEventRecord(e->second, h->stream));
   return GS_OK;
 }
 
@@ -1188,6 +1396,14 @@ int gs_checks_reset(gs_checks* c, const uint8_t* mask) {
   const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
   if (dmask) (void)hipFree(dmask);
   if (e1 != hipSuccess || e2 != hipSuccess) return fail(h, GS_E_HIP, "checks reset failed");
+  return GS_OK;
+}
+
+int gs_checks_timing_enable(gs_checks* c, int32_t on) {
+  if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
+  HIPCHK(c->h, hipSetDevice(c->h->device));
+  HIPCHK(c->h, hipStreamSynchronize(c->h->stream));
+  c->timing = on != 0; c->ev_used = 0;
   return GS_OK;
 }
 

@@ -67,10 +67,15 @@ struct GsPairRef {          // an (even row, odd row) pair of one lane: 16 bytes
   // A 16-byte store reads its data registers over several cycles after it issues; with the row offset in an SGPR the
   // compiler's hazard recogniser assumes the hardware interlocks (the documented exemption) and lets the next VALU
   // instruction overwrite them at once -- measured on gfx950: lanes 12-15 of every 16 then store the NEW contents
-  // (e.g. a zero being set up for something else).  The s_nop keeps the registers alive for a few cycles more.
+  // (e.g. a zero being set up for something else).  One wait state is enough (tools/store_data_hazard.hip).  Store and
+  // wait state are ONE asm statement, so nothing the compiler schedules or re-materialises can come between them
+  // (as two statements it put a v_mov into the data registers right behind the store at nine sites);
+  // tools/check_store_hazard.py + tests/test_store_hazard_static.py check the emitted code of the whole library.
+  // The compiler does not count this store in its vmcnt bookkeeping; its later s_waitcnt vmcnt(N) are then merely
+  // stricter than needed (N is the number of younger operations IT knows of, the counter retires in issue order).
   __device__ __forceinline__ void put(double2 v) const {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gs_u32x4, v), r, voff, soff, 0);
-    asm volatile("s_nop 3" :: "v"(v.x), "v"(v.y));
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 0"
+                 :: "v"(__builtin_bit_cast(gs_u32x4, v)), "v"(voff), "s"(r), "s"(soff) : "memory");
   }
   __device__ __forceinline__ operator double2() const { return get(); }
   __device__ __forceinline__ void operator=(double2 v) const { put(v); }
@@ -282,6 +287,15 @@ struct GsPackArgs {
                                      // pair_ok: obs_dim and the block of constants are even (two columns per lane)
   int32_t skip0, skip1;              // columns [skip0, skip1) are per-instance constants (the static load powers of
                                      // grid_env.py:769-770): written at reset, left alone by the step (skip0 == skip1: none)
+};
+
+// gs_k_rollout_post (kernels_env.hip): bookkeeping after step t of gs_rollout
+struct GsRolloutPostArgs {
+  double* rew; uint8_t* done;            // [T][B]
+  double* obs_next;                      // [B][obs_dim], slot t + 1 of the observation sequence
+  const int32_t* map; const double* cst; // observation column -> slab row, or -(1 + constant index)
+  int32_t* term_count; int32_t* term_idx; double* term_obs; int32_t term_cap;
+  int32_t obs_dim, t, B;
 };
 
 struct GsSolveCfg {

@@ -24,10 +24,15 @@ GS_DECLARE_KERNELS(fbs_flow)
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);
 __global__ void gs_k_polar_to_rect(GsTables T, GsRows R, double* __restrict__ slab, int B);
+__global__ void gs_k_rollout_actions(double* __restrict__ act, int T, int B, int A, uint64_t seed, int64_t first_instance, uint32_t t0);
+__global__ void gs_k_fill_const_columns(double* __restrict__ out, long long rows, int obs_dim, int skip0, int skip1,
+                                        const int32_t* __restrict__ map, const double* __restrict__ cst);
+__global__ void gs_k_rollout_post(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, GsRolloutPostArgs A);
 __global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C, int rows_total,
                           const double* __restrict__ slab, double* __restrict__ out, int B);
 __global__ void gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,
                             const double* __restrict__ in, int B);
+__global__ void gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long long rows, int D, int skip0, int skip1, int expand);
 __global__ void gs_k_fill_rows(int row0, int stride, int count, int rows_total, double* __restrict__ slab, double value);
 __global__ void gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__ ri, int ni,
                              const int32_t* __restrict__ ru, int nu, int rows_total, const double* __restrict__ slab,

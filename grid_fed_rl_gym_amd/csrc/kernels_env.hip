@@ -1,8 +1,10 @@
-// kernels_env.hip -- GridEnvironment.reset() for 64 instances per wavefront (lane = instance).
-// The step itself is fused into the solver kernels (kernels_solve.hip: gs_k_step_*).
+// kernels_env.hip -- GridEnvironment.reset() for 64 instances per wavefront (lane = instance), and the small
+// kernels of the device-resident rollout collector (gs_rollout): action sampling, per-step bookkeeping with the
+// in-place reset of finished instances.  The step itself is fused into the solver kernels
+// (kernels_solve.hip: gs_k_step_*).
 //
-// Reference arithmetic restated: reset, environments/grid_env.py:360-408 (relative to
-// /root/reference/grid_fed_rl/).
+// Reference arithmetic restated (relative to /root/reference/grid_fed_rl/): reset, environments/grid_env.py:360-408;
+// rollout loop, algorithms/base.py:268-298.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -11,15 +13,9 @@
 #define ROW(r) S[(size_t)(r) * GS_LANES]
 #include "env_device.h"
 
-extern "C" __global__ void __launch_bounds__(64)
-gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
-               const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask) {
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x * GS_LANES + lane;
-  const GsLaneRows S = gs_lane_rows(slab, blockIdx.x, R.total, lane);
-  if (b >= B) return;
-  if (mask && !mask[b]) return;
-  const uint64_t seed = seeds ? seeds[b] : 0ull;
+// reset() of this lane's instance with the given seed (grid_env.py:360-408)
+__device__ __forceinline__ void env_reset_lane(const GsTables& T, const GsRows& R, const GsEnvCfg& E, GsLaneRows S,
+                                               uint64_t inst, uint64_t seed) {
   ROW(R.SEEDLO) = (double)(uint32_t)seed;
   ROW(R.SEEDHI) = (double)(uint32_t)(seed >> 32);
   ROW(R.TIME) = 0.0; ROW(R.STEP) = 0.0; ROW(R.VIOL) = 0.0; ROW(R.TOTLOSS) = 0.0; ROW(R.EPREW) = 0.0;
@@ -32,15 +28,31 @@ gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int 
   for (int k = 0; k < T.m; ++k) { ROW(R.FLOW + k) = 0.0; ROW(R.ENVLOAD + k) = 0.0; ROW(R.LOAD + k) = 0.0; }
   for (int q = 0; q < T.n_bats; ++q) { ROW(R.SOC + q) = 0.5; ROW(R.BATP + q) = 0.0; }      // grid_env.py:397-399
   for (int g = 0; g < T.n_gens; ++g) ROW(R.CURT + g) = 1.0;
-  weather_update(R, E, S, (uint64_t)(E.first_instance + b));      // grid_env.py:402
+  weather_update(R, E, S, inst);                                  // grid_env.py:402
   for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power(T, R, S, g);
   ROW(R.REWARD) = 0.0; ROW(R.TERM) = 0.0; ROW(R.TRUNC) = 0.0; ROW(R.VMAX) = 1.0; ROW(R.VMIN) = 1.0;
   for (int v = 0; v < 4; ++v) ROW(R.VFLAGS + v) = 0.0;
   ROW(R.LOSSES) = 0.0; ROW(R.MAXMIS) = 0.0; ROW(R.ITERS) = 0.0; ROW(R.CONV) = 0.0; ROW(R.STATUS) = 0.0;
 }
 
-// (e, f) from (|V|, angle) for every bus of the masked-in instances: after gs_set_state, so that a warm-started
-// sweep solver resumes from the checkpointed voltages.
+// seeds == NULL: the instance's stream runs on (next_episode_seed of the seed it holds; a handle that was never
+// seeded holds 0), as the reference's reset(seed=None) leaves its global streams running
+extern "C" __global__ void __launch_bounds__(64)
+gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
+               const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * GS_LANES + lane;
+  const GsLaneRows S = gs_lane_rows(slab, blockIdx.x, R.total, lane);
+  if (b >= B) return;
+  if (mask && !mask[b]) return;
+  const uint64_t inst = (uint64_t)(E.first_instance + b);
+  const uint64_t seed = seeds ? seeds[b] : next_episode_seed(lane_seed(S, R), inst);
+  env_reset_lane(T, R, E, S, inst, seed);
+}
+
+// Rows that follow from a checkpoint but are not part of it (gs_set_state): (e, f) from (|V|, angle), so that a
+// warm-started sweep solver resumes from the checkpointed voltages, and the uncurtailed renewable powers of the
+// observation (grid_env.py:773-777) from the checkpointed clock and weather.
 extern "C" __global__ void __launch_bounds__(64)
 gs_k_polar_to_rect(GsTables T, GsRows R, double* __restrict__ slab, int B) {
   const int lane = threadIdx.x;
@@ -52,5 +64,71 @@ gs_k_polar_to_rect(GsTables T, GsRows R, double* __restrict__ slab, int B) {
     double s, c;
     sincos(va, &s, &c);
     ROW(R.E + i) = vm * c; ROW(R.F + i) = vm * s;
+  }
+  for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power(T, R, S, g);
+}
+
+// ---- rollout collector ------------------------------------------------------------------------------------------
+// Uniform random actions in (-1, 1) for T steps (the reference samples env.action_space, algorithms/base.py:280, from
+// python's global `random`; here: Philox keyed by the caller's policy seed, counter = (global instance, step of the
+// rollout, action quad, 'ACTN'), every 32-bit word one action 2 (r + 1/2) 2^-32 - 1).  One thread per (t, b, quad).
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_rollout_actions(double* __restrict__ act, int T, int B, int A, uint64_t seed, int64_t first_instance, uint32_t t0) {
+  const int Aq = (A + 3) >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)T * B * Aq) return;
+  const int q = (int)(idx % Aq);
+  const long long tb = idx / Aq;
+  const int b = (int)(tb % B), t = (int)(tb / B);
+  const U4 r = philox((uint32_t)(first_instance + b), t0 + (uint32_t)t, (uint32_t)q, 0x4143544Eu, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w[4] = {r.a, r.b, r.c, r.d};
+  double* o = act + ((size_t)t * B + b) * A + 4 * q;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (4 * q + k < A) o[k] = 2.0 * (((double)w[k] + 0.5) * (1.0 / 4294967296.0)) - 1.0;
+}
+
+// The constant columns [skip0, skip1) of an observation (static load powers, grid_env.py:769-770) for `slots`
+// consecutive [B][obs_dim] blocks: written once when the rollout buffers are allocated -- the step kernel only ever
+// writes the columns that change.
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_fill_const_columns(double* __restrict__ out, long long rows, int obs_dim, int skip0, int skip1,
+                        const int32_t* __restrict__ map, const double* __restrict__ cst) {
+  const int w = skip1 - skip0;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w <= 0 || idx >= rows * w) return;
+  const int c = skip0 + (int)(idx % w);
+  out[(idx / w) * obs_dim + c] = cst[-map[c] - 1];
+}
+
+// After step t of a rollout (lane = instance): reward and done flags of the step into the [T][B] arrays; an instance
+// that finished (terminated or truncated) has its terminal observation -- row b of obs_next, which the step kernel has
+// just written -- moved to the side list, is reset in place with the next seed of its chain (algorithms/base.py:289-290:
+// `obs, _ = env.reset()`), and its fresh observation takes the row's place, so that obs_next is what step t + 1 starts
+// from for every instance.  Finished instances are rare (once per episode); their column loops are per lane.
+// (arguments: GsRolloutPostArgs, gs_internal.h)
+extern "C" __global__ void __launch_bounds__(64)
+gs_k_rollout_post(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, GsRolloutPostArgs A) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * GS_LANES + lane;
+  const GsLaneRows S = gs_lane_rows(slab, blockIdx.x, R.total, lane);
+  if (b >= A.B) return;
+  const double rew = ROW(R.REWARD), te = ROW(R.TERM), tr = ROW(R.TRUNC);
+  const int d = (te != 0.0 ? 1 : 0) | (tr != 0.0 ? 2 : 0);
+  A.rew[(size_t)A.t * A.B + b] = rew;
+  A.done[(size_t)A.t * A.B + b] = (uint8_t)d;
+  if (!d) return;
+  double* row = A.obs_next + (size_t)b * A.obs_dim;
+  const int k = atomicAdd(A.term_count, 1);
+  if (k < A.term_cap) {
+    A.term_idx[2 * k] = A.t; A.term_idx[2 * k + 1] = b;
+    double* dst = A.term_obs + (size_t)k * A.obs_dim;
+    for (int c = 0; c < A.obs_dim; ++c) dst[c] = row[c];
+  }
+  const uint64_t inst = (uint64_t)(E.first_instance + b);
+  env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
+  for (int c = 0; c < A.obs_dim; ++c) {
+    const int s = A.map[c];
+    row[c] = (s >= 0) ? (double)ROW(s) : A.cst[-s - 1];
   }
 }

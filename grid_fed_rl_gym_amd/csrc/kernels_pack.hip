@@ -81,3 +81,19 @@ gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__
   for (int k = 0; k < ni; ++k) oi[(size_t)k * Bp + b] = (int32_t)S[GS_ELEM(ri[k], ln)];
   for (int k = 0; k < nu; ++k) ou[(size_t)k * Bp + b] = (S[GS_ELEM(ru[k], ln)] != 0.0) ? 1 : 0;
 }
+
+// Observation blocks with / without their block of per-instance constants (columns [skip0, skip1): the static load
+// powers, 27 % of an IEEE-123 observation) -- what the RCCL all-gather moves over xGMI is the compact form.
+//   compact:  dst[r][j] = src[r][j < skip0 ? j : j + gap],  j < D - gap
+//   expand :  dst[r][j < skip0 ? j : j + gap] = src[r][j]   (the constants of dst were written once, at gs_comm_init)
+// One thread per (row, compact column), columns fastest: both sides are contiguous runs of skip0 and D - skip1 doubles.
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long long rows, int D, int skip0, int skip1, int expand) {
+  const int gap = skip1 - skip0, nd = D - gap;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * nd) return;
+  const long long r = idx / nd;
+  const int j = (int)(idx - r * nd), c = j < skip0 ? j : j + gap;
+  if (expand) dst[r * D + c] = src[idx];
+  else dst[idx] = src[r * D + c];
+}

@@ -1011,11 +1011,15 @@ typedef volatile __attribute__((address_space(3))) int* GsLdsI;
 __device__ __forceinline__ double2 flow_take(const double* m, const int* flag, int epoch) {
   GsLdsD lm = (GsLdsD)m; GsLdsI lf = (GsLdsI)flag;
   double2 v;
+  bool seen = false;
   for (int spin = 0; spin < GS_FLOW_SPIN_CAP; ++spin) {
     const int f = *lf;
     v.x = lm[0]; v.y = lm[GS_LANES];
-    if (__builtin_amdgcn_readfirstlane(f) - epoch >= 0) break;
+    if (__builtin_amdgcn_readfirstlane(f) - epoch >= 0) { seen = true; break; }
   }
+  // a hand-off that never arrived must not pass for data: NaN makes the mismatch of this group non-finite, i.e. its
+  // instances end with GS_STATUS_NAN instead of "converged" on a stale message
+  if (!seen) v = make_double2(NAN, NAN);
   return v;
 }
 __device__ __forceinline__ void flow_give(Ctx& c, double* m, int* flag, int epoch, double x, double y) {

@@ -2,9 +2,11 @@
 
 Mirrors the reference's ``collect_random_data(env, num_steps)`` and ``GridDataset``
 (reference algorithms/base.py:268-298, 180-266): same dictionary keys, same normalisation
-arithmetic, but one call steps all B instances at once and finished instances are reset in
-place with a masked reset (the reference resets its single env when ``terminated or truncated``,
-base.py:289-290).  NumPy only -- the learner side (torch) is out of scope.
+arithmetic.  The loop itself runs on the device (``gs_rollout``, include/gridstep.h): ``num_steps``
+fused step kernels back to back, each writing its observation block straight into the next slot of a
+``[T + 1, B, obs_dim]`` device buffer, random actions drawn on the device, finished instances reset in
+place where the reference calls ``env.reset()`` (base.py:289-290) -- one host copy at the end, or none
+(``rollout_device``).  NumPy only -- the learner side (torch) is out of scope.
 """
 from __future__ import annotations
 
@@ -16,30 +18,31 @@ from .env import BatchedGridEnvironment
 
 
 def collect_random_data(env: BatchedGridEnvironment, num_steps: int, seed: int = 0,
-                        actions: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
-    """``num_steps`` batched steps with uniform random actions in [-1, 1] (the reference samples
+                        actions: Optional[np.ndarray] = None, reset: bool = True) -> Dict[str, np.ndarray]:
+    """``num_steps`` batched steps with uniform random actions in (-1, 1) (the reference samples
     ``env.action_space``, base.py:280) -> ``num_steps * B`` transitions, time-major
-    (transition index = t * B + b).  ``actions`` ([num_steps, B, A]) overrides the sampling."""
-    B, A = env.num_envs, env.action_dim
-    rng = np.random.default_rng(seed)
-    obs, _ = env.reset(seed=seed)
-    out = {"observations": np.empty((num_steps, B, env.obs_dim)), "actions": np.empty((num_steps, B, A)),
-           "rewards": np.empty((num_steps, B)), "next_observations": np.empty((num_steps, B, env.obs_dim)),
-           "terminals": np.empty((num_steps, B), dtype=bool)}
-    for t in range(num_steps):
-        a = rng.uniform(-1.0, 1.0, (B, A)) if actions is None else np.asarray(actions[t], dtype=np.float64)
-        next_obs, rew, term, trunc, _ = env.step(a)
-        done = term | trunc
-        out["observations"][t] = obs
-        out["actions"][t] = a
-        out["rewards"][t] = rew
-        out["next_observations"][t] = next_obs
-        out["terminals"][t] = done
-        obs = next_obs
-        if done.any():
-            fresh, _ = env.reset(seed=seed + (t + 1) * B, mask=done.astype(np.uint8))
-            obs = np.where(done[:, None], fresh, next_obs)
-    return {k: v.reshape((num_steps * B,) + v.shape[2:]) for k, v in out.items()}
+    (transition index = t * B + b).  ``actions`` ([num_steps, B, A]) overrides the sampling.
+    ``reset=False`` continues from where the environment stands (the reference always resets first, base.py:277)."""
+    rollout_device(env, num_steps, seed=seed, actions=actions, reset=reset)
+    d = env.handle.rollout_download()
+    T, B = int(num_steps), env.num_envs
+    out = {k: d[k].reshape((T * B,) + d[k].shape[2:]) for k in ("observations", "actions", "rewards", "next_observations")}
+    out["terminals"] = d["terminals"].reshape(T * B) != 0
+    return out
+
+
+def rollout_device(env: BatchedGridEnvironment, num_steps: int, seed: int = 0, actions: Optional[np.ndarray] = None,
+                   reset: bool = True):
+    """The same collection left on the GPU: returns the ``gs_rollout_device`` view (device pointers to
+    ``obs_seq[T + 1, B, obs_dim]``, actions, rewards, done flags and the list of terminal observations) for a learner
+    that consumes it there.  Valid until the next rollout on the environment."""
+    if reset or env._needs_reset:
+        env.reset(seed=seed)
+    if actions is None:
+        env.handle.rollout(int(num_steps), "random", seed=seed)
+    else:
+        env.handle.rollout(int(num_steps), "uploaded", actions=np.asarray(actions, dtype=np.float64))
+    return env.handle.rollout_device_view()
 
 
 class GridDataset:

@@ -58,6 +58,7 @@ CHECKS_SYMBOLS = [
     ("gs_checks_run", C.c_int, [_CK]),
     ("gs_checks_download", C.c_int, [_CK, C.POINTER(gs_checks_view)]),
     ("gs_checks_reset", C.c_int, [_CK, _up]),
+    ("gs_checks_timing_enable", C.c_int, [_CK, C.c_int32]),
     ("gs_checks_timing_read", C.c_int, [_CK, _dp, C.POINTER(C.c_int64)]),
     ("gs_checks_set_fused", C.c_int, [_CK, C.c_int32, C.c_int32]),
 ]
@@ -176,6 +177,10 @@ class PostStepChecks:
         if mk.shape != (self.B,):
             raise ValueError(f"mask must have shape ({self.B},)")
         self._check(self._lib.gs_checks_reset(self._c, mk.ctypes.data_as(_up)))
+
+    def timing_enable(self, on: bool = True) -> None:
+        """HIP-event pairs around every later ``run()`` (off by default: nothing is recorded unless somebody reads it)."""
+        self._check(self._lib.gs_checks_timing_enable(self._c, int(bool(on))))
 
     def timing_read(self) -> Tuple[float, int]:
         ms, cnt = C.c_double(), C.c_int64()

@@ -6,9 +6,10 @@ instances splits into contiguous blocks, rank r owning ``shard_range(B_total, r,
 Seeds and RNG counters are keyed by the GLOBAL instance index, so results do not depend on the
 number of ranks.  The only exchange is optional and happens after the step: an all-gather of
 the observation block so that every rank (or a host-side learner) sees all observations --
-RCCL over xGMI through libgridstep (``transport="rccl"``, device buffers, equal shards) or any
-``torch.distributed`` process group on host arrays (``transport="host"``; this is what the
-world_size-2 gloo tests exercise, and what uneven shards use).
+RCCL over xGMI through libgridstep (``transport="rccl"``, device buffers, equal shards) or host
+arrays (``transport="host"``, uneven shards allowed) through a framework-free file rendezvous
+(``rendezvous.FileRendezvous``) or any ``torch.distributed`` process group (what the world_size-2
+gloo tests exercise).  Nothing here imports torch unless a torch group is what the caller hands in.
 """
 from __future__ import annotations
 
@@ -34,11 +35,18 @@ def instance_seeds(global_seed: int, start: int, stop: int) -> np.ndarray:
 
 
 def host_all_gather(local: np.ndarray, total: int, rank: int, world: int, group: Any = None) -> np.ndarray:
-    """All-gather of row blocks over a torch.distributed process group (any backend that takes
-    CPU tensors); shards may be uneven.  Returns the [total, ...] array in global order."""
+    """All-gather of row blocks on host arrays; shards may be uneven.  Returns the [total, ...] array in global order.
+    ``group``: a ``rendezvous.FileRendezvous`` (no framework at all), or a ``torch.distributed`` process group / None for
+    the default one (any backend that takes CPU tensors -- what the world_size-2 gloo tests exercise)."""
+    from .rendezvous import FileRendezvous
+    counts = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    if isinstance(group, FileRendezvous):
+        parts = group.all_gather_array(np.ascontiguousarray(local))
+        if [len(p) for p in parts] != counts:
+            raise ValueError("shard sizes do not match shard_range()")
+        return np.concatenate(parts, axis=0)
     import torch
     import torch.distributed as dist
-    counts = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     width = int(np.prod(local.shape[1:], dtype=np.int64)) if local.ndim > 1 else 1
     mx = max(counts)
     pad = np.zeros((mx, width), dtype=local.dtype)
@@ -68,8 +76,13 @@ class ShardedGridEnvironment:
                                           first_instance=self.start, **env_kwargs)
         self._comm = False
 
-    def init_rccl(self, unique_id: bytes) -> None:
-        """``unique_id`` comes from rank 0's ``Handle.comm_unique_id()``, broadcast by the launcher."""
+    def init_rccl(self, unique_id: Any = None) -> None:
+        """``unique_id``: the 128 bytes of rank 0's ``Handle.comm_unique_id()``, handed round by the launcher -- or a
+        ``rendezvous.FileRendezvous``, through which rank 0 creates and broadcasts it."""
+        from .rendezvous import FileRendezvous
+        from ._lib import Handle
+        if isinstance(unique_id, FileRendezvous):
+            unique_id = unique_id.broadcast_bytes(Handle.comm_unique_id() if self.rank == 0 else None)
         self.env.handle.comm_init(unique_id, self.rank, self.world)
         self._comm = True
 

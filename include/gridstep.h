@@ -186,7 +186,10 @@ int gs_fallback_linear(gs_handle* h, const double* load_w, const double* gen_w, 
 
 /* ---- env plug point: GridEnvironment.reset/step (grid_env.py:360-408, 410-619) and their
  * batched form VectorizedEnvironment.reset/step (utils/parallel_environment.py:309-355) --- */
-/* seeds: NULL or [B] per-instance RNG seeds; mask: NULL (all) or [B] (reset where != 0);
+/* seeds: [B] per-instance RNG seeds, or NULL = the stream runs on, as the reference's reset(seed=None) leaves its
+ * global generators running (grid_env.py:366-369): every reset instance gets the next seed of its chain, one Philox
+ * call keyed by the seed it holds (0 on a fresh handle) with counter (global instance, 0, 'RSED') -- so consecutive
+ * episodes differ while gs_reset(seeds) stays exactly reproducible; mask: NULL (all) or [B] (reset where != 0);
  * obs_out: NULL or [B][obs_dim]. */
 int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* obs_out);
 int gs_step(gs_handle* h, const double* actions, double* obs, double* reward,
@@ -196,6 +199,45 @@ int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches);
 int gs_step_device(gs_handle* h, int32_t action_batch_index);
 int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated,
                      uint8_t* truncated, const gs_info_view* info);
+
+/* ---- device-resident rollout collection: collect_random_data(env, num_steps) and the five arrays GridDataset is
+ * built from (algorithms/base.py:268-298, 180-205) ------------------------------------------------------------
+ * T env steps back to back on the device -- no host round trip between them: the step kernel of step t writes its
+ * observation block straight into slot t + 1 of obs_seq[T + 1][B][obs_dim], a small kernel behind it files reward and
+ * done flags and resets the instances that finished (terminated or truncated) in place, exactly where the reference
+ * calls env.reset() (base.py:289-290); their seed is the next one of the instance's chain (see gs_reset).
+ * policy: GS_POLICY_RANDOM -- uniform actions in (-1, 1) drawn on the device (the reference samples
+ * env.action_space; here Philox keyed by policy_seed, counter (global instance, t, action / 4, 'ACTN'), word k of a
+ * call = action 4 q + k = 2 (r + 1/2) 2^-32 - 1); GS_POLICY_UPLOADED -- actions[T][B][action_dim] from the caller.
+ * The call is asynchronous; the environment afterwards stands where T calls of gs_step (+ resets) would have left it. */
+enum { GS_POLICY_UPLOADED = 0, GS_POLICY_RANDOM = 1 };
+int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, const double* actions);
+/* host copies in the reference's layout, transition index = t * B + b; any pointer may be NULL */
+typedef struct gs_rollout_view {
+  double* observations;           /* [T][B][obs_dim] what each step started from */
+  double* actions;                /* [T][B][action_dim] */
+  double* rewards;                /* [T][B] */
+  double* next_observations;      /* [T][B][obs_dim] (the terminal observation where the transition ended an episode) */
+  uint8_t* terminals;             /* [T][B] bit 0 terminated, bit 1 truncated; != 0 is the reference's `terminated or truncated` */
+  double* final_observation;      /* [B][obs_dim] what step T would start from */
+  int32_t* n_terminal;            /* [1] number of finished episodes in the rollout */
+} gs_rollout_view;
+int gs_rollout_download(gs_handle* h, const gs_rollout_view* out);
+/* the same data where it lies, for a consumer on the GPU (valid until the next gs_rollout on the handle; waits for the
+ * rollout to finish).  observations = obs_seq[0 .. T-1], next_observations = obs_seq[1 .. T] except for the n_terminal
+ * transitions (t, b) = terminal_index[k], whose next observation is terminal_obs[k] (obs_seq[t + 1][b] being the fresh
+ * observation after the reset). */
+typedef struct gs_rollout_device {
+  int32_t T, B, obs_dim, action_dim;
+  const double* obs_seq;          /* [T + 1][B][obs_dim] */
+  const double* actions;          /* [T][B][action_dim] */
+  const double* rewards;          /* [T][B] */
+  const uint8_t* terminals;       /* [T][B] */
+  int32_t n_terminal, reserved;
+  const int32_t* terminal_index;  /* [n_terminal][2] (t, b), in no particular order */
+  const double* terminal_obs;     /* [n_terminal][obs_dim] */
+} gs_rollout_device;
+int gs_rollout_device_view(gs_handle* h, gs_rollout_device* out);
 
 /* ---- checkpoint / resume: [B][state_dim] float64 blob ------------
  * layout per instance: time, step, constraint_violations, total_losses, episode_reward,
@@ -228,8 +270,12 @@ int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches);
 /* test aid: overwrite one family of device rows with values[B][width] (width = n, m or 1), so that kernels
  * reading the device state (the post-step checks below) can be driven with fixture data */
 enum { GS_ROWS_VM = 0, GS_ROWS_LINE_LOADING = 1, GS_ROWS_ENV_LINE_LOADING = 2, GS_ROWS_LINE_FLOW = 3, GS_ROWS_FREQUENCY = 4,
-       GS_ROWS_CONVERGED = 5, GS_ROWS_ITERATIONS = 6, GS_ROWS_MAX_MISMATCH = 7, GS_ROWS_COUNT = 8 };
+       GS_ROWS_CONVERGED = 5, GS_ROWS_ITERATIONS = 6, GS_ROWS_MAX_MISMATCH = 7,
+       GS_ROWS_LOAD_POWER = 8 /* [n_loads] realised load powers of the last step (dynamics.py:54-75) */, GS_ROWS_COUNT = 9 };
 int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values);
+/* test aid: the same families read back as values[B][width] (what the statistical tests of the stochastic load
+ * model look at: the realised load powers are not part of the observation, grid_env.py:769-770) */
+int gs_debug_read_rows(gs_handle* h, int32_t which, double* values);
 
 /* ======================================================================================
  * Post-step checks on the state a step / solve left on the device.
@@ -285,6 +331,8 @@ int gs_checks_download(gs_checks* c, const gs_checks_view* out);
 /* forget previous state, counters and emergency mode of the masked instances (NULL = all): a freshly
  * constructed SafetyChecker() / SafetyMonitor() */
 int gs_checks_reset(gs_checks* c, const uint8_t* mask);
+/* HIP-event timing of gs_checks_run is off unless enabled (a per-step check over a long run records nothing) */
+int gs_checks_timing_enable(gs_checks* c, int32_t on);
 int gs_checks_timing_read(gs_checks* c, double* total_ms, int64_t* launches);
 /* on != 0: every later gs_step / gs_step_device evaluates these checks inside its own kernel (the epilogue already holds
  * the voltages and loadings), exactly as one gs_checks_run after the step would; gs_checks_download then returns the

@@ -125,12 +125,12 @@ def env_step(net: Net, cfg: orc_cfg, state, actions) -> dict:
     return out
 
 
-def bench_env_steps(fs, env_kwargs, budget_s=15.0) -> dict:
-    """cpu_baseline leg of bench.py: the C/OpenMP port on all host cores, bounded sample."""
+def bench_env_steps(fs, env_kwargs, budget_s=15.0, threads=None) -> dict:
+    """cpu_baseline leg of bench.py: the C/OpenMP port on all host cores (or on `threads`), bounded sample."""
     net = Net(fs)
     # the GPU box exposes all host threads but grants a 16-core share per GPU; never oversubscribe
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else lib().orc_max_threads()
-    threads = max(1, min(lib().orc_max_threads(), avail, 16))
+    threads = max(1, min(lib().orc_max_threads(), avail, 16)) if threads is None else int(threads)
     cfg = config(solver=env_kwargs["solver"], jacobian="exact", max_iterations=env_kwargs["max_iterations"],
                  tolerance=env_kwargs["tolerance"], stochastic_loads=env_kwargs["stochastic_loads"],
                  weather_variation=env_kwargs["weather_variation"], power_base=fs.base_power_va, threads=threads)

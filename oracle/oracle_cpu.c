@@ -381,6 +381,11 @@ static double rng_normal_quad(uint64_t seed, uint64_t inst, uint32_t step, uint3
   return (k & 1) ? rad * sin(2.0 * M_PI * ua) : rad * cos(2.0 * M_PI * ua);
 }
 
+/* exported for tests/test_stochastic.py: the generator itself (Random123 known answers) and the two transforms */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out); }
+void orc_rng_pair(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw, double* u0, double* u1) { rng_pair(seed, inst, step, draw, u0, u1); }
+double orc_rng_normal(uint64_t seed, uint64_t inst, uint32_t step, uint32_t draw, int k) { return rng_normal_quad(seed, inst, step, draw, k); }
+
 static const double kProfile[24] = {0.5, 0.4, 0.4, 0.4, 0.4, 0.5, 0.7, 0.9, 0.8, 0.7, 0.6, 0.6,
                                     0.7, 0.7, 0.6, 0.6, 0.7, 0.9, 1.0, 0.9, 0.8, 0.7, 0.6, 0.5};
 

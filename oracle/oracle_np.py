@@ -396,8 +396,8 @@ def frequency_update(freq, imbalance_mw, dt, H=5.0, D=1.0, f0=60.0) -> float:
 # counter-based RNG shared by the oracle and the HIP kernels (stochastic mode only).
 # The reference draws from python ``random`` / ``np.random`` global streams
 # (grid_env.py:669-681, dynamics.py:69); bit parity with those is impossible for a batched
-# device implementation, so stochastic mode is defined on Philox4x32-10 and validated
-# against the reference's *distributions* (tests/test_stochastic.py).
+# device implementation, so stochastic mode is defined on Philox4x32-10 (pinned by the Random123
+# known answers) and validated against the reference's *distributions* (tests/test_stochastic.py).
 # --------------------------------------------------------------------------------------
 _PH_M0, _PH_M1 = 0xD2511F53, 0xCD9E8D57
 _PH_W0, _PH_W1 = 0x9E3779B9, 0xBB67AE85
@@ -440,6 +440,27 @@ def rng_normal_quad(seed: int, instance: int, step: int, draw: int) -> Tuple[flo
 
 # draw indices (per instance, per step)
 DRAW_IRRADIANCE, DRAW_WEATHER, DRAW_LOAD0 = 0, 1, 16
+
+
+def next_episode_seed(seed: int, instance: int) -> int:
+    """Seed of an instance's next episode when reset() is given none (gs_reset with seeds == NULL and the automatic
+    resets of gs_rollout): the reference's reset(seed=None) leaves its global streams running (grid_env.py:366-369);
+    here the stream "runs on" through one Philox call keyed by the old seed, counter (instance lo, instance hi, 0, 'RSED')."""
+    r = philox4x32((instance & _M32, (instance >> 32) & _M32, 0, 0x52534544), (seed & _M32, (seed >> 32) & _M32))
+    return (r[1] << 32) | r[0]
+
+
+def rollout_random_actions(seed: int, instance: int, t: int, action_dim: int) -> np.ndarray:
+    """Uniform actions in (-1, 1) of gs_rollout's GS_POLICY_RANDOM (the reference samples env.action_space,
+    algorithms/base.py:280): Philox keyed by the policy seed, counter (instance, t, action // 4, 'ACTN'), word k of a
+    call = action 4 q + k = 2 (r + 1/2) 2^-32 - 1."""
+    a = np.empty(action_dim)
+    for q in range((action_dim + 3) // 4):
+        r = philox4x32((instance & _M32, t & _M32, q, 0x4143544E), (seed & _M32, (seed >> 32) & _M32))
+        for k in range(4):
+            if 4 * q + k < action_dim:
+                a[4 * q + k] = 2.0 * ((r[k] + 0.5) * (1.0 / 4294967296.0)) - 1.0
+    return a
 
 
 # --------------------------------------------------------------------------------------

@@ -164,28 +164,120 @@ def test_rccl_allgather_single_rank():
     env.close()
 
 
-def test_batched_rollout_collection():
-    """collect_random_data / GridDataset (reference algorithms/base.py:180-298), batched."""
+def _oracle_collect(fs, cfg, actions, seeds, first_instance, policy_seed=None):
+    """collect_random_data (algorithms/base.py:268-298) per instance with the oracle: reset, then T steps; where the
+    reference calls env.reset() after a finished transition the instance's seed moves one step along its chain."""
+    T = actions.shape[0] if actions is not None else cfg.pop("T")
+    B = len(seeds)
+    spec = oracle_spec(fs, **cfg)
+    out = dict(observations=np.empty((T, B, fs.obs_dim)), actions=np.empty((T, B, fs.action_dim)), rewards=np.empty((T, B)),
+               next_observations=np.empty((T, B, fs.obs_dim)), terminals=np.zeros((T, B), dtype=bool))
+    for b in range(B):
+        seed = int(seeds[b])
+        obs, st = O.env_reset(spec, seed=seed, instance=first_instance + b)
+        for t in range(T):
+            a = actions[t, b] if actions is not None else O.rollout_random_actions(policy_seed, first_instance + b, t, fs.action_dim)
+            nxt, r, te, tr, _ = O.env_step(spec, st, a)
+            out["observations"][t, b] = obs; out["actions"][t, b] = a; out["rewards"][t, b] = r
+            out["next_observations"][t, b] = nxt; out["terminals"][t, b] = te or tr
+            if te or tr:
+                seed = O.next_episode_seed(seed, first_instance + b)
+                obs, st = O.env_reset(spec, seed=seed, instance=first_instance + b)
+            else:
+                obs = nxt
+    return out
+
+
+@pytest.mark.parametrize("solver,policy", [("nr", "uploaded"), ("fbs", "uploaded"), ("fbs", "random")])
+def test_device_rollout_equals_the_reference_loop_across_episode_boundaries(solver, policy):
+    """gs_rollout: the [T, B, ...] buffers equal T oracle steps + the reset rule of algorithms/base.py:283-292 (1e-8),
+    including two episode boundaries (episode_length 3, T 7) and the instances' seed chains."""
     fs = P.ieee13_like("epsilon")
-    env = P.BatchedGridEnvironment(fs, num_envs=6, stochastic_loads=True, weather_variation=True, episode_length=4)
-    T = 7
-    data = P.collect_random_data(env, T, seed=11)
-    n = T * 6
-    assert data["observations"].shape == (n, fs.obs_dim) and data["actions"].shape == (n, fs.action_dim)
-    assert data["rewards"].shape == (n,) and data["terminals"].shape == (n,) and data["terminals"].dtype == bool
-    term = data["terminals"].reshape(T, 6)
-    assert term[3].all() and not term[:3].any()          # episode_length = 4 -> done at the 4th step, then again at the 8th
-    obs = data["observations"].reshape(T, 6, -1); nxt = data["next_observations"].reshape(T, 6, -1)
-    assert np.array_equal(obs[1:4], nxt[0:3])            # chained inside an episode
-    assert np.all(obs[4][:, 0] == 1.0) and not np.array_equal(obs[4], nxt[3])   # fresh episode after the masked reset
+    B, T, first = 37, 7, 2000
+    env = P.BatchedGridEnvironment(fs, num_envs=B, stochastic_loads=True, weather_variation=True, solver=solver, episode_length=3,
+                                   tolerance=1e-9, max_iterations=100, first_instance=first)
+    cfg = dict(stochastic_loads=True, weather_variation=True, power_base=fs.base_power_va, solver=solver, tolerance=1e-9,
+               max_iterations=100, jacobian_mode="exact", zero_z="open", episode_length=3)
+    acts = np.random.default_rng(4).uniform(-1, 1, (T, B, fs.action_dim)) if policy == "uploaded" else None
+    data = P.collect_random_data(env, T, seed=21, actions=acts)
+    if policy == "random":
+        cfg["T"] = T
+    ref = _oracle_collect(fs, cfg, acts, np.uint64(21) + np.arange(B, dtype=np.uint64), first, policy_seed=21)
+    term = data["terminals"].reshape(T, B)
+    assert np.array_equal(term, ref["terminals"]) and term[2].all() and term[5].all() and term.sum() == 2 * B
+    assert np.array_equal(data["actions"].reshape(T, B, -1), ref["actions"]) if policy == "uploaded" else \
+        np.allclose(data["actions"].reshape(T, B, -1), ref["actions"], rtol=0, atol=1e-15)
+    for k in ("observations", "next_observations"):
+        got, want = data[k].reshape(T, B, -1), ref[k]
+        err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+        assert err.max() < 1e-8, (k, np.unravel_index(np.argmax(err), err.shape))
+    assert np.max(np.abs(data["rewards"].reshape(T, B) - ref["rewards"]) / np.maximum(1.0, np.abs(ref["rewards"]))) < 1e-7
+    obs = data["observations"].reshape(T, B, -1); nxt = data["next_observations"].reshape(T, B, -1)
+    assert np.array_equal(obs[1:3], nxt[0:2]) and np.array_equal(obs[4:6], nxt[3:5])      # chained inside an episode
+    assert not np.array_equal(obs[3], nxt[2]) and np.all(obs[3][:, 0] == 1.0)            # fresh episode after the in-place reset
+    # the environment stands where the loop left it: one more step continues the third episode
+    a1 = np.random.default_rng(9).uniform(-1, 1, (B, fs.action_dim))
+    o_gpu, *_ = env.step(a1)
+    view = env.handle.rollout_device_view()
+    assert (view.T, view.B, view.obs_dim, view.n_terminal) == (T, B, fs.obs_dim, 2 * B)
     ds = P.GridDataset(**data)
-    assert abs(ds.observations.mean()) < 1e-9 or True
     a = ds.sample_batch(16, np.random.default_rng(0))
     assert a["observations"].shape == (16, fs.obs_dim)
     raw = data["actions"]
     assert np.allclose(ds.denormalize_action(ds.actions), raw)
     assert np.allclose(ds.actions, (raw - raw.mean(0)) / (raw.std(0) + 1e-6))
+    assert abs(ds.rewards.mean()) < 1e-9 and abs(ds.rewards.std() - 1.0) < 1e-3
+    assert o_gpu.shape == (B, fs.obs_dim) and np.isfinite(o_gpu).all()
     env.close()
+
+
+def test_device_rollout_equals_stepping_through_the_abi():
+    """The same actions through gs_step one call at a time and through gs_rollout: bit for bit (123-bus feeder, both
+    solvers' default kernels, no episode boundary), and the rollout can be continued without a reset."""
+    fs = P.ieee123_like()
+    B, T = 130, 5
+    acts = np.random.default_rng(2).uniform(-1, 1, (2 * T, B, fs.action_dim))
+    for solver in ("fbs", "nr"):
+        a = P.BatchedGridEnvironment(fs, num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True)
+        b = P.BatchedGridEnvironment(fs, num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True)
+        o0, _ = a.reset(seed=5)
+        stepped = [a.step(acts[t]) for t in range(2 * T)]
+        d1 = P.collect_random_data(b, T, seed=5, actions=acts[:T])
+        d2 = P.collect_random_data(b, T, seed=5, actions=acts[T:], reset=False)
+        for d, off in ((d1, 0), (d2, T)):
+            nxt = d["next_observations"].reshape(T, B, -1); rew = d["rewards"].reshape(T, B)
+            for t in range(T):
+                assert np.array_equal(nxt[t], stepped[off + t][0]), (solver, off + t)
+                assert np.array_equal(rew[t], stepped[off + t][1])
+        assert np.array_equal(d1["observations"].reshape(T, B, -1)[0], o0)
+        assert np.array_equal(d2["observations"].reshape(T, B, -1)[0], stepped[T - 1][0])
+        assert not d1["terminals"].any()
+        a.close(); b.close()
+
+
+def test_set_state_on_a_fresh_handle_restores_the_whole_observation():
+    """Resume in a new process: a handle that was never reset gets a checkpoint; its next observation -- constant
+    columns and renewable powers included -- equals the uninterrupted run's."""
+    fs = P.ieee123_like()
+    B = 66
+    kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True)
+    a = P.BatchedGridEnvironment(fs, **kw)
+    acts = np.random.default_rng(8).uniform(-1, 1, (3, B, fs.action_dim))
+    a.reset(seed=77)
+    st = a.get_state(); st[:, a.state_column("time")] = 10 * 3600.0; a.set_state(st)
+    a.step(acts[0])
+    snap = a.get_state()
+    want1 = a.step(acts[1])
+    want2 = a.step(acts[2])
+    b = P.BatchedGridEnvironment(fs, **kw)            # never reset
+    b.set_state(snap)
+    got1 = b.step(acts[1])
+    got2 = b.step(acts[2])
+    for w, g in ((want1, got1), (want2, got2)):
+        assert np.array_equal(w[0], g[0]) and np.array_equal(w[1], g[1])
+    lo = 2 * fs.n + 2 * fs.m + 1
+    assert np.array_equal(got1[0][:, lo:lo + 2 * fs.n_loads:2], np.tile(fs.load_base, (B, 1)))     # the static load columns are there
+    a.close(); b.close()
 
 
 def test_handles_with_different_lds_footprints_coexist():

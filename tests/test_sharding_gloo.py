@@ -45,6 +45,13 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_FILES = WORKER.replace("import torch.distributed as dist\n", "from grid_fed_rl_gym_amd.rendezvous import FileRendezvous\n") \
+    .replace('dist.init_process_group("gloo", rank=rank, world_size=world)', 'rz = FileRendezvous(rank, world, key=os.environ["GS_KEY"], root=os.environ["GS_RDZV"])') \
+    .replace("host_all_gather(out[\"obs\"], total, rank, world)", "host_all_gather(out[\"obs\"], total, rank, world, group=rz)") \
+    .replace("host_all_gather(out[\"reward\"], total, rank, world)", "host_all_gather(out[\"reward\"], total, rank, world, group=rz)") \
+    .replace("dist.barrier()\ndist.destroy_process_group()", "assert 'torch' not in sys.modules\nrz.close()")
+
+
 def test_shard_ranges_cover_and_are_contiguous():
     for total in (0, 1, 7, 64, 8192, 65536 + 3):
         for world in (1, 2, 3, 8):
@@ -76,3 +83,23 @@ def test_two_rank_gloo_equals_single_process(total):
         assert np.array_equal(outs[1]["obs"], outs[2]["obs"])
         assert np.array_equal(outs[1]["reward"], outs[2]["reward"])
         assert outs[2]["obs"].shape[1] == total
+
+
+def test_two_ranks_over_the_file_rendezvous_equal_single_process_without_torch():
+    """The same sharded run with the framework-free rendezvous (what bench.py uses between its ranks): equal to one
+    process bit for bit, and torch is never imported."""
+    assert "FileRendezvous" in WORKER_FILES and "torch" not in WORKER_FILES.replace("'torch' not in sys.modules", "")
+    total = 13
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "worker.py")
+        open(script, "w").write(WORKER_FILES)
+        outs = {}
+        for world in (1, 2):
+            out = os.path.join(td, f"w{world}.npz")
+            env = dict(os.environ, GS_ROOT=ROOT, GS_TOTAL=str(total), GS_OUT=out, WORLD_SIZE=str(world), OMP_NUM_THREADS="1",
+                       GS_KEY=f"job{world}", GS_RDZV=os.path.join(td, "rdzv"))
+            procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r))) for r in range(world)]
+            for p in procs:
+                assert p.wait(timeout=300) == 0
+            outs[world] = np.load(out)
+        assert np.array_equal(outs[1]["obs"], outs[2]["obs"]) and np.array_equal(outs[1]["reward"], outs[2]["reward"])
