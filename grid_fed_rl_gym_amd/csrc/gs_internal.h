@@ -64,18 +64,19 @@ struct GsPairRef {          // an (even row, odd row) pair of one lane: 16 bytes
   unsigned voff;
   int soff;
   __device__ __forceinline__ double2 get() const { return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, GS_LOAD_AUX)); }
-  // A 16-byte store reads its data registers over several cycles after it issues; with the row offset in an SGPR the
-  // compiler's hazard recogniser assumes the hardware interlocks (the documented exemption) and lets the next VALU
-  // instruction overwrite them at once -- measured on gfx950: lanes 12-15 of every 16 then store the NEW contents
-  // (e.g. a zero being set up for something else).  One wait state is enough (tools/store_data_hazard.hip).  Store and
-  // wait state are ONE asm statement, so nothing the compiler schedules or re-materialises can come between them
-  // (as two statements it put a v_mov into the data registers right behind the store at nine sites);
+  // A 16-byte store reads its data registers over several cycles after it issues.  With the row offset in an SGPR
+  // (soffset) the compiler's hazard recogniser assumes the hardware interlocks (the documented exemption) and lets the
+  // next VALU instruction overwrite them at once -- measured on gfx950 it does not: lanes 12-15 of every 16 then store
+  // the NEW register contents (tools/store_data_hazard.hip).  So the STORE carries its row offset in the vector offset
+  // (one v_add) and an immediate soffset: that is the form for which the compiler itself keeps the required wait state,
+  // and every other hazard of a real VMEM instruction too.  (Two earlier forms were both wrong: a separate `s_nop` asm
+  // behind the builtin let the compiler re-materialise operands in between; store + nop as one asm statement hid the
+  // instruction from the hazard recogniser altogether -- with SGPRs spilled to VGPR lanes a v_readlane of the
+  // descriptor landed right in front of the store, inside the 5 wait states a VALU-written SGPR needs before a VMEM
+  // instruction reads it, and the rows of one kernel variant were silently not written.)
   // tools/check_store_hazard.py + tests/test_store_hazard_static.py check the emitted code of the whole library.
-  // The compiler does not count this store in its vmcnt bookkeeping; its later s_waitcnt vmcnt(N) are then merely
-  // stricter than needed (N is the number of younger operations IT knows of, the counter retires in issue order).
   __device__ __forceinline__ void put(double2 v) const {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 0"
-                 :: "v"(__builtin_bit_cast(gs_u32x4, v)), "v"(voff), "s"(r), "s"(soff) : "memory");
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gs_u32x4, v), r, voff + (unsigned)soff, 0, 0);
   }
   __device__ __forceinline__ operator double2() const { return get(); }
   __device__ __forceinline__ void operator=(double2 v) const { put(v); }
@@ -287,6 +288,34 @@ struct GsPackArgs {
                                      // pair_ok: obs_dim and the block of constants are even (two columns per lane)
   int32_t skip0, skip1;              // columns [skip0, skip1) are per-instance constants (the static load powers of
                                      // grid_env.py:769-770): written at reset, left alone by the step (skip0 == skip1: none)
+};
+
+// ---- "flow2" kernels (kernels_flow2.hip): 32 instances per workgroup, the two halves of a wavefront on DIFFERENT buses ----
+// A 64-instance group fills a compute unit's LDS with its per-bus slots, so a batch of 8192 instances used 128 of the
+// 256 CUs.  Here a workgroup owns HALF a slab group (instances g * 64 + hs * 32 + l, l = lane & 31) and the lanes
+// 32..63 of every wavefront work on a second bus (line, load quad ...) of the same 32 instances: every bus-parallel
+// phase issues half the instructions per workgroup, and there are twice as many workgroups.  What used to be
+// wave-uniform (bus index, impedance, child list, row index) is now uniform per HALF: it lives in vector registers,
+// loaded from the per-(wave, item, half) records below.
+#define GS_F2_PITCH 33            /* 16-byte entries per LDS slot: 32 lanes + 1 (transposed reads conflict-free) */
+#define GS_F2_ITEMS 4             /* pair items per wave (kernel unrolls over them) */
+#define GS_F2_CHILDREN 8          /* children per bus in the LDS child table */
+#define GS_F2_WAVES 16
+struct GsF2Rec {                  // one (wave, item, half); 128 bytes
+  int32_t bus, parent, flags, maxch;        // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); maxch: max children of the PAIR
+  int32_t nl, l0, l1, ng;                   // devices at the bus, reference accumulation order (grid_env.py:689-718)
+  int32_t g0, g1, nb, b0;
+  int32_t b1, level, pad1, pad2;
+  double zr, zi, yr, yi;                    // branch to the parent: z = 1 / y
+  double pad[4];
+};
+struct GsF2Tables {
+  const GsF2Rec* recs;            // [GS_F2_WAVES][GS_F2_ITEMS][2]
+  const int32_t* nit;             // [GS_F2_WAVES] items of each wave
+  const int32_t* child;           // [n][GS_F2_CHILDREN] child slots, padded with slot ZERO
+  int32_t n_slots;                // n + 3: buses, then ZERO (0, 0), ONE (1, 0), DUMMY
+  int32_t off_tile, off_flags, off_child, off_env, off_red, off_atom, lds_bytes;     // LDS byte offsets (slots at 0)
+  int32_t env_genp, env_curt, env_batp, env_soc;      // row indices inside the env area ([row][32 lanes] doubles)
 };
 
 // gs_k_rollout_post (kernels_env.hip): bookkeeping after step t of gs_rollout
