@@ -238,8 +238,8 @@ class Handle:
             pass
 
     def describe(self) -> dict:
-        buf = C.create_string_buffer(1024)
-        self._check(self._lib.gs_describe(self._h, buf, 1024))
+        buf = C.create_string_buffer(4096)
+        self._check(self._lib.gs_describe(self._h, buf, 4096))
         return json.loads(buf.value.decode())
 
     def synchronize(self) -> None:

@@ -78,6 +78,9 @@ struct gs_handle {
   struct gs_checks* fused = nullptr;      // checks evaluated inside the step kernel's epilogue (gs_checks_set_fused)
   int solve_kernel = 0;     // 0 tree, 1 lu, 2 fbs, 3 dense, 4 tree with LDS messages, 5 fbs with LDS messages, 6 fbs as a dataflow over LDS
   size_t dyn_lds = 0;
+  // the env step of a handle whose solver is the dataflow sweep runs the second-generation kernel (kernels_flow2.hip:
+  // 32 instances per workgroup, half-waves on different buses) when the feeder fits its tables; gs_solve keeps kernel 6
+  bool flow2 = false; GsF2Tables F2{}; std::string flow2_why;
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
   std::vector<void*> allocs;
@@ -272,6 +275,16 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
     const GsFusedChecks fc = fused_checks_args(h);
+    if (h->flow2) {        // two workgroups per 64-instance slab group, each with its own 32 instances
+      if (fc.enabled)
+        hipLaunchKernelGGL(gs_k_stepc_fbs_flow2, dim3(2 * h->groups), dim3(64 * GS_F2_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
+                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+      else
+        hipLaunchKernelGGL(gs_k_step_fbs_flow2, dim3(2 * h->groups), dim3(64 * GS_F2_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
+                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+      HIPCHK(h, hipGetLastError());
+      return GS_OK;
+    }
 #define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc)
     if (fc.enabled) {
       if (h->solve_kernel == 0) GS_STEP(gs_k_stepc_nr_tree);
@@ -418,6 +431,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", max_dyn));
+    for (const void* f : {(const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2})      // no static LDS in these
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", 160 * 1024));
   }
 
   // ---- rows ----
@@ -565,6 +581,82 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     wb_ptr[h->W] = (int)wbus.size();
   }
 
+  // ---- second-generation sweep kernel for the env step: records per (wave, item, half) ----
+  std::vector<GsF2Rec> f2recs; std::vector<int32_t> f2nit(GS_F2_WAVES, 0), f2child; std::vector<double> f2z;
+  if (h->solve_kernel == 6) {
+    std::string& why = h->flow2_why;
+    const int nsl = ht.n + 3, SL_ZERO = ht.n, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2;
+    // pairs of buses of the same level, dealt in level order (deepest first) to the wave with the fewest so far
+    std::vector<std::vector<std::pair<int, int>>> mine(GS_F2_WAVES);
+    std::vector<std::vector<int>> mine_lv(GS_F2_WAVES);
+    for (int lv = 0; lv < ht.n_levels; ++lv)
+      for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; t += 2) {
+        int w = 0;
+        for (int v = 1; v < GS_F2_WAVES; ++v) if (mine[v].size() < mine[w].size()) w = v;
+        mine[w].push_back({ht.lvl_bus[t], t + 1 < ht.lvl_ptr[lv + 1] ? ht.lvl_bus[t + 1] : -1});
+        mine_lv[w].push_back(lv);
+      }
+    int max_items = 0, max_ch = 0, max_dev = 0;
+    for (auto& v : mine) max_items = std::max<int>(max_items, (int)v.size());
+    for (int i = 0; i < ht.n; ++i) {
+      max_ch = std::max(max_ch, ht.child_ptr[i + 1] - ht.child_ptr[i]);
+      max_dev = std::max({max_dev, ht.bl_ptr[i + 1] - ht.bl_ptr[i], ht.bg_ptr[i + 1] - ht.bg_ptr[i], ht.bb_ptr[i + 1] - ht.bb_ptr[i]});
+    }
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    GsF2Tables& F = h->F2;
+    size_t off = up16((size_t)nsl * GS_F2_PITCH * 16);
+    F.off_tile = (int32_t)off; off += up16(std::max<size_t>((size_t)ht.m * GS_F2_PITCH * 16, (size_t)(topo->n_loads + 4) * 32 * sizeof(double)));
+    F.off_flags = (int32_t)off; off += up16((size_t)nsl * 4);
+    F.off_child = (int32_t)off; off += up16((size_t)ht.n * GS_F2_CHILDREN * 4);
+    F.off_z = (int32_t)off; off += up16((size_t)nsl * 16);
+    F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
+    F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * 32 * sizeof(double));
+    F.off_red = (int32_t)off; off += 2 * GS_F2_WAVES * 32 * sizeof(double);
+    F.off_atom = (int32_t)off; off += 5 * 32 * sizeof(unsigned long long) + 16 * 32 * sizeof(uint32_t);
+    F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack;
+    if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
+    else if (max_items > GS_F2_ITEMS) why = "more than " + std::to_string(GS_F2_ITEMS) + " bus pairs per wave";
+    else if (max_ch > GS_F2_CHILDREN) why = "a bus has more than " + std::to_string(GS_F2_CHILDREN) + " children";
+    else if (max_dev > 2) why = "more than two devices of a kind at one bus";
+    else if (off > 160 * 1024) why = "LDS tables do not fit";
+    else if (ht.n < 2 || ht.m < 1) why = "trivial network";
+    if (why.empty()) {
+      h->flow2 = true;
+      GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE;
+      f2recs.assign((size_t)GS_F2_WAVES * GS_F2_ITEMS * 2, idle);
+      f2child.assign((size_t)ht.n * GS_F2_CHILDREN, SL_ZERO);
+      f2z.assign((size_t)nsl * 2, 0.0);
+      for (int i = 0; i < ht.n; ++i)
+        for (int q = ht.child_ptr[i]; q < ht.child_ptr[i + 1]; ++q) f2child[(size_t)i * GS_F2_CHILDREN + (q - ht.child_ptr[i])] = ht.child_idx[q];
+      for (int w = 0; w < GS_F2_WAVES; ++w) {
+        f2nit[w] = (int)mine[w].size();
+        for (int j = 0; j < (int)mine[w].size(); ++j) {
+          const int pair[2] = {mine[w][j].first, mine[w][j].second};
+          int maxch = 0;
+          for (int hh = 0; hh < 2; ++hh) if (pair[hh] >= 0) maxch = std::max(maxch, ht.child_ptr[pair[hh] + 1] - ht.child_ptr[pair[hh]]);
+          for (int hh = 0; hh < 2; ++hh) {
+            GsF2Rec& r = f2recs[((size_t)w * GS_F2_ITEMS + j) * 2 + hh];
+            r.maxch = maxch; r.level = mine_lv[w][j];
+            const int i = pair[hh];
+            if (i < 0) continue;
+            const int fp = ht.fbs_parent[i], pos = ht.fbs_parent_pos[i];
+            const double yr = -ht.G[pos], yi = -ht.B[pos], yd = yr * yr + yi * yi;      // branch admittance = -Y_ip; z = 1 / y
+            r.bus = i; r.parent = fp; r.flags = 1 | (fp == ht.slack ? 2 : 0);
+            r.zr = yr / yd; r.zi = -yi / yd; r.yr = yr; r.yi = yi;
+            f2z[2 * (size_t)i] = r.zr; f2z[2 * (size_t)i + 1] = r.zi;
+            r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
+            if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
+            if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
+            if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
+            if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
+            if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
+            if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
+          }
+        }
+      }
+    }
+  }
+
   // ---- tables ----
   GsTables& T = h->T;
   T.n = n; T.m = m; T.nnz = ht.nnz; T.n_levels = ht.n_levels;
@@ -594,6 +686,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
 #undef UP
+  if (h->flow2 && ((rc = dev_upload(h, &h->F2.recs, f2recs)) || (rc = dev_upload(h, &h->F2.nit, f2nit)) ||
+                   (rc = dev_upload(h, &h->F2.child, f2child)) || (rc = dev_upload(h, &h->F2.zbus, f2z)))) return bail(rc);
 
   // ---- configs ----
   h->SC.tolerance = cfg->tolerance; h->SC.alpha = cfg->acceleration_factor;
@@ -708,10 +802,13 @@ int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
   snprintf(buf, buflen,
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
-           "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d}",
-           kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
-           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, h->W, h->groups,
-           h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim);
+           "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d, "
+           "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"solve_kernel\": \"%s\", \"flow2\": \"%s\"}",
+           h->flow2 ? "fbs_flow2" : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
+           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, h->flow2 ? GS_F2_WAVES : h->W, h->groups,
+           h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim,
+           h->flow2 ? 32 : 64, h->flow2 ? 2 * h->groups : h->groups, h->flow2 ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576,
+           kn[h->solve_kernel], h->flow2 ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()));
   return GS_OK;
 }
 

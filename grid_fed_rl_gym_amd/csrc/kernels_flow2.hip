@@ -1,0 +1,634 @@
+// kernels_flow2.hip -- the fused env.step() with the forward/backward sweep load flow for small radial feeders,
+// second generation: 32 instances per workgroup, the two halves of every wavefront on DIFFERENT buses.
+//
+// Why: the dataflow sweep kernel of kernels_solve.hip (gs_k_step_fbs_flow) gives a 64-instance group a whole compute
+// unit (its per-bus LDS slots fill it), so BASELINE.json's config 3 -- 8192 instances -- ran on 128 of the chip's 256
+// CUs, and per-group time is set by the number of instructions a wave issues, not by how many lanes are active.
+// Here a workgroup owns half a slab group (32 instances), lanes 0..31 and 32..63 of a wavefront carry the same 32
+// instances on two different buses / lines / load quads, so every bus-parallel phase issues half the instructions per
+// workgroup and twice as many workgroups (256 at B = 8192) fill the chip.  Per-bus constants that used to be
+// wave-uniform scalars are uniform per HALF and live in vector registers (GsF2Rec records, one vector load each).
+//
+// Also new against the first generation:
+//  * LDS slots are [bus][33 x 16 B] (lane-interleaved (re, im) pairs, one ds_read_b128 / ds_write_b128 per message);
+//    with the 33rd entry as padding the epilogue converts every slot IN PLACE to (|V|, angle) and the slots ARE the
+//    transposed observation tile: the observation block is written from LDS, the |V| / angle / flow rows the epilogue
+//    stores are never read back (that re-read was a third of the step's fabric traffic);
+//  * load powers, renewable powers, curtailment, battery state go to the injection pass through LDS, not rows;
+//  * cross-wave maxima / counts are LDS integer atomics on the bit patterns (exact, order-independent); only the two
+//    floating-point SUMS (losses, voltage deviation) keep per-wave partials added in wave order.
+//
+// Reference arithmetic restated (paths relative to /root/reference/grid_fed_rl/environments/): as kernels_solve.hip:
+// mismatch power_flow.py:150-171, line flows / losses :329-358 / :198-200, env step grid_env.py:410-619.
+// The sweep itself is the one of fbs_loop_flow (kernels_solve.hip): same per-bus operations in the same order.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <limits.h>
+
+#include "../../include/gridstep.h"
+#include "gs_internal.h"
+
+#define ROW(r) S[(size_t)(r) * GS_LANES]
+#include "env_device.h"
+
+// No implicit contraction anywhere in this file: the plain and the checks-carrying instantiation of the kernel are
+// compared bit for bit, and which multiply the compiler fuses into which add depends on the code around it.  Fused
+// multiply-adds are written out where they are wanted.
+#pragma clang fp contract(off)
+
+extern __shared__ __attribute__((aligned(16))) char f2_lds[];
+
+#define F2_SLOT_BYTES (GS_F2_PITCH * 16)
+#define F2_SPIN_CAP (1 << 18)
+
+__device__ __forceinline__ void f2_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void f2_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Every LDS access of the kernel goes through an explicit address-space-3 pointer: the compiler does not rewrite
+// VOLATILE generic accesses to LDS ones by itself (they would become flat instructions with 64-bit addresses).
+#define F2_AS3 __attribute__((address_space(3)))
+#define F2_P(type, off) ((type F2_AS3*)((F2_AS3 char*)f2_lds + (off)))
+#define F2_VP(type, off) ((volatile type F2_AS3*)((F2_AS3 char*)f2_lds + (off)))
+__device__ __forceinline__ unsigned f2_slot(int slot, int l) { return (unsigned)slot * F2_SLOT_BYTES + ((unsigned)l << 4); }
+typedef double f2_v2 __attribute__((ext_vector_type(2)));        // 16 bytes: one ds_read_b128 / ds_write_b128
+__device__ __forceinline__ double2 f2_ld2(unsigned off) { const f2_v2 v = *F2_P(const f2_v2, off); return make_double2(v.x, v.y); }
+__device__ __forceinline__ void f2_st2(unsigned off, double2 v) { f2_v2 w; w.x = v.x; w.y = v.y; *F2_P(f2_v2, off) = w; }
+__device__ __forceinline__ double f2_ld(unsigned off) { return *F2_P(const double, off); }
+__device__ __forceinline__ void f2_st(unsigned off, double v) { *F2_P(double, off) = v; }
+
+// message protocol of the sweeps (see fbs_loop_flow): producer writes the message, then the epoch into the bus's flag
+// word; consumer asks for flag and message in ONE round trip and asks again until the flag is there.  The LDS executes a
+// compute unit's instructions in issue order, so no wait is needed in between on either side.
+__device__ __forceinline__ double2 f2_take(unsigned msg_off, unsigned flag_off, int epoch) {
+  double2 v = make_double2(0.0, 0.0);
+  bool seen = false;
+  for (int spin = 0; spin < F2_SPIN_CAP; ++spin) {
+    const int f = *F2_VP(int, flag_off);
+    v.x = *F2_VP(double, msg_off);
+    v.y = *F2_VP(double, msg_off + 8);
+    if (__all(f - epoch >= 0)) { seen = true; break; }
+  }
+  if (!seen) v = make_double2(NAN, NAN);        // a hand-off that never arrived must not pass for data (status NAN)
+  return v;
+}
+__device__ __forceinline__ void f2_give(unsigned msg_off, unsigned flag_off, int epoch, int l, double x, double y) {
+  *F2_VP(double, msg_off) = x;
+  *F2_VP(double, msg_off + 8) = y;
+  if (l == 0) *F2_VP(int, flag_off) = epoch;
+}
+__device__ __forceinline__ double2 f2_vld2(unsigned off) { return make_double2(*F2_VP(double, off), *F2_VP(double, off + 8)); }
+
+// LDS integer atomics (exact and order-independent; workgroup scope is all LDS needs)
+#define atomicMax(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define atomicMin(p, v) __hip_atomic_fetch_min((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define atomicAdd(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define atomicOr(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+__device__ __forceinline__ double f2_xhalf(double v) { return __shfl_xor(v, 32); }      // the same instance's value in the other half
+__device__ __forceinline__ unsigned long long f2_bits(double v) { return __builtin_bit_cast(unsigned long long, v); }
+__device__ __forceinline__ double f2_dbl(unsigned long long b) { return __builtin_bit_cast(double, b); }
+
+// per-lane rows (row index differs between the halves of a wave)
+__device__ __forceinline__ GsRowRef f2_row(const GsLaneRows& S, int row) { return S.lane_row((size_t)row * GS_LANES); }
+__device__ __forceinline__ GsPairRef f2_pair(const GsLaneRows& S, int even_row) {
+  return GsPairRef{S.r, S.lane16 + (((unsigned)even_row >> 1) << 10), 0};
+}
+
+struct F2State { double mm; int iters, conv, status; bool done; };
+__device__ __forceinline__ void f2_check(F2State& st, double mm, int it, double tol) {      // power_flow.py:148, 168-171, 204
+  if (!st.done) {
+    st.mm = mm; st.iters = it + 1;
+    if (!(mm < INFINITY)) { st.status = GS_STATUS_NAN; st.done = true; }
+    else if (mm < tol) { st.conv = 1; st.status = GS_STATUS_OK; st.done = true; }
+  }
+}
+
+// Bus voltage angle from (e, f) (see bus_angle in kernels_solve.hip): series for small angles, libm otherwise.
+__device__ __forceinline__ double f2_angle(double f, double e) {
+  if (!__all(e > 0.0 && fabs(f) <= 0.125 * e)) return atan2(f, e);
+  const double t = f / e, z = t * t;
+  double p = -1.0 / 19.0;
+  p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, -1.0 / 15.0); p = __builtin_fma(p, z, 1.0 / 13.0);
+  p = __builtin_fma(p, z, -1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0); p = __builtin_fma(p, z, -1.0 / 7.0);
+  p = __builtin_fma(p, z, 1.0 / 5.0); p = __builtin_fma(p, z, -1.0 / 3.0);
+  return __builtin_fma(t * z, p, t);
+}
+
+enum { F2_ST_PROLOGUE = 0, F2_ST_INIT, F2_ST_MISMATCH, F2_ST_BOTTOM_UP, F2_ST_FLAG, F2_ST_TOP_DOWN, F2_ST_FINAL_MISMATCH, F2_ST_EPILOGUE,
+       F2_ST_PRO_SCALAR, F2_ST_PRO_SPARE, F2_ST_EPI_BUSES, F2_ST_EPI_LINES, F2_ST_EPI_REDUCE, F2_ST_EPI_SCALARS };
+struct F2Stamp {
+  unsigned long long* p; unsigned long long t; bool mine;
+  __device__ __forceinline__ void hit(int k) {
+    if (p == nullptr) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    if (mine) p[k] += now - t;
+    t = now;
+  }
+};
+
+template <int CHK>
+__device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
+                                        double* __restrict__ slab, int B, const double* __restrict__ actions, double total_load,
+                                        const GsPackArgs& PA, const GsFusedChecks& FC) {
+  const int lane = threadIdx.x & 63, l = lane & 31, hv = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blockIdx.x >> 1, hs = blockIdx.x & 1, L = hs * 32 + l;
+  const int b = g * GS_LANES + L;
+  const bool valid = b < B;
+  const GsLaneRows S = gs_lane_rows(slab, g, R.total, L);
+  const int n = T.n, m = T.m, nsl = F.n_slots;
+  const int SL_ZERO = n, SL_ONE = n + 1, SL_DUMMY = n + 2;
+  (void)SL_ONE; (void)SL_DUMMY;
+  int F2_AS3* const flags = F2_P(int, F.off_flags);
+  int F2_AS3* const child_lds = F2_P(int, F.off_child);
+  double F2_AS3* const env_lds = F2_P(double, F.off_env);                 // [row][32 lanes]
+  double F2_AS3* const loadp_lds = F2_P(double, F.off_tile);               // [load][32 lanes], dead before the line tile is written
+  double F2_AS3* const red_lsum = F2_P(double, F.off_red);                 // [16 waves][32 lanes]
+  double F2_AS3* const red_dev = red_lsum + GS_F2_WAVES * 32;
+  unsigned long long F2_AS3* const cell = F2_P(unsigned long long, F.off_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits
+  unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 5 * 32);                // [16][32] integer counts
+  F2Stamp stp{C.stamps, 0ull, blockIdx.x == 0 && wave == C.stamp_wave && lane == 0};
+  if (C.stamps) stp.t = __builtin_readcyclecounter();
+
+  // ---- LDS init: flat start in every slot, flags, child table, cells -----------------------------------------------
+  for (int k = threadIdx.x; k < nsl * 32; k += blockDim.x) {
+    const int s = k >> 5, ll = k & 31;
+    double e = 1.0;
+    if (s < n) e = T.fixed_v[s] ? T.v_set[s] : 1.0;
+    else if (s == SL_ZERO) e = 0.0;
+    f2_st2(f2_slot(s, ll), make_double2(e, 0.0));
+  }
+  for (int s = threadIdx.x; s < nsl; s += blockDim.x) flags[s] = (s < n && T.lvl_pos[s] >= 0) ? 0 : INT_MAX;   // nobody's item: never polled for
+  for (int k = threadIdx.x; k < n * GS_F2_CHILDREN; k += blockDim.x) child_lds[k] = F.child[k];
+  for (int k = threadIdx.x; k < 2 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];
+  for (int k = threadIdx.x; k < 5 * 32; k += blockDim.x) cell[k] = (k >= 4 * 32) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
+  for (int k = threadIdx.x; k < 16 * 32; k += blockDim.x) icell[k] = 0u;
+
+  // ---- clock; then three independent chains on different waves (grid_env.py:433-477) --------------------------------
+  const uint64_t inst = (uint64_t)(E.first_instance + b);
+  const double told = ROW(R.TIME), kold = ROW(R.STEP), tnew = told + E.timestep;
+  const uint32_t snew = (uint32_t)(kold + 1.0);
+  const uint64_t seed = lane_seed(S, R);
+  f2_sync();
+  const int nb = T.n_bats, ng = T.n_gens, nl_ = T.n_loads;
+  if (wave == 0) {
+    // _apply_actions (grid_env.py:621-651, dynamics.py:189-220): the halves take alternate batteries / generators
+    const double* act = actions + (size_t)(valid ? b : 0) * (nb + ng);
+    const double dt = E.timestep;
+    for (int q0 = 0; q0 < nb; q0 += 2) {
+      const int q = q0 + hv; const bool on = q < nb; const int qq = on ? q : 0;
+      const double a = act[qq], rating = T.bat_rating[qq], cap = T.bat_cap[qq], eff = T.bat_eff[qq];
+      double soc = f2_row(S, R.SOC + qq), bp = f2_row(S, R.BATP + qq);
+      const double cmd = a * rating;
+      if (valid && cmd > 0.0) {                               // discharge, dynamics.py:206-220
+        const double p = fmin(cmd, rating);
+        const double e = fmin(p * dt / 3600.0, soc * cap * eff);
+        soc -= e / (cap * eff);
+        bp = e * 3600.0 / dt;
+      } else if (valid && cmd < 0.0) {                        // charge, dynamics.py:189-204
+        const double p = fmin(-cmd, rating);
+        const double max_e = (1.0 - soc) * cap;
+        const double e = fmin(p * dt / 3600.0, max_e / eff);
+        soc += e * eff / cap;
+        bp = -(e * 3600.0 / dt);
+      }
+      if (on) {
+        if (valid && cmd != 0.0) { f2_row(S, R.SOC + q) = soc; f2_row(S, R.BATP + q) = bp; }
+        env_lds[(F.env_soc + q) * 32 + l] = soc; env_lds[(F.env_batp + q) * 32 + l] = bp;
+      }
+    }
+    for (int g0 = 0; g0 < ng; g0 += 2) {
+      const int gi = g0 + hv; const bool on = gi < ng; const int gg = on ? gi : 0;
+      const double c = valid ? (act[nb + gg] + 1.0) / 2.0 : (double)f2_row(S, R.CURT + gg);
+      if (on) { if (valid) f2_row(S, R.CURT + gi) = c; env_lds[(F.env_curt + gi) * 32 + l] = c; }
+    }
+    if (valid && hv == 0) { ROW(R.TIME) = told + dt; ROW(R.STEP) = kold + 1.0; }      // grid_env.py:470-471
+  } else if (wave == 1) {
+    // _update_weather + renewable models (grid_env.py:653-681, dynamics.py:120-142, 158-170); the halves take alternate generators
+    const GsWeather wx = weather_step(R, E, S, inst, tnew, snew, valid);
+    const double elev = solar_elevation(valid ? tnew : told);
+    for (int g0 = 0; g0 < ng; g0 += 2) {
+      const int gi = g0 + hv; const bool on = gi < ng; const int gg = on ? gi : 0;
+      const double cap = T.gen_cap[gg], p0 = T.gen_p0[gg], p1 = T.gen_p1[gg], p2 = T.gen_p2[gg];
+      double pw;
+      if (T.gen_kind[gg] == 0) {
+        const double irr = 1000.0 * elev * (1.0 - 0.8 * wx.cloud);
+        const double tf = 1.0 - 0.004 * fmax(0.0, wx.temp - 25.0);
+        pw = fmin(irr * p1 * p0 * tf, cap);
+      } else if (wx.wind < p0 || wx.wind > p2) pw = 0.0;
+      else if (wx.wind <= p1) { const double q = (wx.wind - p0) / (p1 - p0); pw = cap * (q * q * q); }
+      else pw = cap;
+      if (on) { f2_row(S, R.GENP + gi) = pw; env_lds[(F.env_genp + gi) * 32 + l] = pw; }
+    }
+  } else {
+    // realised load powers (dynamics.py:54-75): loads 4 p .. 4 p + 3 share one Philox call; one quad per HALF wave
+    const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
+    for (int p = (wave - 2) * 2 + hv; 4 * p < nl_; p += (GS_F2_WAVES - 2) * 2) {
+      double z[4] = {0.0, 0.0, 0.0, 0.0};
+      if (E.stochastic_loads) rng_normal_quad(seed, inst, snew, DRAW_LOAD0 + p, z);
+      const int l0 = 4 * p;
+      double lp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int li = min(l0 + k, nl_ - 1);
+        const double base = T.load_base[li];
+        lp[k] = E.stochastic_loads ? fmax(0.0, base * (prof * (1.0 + 0.1 * z[k])) * 1.0) : base;
+        if (l0 + k < nl_) loadp_lds[(l0 + k) * 32 + l] = lp[k];
+      }
+      // LOADP starts on an even row: (l0, l0 + 1) and (l0 + 2, l0 + 3) are row pairs
+      if (l0 + 1 < nl_) f2_pair(S, R.LOADP + l0) = make_double2(lp[0], lp[1]); else f2_row(S, R.LOADP + l0) = lp[0];
+      if (l0 + 3 < nl_) f2_pair(S, R.LOADP + l0 + 2) = make_double2(lp[2], lp[3]); else if (l0 + 2 < nl_) f2_row(S, R.LOADP + l0 + 2) = lp[2];
+    }
+  }
+  stp.hit(F2_ST_PRO_SPARE);
+  f2_lds_sync();                                  // what the injection pass reads is in LDS
+  stp.hit(F2_ST_PRO_SCALAR);
+
+  // ---- the records of this lane's items --------------------------------------------------------------------------
+  const int nit = __builtin_amdgcn_readfirstlane(F.nit[wave]);
+  const GsF2Rec* const rec0 = F.recs + ((size_t)wave * GS_F2_ITEMS) * 2 + hv;
+  // (bus, parent) stay in registers; the branch impedance comes from an LDS table by bus -- requested together with the
+  // bus's own message, i.e. it adds nothing to a hop --, "root" is "the parent is the slack bus", "idle half" is "bus >= n"
+  int ibus[GS_F2_ITEMS], ipar[GS_F2_ITEMS], imaxch[GS_F2_ITEMS];
+#pragma unroll
+  for (int j = 0; j < GS_F2_ITEMS; ++j) {
+    const GsF2Rec* q = rec0 + 2 * j;
+    ibus[j] = q->bus; ipar[j] = q->parent; imaxch[j] = __builtin_amdgcn_readfirstlane(q->maxch);
+  }
+
+  // ---- injections of this lane's buses, reference accumulation order (grid_env.py:683-720, power_flow.py:112-121) ----
+  double Pj[GS_F2_ITEMS], IR[GS_F2_ITEMS], II[GS_F2_ITEMS];
+#pragma unroll
+  for (int j = 0; j < GS_F2_ITEMS; ++j) {
+    const GsF2Rec* q = rec0 + 2 * j;
+    const int nl = q->nl, l0 = q->l0, l1 = q->l1, ngj = q->ng, g0 = q->g0, g1 = q->g1, nbj = q->nb, b0 = q->b0, b1 = q->b1;
+    double ls = 0.0, gs = 0.0;
+    if (nl > 0) ls += loadp_lds[l0 * 32 + l];
+    if (nl > 1) ls += loadp_lds[l1 * 32 + l];
+    if (ngj > 0) gs += env_lds[(F.env_genp + g0) * 32 + l] * env_lds[(F.env_curt + g0) * 32 + l];
+    if (ngj > 1) gs += env_lds[(F.env_genp + g1) * 32 + l] * env_lds[(F.env_curt + g1) * 32 + l];
+    if (nbj > 0) { const double bp = env_lds[(F.env_batp + b0) * 32 + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+    if (nbj > 1) { const double bp = env_lds[(F.env_batp + b1) * 32 + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+    Pj[j] = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base);
+    IR[j] = 0.0; II[j] = 0.0;
+  }
+  stp.hit(F2_ST_PROLOGUE);
+
+  // ================= the sweeps (see fbs_loop_flow, kernels_solve.hip, for the algorithm) =================
+  F2State st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
+  double psum = 0.0;
+  int epoch = 1, check = 0;
+  // cross-wave maximum of the mismatch: LDS integer maximum on the bit pattern (mismatch >= 0; inf and NaN patterns are
+  // the largest), three cells in rotation so that nobody clears one that is still being read
+  auto wg_max = [&](double lmax) -> double {
+    const int c0 = check % 3, c1 = (check + 1) % 3;
+    ++check;
+    lmax = fmax(lmax, f2_xhalf(lmax));
+    if (wave == 0 && hv == 0) cell[c1 * 32 + l] = 0ull;
+    if (hv == 0) atomicMax(cell + c0 * 32 + l, f2_bits(lmax));
+    f2_lds_sync();
+    return f2_dbl(cell[c0 * 32 + l]);
+  };
+  stp.hit(F2_ST_INIT);
+  {  // first backward chain, at the flat start: every voltage but the slack's is 1, S_calc = conj(K) with K = y (1 - V_parent)
+    double lmax = 0.0, bad = 0.0;
+#pragma unroll
+    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+      if (j < nit) {
+        const GsF2Rec* q = rec0 + 2 * j;
+        const double p = Pj[j];
+        const bool root = ipar[j] == F.slack;
+        const double ep = root ? f2_ld(f2_slot(ipar[j], l)) : 1.0;
+        const double dr = 1.0 - ep;
+        const double kr = q->yr * dr, ki = q->yi * dr;
+        const double pc = kr, qc = -ki;
+        const double dP = p - pc, dQ = 0.0 - qc;
+        lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
+        psum += pc;
+        if (root) psum -= ep * kr;                            // the slack's share: Re(V_s conj(-K_root))
+        IR[j] = p; II[j] = -0.0;                              // I = conj(S_spec / V) at V = 1
+        double jr = -p, ji = 0.0;                             // J_i = -I_i + sum J_c
+        const unsigned cbase = (unsigned)ibus[j] * GS_F2_CHILDREN;
+        for (int u = 0; u < imaxch[j]; ++u) {
+          const int ch = ibus[j] < n ? child_lds[cbase + u] : SL_ZERO;
+          const double2 jc = f2_take(f2_slot(ch, l), F.off_flags + 4u * ch, epoch);
+          jr += jc.x; ji += jc.y;
+        }
+        f2_give(f2_slot(ibus[j], l), F.off_flags + 4u * ibus[j], epoch, l, jr, ji);
+      }
+    }
+    if (bad != bad) lmax = INFINITY;
+    stp.hit(F2_ST_BOTTOM_UP);
+    const double mm = wg_max(lmax);
+    stp.hit(F2_ST_FLAG);
+    f2_check(st, mm, 0, C.tolerance);
+  }
+  for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
+    const bool upd = !st.done;
+    double lmax = 0.0, pnew = 0.0, bad = 0.0;
+    ++epoch;
+    // forward chain: V_i = V_parent - z_i J_i
+#pragma unroll
+    for (int j = GS_F2_ITEMS - 1; j >= 0; --j) {
+      if (j < nit) {
+        const unsigned own = f2_slot(ibus[j], l);
+        const double2 cj = f2_vld2(own); const double cjr = cj.x, cji = cj.y;   // this lane's own backward item left it there
+        const double2 z = f2_ld2(F.off_z + 16u * ibus[j]);
+        const double zjr = __builtin_fma(cjr, z.x, -(cji * z.y)), zji = __builtin_fma(cjr, z.y, cji * z.x);   // z J: known before the parent is
+        const double2 vp = f2_take(f2_slot(ipar[j], l), F.off_flags + 4u * ipar[j], epoch);
+        if (ipar[j] == F.slack) pnew += vp.x * cjr;                  // the slack's share of the losses sum: Re(V_s conj(J_root)), V_s real
+        f2_give(own, F.off_flags + 4u * ibus[j], epoch, l, vp.x - zjr, vp.y - zji);
+      }
+    }
+    stp.hit(F2_ST_TOP_DOWN);
+    // body: mismatch and sum of P_calc at the new voltages (power_flow.py:150-168)
+#pragma unroll
+    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+      if (j < nit) {
+        const unsigned own = f2_slot(ibus[j], l);
+        const double2 vn = f2_vld2(own); const double en = vn.x, fn = vn.y;
+        const double pc = __builtin_fma(en, IR[j], fn * II[j]), qc = __builtin_fma(fn, IR[j], -(en * II[j]));     // S_calc = V_new conj(I_old)
+        const double dP = Pj[j] - pc, dQ = 0.0 - qc;
+        lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
+        pnew += pc;
+      }
+    }
+    if (bad != bad) lmax = INFINITY;
+    stp.hit(F2_ST_MISMATCH);
+    if (upd) psum = pnew;                                     // losses at the voltages just stored
+    if (it + 1 >= C.max_iterations) break;                    // iteration cap: mismatch / count stay the last check's
+    const double mm = wg_max(lmax);
+    stp.hit(F2_ST_FLAG);
+    f2_check(st, mm, it + 1, C.tolerance);
+    if (__all(st.done)) break;
+    ++epoch;
+    // I_new = conj(S_spec / V_new) for the lanes that go on; a lane that has converged keeps the current that produced
+    // its voltages: its J and V repeat bit for bit while the rest of the group iterates
+#pragma unroll
+    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+      if (j < nit) {
+        const unsigned own = f2_slot(ibus[j], l);
+        const double2 vn = f2_vld2(own); const double en = vn.x, fn = vn.y;
+        const double rd = 1.0 / __builtin_fma(en, en, fn * fn);
+        // (an idle half shares the DUMMY slot with the idle halves of other waves, which may hold a current or a voltage
+        // by now: its own current stays zero whatever is there)
+        if (!st.done && ibus[j] < n) { IR[j] = (Pj[j] * en) * rd; II[j] = (Pj[j] * fn) * rd; }
+      }
+    }
+    // backward chain: J_i = -I_i + sum J_c
+#pragma unroll
+    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+      if (j < nit) {
+        double jr = -IR[j], ji = -II[j];
+        const unsigned cbase = (unsigned)ibus[j] * GS_F2_CHILDREN;
+        for (int u = 0; u < imaxch[j]; ++u) {
+          const int ch = ibus[j] < n ? child_lds[cbase + u] : SL_ZERO;
+          const double2 jc = f2_take(f2_slot(ch, l), F.off_flags + 4u * ch, epoch);
+          jr += jc.x; ji += jc.y;
+        }
+        f2_give(f2_slot(ibus[j], l), F.off_flags + 4u * ibus[j], epoch, l, jr, ji);
+      }
+    }
+    stp.hit(F2_ST_BOTTOM_UP);
+  }
+  f2_sync();                         // every slot final
+  stp.hit(F2_ST_FINAL_MISMATCH);
+
+  // ================= epilogue =================
+  // a lane that stopped at the very first check keeps the flat start (its slots went on iterating with its group)
+  const bool flat_lane = st.done && st.iters <= 1, any_flat = __any(flat_lane);
+  auto final_ef = [&](int bus) -> double2 {
+    double2 v = f2_ld2(f2_slot(bus, l));
+    if (any_flat) { const double fv = T.fixed_v[bus] ? T.v_set[bus] : 1.0; if (flat_lane) v = make_double2(fv, 0.0); }
+    return v;
+  };
+  // scalar state of wave 0's part, requested now, used after the second barrier
+  double totloss0 = 0.0, f_old = 0.0, viol0 = 0.0, step0 = 0.0, eprew0 = 0.0;
+  if (wave == 0) { totloss0 = ROW(R.TOTLOSS); f_old = ROW(R.FREQ); viol0 = ROW(R.VIOL); eprew0 = ROW(R.EPREW); step0 = valid ? kold + 1.0 : kold; }
+  const bool chk = CHK && FC.enabled;
+  if (chk && wave == 0 && hv == 0) { cell[l] = 0ull; cell[32 + l] = 0ull; }      // the first two convergence cells take two maxima of the checks
+  const GsChecksCfg& K = FC.C;
+  double* Pv = chk ? FC.prev + (size_t)g * (n + 1) * GS_LANES + L : nullptr;
+  int k_nlow = 0, k_nhigh = 0, k_mhigh = 0, k_mlow = 0, k_mem = 0, k_cover = 0, k_mover = 0, k_vbad = 0, k_fbad = 0;
+  double k_dv = 0.0, k_ql = 0.0; int k_dvnan = 0, k_qlnan = 0;
+
+  // lines (power_flow.py:340-356; Line.update_state, base.py:261-264): two lines per wave instruction
+  int over = 0;
+  for (int k0 = wave * 2 + hv; k0 < ((m + 31) & ~31); k0 += 32) {
+    const bool on = k0 < m; const int k = on ? k0 : m - 1;
+    const int li = T.lfrom[k], lj = T.lto[k];
+    const double yr = T.lyr[k], yi = T.lyi[k], rating = T.lrating[k], rinv = T.lrating_inv[k];
+    const double2 vi = final_ef(li), vj = final_ef(lj);
+    const double dr = vi.x - vj.x, di = vi.y - vj.y;
+    const double ir = __builtin_fma(yr, dr, -(yi * di)), ii = __builtin_fma(yr, di, yi * dr);        // I = y (Vi - Vj)
+    const double sr = __builtin_fma(vi.x, ir, vi.y * ii), si = __builtin_fma(vi.y, ir, -(vi.x * ii));  // S = Vi conj(I)
+    const double ql = (rating > 0.0) ? gs_div_by(sqrt(__builtin_fma(sr, sr, si * si)), rating, rinv) : 0.0;
+    const double ld = (rating > 0.0) ? gs_div_by(fabs(sr), rating, rinv) : 0.0;
+    if (on) {
+      f2_row(S, R.LOAD + k) = ql;
+      f2_pair(S, R.FLOW + k) = make_double2(sr, ld);
+      f2_st2(F.off_tile + (unsigned)k * F2_SLOT_BYTES + ((unsigned)l << 4), make_double2(sr, ld));
+      over += (ld > 0.8) ? 1 : 0;
+      if (chk) {
+        const double cld_ = K.stride_cload == 2 ? ld : ql;             // which loading the limits apply to
+        const bool co = cld_ > K.c_load, mo = cld_ > K.m_load;         // safety.py:150-154, :364-365
+        k_cover += co; k_mover += mo;
+        if (ql != ql) k_qlnan = 1; else k_ql = fmax(k_ql, ql);
+        if (!(fabs(sr) < INFINITY)) k_fbad = 1;
+        if (FC.line_mask) FC.line_mask[((size_t)g * m + k) * GS_LANES + L] = (uint8_t)(co | (mo << 1));
+      }
+    }
+  }
+  stp.hit(F2_ST_EPI_LINES);
+  f2_lds_sync();                     // every (e, f) has been read: the slots may now be converted in place
+  // buses: (e, f) -> (|V|, angle) in place (the slots become the observation tile), state rows, reward / flag partials
+  double dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
+  int vflags = 0;
+  for (int i0 = wave * 2 + hv; i0 < ((n + 31) & ~31); i0 += 32) {
+    const bool on = i0 < n; const int i = on ? i0 : n - 1;
+    double2 ef = final_ef(i);
+    if (!on) ef = make_double2(1.0, 0.0);                     // keep the wave on the series branch of the angle
+    const double v = sqrt(__builtin_fma(ef.x, ef.x, ef.y * ef.y));
+    const double ang = f2_angle(ef.y, ef.x);
+    if (on) {
+      f2_st2(f2_slot(i, l), make_double2(v, ang));
+      f2_pair(S, R.VM + i) = make_double2(v, ang);
+      dev += fabs(v - 1.0);                                   // reward / flags, grid_env.py:790-792, base.py:156-159
+      vmax = fmax(vmax, v); vmin = fmin(vmin, v);
+      vflags |= (v > E.v_max) ? 1 : 0;
+      vflags |= (v < E.v_min) ? 2 : 0;
+      if (chk) {
+        const double pv = Pv[(size_t)i * GS_LANES];
+        const bool cl = v < K.c_vlo, ch = !cl && v > K.c_vhi;                // safety.py:129-137 (elif)
+        const bool mh = v > K.m_vhi, ml = v < K.m_vlo;                       // :333-337
+        const bool em = v > K.m_evhi || v < K.m_evlo;                        // :340-341
+        k_nlow += cl; k_nhigh += ch; k_mhigh += mh; k_mlow += ml; k_mem += em;
+        const double d = fabs(v - pv);                                       // :168 (np.max propagates NaN)
+        if (d != d) k_dvnan = 1; else k_dv = fmax(k_dv, d);
+        Pv[(size_t)i * GS_LANES] = v;                                        // :181-184
+        if (!(fabs(v) < INFINITY)) k_vbad = 1;                               // robust_power_flow.py:643-647
+        if (FC.bus_mask) FC.bus_mask[((size_t)g * n + i) * GS_LANES + L] = (uint8_t)(cl | (ch << 1) | (ml << 2) | (mh << 3) | (em << 4));
+      }
+    }
+  }
+  stp.hit(F2_ST_EPI_BUSES);
+  {  // partial results: sums keep per-wave partials (added in wave order below), everything else is an integer atomic
+    const double ls2 = psum + f2_xhalf(psum), dv2 = dev + f2_xhalf(dev);            // half 0 + half 1, the same on both sides
+    if (hv == 0) { red_lsum[wave * 32 + l] = ls2; red_dev[wave * 32 + l] = dv2; }
+    if (vmax == vmax && vmax > -INFINITY) atomicMax(cell + 3 * 32 + l, f2_bits(vmax));       // |V| >= 0: bit patterns order like the values
+    if (vmin == vmin && vmin < INFINITY) atomicMin(cell + 4 * 32 + l, f2_bits(vmin));
+    if (over) atomicAdd(icell + 0 * 32 + l, (unsigned)over);
+    if (vflags) atomicOr(icell + 1 * 32 + l, (unsigned)vflags);
+    if (chk) {
+      if (k_nlow) atomicAdd(icell + 2 * 32 + l, (unsigned)k_nlow);
+      if (k_nhigh) atomicAdd(icell + 3 * 32 + l, (unsigned)k_nhigh);
+      if (k_mhigh) atomicAdd(icell + 4 * 32 + l, (unsigned)k_mhigh);
+      if (k_mlow) atomicAdd(icell + 5 * 32 + l, (unsigned)k_mlow);
+      if (k_mem) atomicAdd(icell + 6 * 32 + l, (unsigned)k_mem);
+      if (k_cover) atomicAdd(icell + 7 * 32 + l, (unsigned)k_cover);
+      if (k_mover) atomicAdd(icell + 8 * 32 + l, (unsigned)k_mover);
+      const unsigned fl = (unsigned)(k_vbad | (k_fbad << 1) | (k_dvnan << 2) | (k_qlnan << 3));
+      if (fl) atomicOr(icell + 9 * 32 + l, fl);
+      // the convergence cells are free by now: [0] max |dV|, [1] max loading (both >= 0)
+      atomicMax(cell + 0 * 32 + l, f2_bits(k_dv));
+      atomicMax(cell + 1 * 32 + l, f2_bits(k_ql));
+    }
+  }
+  // (the convergence cells [0], [1] were last read before the solver's final barrier; cell [2] is not reused)
+  f2_lds_sync();
+  stp.hit(F2_ST_EPI_REDUCE);
+
+  if (wave != 0) {
+    // ---- observation block of this workgroup's 32 instances, straight from the two LDS tiles: lane = column pair ----
+    // (|V|, angle) per bus and (flow, loading) per line are adjacent observation columns (grid_env.py:758-763)
+    if (PA.out != nullptr) {
+      for (int r = wave - 1; r < 32; r += GS_F2_WAVES - 1) {
+        const int br = g * GS_LANES + hs * 32 + r;
+        if (br >= B) continue;
+        double* o = PA.out + (size_t)br * PA.obs_dim;
+        if (!(PA.obs_dim & 1)) {            // every row of the block starts on a 16-byte boundary: one store per column pair
+          for (int cp = lane; cp < n; cp += 64) *(double2*)(o + 2 * cp) = f2_ld2(f2_slot(cp, r));
+          for (int cp = lane; cp < m; cp += 64) *(double2*)(o + 2 * n + 2 * cp) = f2_ld2(F.off_tile + (unsigned)cp * F2_SLOT_BYTES + ((unsigned)r << 4));
+        } else {
+          for (int cp = lane; cp < n; cp += 64) { const double2 v = f2_ld2(f2_slot(cp, r)); o[2 * cp] = v.x; o[2 * cp + 1] = v.y; }
+          for (int cp = lane; cp < m; cp += 64) {
+            const double2 v = f2_ld2(F.off_tile + (unsigned)cp * F2_SLOT_BYTES + ((unsigned)r << 4)); o[2 * n + 2 * cp] = v.x; o[2 * n + 2 * cp + 1] = v.y; }
+        }
+      }
+    }
+    stp.hit(F2_ST_EPILOGUE);
+    return;
+  }
+  // ---- wave 0: everything of step() that follows the load flow, per instance (grid_env.py:553-617) ----
+  double losses = 0.0;
+  dev = 0.0;
+  for (int w = 0; w < GS_F2_WAVES; ++w) { losses += red_lsum[w * 32 + l]; dev += red_dev[w * 32 + l]; }
+  vmax = f2_dbl(cell[3 * 32 + l]); vmin = f2_dbl(cell[4 * 32 + l]);
+  over = (int)icell[0 * 32 + l]; vflags = (int)icell[1 * 32 + l];
+  const bool st_lane = hv == 0;                       // both halves hold the same values; half 0 stores
+  if (st_lane) {
+    ROW(R.LOSSES) = losses; ROW(R.MAXMIS) = st.mm; ROW(R.ITERS) = (double)st.iters; ROW(R.CONV) = (double)st.conv; ROW(R.STATUS) = (double)st.status;
+  }
+  const double dt = E.timestep;
+  double total_gen = 0.0, total_curt = 0.0;                            // grid_env.py:744-751, 807-816
+  for (int gi = 0; gi < ng; ++gi) {
+    const double p = env_lds[(F.env_genp + gi) * 32 + l];
+    total_gen += p;
+    total_curt += p * (1.0 - env_lds[(F.env_curt + gi) * 32 + l]);
+  }
+  const double totloss = totloss0 + losses * dt / 3600.0;              // grid_env.py:739
+  const double imbalance = (total_gen - total_load - losses * E.power_base) / 1e6;
+  double f = f_old;                                                    // dynamics.py:260-273
+  f += ((imbalance - E.D * (f - E.f0)) / (2.0 * E.H * E.f0)) * dt;
+  f = fmax(55.0, fmin(65.0, f));
+  double reward = 0.0;                                                 // grid_env.py:785-826
+  reward -= dev * 10.0;
+  reward -= fabs(f - 60.0) * 20.0;
+  reward -= (double)(over * 50);
+  reward -= totloss * 0.1;
+  reward += (total_gen - total_curt) * 1e-5;
+  for (int q = 0; q < nb; ++q) {
+    const double soc = env_lds[(F.env_soc + q) * 32 + l];
+    reward += (soc >= 0.2 && soc <= 0.8) ? 1.0 : -5.0;
+  }
+  const int vhigh = vflags & 1, vlow = (vflags >> 1) & 1, fhigh = f > E.f_max, flow_ = f < E.f_min;
+  double viol = viol0, trunc = 0.0;
+  if (vhigh | vlow | fhigh | flow_) {
+    viol += 1.0;
+    if (viol > 10.0) { trunc = 1.0; reward -= E.safety_penalty; }     // grid_env.py:604-606
+  }
+  if (st_lane) {
+    ROW(R.TOTLOSS) = totloss; ROW(R.FREQ) = f; ROW(R.VIOL) = viol; ROW(R.TRUNC) = trunc;
+    ROW(R.TERM) = (step0 >= (double)E.episode_length) ? 1.0 : 0.0;     // base.py:140-142
+    ROW(R.REWARD) = reward; ROW(R.EPREW) = eprew0 + reward;
+    ROW(R.VMAX) = vmax; ROW(R.VMIN) = vmin;
+    ROW(R.VFLAGS + 0) = (double)vhigh; ROW(R.VFLAGS + 1) = (double)vlow;
+    ROW(R.VFLAGS + 2) = (double)fhigh; ROW(R.VFLAGS + 3) = (double)flow_;
+    // the observation columns that are neither bus nor line pairs: frequency, renewable powers, battery state
+    // (grid_env.py:766, 773-781); the static load columns in between are written at reset and never change
+    if (PA.out != nullptr && valid) {
+      double* o = PA.out + (size_t)b * PA.obs_dim;
+      const int c_f = 2 * n + 2 * m, c_g = c_f + 1 + 2 * nl_, c_b = c_g + ng;
+      o[c_f] = f;
+      for (int gi = 0; gi < ng; ++gi) o[c_g + gi] = env_lds[(F.env_genp + gi) * 32 + l];
+      for (int q = 0; q < nb; ++q) { o[c_b + 2 * q] = env_lds[(F.env_soc + q) * 32 + l]; o[c_b + 2 * q + 1] = env_lds[(F.env_batp + q) * 32 + l]; }
+    }
+  }
+  if (chk && st_lane && b < (int)FC.Bp && valid) {
+    // same finalisation as gs_k_checks (kernels_checks.hip) / the first-generation fused epilogue, on the values of this very step
+    const int c_nlow = (int)icell[2 * 32 + l], c_nhigh = (int)icell[3 * 32 + l], m_nhigh = (int)icell[4 * 32 + l], m_nlow = (int)icell[5 * 32 + l];
+    const int m_nem = (int)icell[6 * 32 + l], c_nover = (int)icell[7 * 32 + l], m_nover = (int)icell[8 * 32 + l];
+    const unsigned fl = icell[9 * 32 + l];
+    const int vbad = fl & 1, fbad = (fl >> 1) & 1;
+    k_dv = (fl & 4) ? NAN : f2_dbl(cell[0 * 32 + l]);
+    k_ql = (fl & 8) ? NAN : f2_dbl(cell[1 * 32 + l]);
+    if (m == 0) k_ql = -INFINITY;
+    int32_t* has_prev = FC.state + b; int32_t* consec = FC.state + FC.Bp + b; int32_t* emode = FC.state + 2 * FC.Bp + b;
+#define OI(k) FC.out_i[(size_t)(k) * FC.Bp + b]
+#define OF(k) FC.out_f[(size_t)(k) * FC.Bp + b]
+    const int c_flow = f < K.c_flo, c_fhigh = !c_flow && f > K.c_fhi;        // safety.py:140-147
+    const double vrate = k_dv / K.dt;                                        // NaN stays NaN
+    const double frate = fabs(f - Pv[(size_t)n * GS_LANES]) / K.dt;          // :174
+    const int hp = *has_prev;
+    const int c_vr = hp && vrate > K.c_rocv, c_fr = hp && frate > K.c_rocf;
+    Pv[(size_t)n * GS_LANES] = f; *has_prev = 1;
+    const int c_total = c_nlow + c_nhigh + c_flow + c_fhigh + c_nover + c_vr + c_fr;
+    OI(GS_CI_C_NLOW) = c_nlow; OI(GS_CI_C_NHIGH) = c_nhigh; OI(GS_CI_C_FLOW) = c_flow; OI(GS_CI_C_FHIGH) = c_fhigh;
+    OI(GS_CI_C_NOVER) = c_nover; OI(GS_CI_C_VRATE) = c_vr; OI(GS_CI_C_FRATE) = c_fr; OI(GS_CI_C_TOTAL) = c_total;
+    OI(GS_CI_C_SEVERITY) = c_total > 5 ? 3 : (c_total > 2 ? 2 : (c_total > 0 ? 1 : 0));
+    OF(GS_CF_VRATE) = vrate; OF(GS_CF_FRATE) = frate;
+    const int m_fhigh = f > K.m_fhi, m_flow = !m_fhigh && f < K.m_flo, m_fem = f > K.m_efhi || f < K.m_eflo;
+    const int m_total = m_nhigh + m_nlow + m_nem + m_fhigh + m_flow + m_fem + m_nover;
+    const int cs = m_total > 0 ? *consec + 1 : 0;
+    const int trigger = (m_nem > 0) || m_fem || cs > 5 || m_total > 10;
+    const int mode = *emode | trigger;
+    *consec = cs; *emode = mode;
+    OI(GS_CI_M_NHIGH) = m_nhigh; OI(GS_CI_M_NLOW) = m_nlow; OI(GS_CI_M_NEMERG) = m_nem; OI(GS_CI_M_FHIGH) = m_fhigh; OI(GS_CI_M_FLOW) = m_flow;
+    OI(GS_CI_M_FEMERG) = m_fem; OI(GS_CI_M_NOVER) = m_nover; OI(GS_CI_M_TOTAL) = m_total; OI(GS_CI_M_ACTION) = trigger;
+    OI(GS_CI_M_CONSEC) = cs; OI(GS_CI_M_EMODE) = mode;
+    double q = 1.0;                                                          // robust_power_flow.py:615-657
+    if (vmin < 0.8 || vmax > 1.2) q *= 0.3;
+    else if (vmin < 0.9 || vmax > 1.1) q *= 0.7;
+    if (m > 0 && k_ql == k_ql) { if (k_ql > 2.0) q *= 0.2; else if (k_ql > 1.0) q *= 0.5; }
+    if (st.mm > K.q_tol * 100.0) q *= 0.6;
+    if (st.iters <= 5) q *= 1.1; else if (st.iters > 20) q *= 0.9;
+    q = fmin(q, 1.0);
+    if (!st.conv || vbad || fbad) q = 0.0;
+    OF(GS_CF_QUALITY) = q;
+#undef OI
+#undef OF
+  }
+  stp.hit(F2_ST_EPI_SCALARS);
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+gs_k_step_fbs_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
+  f2_step<0>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);
+}
+extern "C" __global__ void __launch_bounds__(1024)     /* the step with the post-step checks in its epilogue */
+gs_k_stepc_fbs_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
+  f2_step<1>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);
+}

@@ -232,12 +232,12 @@ def test_dataflow_sweeps_on_a_bus_with_many_children(monkeypatch):
     P_spec[3] = 0.0                                        # nothing to solve: stops at the flat start
     flow = P.BatchedForwardBackwardSweepSolver(tolerance=1e-10, max_iterations=100)
     a = flow.solve_batch(spec, P_spec)
-    assert flow.handle_for(spec, B).describe()["kernel"] == "fbs_flow"
+    assert flow.handle_for(spec, B).describe()["solve_kernel"] == "fbs_flow"
     monkeypatch.setenv("GS_NO_FLOW", "1")
     sync = P.BatchedForwardBackwardSweepSolver(tolerance=1e-10, max_iterations=100)
     b = sync.solve_batch(spec, P_spec)
     monkeypatch.delenv("GS_NO_FLOW")
-    assert sync.handle_for(spec, B).describe()["kernel"] in ("fbs_lds", "fbs")
+    assert sync.handle_for(spec, B).describe()["solve_kernel"] in ("fbs_lds", "fbs")
     nr = P.BatchedNewtonRaphsonSolver(tolerance=1e-12, max_iterations=50).solve_batch(spec, P_spec)
     assert a.converged.all() and b.converged.all() and nr.converged.all()
     assert np.array_equal(a.iterations, b.iterations)
