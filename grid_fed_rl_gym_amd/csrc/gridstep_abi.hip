@@ -581,79 +581,84 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     wb_ptr[h->W] = (int)wbus.size();
   }
 
-  // ---- second-generation sweep kernel for the env step: records per (wave, item, half) ----
-  std::vector<GsF2Rec> f2recs; std::vector<int32_t> f2nit(GS_F2_WAVES, 0), f2child; std::vector<double> f2z;
+  // ---- second-generation sweep kernel for the env step: one record per position of the forest's preorder ----
+  std::vector<GsF2Rec> f2recs; std::vector<int32_t> f2anc; std::vector<double> f2z;
   if (h->solve_kernel == 6) {
     std::string& why = h->flow2_why;
-    const int nsl = ht.n + 3, SL_ZERO = ht.n, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2;
-    // pairs of buses of the same level, dealt in level order (deepest first) to the wave with the fewest so far
-    std::vector<std::vector<std::pair<int, int>>> mine(GS_F2_WAVES);
-    std::vector<std::vector<int>> mine_lv(GS_F2_WAVES);
-    for (int lv = 0; lv < ht.n_levels; ++lv)
-      for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; t += 2) {
-        int w = 0;
-        for (int v = 1; v < GS_F2_WAVES; ++v) if (mine[v].size() < mine[w].size()) w = v;
-        mine[w].push_back({ht.lvl_bus[t], t + 1 < ht.lvl_ptr[lv + 1] ? ht.lvl_bus[t + 1] : -1});
-        mine_lv[w].push_back(lv);
+    const int nsl = ht.n + 3, SL_ZERO = ht.n, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2, NPOS = GS_F2_WAVES * 2 * GS_F2_ITEMS;
+    // preorder of the tree below the slack (children in list order), subtree sizes, depth in edges from the slack
+    std::vector<int> order, size(ht.n, 1), depth(ht.n, 0);
+    {
+      std::vector<std::vector<int>> kids(ht.n);
+      std::vector<int> roots;
+      for (int lv = ht.n_levels - 1; lv >= 0; --lv)
+        for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; ++t) {
+          const int i = ht.lvl_bus[t], fp = ht.fbs_parent[i];
+          if (fp == ht.slack) roots.push_back(i); else kids[fp].push_back(i);
+        }
+      std::sort(roots.begin(), roots.end());
+      for (auto& k : kids) std::sort(k.begin(), k.end());
+      std::vector<std::pair<int, int>> stack;
+      for (int ri = (int)roots.size() - 1; ri >= 0; --ri) stack.push_back({roots[ri], 1});
+      while (!stack.empty()) {
+        auto [i, d] = stack.back(); stack.pop_back();
+        order.push_back(i); depth[i] = d;
+        for (int q = (int)kids[i].size() - 1; q >= 0; --q) stack.push_back({kids[i][q], d + 1});
       }
-    int max_items = 0, max_ch = 0, max_dev = 0;
-    for (auto& v : mine) max_items = std::max<int>(max_items, (int)v.size());
-    for (int i = 0; i < ht.n; ++i) {
-      max_ch = std::max(max_ch, ht.child_ptr[i + 1] - ht.child_ptr[i]);
-      max_dev = std::max({max_dev, ht.bl_ptr[i + 1] - ht.bl_ptr[i], ht.bg_ptr[i + 1] - ht.bg_ptr[i], ht.bb_ptr[i + 1] - ht.bb_ptr[i]});
+      for (int p = (int)order.size() - 1; p >= 0; --p) { const int i = order[p], fp = ht.fbs_parent[i]; if (fp != ht.slack) size[fp] += size[i]; }
     }
+    const int N = (int)order.size();
+    int max_depth = 1, max_dev = 0;
+    for (int i : order) max_depth = std::max(max_depth, depth[i]);
+    for (int i = 0; i < ht.n; ++i)
+      max_dev = std::max({max_dev, ht.bl_ptr[i + 1] - ht.bl_ptr[i], ht.bg_ptr[i + 1] - ht.bg_ptr[i], ht.bb_ptr[i + 1] - ht.bb_ptr[i]});
+    int n_jump = 0;
+    while ((1 << n_jump) < max_depth) ++n_jump;
+    n_jump = std::max(2, (n_jump + 1) & ~1);                         // even: the last round then reads the second buffer
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     GsF2Tables& F = h->F2;
     size_t off = up16((size_t)nsl * GS_F2_PITCH * 16);
-    F.off_tile = (int32_t)off; off += up16(std::max<size_t>((size_t)ht.m * GS_F2_PITCH * 16, (size_t)(topo->n_loads + 4) * 32 * sizeof(double)));
-    F.off_flags = (int32_t)off; off += up16((size_t)nsl * 4);
-    F.off_child = (int32_t)off; off += up16((size_t)ht.n * GS_F2_CHILDREN * 4);
+    // second buffer: the solver's ping-pong partner / prefix sums (slot numbering of the first), the load powers before,
+    // the line tile of the observation block after
+    F.off_tile = (int32_t)off; off += up16(std::max<size_t>({(size_t)nsl * GS_F2_PITCH * 16, (size_t)ht.m * GS_F2_PITCH * 16, (size_t)(topo->n_loads + 4) * 32 * sizeof(double)}));
+    F.off_anc = (int32_t)off; off += up16((size_t)n_jump * nsl * 4);
     F.off_z = (int32_t)off; off += up16((size_t)nsl * 16);
     F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
     F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * 32 * sizeof(double));
     F.off_red = (int32_t)off; off += 2 * GS_F2_WAVES * 32 * sizeof(double);
     F.off_atom = (int32_t)off; off += 5 * 32 * sizeof(unsigned long long) + 16 * 32 * sizeof(uint32_t);
-    F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack;
+    F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack; F.n_jump = n_jump;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
-    else if (max_items > GS_F2_ITEMS) why = "more than " + std::to_string(GS_F2_ITEMS) + " bus pairs per wave";
-    else if (max_ch > GS_F2_CHILDREN) why = "a bus has more than " + std::to_string(GS_F2_CHILDREN) + " children";
+    else if (N > NPOS) why = "more than " + std::to_string(NPOS) + " buses below the slack";
+    else if (N != ht.lvl_ptr[ht.n_levels]) why = "part of the forest does not hang off the slack bus";
     else if (max_dev > 2) why = "more than two devices of a kind at one bus";
     else if (off > 160 * 1024) why = "LDS tables do not fit";
-    else if (ht.n < 2 || ht.m < 1) why = "trivial network";
+    else if (ht.n < 2 || ht.m < 1 || N < 1) why = "trivial network";
     if (why.empty()) {
       h->flow2 = true;
-      GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE;
-      f2recs.assign((size_t)GS_F2_WAVES * GS_F2_ITEMS * 2, idle);
-      f2child.assign((size_t)ht.n * GS_F2_CHILDREN, SL_ZERO);
+      GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY;
+      f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 2, 0.0);
-      for (int i = 0; i < ht.n; ++i)
-        for (int q = ht.child_ptr[i]; q < ht.child_ptr[i + 1]; ++q) f2child[(size_t)i * GS_F2_CHILDREN + (q - ht.child_ptr[i])] = ht.child_idx[q];
-      for (int w = 0; w < GS_F2_WAVES; ++w) {
-        f2nit[w] = (int)mine[w].size();
-        for (int j = 0; j < (int)mine[w].size(); ++j) {
-          const int pair[2] = {mine[w][j].first, mine[w][j].second};
-          int maxch = 0;
-          for (int hh = 0; hh < 2; ++hh) if (pair[hh] >= 0) maxch = std::max(maxch, ht.child_ptr[pair[hh] + 1] - ht.child_ptr[pair[hh]]);
-          for (int hh = 0; hh < 2; ++hh) {
-            GsF2Rec& r = f2recs[((size_t)w * GS_F2_ITEMS + j) * 2 + hh];
-            r.maxch = maxch; r.level = mine_lv[w][j];
-            const int i = pair[hh];
-            if (i < 0) continue;
-            const int fp = ht.fbs_parent[i], pos = ht.fbs_parent_pos[i];
-            const double yr = -ht.G[pos], yi = -ht.B[pos], yd = yr * yr + yi * yi;      // branch admittance = -Y_ip; z = 1 / y
-            r.bus = i; r.parent = fp; r.flags = 1 | (fp == ht.slack ? 2 : 0);
-            r.zr = yr / yd; r.zi = -yi / yd; r.yr = yr; r.yi = yi;
-            f2z[2 * (size_t)i] = r.zr; f2z[2 * (size_t)i + 1] = r.zi;
-            r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
-            if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
-            if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
-            if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
-            if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
-            if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
-            if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
-          }
-        }
+      f2anc.assign((size_t)n_jump * nsl, SL_ZERO);
+      for (int p = 0; p < N; ++p) {
+        GsF2Rec& r = f2recs[p];
+        const int i = order[p];
+        const int fp = ht.fbs_parent[i], pos = ht.fbs_parent_pos[i];
+        const double yr = -ht.G[pos], yi = -ht.B[pos], yd = yr * yr + yi * yi;      // branch admittance = -Y_ip; z = 1 / y
+        r.bus = i; r.parent = fp; r.flags = 1 | (fp == ht.slack ? 2 : 0); r.last = order[p + size[i] - 1]; r.level = depth[i];
+        r.zr = yr / yd; r.zi = -yi / yd; r.yr = yr; r.yi = yi;
+        f2z[2 * (size_t)i] = r.zr; f2z[2 * (size_t)i + 1] = r.zi;
+        f2anc[i] = fp == ht.slack ? SL_ZERO : fp;
+        r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
+        if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
+        if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
+        if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
+        if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
+        if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
+        if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
       }
+      for (int r = 1; r < n_jump; ++r)
+        for (int sidx = 0; sidx < nsl; ++sidx) f2anc[(size_t)r * nsl + sidx] = f2anc[(size_t)(r - 1) * nsl + f2anc[(size_t)(r - 1) * nsl + sidx]];
     }
   }
 
@@ -686,8 +691,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
 #undef UP
-  if (h->flow2 && ((rc = dev_upload(h, &h->F2.recs, f2recs)) || (rc = dev_upload(h, &h->F2.nit, f2nit)) ||
-                   (rc = dev_upload(h, &h->F2.child, f2child)) || (rc = dev_upload(h, &h->F2.zbus, f2z)))) return bail(rc);
+  if (h->flow2 && ((rc = dev_upload(h, &h->F2.recs, f2recs)) || (rc = dev_upload(h, &h->F2.anc, f2anc)) ||
+                   (rc = dev_upload(h, &h->F2.zbus, f2z)))) return bail(rc);
 
   // ---- configs ----
   h->SC.tolerance = cfg->tolerance; h->SC.alpha = cfg->acceleration_factor;

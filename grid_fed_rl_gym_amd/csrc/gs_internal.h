@@ -298,25 +298,23 @@ struct GsPackArgs {
 // wave-uniform (bus index, impedance, child list, row index) is now uniform per HALF: it lives in vector registers,
 // loaded from the per-(wave, item, half) records below.
 #define GS_F2_PITCH 33            /* 16-byte entries per LDS slot: 32 lanes + 1 (transposed reads conflict-free) */
-#define GS_F2_ITEMS 5             /* pair items per wave (kernel unrolls over them) */
-#define GS_F2_CHILDREN 8          /* children per bus in the LDS child table */
+#define GS_F2_ITEMS 4             /* buses per half wave: 16 waves x 2 halves x 4 = 128 positions of the forest's preorder */
 #define GS_F2_WAVES 16
-struct GsF2Rec {                  // one (wave, item, half); 128 bytes
-  int32_t bus, parent, flags, maxch;        // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); maxch: max children of the PAIR
+struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half) * GS_F2_ITEMS + item); 96 bytes
+  int32_t bus, parent, flags, last;         // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); last: the bus at the LAST position of this bus's subtree
   int32_t nl, l0, l1, ng;                   // devices at the bus, reference accumulation order (grid_env.py:689-718)
   int32_t g0, g1, nb, b0;
   int32_t b1, level, pad1, pad2;
   double zr, zi, yr, yi;                    // branch to the parent: z = 1 / y
-  double pad[4];
 };
 struct GsF2Tables {
-  const GsF2Rec* recs;            // [GS_F2_WAVES][GS_F2_ITEMS][2]
-  const int32_t* nit;             // [GS_F2_WAVES] items of each wave
-  const int32_t* child;           // [n][GS_F2_CHILDREN] child slots, padded with slot ZERO
+  const GsF2Rec* recs;            // [GS_F2_WAVES * 2 * GS_F2_ITEMS]
+  const int32_t* anc;             // [n_jump][n_slots] 2^r-th ancestor of every slot on its way to the slack, ZERO beyond
   const double* zbus;             // [n_slots][2] impedance of the branch from each bus to its parent (0 where there is none)
   int32_t n_slots;                // n + 3: buses, then ZERO (0, 0), ONE (1, 0), DUMMY
   int32_t slack;                  // slot of the slack bus
-  int32_t off_tile, off_flags, off_child, off_z, off_env, off_red, off_atom, lds_bytes;     // LDS byte offsets (slots at 0)
+  int32_t n_jump;                 // rounds of the forward sweep's pointer jumping: ceil(log2(depth)), rounded up to even
+  int32_t off_tile, off_anc, off_z, off_env, off_red, off_atom, lds_bytes;     // LDS byte offsets (slots at 0)
   int32_t env_genp, env_curt, env_batp, env_soc;      // row indices inside the env area ([row][32 lanes] doubles)
 };
 

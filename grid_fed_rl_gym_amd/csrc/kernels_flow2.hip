@@ -56,28 +56,6 @@ __device__ __forceinline__ void f2_st2(unsigned off, double2 v) { f2_v2 w; w.x =
 __device__ __forceinline__ double f2_ld(unsigned off) { return *F2_P(const double, off); }
 __device__ __forceinline__ void f2_st(unsigned off, double v) { *F2_P(double, off) = v; }
 
-// message protocol of the sweeps (see fbs_loop_flow): producer writes the message, then the epoch into the bus's flag
-// word; consumer asks for flag and message in ONE round trip and asks again until the flag is there.  The LDS executes a
-// compute unit's instructions in issue order, so no wait is needed in between on either side.
-__device__ __forceinline__ double2 f2_take(unsigned msg_off, unsigned flag_off, int epoch) {
-  double2 v = make_double2(0.0, 0.0);
-  bool seen = false;
-  for (int spin = 0; spin < F2_SPIN_CAP; ++spin) {
-    const int f = *F2_VP(int, flag_off);
-    v.x = *F2_VP(double, msg_off);
-    v.y = *F2_VP(double, msg_off + 8);
-    if (__all(f - epoch >= 0)) { seen = true; break; }
-  }
-  if (!seen) v = make_double2(NAN, NAN);        // a hand-off that never arrived must not pass for data (status NAN)
-  return v;
-}
-__device__ __forceinline__ void f2_give(unsigned msg_off, unsigned flag_off, int epoch, int l, double x, double y) {
-  *F2_VP(double, msg_off) = x;
-  *F2_VP(double, msg_off + 8) = y;
-  if (l == 0) *F2_VP(int, flag_off) = epoch;
-}
-__device__ __forceinline__ double2 f2_vld2(unsigned off) { return make_double2(*F2_VP(double, off), *F2_VP(double, off + 8)); }
-
 // LDS integer atomics (exact and order-independent; workgroup scope is all LDS needs)
 #define atomicMax(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define atomicMin(p, v) __hip_atomic_fetch_min((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -136,10 +114,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const bool valid = b < B;
   const GsLaneRows S = gs_lane_rows(slab, g, R.total, L);
   const int n = T.n, m = T.m, nsl = F.n_slots;
-  const int SL_ZERO = n, SL_ONE = n + 1, SL_DUMMY = n + 2;
-  (void)SL_ONE; (void)SL_DUMMY;
-  int F2_AS3* const flags = F2_P(int, F.off_flags);
-  int F2_AS3* const child_lds = F2_P(int, F.off_child);
+  const int SL_ZERO = n;                 // slots n, n + 1, n + 2: ZERO (0, 0), ONE (1, 0), DUMMY (idle positions)
   double F2_AS3* const env_lds = F2_P(double, F.off_env);                 // [row][32 lanes]
   double F2_AS3* const loadp_lds = F2_P(double, F.off_tile);               // [load][32 lanes], dead before the line tile is written
   double F2_AS3* const red_lsum = F2_P(double, F.off_red);                 // [16 waves][32 lanes]
@@ -149,7 +124,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   F2Stamp stp{C.stamps, 0ull, blockIdx.x == 0 && wave == C.stamp_wave && lane == 0};
   if (C.stamps) stp.t = __builtin_readcyclecounter();
 
-  // ---- LDS init: flat start in every slot, flags, child table, cells -----------------------------------------------
+  // ---- LDS init: flat start in every slot, ancestor and impedance tables, cells -----------------------------------------------
   for (int k = threadIdx.x; k < nsl * 32; k += blockDim.x) {
     const int s = k >> 5, ll = k & 31;
     double e = 1.0;
@@ -157,8 +132,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     else if (s == SL_ZERO) e = 0.0;
     f2_st2(f2_slot(s, ll), make_double2(e, 0.0));
   }
-  for (int s = threadIdx.x; s < nsl; s += blockDim.x) flags[s] = (s < n && T.lvl_pos[s] >= 0) ? 0 : INT_MAX;   // nobody's item: never polled for
-  for (int k = threadIdx.x; k < n * GS_F2_CHILDREN; k += blockDim.x) child_lds[k] = F.child[k];
+  for (int k = threadIdx.x; k < F.n_jump * nsl; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];
   for (int k = threadIdx.x; k < 2 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];
   for (int k = threadIdx.x; k < 5 * 32; k += blockDim.x) cell[k] = (k >= 4 * 32) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
   for (int k = threadIdx.x; k < 16 * 32; k += blockDim.x) icell[k] = 0u;
@@ -243,23 +217,18 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   f2_lds_sync();                                  // what the injection pass reads is in LDS
   stp.hit(F2_ST_PRO_SCALAR);
 
-  // ---- the records of this lane's items --------------------------------------------------------------------------
-  const int nit = __builtin_amdgcn_readfirstlane(F.nit[wave]);
-  const GsF2Rec* const rec0 = F.recs + ((size_t)wave * GS_F2_ITEMS) * 2 + hv;
-  // (bus, parent) stay in registers; the branch impedance comes from an LDS table by bus -- requested together with the
-  // bus's own message, i.e. it adds nothing to a hop --, "root" is "the parent is the slack bus", "idle half" is "bus >= n"
-  int ibus[GS_F2_ITEMS], ipar[GS_F2_ITEMS], imaxch[GS_F2_ITEMS];
+  // ---- the records of this lane's items: position p = ((wave * 2 + half) * GS_F2_ITEMS + j) of the forest's preorder ----
+  const GsF2Rec* const rec0 = F.recs + ((size_t)(wave * 2 + hv) * GS_F2_ITEMS);
+  int ibus[GS_F2_ITEMS], ilast[GS_F2_ITEMS];
+  unsigned roots = 0u;                   // bit j: item j hangs off the slack bus
 #pragma unroll
-  for (int j = 0; j < GS_F2_ITEMS; ++j) {
-    const GsF2Rec* q = rec0 + 2 * j;
-    ibus[j] = q->bus; ipar[j] = q->parent; imaxch[j] = __builtin_amdgcn_readfirstlane(q->maxch);
-  }
+  for (int j = 0; j < GS_F2_ITEMS; ++j) { ibus[j] = rec0[j].bus; ilast[j] = rec0[j].last; roots |= (rec0[j].flags & 2) ? (1u << j) : 0u; }
 
   // ---- injections of this lane's buses, reference accumulation order (grid_env.py:683-720, power_flow.py:112-121) ----
-  double Pj[GS_F2_ITEMS], IR[GS_F2_ITEMS], II[GS_F2_ITEMS];
+  double Pj[GS_F2_ITEMS], IR[GS_F2_ITEMS], II[GS_F2_ITEMS], JR[GS_F2_ITEMS], JI[GS_F2_ITEMS];
 #pragma unroll
   for (int j = 0; j < GS_F2_ITEMS; ++j) {
-    const GsF2Rec* q = rec0 + 2 * j;
+    const GsF2Rec* q = rec0 + j;
     const int nl = q->nl, l0 = q->l0, l1 = q->l1, ngj = q->ng, g0 = q->g0, g1 = q->g1, nbj = q->nb, b0 = q->b0, b1 = q->b1;
     double ls = 0.0, gs = 0.0;
     if (nl > 0) ls += loadp_lds[l0 * 32 + l];
@@ -269,14 +238,33 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     if (nbj > 0) { const double bp = env_lds[(F.env_batp + b0) * 32 + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
     if (nbj > 1) { const double bp = env_lds[(F.env_batp + b1) * 32 + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
     Pj[j] = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base);
-    IR[j] = 0.0; II[j] = 0.0;
+    IR[j] = 0.0; II[j] = 0.0; JR[j] = 0.0; JI[j] = 0.0;
   }
   stp.hit(F2_ST_PROLOGUE);
+  f2_lds_sync();                     // the load powers (tile region) have been read: the region becomes the solver's second buffer
+  if (wave == 0) f2_st2((unsigned)F.off_tile + f2_slot(SL_ZERO, l), make_double2(0.0, 0.0));      // "no ancestor" reads as 0 in both buffers
 
-  // ================= the sweeps (see fbs_loop_flow, kernels_solve.hip, for the algorithm) =================
+  // ================= the sweeps =================
+  // The algorithm is the one of fbs_loop_flow (kernels_solve.hip): flat start, mismatch S_spec - V conj(I) evaluated on
+  // the way down, one division per bus and iteration, converged lanes keep their currents.  What differs is how the two
+  // tree recurrences are evaluated.  With per-bus messages a sweep costs one LDS hand-off per tree LEVEL (11 on the
+  // IEEE-123 feeder, ~900 cycles each with sixteen waves polling), and the six to eight sweeps of a solve were 60 % of
+  // the step.  Both recurrences are sums, so they have log-depth forms with plain barriers in between:
+  //   backward  J_i = -I_i + sum_children J_c = sum of -I over the SUBTREE of i.  The buses sit in preorder of the forest,
+  //             a subtree is the contiguous range [p_i, last_i], so J_i = Q[last_i] - Q[p_i - 1] with Q the inclusive
+  //             prefix sums of -I: a scan of <= 128 values per instance = local scan of a lane's items, the 16 wave
+  //             totals through LDS, one barrier, offsets, Q to LDS, one barrier, one read.
+  //   forward   V_i = V_slack - sum of z_k J_k over the PATH root .. i.  Pointer jumping: S_i starts as D_i = z_i J_i
+  //             and in round r adds the S of the 2^r-th ancestor (ancestor tables from the host); ceil(log2 depth)
+  //             rounds, two LDS buffers in turn, a barrier per round.
+  // The sums associate differently from the sequential recurrences: results agree with them to a few ulp of |V|
+  // (absolute ~1e-16 in J, ~1e-15 in V; the tests compare at 1e-12).
   F2State st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
-  int epoch = 1, check = 0;
+  int check = 0;
+  const unsigned bufA = 0u, bufB = (unsigned)F.off_tile;
+  f2_v2 F2_AS3* const tot_lds = F2_P(f2_v2, F.off_red);            // [16 waves][32 lanes] wave totals of the scan
+  const int F2_AS3* const anc_lds = F2_P(const int, F.off_anc);    // [n_jump][n_slots]
   // cross-wave maximum of the mismatch: LDS integer maximum on the bit pattern (mismatch >= 0; inf and NaN patterns are
   // the largest), three cells in rotation so that nobody clears one that is still being read
   auto wg_max = [&](double lmax) -> double {
@@ -288,71 +276,99 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_lds_sync();
     return f2_dbl(cell[c0 * 32 + l]);
   };
+  // backward sweep: J of this lane's buses from the injection currents of all buses
+  auto backward = [&]() {
+    double qr[GS_F2_ITEMS], qi[GS_F2_ITEMS];
+    double ar = 0.0, ai = 0.0;
+#pragma unroll
+    for (int j = 0; j < GS_F2_ITEMS; ++j) { ar += -IR[j]; ai += -II[j]; qr[j] = ar; qi[j] = ai; }      // local inclusive scan
+    const double orr = f2_xhalf(ar), oi = f2_xhalf(ai);
+    const double t0r = hv ? orr : ar, t0i = hv ? oi : ai, t1r = hv ? ar : orr, t1i = hv ? ai : oi;      // half 0's and half 1's totals
+    if (hv == 0) { f2_v2 t; t.x = t0r + t1r; t.y = t0i + t1i; tot_lds[wave * 32 + l] = t; }
+    f2_lds_sync();
+    double br = 0.0, bi = 0.0;                                    // sum of the totals of the waves before this one, in wave order
+    for (int w = 0; w < wave; ++w) { const f2_v2 t = tot_lds[w * 32 + l]; br += t.x; bi += t.y; }
+    if (hv) { br += t0r; bi += t0i; }
+    // Q of position p is filed under the BUS at that position (buffer B shares the slot numbering of buffer A, whose
+    // "no ancestor" slot must stay zero); idle positions all file under the DUMMY slot, which nobody reads
+#pragma unroll
+    for (int j = 0; j < GS_F2_ITEMS; ++j) f2_st2(bufB + f2_slot(ibus[j], l), make_double2(br + qr[j], bi + qi[j]));      // Q[p]
+    f2_lds_sync();
+#pragma unroll
+    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+      const double2 ql = f2_ld2(bufB + f2_slot(ilast[j], l));       // Q at the last position of the bus's subtree
+      const double er = j ? br + qr[j ? j - 1 : 0] : br, ei = j ? bi + qi[j ? j - 1 : 0] : bi;             // Q[p - 1]
+      JR[j] = ibus[j] < n ? ql.x - er : 0.0; JI[j] = ibus[j] < n ? ql.y - ei : 0.0;
+    }
+  };
   stp.hit(F2_ST_INIT);
-  {  // first backward chain, at the flat start: every voltage but the slack's is 1, S_calc = conj(K) with K = y (1 - V_parent)
+  {  // at the flat start: every voltage but the slack's is 1, S_calc = conj(K) with K = y (1 - V_slack) at the roots
     double lmax = 0.0, bad = 0.0;
 #pragma unroll
     for (int j = 0; j < GS_F2_ITEMS; ++j) {
-      if (j < nit) {
-        const GsF2Rec* q = rec0 + 2 * j;
-        const double p = Pj[j];
-        const bool root = ipar[j] == F.slack;
-        const double ep = root ? f2_ld(f2_slot(ipar[j], l)) : 1.0;
-        const double dr = 1.0 - ep;
-        const double kr = q->yr * dr, ki = q->yi * dr;
-        const double pc = kr, qc = -ki;
-        const double dP = p - pc, dQ = 0.0 - qc;
-        lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
-        bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
-        psum += pc;
-        if (root) psum -= ep * kr;                            // the slack's share: Re(V_s conj(-K_root))
-        IR[j] = p; II[j] = -0.0;                              // I = conj(S_spec / V) at V = 1
-        double jr = -p, ji = 0.0;                             // J_i = -I_i + sum J_c
-        const unsigned cbase = (unsigned)ibus[j] * GS_F2_CHILDREN;
-        for (int u = 0; u < imaxch[j]; ++u) {
-          const int ch = ibus[j] < n ? child_lds[cbase + u] : SL_ZERO;
-          const double2 jc = f2_take(f2_slot(ch, l), F.off_flags + 4u * ch, epoch);
-          jr += jc.x; ji += jc.y;
-        }
-        f2_give(f2_slot(ibus[j], l), F.off_flags + 4u * ibus[j], epoch, l, jr, ji);
-      }
+      const GsF2Rec* q = rec0 + j;
+      const double p = Pj[j];
+      const bool root = (roots >> j) & 1u;
+      const double ep = root ? f2_ld(f2_slot(F.slack, l)) : 1.0;
+      const double dr = 1.0 - ep;
+      const double kr = q->yr * dr, ki = q->yi * dr;
+      const double pc = kr, qc = -ki;
+      const double dP = p - pc, dQ = 0.0 - qc;
+      lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+      bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
+      psum += pc;
+      if (root) psum -= ep * kr;                              // the slack's share: Re(V_s conj(-K_root))
+      IR[j] = p; II[j] = -0.0;                                // I = conj(S_spec / V) at V = 1
     }
     if (bad != bad) lmax = INFINITY;
-    stp.hit(F2_ST_BOTTOM_UP);
     const double mm = wg_max(lmax);
     stp.hit(F2_ST_FLAG);
     f2_check(st, mm, 0, C.tolerance);
+    if (!__all(st.done)) backward();
+    stp.hit(F2_ST_BOTTOM_UP);
   }
+  const double vs_r = f2_ld(f2_slot(F.slack, l));               // the slack's set point (real)
+  const int R2 = F.n_jump;                                      // even
   for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
     const bool upd = !st.done;
     double lmax = 0.0, pnew = 0.0, bad = 0.0;
-    ++epoch;
-    // forward chain: V_i = V_parent - z_i J_i
+    // forward sweep by pointer jumping; buffers alternate so that the last round reads B (then A may take the voltages)
+    double sr[GS_F2_ITEMS], si[GS_F2_ITEMS];
 #pragma unroll
-    for (int j = GS_F2_ITEMS - 1; j >= 0; --j) {
-      if (j < nit) {
-        const unsigned own = f2_slot(ibus[j], l);
-        const double2 cj = f2_vld2(own); const double cjr = cj.x, cji = cj.y;   // this lane's own backward item left it there
-        const double2 z = f2_ld2(F.off_z + 16u * ibus[j]);
-        const double zjr = __builtin_fma(cjr, z.x, -(cji * z.y)), zji = __builtin_fma(cjr, z.y, cji * z.x);   // z J: known before the parent is
-        const double2 vp = f2_take(f2_slot(ipar[j], l), F.off_flags + 4u * ipar[j], epoch);
-        if (ipar[j] == F.slack) pnew += vp.x * cjr;                  // the slack's share of the losses sum: Re(V_s conj(J_root)), V_s real
-        f2_give(own, F.off_flags + 4u * ibus[j], epoch, l, vp.x - zjr, vp.y - zji);
+    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+      const double2 z = f2_ld2(F.off_z + 16u * ibus[j]);
+      sr[j] = __builtin_fma(JR[j], z.x, -(JI[j] * z.y)); si[j] = __builtin_fma(JR[j], z.y, JI[j] * z.x);      // D = z J
+      f2_st2(bufA + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
+      if ((roots >> j) & 1u) pnew += vs_r * JR[j];              // the slack's share of the losses sum: Re(V_s conj(J_root)), V_s real
+    }
+    f2_lds_sync();
+    for (int r = 0; r < R2; ++r) {
+      const unsigned rd = (r & 1) ? bufB : bufA, wr = (r & 1) ? bufA : bufB;
+#pragma unroll
+      for (int j = 0; j < GS_F2_ITEMS; ++j) {
+        const int a = anc_lds[r * nsl + ibus[j]];
+        const double2 sa = f2_ld2(rd + f2_slot(a, l));
+        sr[j] += sa.x; si[j] += sa.y;
+      }
+      if (r + 1 < R2) {
+#pragma unroll
+        for (int j = 0; j < GS_F2_ITEMS; ++j) f2_st2(wr + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
+        f2_lds_sync();
       }
     }
     stp.hit(F2_ST_TOP_DOWN);
-    // body: mismatch and sum of P_calc at the new voltages (power_flow.py:150-168)
+    // V = V_slack - S; mismatch and sum of P_calc at the new voltages (power_flow.py:150-168); the voltages go to buffer A
+    // (its last reader was round R2 - 2, a barrier ago), where the epilogue finds those of the last sweep
 #pragma unroll
     for (int j = 0; j < GS_F2_ITEMS; ++j) {
-      if (j < nit) {
-        const unsigned own = f2_slot(ibus[j], l);
-        const double2 vn = f2_vld2(own); const double en = vn.x, fn = vn.y;
-        const double pc = __builtin_fma(en, IR[j], fn * II[j]), qc = __builtin_fma(fn, IR[j], -(en * II[j]));     // S_calc = V_new conj(I_old)
-        const double dP = Pj[j] - pc, dQ = 0.0 - qc;
-        lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
-        bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
-        pnew += pc;
-      }
+      const double en = vs_r - sr[j], fn = 0.0 - si[j];
+      sr[j] = en; si[j] = fn;
+      f2_st2(bufA + f2_slot(ibus[j], l), make_double2(en, fn));
+      const double pc = __builtin_fma(en, IR[j], fn * II[j]), qc = __builtin_fma(fn, IR[j], -(en * II[j]));     // S_calc = V_new conj(I_old)
+      const double dP = Pj[j] - pc, dQ = 0.0 - qc;
+      lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+      bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
+      pnew += pc;
     }
     if (bad != bad) lmax = INFINITY;
     stp.hit(F2_ST_MISMATCH);
@@ -362,34 +378,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     stp.hit(F2_ST_FLAG);
     f2_check(st, mm, it + 1, C.tolerance);
     if (__all(st.done)) break;
-    ++epoch;
     // I_new = conj(S_spec / V_new) for the lanes that go on; a lane that has converged keeps the current that produced
     // its voltages: its J and V repeat bit for bit while the rest of the group iterates
 #pragma unroll
     for (int j = 0; j < GS_F2_ITEMS; ++j) {
-      if (j < nit) {
-        const unsigned own = f2_slot(ibus[j], l);
-        const double2 vn = f2_vld2(own); const double en = vn.x, fn = vn.y;
-        const double rd = 1.0 / __builtin_fma(en, en, fn * fn);
-        // (an idle half shares the DUMMY slot with the idle halves of other waves, which may hold a current or a voltage
-        // by now: its own current stays zero whatever is there)
-        if (!st.done && ibus[j] < n) { IR[j] = (Pj[j] * en) * rd; II[j] = (Pj[j] * fn) * rd; }
-      }
+      const double rd = 1.0 / __builtin_fma(sr[j], sr[j], si[j] * si[j]);
+      if (!st.done && ibus[j] < n) { IR[j] = (Pj[j] * sr[j]) * rd; II[j] = (Pj[j] * si[j]) * rd; }      // (idle positions keep a zero current)
     }
-    // backward chain: J_i = -I_i + sum J_c
-#pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) {
-      if (j < nit) {
-        double jr = -IR[j], ji = -II[j];
-        const unsigned cbase = (unsigned)ibus[j] * GS_F2_CHILDREN;
-        for (int u = 0; u < imaxch[j]; ++u) {
-          const int ch = ibus[j] < n ? child_lds[cbase + u] : SL_ZERO;
-          const double2 jc = f2_take(f2_slot(ch, l), F.off_flags + 4u * ch, epoch);
-          jr += jc.x; ji += jc.y;
-        }
-        f2_give(f2_slot(ibus[j], l), F.off_flags + 4u * ibus[j], epoch, l, jr, ji);
-      }
-    }
+    backward();
     stp.hit(F2_ST_BOTTOM_UP);
   }
   f2_sync();                         // every slot final

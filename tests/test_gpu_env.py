@@ -332,7 +332,7 @@ def test_warm_started_sweep_solver_agrees_with_the_cold_start():
         assert np.max(np.abs(oc - ow) / np.maximum(1.0, np.abs(oc))) < 1e-7
         its_c += ic["iterations"].sum(); its_w += iw["iterations"].sum()
         if t == 0:
-            assert np.max(np.abs(oc - ow)) < 1e-15                 # the first step after reset starts flat either way
+            assert np.max(np.abs(oc - ow) / np.maximum(1.0, np.abs(oc))) < 1e-12     # the first step after reset starts flat either way (two kernels: sums associate differently)
         if t == 2:
             snap = warm.get_state()
     assert its_w < its_c                    # independent 10 % load noise every step leaves little to resume from: ~0.4 sweeps
