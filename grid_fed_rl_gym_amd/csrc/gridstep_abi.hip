@@ -81,6 +81,7 @@ struct gs_handle {
   // the env step of a handle whose solver is the dataflow sweep runs the second-generation kernel (kernels_flow2.hip:
   // 32 instances per workgroup, half-waves on different buses) when the feeder fits its tables; gs_solve keeps kernel 6
   bool flow2 = false; GsF2Tables F2{}; std::string flow2_why;
+  bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
   std::vector<void*> allocs;
@@ -275,6 +276,16 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
     const GsFusedChecks fc = fused_checks_args(h);
+    if (h->nr2) {
+      if (fc.enabled)
+        hipLaunchKernelGGL(gs_k_stepc_nr_flow2, dim3(2 * h->groups), dim3(64 * GS_F2N_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
+                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+      else
+        hipLaunchKernelGGL(gs_k_step_nr_flow2, dim3(2 * h->groups), dim3(64 * GS_F2N_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
+                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+      HIPCHK(h, hipGetLastError());
+      return GS_OK;
+    }
     if (h->flow2) {        // two workgroups per 64-instance slab group, each with its own 32 instances
       if (fc.enabled)
         hipLaunchKernelGGL(gs_k_stepc_fbs_flow2, dim3(2 * h->groups), dim3(64 * GS_F2_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
@@ -431,7 +442,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", max_dyn));
-    for (const void* f : {(const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2})      // no static LDS in these
+    for (const void* f : {(const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2, (const void*)gs_k_step_nr_flow2,
+                          (const void*)gs_k_stepc_nr_flow2})      // no static LDS in these
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", 160 * 1024));
   }
@@ -662,6 +674,100 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     }
   }
 
+  // ---- Newton-Raphson member of the second-generation family: pairs of same-level buses per (wave, item) ----
+  if (h->solve_kernel == 4 && ht.fbs_ok) {
+    std::string& why = h->flow2_why;
+    const int NW = GS_F2N_WAVES, NI = GS_F2N_ITEMS, NPOS = NW * 2 * NI;
+    const int nsl = ht.n + 3, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2, maxw = ht.max_level_width;
+    std::vector<std::vector<std::pair<int, int>>> mine(NW);
+    std::vector<std::vector<int>> mine_lv(NW);
+    bool all_pq = true, off_slack = true;
+    for (int lv = 0; lv < ht.n_levels; ++lv)
+      for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; t += 2) {
+        int w = 0;
+        for (int v = 1; v < NW; ++v) if (mine[v].size() < mine[w].size()) w = v;
+        mine[w].push_back({ht.lvl_bus[t], t + 1 < ht.lvl_ptr[lv + 1] ? ht.lvl_bus[t + 1] : -1});
+        mine_lv[w].push_back(lv);
+      }
+    int max_items = 0, max_ch = 0, max_dev = 0;
+    for (auto& v : mine) max_items = std::max<int>(max_items, (int)v.size());
+    for (int i = 0; i < ht.n; ++i) {
+      max_ch = std::max(max_ch, ht.child_ptr[i + 1] - ht.child_ptr[i]);
+      max_dev = std::max({max_dev, ht.bl_ptr[i + 1] - ht.bl_ptr[i], ht.bg_ptr[i + 1] - ht.bg_ptr[i], ht.bb_ptr[i + 1] - ht.bb_ptr[i]});
+      if (i != ht.slack && ht.lvl_pos[i] >= 0 && !(ht.th_free[i] && ht.vm_free[i])) all_pq = false;
+      if (i != ht.slack && ht.lvl_pos[i] < 0) off_slack = false;                       // a bus outside the forest
+      if (ht.lvl_pos[i] >= 0 && ht.parent[i] < 0 && ht.fbs_parent[i] != ht.slack) off_slack = false;
+    }
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    GsF2Tables& F = h->F2;
+    size_t off = up16((size_t)nsl * GS_F2_PITCH * 16);
+    const size_t ring_bytes = (size_t)2 * maxw * 3 * 32 * 16;
+    F.off_tile = (int32_t)off; off += up16(std::max<size_t>({(size_t)nsl * GS_F2_PITCH * 16, ring_bytes, (size_t)ht.m * GS_F2_PITCH * 16, (size_t)(topo->n_loads + 4) * 32 * sizeof(double)}));
+    const int pos_off = (2 * ht.n * GS_F2_CHILDREN + nsl + 3) & ~3;
+    const int n_ints = pos_off + NPOS * 4;
+    F.off_anc = (int32_t)off; off += up16((size_t)n_ints * 4);
+    F.off_z = (int32_t)off; off += up16((size_t)nsl * 32);
+    F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
+    F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * 32 * sizeof(double));
+    F.off_red = (int32_t)off; off += 2 * NW * 32 * sizeof(double);
+    F.off_atom = (int32_t)off; off += 5 * 32 * sizeof(unsigned long long) + 16 * 32 * sizeof(uint32_t);
+    F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack; F.n_jump = 0; F.n_levels = ht.n_levels; F.pos_off = pos_off; F.n_anc_ints = n_ints;
+    if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
+    else if (!h->SC.jacobian_exact && cfg->jacobian_mode != GS_JACOBIAN_EXACT) why = "as-coded Jacobian";
+    else if (!all_pq) why = "a bus below the slack is not a PQ bus";
+    else if (!off_slack) why = "part of the network does not hang off the slack bus";
+    else if (max_items > NI) why = "more than " + std::to_string(NI) + " bus pairs per wave";
+    else if (max_ch > GS_F2_CHILDREN) why = "a bus has more than " + std::to_string(GS_F2_CHILDREN) + " children";
+    else if (max_dev > 2) why = "more than two devices of a kind at one bus";
+    else if (off > 160 * 1024) why = "LDS tables do not fit";
+    else if (ht.n < 2 || ht.m < 1) why = "trivial network";
+    if (why.empty()) {
+      h->nr2 = true;
+      GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY; idle.level = -1;
+      f2recs.assign((size_t)NPOS, idle);
+      f2z.assign((size_t)nsl * 4, 0.0);
+      f2anc.assign((size_t)n_ints, 0);
+      int32_t* child_bus = f2anc.data(); int32_t* child_ring = child_bus + ht.n * GS_F2_CHILDREN; int32_t* nch = child_ring + ht.n * GS_F2_CHILDREN;
+      int32_t* pos_tab = f2anc.data() + pos_off;
+      std::vector<int> level_of(ht.n, 0);
+      for (int lv = 0; lv < ht.n_levels; ++lv) for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; ++t) level_of[ht.lvl_bus[t]] = lv;
+      auto ring_of = [&](int i) { return (level_of[i] & 1) * maxw + ht.lvl_pos[i]; };
+      for (int i = 0; i < ht.n; ++i) {
+        nch[i] = ht.child_ptr[i + 1] - ht.child_ptr[i];
+        for (int q = ht.child_ptr[i]; q < ht.child_ptr[i + 1]; ++q) {
+          const int c = ht.child_idx[q];
+          child_bus[i * GS_F2_CHILDREN + (q - ht.child_ptr[i])] = c; child_ring[i * GS_F2_CHILDREN + (q - ht.child_ptr[i])] = ring_of(c);
+        }
+        if (ht.lvl_pos[i] >= 0) {
+          const int pos = ht.fbs_parent_pos[i];
+          f2z[4 * (size_t)i] = ht.G[pos]; f2z[4 * (size_t)i + 1] = ht.B[pos]; f2z[4 * (size_t)i + 2] = ht.Gd[i]; f2z[4 * (size_t)i + 3] = ht.Bd[i];
+        }
+      }
+      for (int p = 0; p < NPOS; ++p) { pos_tab[4 * p] = SL_DUMMY; pos_tab[4 * p + 1] = SL_ONE; pos_tab[4 * p + 2] = 0; pos_tab[4 * p + 3] = 0; }
+      for (int w = 0; w < NW; ++w)
+        for (int j = 0; j < (int)mine[w].size(); ++j) {
+          const int pair[2] = {mine[w][j].first, mine[w][j].second};
+          for (int hh = 0; hh < 2; ++hh) {
+            const int p = (w * 2 + hh) * NI + j;
+            GsF2Rec& r = f2recs[p];
+            r.level = mine_lv[w][j];
+            const int i = pair[hh];
+            if (i < 0) continue;
+            const int fp = ht.fbs_parent[i];
+            r.bus = i; r.parent = fp; r.flags = 1 | (fp == ht.slack ? 2 : 0); r.last = i;
+            pos_tab[4 * p] = i; pos_tab[4 * p + 1] = fp; pos_tab[4 * p + 2] = ring_of(i); pos_tab[4 * p + 3] = fp == ht.slack ? 0 : ring_of(fp);
+            r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
+            if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
+            if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
+            if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
+            if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
+            if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
+            if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
+          }
+        }
+    }
+  }
+
   // ---- tables ----
   GsTables& T = h->T;
   T.n = n; T.m = m; T.nnz = ht.nnz; T.n_levels = ht.n_levels;
@@ -691,7 +797,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
 #undef UP
-  if (h->flow2 && ((rc = dev_upload(h, &h->F2.recs, f2recs)) || (rc = dev_upload(h, &h->F2.anc, f2anc)) ||
+  if ((h->flow2 || h->nr2) && ((rc = dev_upload(h, &h->F2.recs, f2recs)) || (rc = dev_upload(h, &h->F2.anc, f2anc)) ||
                    (rc = dev_upload(h, &h->F2.zbus, f2z)))) return bail(rc);
 
   // ---- configs ----
@@ -809,11 +915,11 @@ int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
            "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d, "
            "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"solve_kernel\": \"%s\", \"flow2\": \"%s\"}",
-           h->flow2 ? "fbs_flow2" : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
-           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, h->flow2 ? GS_F2_WAVES : h->W, h->groups,
+           h->flow2 ? "fbs_flow2" : h->nr2 ? "nr_flow2" : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
+           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, h->flow2 ? GS_F2_WAVES : h->nr2 ? GS_F2N_WAVES : h->W, h->groups,
            h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim,
-           h->flow2 ? 32 : 64, h->flow2 ? 2 * h->groups : h->groups, h->flow2 ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576,
-           kn[h->solve_kernel], h->flow2 ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()));
+           (h->flow2 || h->nr2) ? 32 : 64, (h->flow2 || h->nr2) ? 2 * h->groups : h->groups, (h->flow2 || h->nr2) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576,
+           kn[h->solve_kernel], (h->flow2 || h->nr2) ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()));
   return GS_OK;
 }
 

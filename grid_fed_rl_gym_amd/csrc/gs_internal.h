@@ -300,6 +300,9 @@ struct GsPackArgs {
 #define GS_F2_PITCH 33            /* 16-byte entries per LDS slot: 32 lanes + 1 (transposed reads conflict-free) */
 #define GS_F2_ITEMS 4             /* buses per half wave: 16 waves x 2 halves x 4 = 128 positions of the forest's preorder */
 #define GS_F2_WAVES 16
+#define GS_F2N_WAVES 8            /* the Newton-Raphson member of the family: 8 waves x 2 halves x 8 buses (its bus state needs the registers) */
+#define GS_F2N_ITEMS 8
+#define GS_F2_CHILDREN 8          /* children per bus in the Newton-Raphson kernel's LDS child tables */
 struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half) * GS_F2_ITEMS + item); 96 bytes
   int32_t bus, parent, flags, last;         // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); last: the bus at the LAST position of this bus's subtree
   int32_t nl, l0, l1, ng;                   // devices at the bus, reference accumulation order (grid_env.py:689-718)
@@ -309,11 +312,15 @@ struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half
 };
 struct GsF2Tables {
   const GsF2Rec* recs;            // [GS_F2_WAVES * 2 * GS_F2_ITEMS]
-  const int32_t* anc;             // [n_jump][n_slots] 2^r-th ancestor of every slot on its way to the slack, ZERO beyond
-  const double* zbus;             // [n_slots][2] impedance of the branch from each bus to its parent (0 where there is none)
+  const int32_t* anc;             // sweeps: [n_jump][n_slots] 2^r-th ancestor of every slot on its way to the slack, ZERO beyond;
+                                  // Newton-Raphson: child buses [n][8], child ring slots [n][8], child counts [n_slots], then at
+                                  // pos_off (a multiple of 4) per position (bus, parent, own ring slot, parent's ring slot); n_anc_ints in all
+  const double* zbus;             // sweeps: [n_slots][2] impedance of the branch from each bus to its parent (0 where there is none);
+                                  // Newton-Raphson: [n_slots][4] (G_ip, B_ip, G_ii, B_ii)
   int32_t n_slots;                // n + 3: buses, then ZERO (0, 0), ONE (1, 0), DUMMY
   int32_t slack;                  // slot of the slack bus
   int32_t n_jump;                 // rounds of the forward sweep's pointer jumping: ceil(log2(depth)), rounded up to even
+  int32_t n_levels, pos_off, n_anc_ints, pad0;   // Newton-Raphson: levels of the tree below the slack; layout of `anc`
   int32_t off_tile, off_anc, off_z, off_env, off_red, off_atom, lds_bytes;     // LDS byte offsets (slots at 0)
   int32_t env_genp, env_curt, env_batp, env_soc;      // row indices inside the env area ([row][32 lanes] doubles)
 };

@@ -51,11 +51,15 @@ __device__ __forceinline__ void f2_lds_sync() { asm volatile("s_waitcnt lgkmcnt(
 #define F2_VP(type, off) ((volatile type F2_AS3*)((F2_AS3 char*)f2_lds + (off)))
 __device__ __forceinline__ unsigned f2_slot(int slot, int l) { return (unsigned)slot * F2_SLOT_BYTES + ((unsigned)l << 4); }
 typedef double f2_v2 __attribute__((ext_vector_type(2)));        // 16 bytes: one ds_read_b128 / ds_write_b128
+typedef int f2_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double2 f2_ld2(unsigned off) { const f2_v2 v = *F2_P(const f2_v2, off); return make_double2(v.x, v.y); }
 __device__ __forceinline__ void f2_st2(unsigned off, double2 v) { f2_v2 w; w.x = v.x; w.y = v.y; *F2_P(f2_v2, off) = w; }
 __device__ __forceinline__ double f2_ld(unsigned off) { return *F2_P(const double, off); }
 __device__ __forceinline__ void f2_st(unsigned off, double v) { *F2_P(double, off) = v; }
 
+// Keeps the compiler from hoisting everything derived from a per-item index (slot, table and ring addresses of 8 items x
+// three phases: ~100 registers) out of the Newton loop: the addresses are a shift and an add away wherever they are used.
+#define F2_OPAQUE(x) asm volatile("" : "+v"(x))
 // LDS integer atomics (exact and order-independent; workgroup scope is all LDS needs)
 #define atomicMax(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define atomicMin(p, v) __hip_atomic_fetch_min((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -91,6 +95,22 @@ __device__ __forceinline__ double f2_angle(double f, double e) {
   return __builtin_fma(t * z, p, t);
 }
 
+// The rare path of the Newton correction (a step of more than half a radian, or a magnitude that changes sign): the new
+// voltage through libm, as power_flow.py:315-327 does.  Not inlined: libm's atan2 / sincos bring three dozen constants that
+// would otherwise be hoisted into vector registers for the whole Newton loop.
+__device__ __attribute__((noinline)) double2 f2_polar_update(double e, double f, double dth, double vmn) {
+  double vmm = vmn, vaa = atan2(f, e) + dth;
+  if (vmm < 0.0) { vmm = -vmm; vaa += M_PI; }
+  double sn, cs;
+  sincos(vaa, &sn, &cs);
+  return make_double2(vmm * cs, vmm * sn);
+}
+
+// Taylor coefficients of (sin x - x) / x^3 and (cos x - 1) / x^2 in x^2, highest power first (|x| <= 0.5: truncation < 1e-21)
+__device__ const double kF2Series[16] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0,
+                                         1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0,
+                                         1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0, 1.0 / 40320.0,
+                                         -1.0 / 720.0, 1.0 / 24.0, -0.5};
 enum { F2_ST_PROLOGUE = 0, F2_ST_INIT, F2_ST_MISMATCH, F2_ST_BOTTOM_UP, F2_ST_FLAG, F2_ST_TOP_DOWN, F2_ST_FINAL_MISMATCH, F2_ST_EPILOGUE,
        F2_ST_PRO_SCALAR, F2_ST_PRO_SPARE, F2_ST_EPI_BUSES, F2_ST_EPI_LINES, F2_ST_EPI_REDUCE, F2_ST_EPI_SCALARS };
 struct F2Stamp {
@@ -103,7 +123,11 @@ struct F2Stamp {
   }
 };
 
-template <int CHK>
+// SOLVER: 0 forward/backward sweep, 1 Newton-Raphson.  NW wavefronts per workgroup, NI buses per half wave (NW * 2 * NI = 128
+// positions): the sweep kernel runs 16 x 4, Newton-Raphson -- whose bus state (voltage, the T and s of the elimination)
+// lives in registers across its two sweeps -- 8 x 8, i.e. twice the registers per wave.
+enum { F2_FBS = 0, F2_NR = 1 };
+template <int SOLVER, int CHK, int NW, int NI>
 __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                         double* __restrict__ slab, int B, const double* __restrict__ actions, double total_load,
                                         const GsPackArgs& PA, const GsFusedChecks& FC) {
@@ -118,7 +142,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   double F2_AS3* const env_lds = F2_P(double, F.off_env);                 // [row][32 lanes]
   double F2_AS3* const loadp_lds = F2_P(double, F.off_tile);               // [load][32 lanes], dead before the line tile is written
   double F2_AS3* const red_lsum = F2_P(double, F.off_red);                 // [16 waves][32 lanes]
-  double F2_AS3* const red_dev = red_lsum + GS_F2_WAVES * 32;
+  double F2_AS3* const red_dev = red_lsum + NW * 32;
   unsigned long long F2_AS3* const cell = F2_P(unsigned long long, F.off_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits
   unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 5 * 32);                // [16][32] integer counts
   F2Stamp stp{C.stamps, 0ull, blockIdx.x == 0 && wave == C.stamp_wave && lane == 0};
@@ -132,8 +156,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     else if (s == SL_ZERO) e = 0.0;
     f2_st2(f2_slot(s, ll), make_double2(e, 0.0));
   }
-  for (int k = threadIdx.x; k < F.n_jump * nsl; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];
-  for (int k = threadIdx.x; k < 2 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];
+  if (SOLVER == F2_FBS) {
+    for (int k = threadIdx.x; k < F.n_jump * nsl; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];
+    for (int k = threadIdx.x; k < 2 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];
+  } else {
+    for (int k = threadIdx.x; k < F.n_anc_ints; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];          // child tables + per-position indices
+    for (int k = threadIdx.x; k < 4 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];             // (G_ip, B_ip, G_ii, B_ii) per bus
+  }
   for (int k = threadIdx.x; k < 5 * 32; k += blockDim.x) cell[k] = (k >= 4 * 32) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
   for (int k = threadIdx.x; k < 16 * 32; k += blockDim.x) icell[k] = 0u;
 
@@ -196,7 +225,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   } else {
     // realised load powers (dynamics.py:54-75): loads 4 p .. 4 p + 3 share one Philox call; one quad per HALF wave
     const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
-    for (int p = (wave - 2) * 2 + hv; 4 * p < nl_; p += (GS_F2_WAVES - 2) * 2) {
+    for (int p = (wave - 2) * 2 + hv; 4 * p < nl_; p += (NW - 2) * 2) {
       double z[4] = {0.0, 0.0, 0.0, 0.0};
       if (E.stochastic_loads) rng_normal_quad(seed, inst, snew, DRAW_LOAD0 + p, z);
       const int l0 = 4 * p;
@@ -217,17 +246,17 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   f2_lds_sync();                                  // what the injection pass reads is in LDS
   stp.hit(F2_ST_PRO_SCALAR);
 
-  // ---- the records of this lane's items: position p = ((wave * 2 + half) * GS_F2_ITEMS + j) of the forest's preorder ----
-  const GsF2Rec* const rec0 = F.recs + ((size_t)(wave * 2 + hv) * GS_F2_ITEMS);
-  int ibus[GS_F2_ITEMS], ilast[GS_F2_ITEMS];
+  // ---- the records of this lane's items: position p = ((wave * 2 + half) * NI + j) of the forest's preorder ----
+  const GsF2Rec* const rec0 = F.recs + ((size_t)(wave * 2 + hv) * NI);
+  int ibus[NI], ilast[NI];
   unsigned roots = 0u;                   // bit j: item j hangs off the slack bus
 #pragma unroll
-  for (int j = 0; j < GS_F2_ITEMS; ++j) { ibus[j] = rec0[j].bus; ilast[j] = rec0[j].last; roots |= (rec0[j].flags & 2) ? (1u << j) : 0u; }
+  for (int j = 0; j < NI; ++j) { ibus[j] = rec0[j].bus; ilast[j] = rec0[j].last; roots |= (rec0[j].flags & 2) ? (1u << j) : 0u; }
 
   // ---- injections of this lane's buses, reference accumulation order (grid_env.py:683-720, power_flow.py:112-121) ----
-  double Pj[GS_F2_ITEMS], IR[GS_F2_ITEMS], II[GS_F2_ITEMS], JR[GS_F2_ITEMS], JI[GS_F2_ITEMS];
+  double Pj[NI], IR[NI], II[NI], JR[NI], JI[NI];
 #pragma unroll
-  for (int j = 0; j < GS_F2_ITEMS; ++j) {
+  for (int j = 0; j < NI; ++j) {
     const GsF2Rec* q = rec0 + j;
     const int nl = q->nl, l0 = q->l0, l1 = q->l1, ngj = q->ng, g0 = q->g0, g1 = q->g1, nbj = q->nb, b0 = q->b0, b1 = q->b1;
     double ls = 0.0, gs = 0.0;
@@ -244,6 +273,217 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   f2_lds_sync();                     // the load powers (tile region) have been read: the region becomes the solver's second buffer
   if (wave == 0) f2_st2((unsigned)F.off_tile + f2_slot(SL_ZERO, l), make_double2(0.0, 0.0));      // "no ancestor" reads as 0 in both buffers
 
+  F2State st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
+  double psum = 0.0;
+  int check = 0;
+  // cross-wave maximum of the mismatch: LDS integer maximum on the bit pattern (mismatch >= 0; inf and NaN patterns are
+  // the largest), three cells in rotation so that nobody clears one that is still being read
+  auto wg_max = [&](double lmax) -> double {
+    const int c0 = check % 3, c1 = (check + 1) % 3;
+    ++check;
+    lmax = fmax(lmax, f2_xhalf(lmax));
+    if (wave == 0 && hv == 0) cell[c1 * 32 + l] = 0ull;
+    if (hv == 0) atomicMax(cell + c0 * 32 + l, f2_bits(lmax));
+    f2_lds_sync();
+    return f2_dbl(cell[c0 * 32 + l]);
+  };
+
+  if constexpr (SOLVER == F2_NR) {
+  // ================= Newton-Raphson (power_flow.py:143-193), exact Jacobian, 2x2-block elimination along the tree =================
+  // Same arithmetic as newton_loop / linsolve_tree_lds of kernels_solve.hip (mismatch :150-171, Jacobian entries :243-287,
+  // corrections :297-327); what differs is where the data lives.  There a bus's state went through slab rows every
+  // iteration (T_i, s_i, V, 1/V, e, f, P/Q calculated: 9x the algorithmic traffic); here vm, va, P_spec and -- between
+  // the bottom-up and the top-down sweep -- T_i and s_i stay in the REGISTERS of the half wave that owns the bus,
+  // (e, f) of every bus sit in the LDS slots (neighbours read them), branch currents K = y (V_i - V_parent) and the
+  // child -> parent / parent -> child messages share the second LDS region.  The two sweeps are level-synchronous
+  // (2x2 inverses do not compose into prefix sums): a wave's items are pairs of buses of one level, walked in level order
+  // with an LDS barrier per level.
+  const unsigned bufA = 0u, bufB = (unsigned)F.off_tile;
+  const int F2_AS3* const tab = F2_P(const int, F.off_anc);
+  const int F2_AS3* const child_bus = tab;                          // [n][8]
+  const int F2_AS3* const child_ring = tab + n * 8;                 // [n][8] ring slots of the children's messages
+  const int F2_AS3* const nch_tab = tab + 2 * n * 8;                // [n_slots]
+  const int F2_AS3* const pos_tab = tab + F.pos_off;                // [positions][4]: bus, parent, ring, parent's ring
+  int ilev[NI];                                                     // level of the wave's j-th pair (-1: none), wave-uniform
+#pragma unroll
+  for (int j = 0; j < NI; ++j) ilev[j] = __builtin_amdgcn_readfirstlane(rec0[j].level);
+  const int pos0 = (wave * 2 + hv) * NI;
+  const int NL = F.n_levels;
+  auto ring3 = [&](int slot, int part) -> unsigned { return bufB + ((unsigned)(slot * 3 + part) * 32u + (unsigned)l) * 16u; };
+  // flat start: the slots hold it already (every bus below the slack is a PQ bus, the host checks).  |V| and the angle are
+  // not kept: |V| = sqrt(e^2 + f^2) where it is needed, corrections rotate (e, f) by the angle increment
+  double pcj[NI], qcj[NI];
+  // S = V conj(Y V) through the branch currents: (Y V)_i = K_i - sum over children K_c; returns this lane's max |mismatch|
+  auto mismatch = [&](bool want_max) -> double {
+    double kr[NI], ki[NI], ee[NI], ff[NI], sl[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+      int bus = ibus[j]; F2_OPAQUE(bus);
+      const int par = pos_tab[(pos0 + j) * 4 + 1];
+      const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(par, l)), y = f2_ld2(F.off_z + 32u * bus);
+      const double dr = v.x - vp.x, di = v.y - vp.y;
+      // branch admittance = -Y_ip
+      kr[j] = __builtin_fma(-y.x, dr, y.y * di); ki[j] = -__builtin_fma(y.x, di, y.y * dr);
+      ee[j] = v.x; ff[j] = v.y;
+      sl[j] = ((roots >> j) & 1u) ? __builtin_fma(vp.x, kr[j], vp.y * ki[j]) : 0.0;      // Re(V_s conj(K_root)): the slack's share of the losses sum, negated below
+      f2_st2(bufB + f2_slot(bus, l), make_double2(kr[j], ki[j]));
+    }
+    f2_lds_sync();
+    double lmax = 0.0, bad = 0.0, ps = 0.0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+      int bus = ibus[j]; F2_OPAQUE(bus);
+      double icr = kr[j], ici = ki[j];
+      const int nch = nch_tab[bus];
+      for (int u = 0; u < nch; ++u) { const double2 kc = f2_ld2(bufB + f2_slot(child_bus[bus * 8 + u], l)); icr -= kc.x; ici -= kc.y; }
+      const double pc = __builtin_fma(ee[j], icr, ff[j] * ici), qc = __builtin_fma(ff[j], icr, -(ee[j] * ici));
+      pcj[j] = pc; qcj[j] = qc;
+      const double dP = Pj[j] - pc, dQ = 0.0 - qc;
+      if (bus < n) { lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ))); bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad)); }
+      ps += pc; ps -= sl[j];
+    }
+    if (bad != bad) lmax = INFINITY;
+    psum = ps;
+    (void)want_max;
+    return lmax;
+  };
+  bool stale = true;
+  for (int it = 0; it < C.max_iterations; ++it) {
+    const double lm = mismatch(true);
+    stp.hit(F2_ST_MISMATCH);
+    const double mm = wg_max(lm);                     // (its barrier also protects the K slots before the ring reuses the region)
+    stp.hit(F2_ST_FLAG);
+    f2_check(st, mm, it, C.tolerance);
+    stale = false;
+    if (__all(st.done)) break;
+    // ---------------- bottom-up: D_i = J_ii - sum C_c, r_i = rhs_i - sum q_c, T_i = D_i^-1 J_ip, s_i = D_i^-1 r_i ----------------
+    double T00[NI], T01[NI], T10[NI], T11[NI], s0[NI], s1[NI];
+    int sing = 0;
+    {
+      int lv = 0;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int lev = ilev[j];
+        const bool live = lev >= 0;                   // an item of this wave (both halves share the level)
+        if (live) { while (lv < lev) { f2_lds_sync(); ++lv; } }
+        int bus = ibus[j]; F2_OPAQUE(bus);
+        int pj = pos0 + j; F2_OPAQUE(pj);
+        const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);      // bus, parent, ring, parent's ring
+        const double2 yo = f2_ld2(F.off_z + 32u * bus), yd = f2_ld2(F.off_z + 32u * bus + 16u);       // (G_ip, B_ip), (G_ii, B_ii)
+        const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(px[1], l));
+        const double vmi = sqrt(__builtin_fma(v.x, v.x, v.y * v.y)), rvm = 1.0 / vmi;
+        const double pc = pcj[j], qc = qcj[j];
+        // diagonal block (power_flow.py:247-248 exact sign, 259-260, 270-271, 283-284)
+        const double vvb = vmi * vmi * yd.y;
+        double d00 = -qc - vvb, d01 = pc * rvm + vmi * yd.x, d10 = pc - vmi * vmi * yd.x, d11 = qc * rvm - vmi * yd.y;
+        double r0 = Pj[j] - pc, r1 = 0.0 - qc;                                   // power_flow.py:159-165
+        const int nch = live && bus < n ? nch_tab[bus] : 0;
+        for (int u = 0; u < nch; ++u) {
+          const int cr = child_ring[bus * 8 + u];
+          const double2 c0 = f2_ld2(ring3(cr, 0)), c1 = f2_ld2(ring3(cr, 1)), cq = f2_ld2(ring3(cr, 2));
+          d00 -= c0.x; d01 -= c0.y; d10 -= c1.x; d11 -= c1.y; r0 -= cq.x; r1 -= cq.y;
+        }
+        const double det = d00 * d11 - d01 * d10;
+        if (live && bus < n && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;       // power_flow.py:188-190: only an exactly singular matrix raises
+        const double rdet = 1.0 / det;
+        const double i00 = d11 * rdet, i01 = -d01 * rdet, i10 = -d10 * rdet, i11 = d00 * rdet;
+        s0[j] = i00 * r0 + i01 * r1; s1[j] = i10 * r0 + i11 * r1;
+        T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0;
+        if (live && bus < n && !((roots >> j) & 1u)) {
+          // J(i, p) and J(p, i) of the branch (power_flow.py:251, 263, 274, 287)
+          const double rvmp = 1.0 / sqrt(__builtin_fma(vp.x, vp.x, vp.y * vp.y));
+          const double a = v.x * vp.x + v.y * vp.y, bbi = v.y * vp.x - v.x * vp.y, bbp = -bbi;
+          const double gsi = yo.x * bbi - yo.y * a, gci = yo.x * a + yo.y * bbi;             // row i, column p
+          const double gsp = yo.x * bbp - yo.y * a, gcp = yo.x * a + yo.y * bbp;             // row p, column i
+          const double u00 = gsi, u01 = gci * rvmp, u10 = -gci, u11 = gsi * rvmp;
+          const double l00 = gsp, l01 = gcp * rvm, l10 = -gcp, l11 = gsp * rvm;
+          const double t00 = i00 * u00 + i01 * u10, t01 = i00 * u01 + i01 * u11, t10 = i10 * u00 + i11 * u10, t11 = i10 * u01 + i11 * u11;
+          T00[j] = t00; T01[j] = t01; T10[j] = t10; T11[j] = t11;
+          f2_st2(ring3(px[2], 0), make_double2(l00 * t00 + l01 * t10, l00 * t01 + l01 * t11));
+          f2_st2(ring3(px[2], 1), make_double2(l10 * t00 + l11 * t10, l10 * t01 + l11 * t11));
+          f2_st2(ring3(px[2], 2), make_double2(l00 * s0[j] + l01 * s1[j], l10 * s0[j] + l11 * s1[j]));
+        }
+      }
+      while (lv < NL) { f2_lds_sync(); ++lv; }
+    }
+    stp.hit(F2_ST_BOTTOM_UP);
+    {  // exact singularity anywhere in the instance: stop it where it is (status 2), as the reference's LinAlgError break does
+      sing |= __shfl_xor(sing, 32);
+      if (sing && hv == 0) atomicOr(icell + 15 * 32 + l, 1u);
+      f2_lds_sync();
+      const unsigned sa = icell[15 * 32 + l];
+      if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+    }
+    const bool upd = !st.done;
+    // ---------------- top-down: x_i = s_i - T_i x_p; corrections (power_flow.py:315-327); new (e, f) into the slots ----------------
+    {
+      int lv = NL - 1;
+#pragma unroll
+      for (int j = NI - 1; j >= 0; --j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int lev = ilev[j];
+        const bool live = lev >= 0;
+        if (live) { while (lv > lev) { f2_lds_sync(); --lv; } }
+        int bus = ibus[j]; F2_OPAQUE(bus);
+        int pj = pos0 + j; F2_OPAQUE(pj);
+        const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);
+        double x0 = s0[j], x1 = s1[j];
+        if (live && bus < n && !((roots >> j) & 1u)) {
+          const double2 xp = f2_ld2(ring3(px[3], 0));
+          x0 -= T00[j] * xp.x + T01[j] * xp.y;
+          x1 -= T10[j] * xp.x + T11[j] * xp.y;
+        }
+        if (live && bus < n) f2_st2(ring3(px[2], 0), make_double2(x0, x1));
+        s0[j] = x0; s1[j] = x1;                       // the Newton step of the bus; applied below, when T is no longer live
+      }
+      while (lv >= 0) { f2_lds_sync(); --lv; }
+    }
+    // corrections (power_flow.py:315-327): theta += alpha dtheta, |V| += alpha d|V|, as a rotation and scaling of (e, f)
+    if (__any(upd)) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        int bus = ibus[j]; F2_OPAQUE(bus);
+        if (upd && bus < n) {
+          const double x0 = s0[j], x1 = s1[j];
+          const double2 v = f2_ld2(bufA + f2_slot(bus, l));
+          const double vm0 = sqrt(__builtin_fma(v.x, v.x, v.y * v.y));
+          const double dth = C.alpha * x0, vmn = vm0 + C.alpha * x1;
+          double en, fn;
+          if (__any(fabs(dth) > 0.5 || !(vmn > 0.0))) {        // large step or sign flip somewhere in the wave: full evaluation
+            const double2 w = f2_polar_update(v.x, v.y, dth, vmn);
+            en = w.x; fn = w.y;
+          } else {
+            // V' = (Vm'/Vm) V e^{j dth}: rotate the rectangular voltage by the increment (Taylor series, |dth| <= 0.5)
+            // (coefficients through the scalar path: as 64-bit literals they would sit in sixteen vector register pairs for
+            // the whole Newton loop)
+            const GS_CONST double* kc = (const GS_CONST double*)kF2Series;
+            const double z = dth * dth;
+            double sp = kc[0];
+            sp = __builtin_fma(sp, z, kc[1]); sp = __builtin_fma(sp, z, kc[2]); sp = __builtin_fma(sp, z, kc[3]);
+            sp = __builtin_fma(sp, z, kc[4]); sp = __builtin_fma(sp, z, kc[5]); sp = __builtin_fma(sp, z, kc[6]); sp = __builtin_fma(sp, z, kc[7]);
+            const double sn = dth - dth * z * sp;
+            double cp = kc[8];
+            cp = __builtin_fma(cp, z, kc[9]); cp = __builtin_fma(cp, z, kc[10]); cp = __builtin_fma(cp, z, kc[11]);
+            cp = __builtin_fma(cp, z, kc[12]); cp = __builtin_fma(cp, z, kc[13]); cp = __builtin_fma(cp, z, kc[14]); cp = __builtin_fma(cp, z, kc[15]);
+            const double cs = __builtin_fma(z, cp, 1.0);
+            const double ratio = vmn / vm0;
+            en = ratio * (v.x * cs - v.y * sn);
+            fn = ratio * (v.x * sn + v.y * cs);
+          }
+          f2_st2(bufA + f2_slot(bus, l), make_double2(en, fn));
+        }
+      }
+    }
+    f2_lds_sync();                   // the new voltages are read by the neighbours' lanes in the next mismatch
+    stp.hit(F2_ST_TOP_DOWN);
+    stale = true;
+  }
+  if (stale) { (void)mismatch(false); }       // iteration cap reached after an update: the losses sum at the final voltages
+  } else {
   // ================= the sweeps =================
   // The algorithm is the one of fbs_loop_flow (kernels_solve.hip): flat start, mismatch S_spec - V conj(I) evaluated on
   // the way down, one division per bus and iteration, converged lanes keep their currents.  What differs is how the two
@@ -259,29 +499,15 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   //             rounds, two LDS buffers in turn, a barrier per round.
   // The sums associate differently from the sequential recurrences: results agree with them to a few ulp of |V|
   // (absolute ~1e-16 in J, ~1e-15 in V; the tests compare at 1e-12).
-  F2State st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
-  double psum = 0.0;
-  int check = 0;
   const unsigned bufA = 0u, bufB = (unsigned)F.off_tile;
   f2_v2 F2_AS3* const tot_lds = F2_P(f2_v2, F.off_red);            // [16 waves][32 lanes] wave totals of the scan
   const int F2_AS3* const anc_lds = F2_P(const int, F.off_anc);    // [n_jump][n_slots]
-  // cross-wave maximum of the mismatch: LDS integer maximum on the bit pattern (mismatch >= 0; inf and NaN patterns are
-  // the largest), three cells in rotation so that nobody clears one that is still being read
-  auto wg_max = [&](double lmax) -> double {
-    const int c0 = check % 3, c1 = (check + 1) % 3;
-    ++check;
-    lmax = fmax(lmax, f2_xhalf(lmax));
-    if (wave == 0 && hv == 0) cell[c1 * 32 + l] = 0ull;
-    if (hv == 0) atomicMax(cell + c0 * 32 + l, f2_bits(lmax));
-    f2_lds_sync();
-    return f2_dbl(cell[c0 * 32 + l]);
-  };
   // backward sweep: J of this lane's buses from the injection currents of all buses
   auto backward = [&]() {
-    double qr[GS_F2_ITEMS], qi[GS_F2_ITEMS];
+    double qr[NI], qi[NI];
     double ar = 0.0, ai = 0.0;
 #pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) { ar += -IR[j]; ai += -II[j]; qr[j] = ar; qi[j] = ai; }      // local inclusive scan
+    for (int j = 0; j < NI; ++j) { ar += -IR[j]; ai += -II[j]; qr[j] = ar; qi[j] = ai; }      // local inclusive scan
     const double orr = f2_xhalf(ar), oi = f2_xhalf(ai);
     const double t0r = hv ? orr : ar, t0i = hv ? oi : ai, t1r = hv ? ar : orr, t1i = hv ? ai : oi;      // half 0's and half 1's totals
     if (hv == 0) { f2_v2 t; t.x = t0r + t1r; t.y = t0i + t1i; tot_lds[wave * 32 + l] = t; }
@@ -292,10 +518,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // Q of position p is filed under the BUS at that position (buffer B shares the slot numbering of buffer A, whose
     // "no ancestor" slot must stay zero); idle positions all file under the DUMMY slot, which nobody reads
 #pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) f2_st2(bufB + f2_slot(ibus[j], l), make_double2(br + qr[j], bi + qi[j]));      // Q[p]
+    for (int j = 0; j < NI; ++j) f2_st2(bufB + f2_slot(ibus[j], l), make_double2(br + qr[j], bi + qi[j]));      // Q[p]
     f2_lds_sync();
 #pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const double2 ql = f2_ld2(bufB + f2_slot(ilast[j], l));       // Q at the last position of the bus's subtree
       const double er = j ? br + qr[j ? j - 1 : 0] : br, ei = j ? bi + qi[j ? j - 1 : 0] : bi;             // Q[p - 1]
       JR[j] = ibus[j] < n ? ql.x - er : 0.0; JI[j] = ibus[j] < n ? ql.y - ei : 0.0;
@@ -305,7 +531,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   {  // at the flat start: every voltage but the slack's is 1, S_calc = conj(K) with K = y (1 - V_slack) at the roots
     double lmax = 0.0, bad = 0.0;
 #pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const GsF2Rec* q = rec0 + j;
       const double p = Pj[j];
       const bool root = (roots >> j) & 1u;
@@ -333,9 +559,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     const bool upd = !st.done;
     double lmax = 0.0, pnew = 0.0, bad = 0.0;
     // forward sweep by pointer jumping; buffers alternate so that the last round reads B (then A may take the voltages)
-    double sr[GS_F2_ITEMS], si[GS_F2_ITEMS];
+    double sr[NI], si[NI];
 #pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const double2 z = f2_ld2(F.off_z + 16u * ibus[j]);
       sr[j] = __builtin_fma(JR[j], z.x, -(JI[j] * z.y)); si[j] = __builtin_fma(JR[j], z.y, JI[j] * z.x);      // D = z J
       f2_st2(bufA + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
@@ -345,14 +571,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     for (int r = 0; r < R2; ++r) {
       const unsigned rd = (r & 1) ? bufB : bufA, wr = (r & 1) ? bufA : bufB;
 #pragma unroll
-      for (int j = 0; j < GS_F2_ITEMS; ++j) {
+      for (int j = 0; j < NI; ++j) {
         const int a = anc_lds[r * nsl + ibus[j]];
         const double2 sa = f2_ld2(rd + f2_slot(a, l));
         sr[j] += sa.x; si[j] += sa.y;
       }
       if (r + 1 < R2) {
 #pragma unroll
-        for (int j = 0; j < GS_F2_ITEMS; ++j) f2_st2(wr + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
+        for (int j = 0; j < NI; ++j) f2_st2(wr + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
         f2_lds_sync();
       }
     }
@@ -360,7 +586,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // V = V_slack - S; mismatch and sum of P_calc at the new voltages (power_flow.py:150-168); the voltages go to buffer A
     // (its last reader was round R2 - 2, a barrier ago), where the epilogue finds those of the last sweep
 #pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const double en = vs_r - sr[j], fn = 0.0 - si[j];
       sr[j] = en; si[j] = fn;
       f2_st2(bufA + f2_slot(ibus[j], l), make_double2(en, fn));
@@ -381,12 +607,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // I_new = conj(S_spec / V_new) for the lanes that go on; a lane that has converged keeps the current that produced
     // its voltages: its J and V repeat bit for bit while the rest of the group iterates
 #pragma unroll
-    for (int j = 0; j < GS_F2_ITEMS; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const double rd = 1.0 / __builtin_fma(sr[j], sr[j], si[j] * si[j]);
       if (!st.done && ibus[j] < n) { IR[j] = (Pj[j] * sr[j]) * rd; II[j] = (Pj[j] * si[j]) * rd; }      // (idle positions keep a zero current)
     }
     backward();
     stp.hit(F2_ST_BOTTOM_UP);
+  }
   }
   f2_sync();                         // every slot final
   stp.hit(F2_ST_FINAL_MISMATCH);
@@ -411,7 +638,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 
   // lines (power_flow.py:340-356; Line.update_state, base.py:261-264): two lines per wave instruction
   int over = 0;
-  for (int k0 = wave * 2 + hv; k0 < ((m + 31) & ~31); k0 += 32) {
+  for (int k0 = wave * 2 + hv; k0 < ((m + 2 * NW - 1) / (2 * NW)) * (2 * NW); k0 += 2 * NW) {
     const bool on = k0 < m; const int k = on ? k0 : m - 1;
     const int li = T.lfrom[k], lj = T.lto[k];
     const double yr = T.lyr[k], yi = T.lyi[k], rating = T.lrating[k], rinv = T.lrating_inv[k];
@@ -441,7 +668,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // buses: (e, f) -> (|V|, angle) in place (the slots become the observation tile), state rows, reward / flag partials
   double dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int vflags = 0;
-  for (int i0 = wave * 2 + hv; i0 < ((n + 31) & ~31); i0 += 32) {
+  for (int i0 = wave * 2 + hv; i0 < ((n + 2 * NW - 1) / (2 * NW)) * (2 * NW); i0 += 2 * NW) {
     const bool on = i0 < n; const int i = on ? i0 : n - 1;
     double2 ef = final_ef(i);
     if (!on) ef = make_double2(1.0, 0.0);                     // keep the wave on the series branch of the angle
@@ -499,7 +726,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // ---- observation block of this workgroup's 32 instances, straight from the two LDS tiles: lane = column pair ----
     // (|V|, angle) per bus and (flow, loading) per line are adjacent observation columns (grid_env.py:758-763)
     if (PA.out != nullptr) {
-      for (int r = wave - 1; r < 32; r += GS_F2_WAVES - 1) {
+      for (int r = wave - 1; r < 32; r += NW - 1) {
         const int br = g * GS_LANES + hs * 32 + r;
         if (br >= B) continue;
         double* o = PA.out + (size_t)br * PA.obs_dim;
@@ -519,7 +746,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // ---- wave 0: everything of step() that follows the load flow, per instance (grid_env.py:553-617) ----
   double losses = 0.0;
   dev = 0.0;
-  for (int w = 0; w < GS_F2_WAVES; ++w) { losses += red_lsum[w * 32 + l]; dev += red_dev[w * 32 + l]; }
+  for (int w = 0; w < NW; ++w) { losses += red_lsum[w * 32 + l]; dev += red_dev[w * 32 + l]; }
   vmax = f2_dbl(cell[3 * 32 + l]); vmin = f2_dbl(cell[4 * 32 + l]);
   over = (int)icell[0 * 32 + l]; vflags = (int)icell[1 * 32 + l];
   const bool st_lane = hv == 0;                       // both halves hold the same values; half 0 stores
@@ -618,13 +845,16 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   stp.hit(F2_ST_EPI_SCALARS);
 }
 
-extern "C" __global__ void __launch_bounds__(1024)
-gs_k_step_fbs_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
-                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
-  f2_step<0>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);
-}
-extern "C" __global__ void __launch_bounds__(1024)     /* the step with the post-step checks in its epilogue */
-gs_k_stepc_fbs_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
-                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
-  f2_step<1>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);
-}
+#define F2_KERNELS(name, SOLVER, NW, NI)                                                                                   \
+  extern "C" __global__ void __launch_bounds__(64 * NW)                                                                    \
+  gs_k_step_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,         \
+                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {               \
+    f2_step<SOLVER, 0, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);                                       \
+  }                                                                                                                        \
+  extern "C" __global__ void __launch_bounds__(64 * NW)     /* the step with the post-step checks in its epilogue */       \
+  gs_k_stepc_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,        \
+                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {              \
+    f2_step<SOLVER, 1, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);                                       \
+  }
+F2_KERNELS(fbs_flow2, F2_FBS, 16, 4)
+F2_KERNELS(nr_flow2, F2_NR, 8, 8)
