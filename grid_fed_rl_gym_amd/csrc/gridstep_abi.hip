@@ -751,6 +751,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
             const int p = (w * 2 + hh) * NI + j;
             GsF2Rec& r = f2recs[p];
             r.level = mine_lv[w][j];
+            for (int h2 = 0; h2 < 2; ++h2) if (pair[h2] >= 0) r.pad1 = std::max(r.pad1, ht.child_ptr[pair[h2] + 1] - ht.child_ptr[pair[h2]]);   // most children of the pair
             const int i = pair[hh];
             if (i < 0) continue;
             const int fp = ht.fbs_parent[i];

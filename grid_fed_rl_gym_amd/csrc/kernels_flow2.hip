@@ -95,17 +95,6 @@ __device__ __forceinline__ double f2_angle(double f, double e) {
   return __builtin_fma(t * z, p, t);
 }
 
-// The rare path of the Newton correction (a step of more than half a radian, or a magnitude that changes sign): the new
-// voltage through libm, as power_flow.py:315-327 does.  Not inlined: libm's atan2 / sincos bring three dozen constants that
-// would otherwise be hoisted into vector registers for the whole Newton loop.
-__device__ __attribute__((noinline)) double2 f2_polar_update(double e, double f, double dth, double vmn) {
-  double vmm = vmn, vaa = atan2(f, e) + dth;
-  if (vmm < 0.0) { vmm = -vmm; vaa += M_PI; }
-  double sn, cs;
-  sincos(vaa, &sn, &cs);
-  return make_double2(vmm * cs, vmm * sn);
-}
-
 // Taylor coefficients of (sin x - x) / x^3 and (cos x - 1) / x^2 in x^2, highest power first (|x| <= 0.5: truncation < 1e-21)
 __device__ const double kF2Series[16] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0,
                                          1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0,
@@ -300,13 +289,15 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // with an LDS barrier per level.
   const unsigned bufA = 0u, bufB = (unsigned)F.off_tile;
   const int F2_AS3* const tab = F2_P(const int, F.off_anc);
-  const int F2_AS3* const child_bus = tab;                          // [n][8]
-  const int F2_AS3* const child_ring = tab + n * 8;                 // [n][8] ring slots of the children's messages
+  // tab: child buses [n][8], ring slots of the children's messages [n][8], then:
   const int F2_AS3* const nch_tab = tab + 2 * n * 8;                // [n_slots]
   const int F2_AS3* const pos_tab = tab + F.pos_off;                // [positions][4]: bus, parent, ring, parent's ring
   int ilev[NI];                                                     // level of the wave's j-th pair (-1: none), wave-uniform
 #pragma unroll
   for (int j = 0; j < NI; ++j) ilev[j] = __builtin_amdgcn_readfirstlane(rec0[j].level);
+  int imax[NI];                                                     // most children of the pair's two buses, wave-uniform
+#pragma unroll
+  for (int j = 0; j < NI; ++j) imax[j] = __builtin_amdgcn_readfirstlane(rec0[j].pad1);
   const int pos0 = (wave * 2 + hv) * NI;
   const int NL = F.n_levels;
   auto ring3 = [&](int slot, int part) -> unsigned { return bufB + ((unsigned)(slot * 3 + part) * 32u + (unsigned)l) * 16u; };
@@ -318,7 +309,6 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     double kr[NI], ki[NI], ee[NI], ff[NI], sl[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      __builtin_amdgcn_sched_barrier(0);
       int bus = ibus[j]; F2_OPAQUE(bus);
       const int par = pos_tab[(pos0 + j) * 4 + 1];
       const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(par, l)), y = f2_ld2(F.off_z + 32u * bus);
@@ -333,11 +323,21 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     double lmax = 0.0, bad = 0.0, ps = 0.0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      __builtin_amdgcn_sched_barrier(0);
       int bus = ibus[j]; F2_OPAQUE(bus);
       double icr = kr[j], ici = ki[j];
       const int nch = nch_tab[bus];
-      for (int u = 0; u < nch; ++u) { const double2 kc = f2_ld2(bufB + f2_slot(child_bus[bus * 8 + u], l)); icr -= kc.x; ici -= kc.y; }
+      {   // the children's currents: the row of child indices first, then every current in one batch (no wait in between)
+        const int cb = bus < n ? bus : 0;
+        const f2_i4 c_lo = *F2_P(const f2_i4, F.off_anc + 32u * cb), c_hi = *F2_P(const f2_i4, F.off_anc + 32u * cb + 16u);
+#pragma unroll
+        for (int u = 0; u < GS_F2_CHILDREN; ++u) {
+          if (u < imax[j]) {
+            const int c = u < 4 ? c_lo[u & 3] : c_hi[u & 3];
+            const double2 kc = f2_ld2(bufB + f2_slot(u < nch ? c : bus, l));
+            if (u < nch) { icr -= kc.x; ici -= kc.y; }
+          }
+        }
+      }
       const double pc = __builtin_fma(ee[j], icr, ff[j] * ici), qc = __builtin_fma(ff[j], icr, -(ee[j] * ici));
       pcj[j] = pc; qcj[j] = qc;
       const double dP = Pj[j] - pc, dQ = 0.0 - qc;
@@ -368,23 +368,42 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         __builtin_amdgcn_sched_barrier(0);
         const int lev = ilev[j];
         const bool live = lev >= 0;                   // an item of this wave (both halves share the level)
-        if (live) { while (lv < lev) { f2_lds_sync(); ++lv; } }
+        // everything that does not depend on the children's messages comes BEFORE the wait for the item's level (it
+        // overlaps the levels below): own and parent voltage, 1 / |V| of both, the branch's two off-diagonal blocks, the
+        // diagonal block and right-hand side without the children's contributions
         int bus = ibus[j]; F2_OPAQUE(bus);
         int pj = pos0 + j; F2_OPAQUE(pj);
         const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);      // bus, parent, ring, parent's ring
         const double2 yo = f2_ld2(F.off_z + 32u * bus), yd = f2_ld2(F.off_z + 32u * bus + 16u);       // (G_ip, B_ip), (G_ii, B_ii)
         const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(px[1], l));
         const double vmi = sqrt(__builtin_fma(v.x, v.x, v.y * v.y)), rvm = 1.0 / vmi;
+        const double rvmp = 1.0 / sqrt(__builtin_fma(vp.x, vp.x, vp.y * vp.y));
         const double pc = pcj[j], qc = qcj[j];
         // diagonal block (power_flow.py:247-248 exact sign, 259-260, 270-271, 283-284)
         const double vvb = vmi * vmi * yd.y;
         double d00 = -qc - vvb, d01 = pc * rvm + vmi * yd.x, d10 = pc - vmi * vmi * yd.x, d11 = qc * rvm - vmi * yd.y;
         double r0 = Pj[j] - pc, r1 = 0.0 - qc;                                   // power_flow.py:159-165
+        // J(i, p) and J(p, i) of the branch (power_flow.py:251, 263, 274, 287)
+        const double a = v.x * vp.x + v.y * vp.y, bbi = v.y * vp.x - v.x * vp.y, bbp = -bbi;
+        const double gsi = yo.x * bbi - yo.y * a, gci = yo.x * a + yo.y * bbi;             // row i, column p
+        const double gsp = yo.x * bbp - yo.y * a, gcp = yo.x * a + yo.y * bbp;             // row p, column i
+        const double u00 = gsi, u01 = gci * rvmp, u10 = -gci, u11 = gsi * rvmp;
+        const double l00 = gsp, l01 = gcp * rvm, l10 = -gcp, l11 = gsp * rvm;
         const int nch = live && bus < n ? nch_tab[bus] : 0;
-        for (int u = 0; u < nch; ++u) {
-          const int cr = child_ring[bus * 8 + u];
-          const double2 c0 = f2_ld2(ring3(cr, 0)), c1 = f2_ld2(ring3(cr, 1)), cq = f2_ld2(ring3(cr, 2));
-          d00 -= c0.x; d01 -= c0.y; d10 -= c1.x; d11 -= c1.y; r0 -= cq.x; r1 -= cq.y;
+        const int cbr = bus < n ? bus : 0;
+        const f2_i4 r_lo = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr + 16u);
+        if (live) { while (lv < lev) { f2_lds_sync(); ++lv; } }
+        // the children's messages, two children (six 16-byte reads) per round trip
+#pragma unroll
+        for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
+          if (u0 < imax[j]) {
+            const int ca = u0 < 4 ? r_lo[u0 & 3] : r_hi[u0 & 3], cb2 = u0 + 1 < 4 ? r_lo[(u0 + 1) & 3] : r_hi[(u0 + 1) & 3];
+            const int sa = u0 < nch ? ca : 0, sb = u0 + 1 < nch ? cb2 : 0;
+            const double2 a0 = f2_ld2(ring3(sa, 0)), a1 = f2_ld2(ring3(sa, 1)), aq = f2_ld2(ring3(sa, 2));
+            const double2 b0 = f2_ld2(ring3(sb, 0)), b1 = f2_ld2(ring3(sb, 1)), bq = f2_ld2(ring3(sb, 2));
+            if (u0 < nch) { d00 -= a0.x; d01 -= a0.y; d10 -= a1.x; d11 -= a1.y; r0 -= aq.x; r1 -= aq.y; }
+            if (u0 + 1 < nch) { d00 -= b0.x; d01 -= b0.y; d10 -= b1.x; d11 -= b1.y; r0 -= bq.x; r1 -= bq.y; }
+          }
         }
         const double det = d00 * d11 - d01 * d10;
         if (live && bus < n && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;       // power_flow.py:188-190: only an exactly singular matrix raises
@@ -393,13 +412,6 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         s0[j] = i00 * r0 + i01 * r1; s1[j] = i10 * r0 + i11 * r1;
         T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0;
         if (live && bus < n && !((roots >> j) & 1u)) {
-          // J(i, p) and J(p, i) of the branch (power_flow.py:251, 263, 274, 287)
-          const double rvmp = 1.0 / sqrt(__builtin_fma(vp.x, vp.x, vp.y * vp.y));
-          const double a = v.x * vp.x + v.y * vp.y, bbi = v.y * vp.x - v.x * vp.y, bbp = -bbi;
-          const double gsi = yo.x * bbi - yo.y * a, gci = yo.x * a + yo.y * bbi;             // row i, column p
-          const double gsp = yo.x * bbp - yo.y * a, gcp = yo.x * a + yo.y * bbp;             // row p, column i
-          const double u00 = gsi, u01 = gci * rvmp, u10 = -gci, u11 = gsi * rvmp;
-          const double l00 = gsp, l01 = gcp * rvm, l10 = -gcp, l11 = gsp * rvm;
           const double t00 = i00 * u00 + i01 * u10, t01 = i00 * u01 + i01 * u11, t10 = i10 * u00 + i11 * u10, t11 = i10 * u01 + i11 * u11;
           T00[j] = t00; T01[j] = t01; T10[j] = t10; T11[j] = t11;
           f2_st2(ring3(px[2], 0), make_double2(l00 * t00 + l01 * t10, l00 * t01 + l01 * t11));
@@ -418,6 +430,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
     }
     const bool upd = !st.done;
+    stp.hit(F2_ST_INIT);
     // ---------------- top-down: x_i = s_i - T_i x_p; corrections (power_flow.py:315-327); new (e, f) into the slots ----------------
     {
       int lv = NL - 1;
@@ -441,6 +454,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       }
       while (lv >= 0) { f2_lds_sync(); --lv; }
     }
+    stp.hit(F2_ST_TOP_DOWN);
     // corrections (power_flow.py:315-327): theta += alpha dtheta, |V| += alpha d|V|, as a rotation and scaling of (e, f)
     if (__any(upd)) {
 #pragma unroll
@@ -452,34 +466,41 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           const double2 v = f2_ld2(bufA + f2_slot(bus, l));
           const double vm0 = sqrt(__builtin_fma(v.x, v.x, v.y * v.y));
           const double dth = C.alpha * x0, vmn = vm0 + C.alpha * x1;
-          double en, fn;
-          if (__any(fabs(dth) > 0.5 || !(vmn > 0.0))) {        // large step or sign flip somewhere in the wave: full evaluation
-            const double2 w = f2_polar_update(v.x, v.y, dth, vmn);
-            en = w.x; fn = w.y;
-          } else {
-            // V' = (Vm'/Vm) V e^{j dth}: rotate the rectangular voltage by the increment (Taylor series, |dth| <= 0.5)
-            // (coefficients through the scalar path: as 64-bit literals they would sit in sixteen vector register pairs for
-            // the whole Newton loop)
-            const GS_CONST double* kc = (const GS_CONST double*)kF2Series;
-            const double z = dth * dth;
-            double sp = kc[0];
-            sp = __builtin_fma(sp, z, kc[1]); sp = __builtin_fma(sp, z, kc[2]); sp = __builtin_fma(sp, z, kc[3]);
-            sp = __builtin_fma(sp, z, kc[4]); sp = __builtin_fma(sp, z, kc[5]); sp = __builtin_fma(sp, z, kc[6]); sp = __builtin_fma(sp, z, kc[7]);
-            const double sn = dth - dth * z * sp;
-            double cp = kc[8];
-            cp = __builtin_fma(cp, z, kc[9]); cp = __builtin_fma(cp, z, kc[10]); cp = __builtin_fma(cp, z, kc[11]);
-            cp = __builtin_fma(cp, z, kc[12]); cp = __builtin_fma(cp, z, kc[13]); cp = __builtin_fma(cp, z, kc[14]); cp = __builtin_fma(cp, z, kc[15]);
-            const double cs = __builtin_fma(z, cp, 1.0);
-            const double ratio = vmn / vm0;
-            en = ratio * (v.x * cs - v.y * sn);
-            fn = ratio * (v.x * sn + v.y * cs);
+          // V' = (Vm' / Vm) V e^{j dth}: the rectangular voltage scaled and rotated by the increment -- a negative Vm' gives
+          // (|Vm'|, angle + pi), what the reference's abs / angle round trip yields.  sin and cos of the increment from
+          // their Taylor series (|h| <= 0.5: truncation < 1e-21; coefficients through the scalar path: as 64-bit literals
+          // they would occupy sixteen vector register pairs for the whole Newton loop).  A wave with a step beyond half a
+          // radian (diverging iterates) reduces the angle to [-pi, pi], takes an eighth of it and doubles three times.
+          const bool big = __any(fabs(dth) > 0.5);
+          double h = dth;
+          if (big) {
+            const double k = rint(dth * 0.15915494309189535);
+            h = __builtin_fma(-k, 6.283185307179586, dth);
+            h = __builtin_fma(-k, 2.4492935982947064e-16, h);
+            h *= 0.125;
           }
+          const GS_CONST double* kc = (const GS_CONST double*)kF2Series;
+          const double z = h * h;
+          double sp = kc[0];
+          sp = __builtin_fma(sp, z, kc[1]); sp = __builtin_fma(sp, z, kc[2]); sp = __builtin_fma(sp, z, kc[3]);
+          sp = __builtin_fma(sp, z, kc[4]); sp = __builtin_fma(sp, z, kc[5]); sp = __builtin_fma(sp, z, kc[6]); sp = __builtin_fma(sp, z, kc[7]);
+          double sn = h - h * z * sp;
+          double cp = kc[8];
+          cp = __builtin_fma(cp, z, kc[9]); cp = __builtin_fma(cp, z, kc[10]); cp = __builtin_fma(cp, z, kc[11]);
+          cp = __builtin_fma(cp, z, kc[12]); cp = __builtin_fma(cp, z, kc[13]); cp = __builtin_fma(cp, z, kc[14]); cp = __builtin_fma(cp, z, kc[15]);
+          double cs = __builtin_fma(z, cp, 1.0);
+          if (big) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const double c2 = __builtin_fma(cs, cs, -(sn * sn)), s2 = 2.0 * cs * sn; cs = c2; sn = s2; }
+          }
+          const double ratio = vmn / vm0;
+          const double en = ratio * (v.x * cs - v.y * sn), fn = ratio * (v.x * sn + v.y * cs);
           f2_st2(bufA + f2_slot(bus, l), make_double2(en, fn));
         }
       }
     }
     f2_lds_sync();                   // the new voltages are read by the neighbours' lanes in the next mismatch
-    stp.hit(F2_ST_TOP_DOWN);
+    stp.hit(14);
     stale = true;
   }
   if (stale) { (void)mismatch(false); }       // iteration cap reached after an update: the losses sum at the final voltages
