@@ -717,6 +717,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     else if (!all_pq) why = "a bus below the slack is not a PQ bus";
     else if (!off_slack) why = "part of the network does not hang off the slack bus";
     else if (max_items > NI) why = "more than " + std::to_string(NI) + " bus pairs per wave";
+    // a feeder of a dozen buses leaves seven of a wave's eight items empty: the level-synchronous kernel of the first
+    // generation (16 waves on 64 instances) is faster there (IEEE-13, B = 4096: 50 us against 61 us); GS_FORCE_FLOW2 overrides
+    else if (ht.lvl_ptr[ht.n_levels] < 2 * NW * 2 && !getenv("GS_FORCE_FLOW2")) why = "fewer than " + std::to_string(2 * NW * 2) + " buses: first-generation kernel";
     else if (max_ch > GS_F2_CHILDREN) why = "a bus has more than " + std::to_string(GS_F2_CHILDREN) + " children";
     else if (max_dev > 2) why = "more than two devices of a kind at one bus";
     else if (off > 160 * 1024) why = "LDS tables do not fit";

@@ -75,6 +75,20 @@ __device__ __forceinline__ GsPairRef f2_pair(const GsLaneRows& S, int even_row) 
   return GsPairRef{S.r, S.lane16 + (((unsigned)even_row >> 1) << 10), 0};
 }
 
+// 1 / x and 1 / sqrt(x) for normal, finite x of ordinary magnitude (voltages, determinants): the hardware estimate and two
+// Newton steps, accurate to about an ulp.  The compiler's IEEE division is ~40 instructions, its square root ~30, and the
+// Newton-Raphson item (three reciprocals, two square roots) was bound by exactly that instruction count.
+__device__ __forceinline__ double f2_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ double f2_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-(x * y), y, 1.0), y);
+  return __builtin_fma(0.5 * y, __builtin_fma(-(x * y), y, 1.0), y);
+}
+
 struct F2State { double mm; int iters, conv, status; bool done; };
 __device__ __forceinline__ void f2_check(F2State& st, double mm, int it, double tol) {      // power_flow.py:148, 168-171, 204
   if (!st.done) {
@@ -368,6 +382,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         __builtin_amdgcn_sched_barrier(0);
         const int lev = ilev[j];
         const bool live = lev >= 0;                   // an item of this wave (both halves share the level)
+        T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; s0[j] = 0.0; s1[j] = 0.0;
+        if (live) {
         // everything that does not depend on the children's messages comes BEFORE the wait for the item's level (it
         // overlaps the levels below): own and parent voltage, 1 / |V| of both, the branch's two off-diagonal blocks, the
         // diagonal block and right-hand side without the children's contributions
@@ -376,8 +392,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);      // bus, parent, ring, parent's ring
         const double2 yo = f2_ld2(F.off_z + 32u * bus), yd = f2_ld2(F.off_z + 32u * bus + 16u);       // (G_ip, B_ip), (G_ii, B_ii)
         const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(px[1], l));
-        const double vmi = sqrt(__builtin_fma(v.x, v.x, v.y * v.y)), rvm = 1.0 / vmi;
-        const double rvmp = 1.0 / sqrt(__builtin_fma(vp.x, vp.x, vp.y * vp.y));
+        const double v2 = __builtin_fma(v.x, v.x, v.y * v.y), rvm = f2_rsq(v2), vmi = v2 * rvm;
+        const double rvmp = f2_rsq(__builtin_fma(vp.x, vp.x, vp.y * vp.y));
         const double pc = pcj[j], qc = qcj[j];
         // diagonal block (power_flow.py:247-248 exact sign, 259-260, 270-271, 283-284)
         const double vvb = vmi * vmi * yd.y;
@@ -392,7 +408,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const int nch = live && bus < n ? nch_tab[bus] : 0;
         const int cbr = bus < n ? bus : 0;
         const f2_i4 r_lo = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr + 16u);
-        if (live) { while (lv < lev) { f2_lds_sync(); ++lv; } }
+        while (lv < lev) { f2_lds_sync(); ++lv; }
         // the children's messages, two children (six 16-byte reads) per round trip
 #pragma unroll
         for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
@@ -407,10 +423,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         }
         const double det = d00 * d11 - d01 * d10;
         if (live && bus < n && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;       // power_flow.py:188-190: only an exactly singular matrix raises
-        const double rdet = 1.0 / det;
+        const double rdet = f2_rcp(det);
         const double i00 = d11 * rdet, i01 = -d01 * rdet, i10 = -d10 * rdet, i11 = d00 * rdet;
         s0[j] = i00 * r0 + i01 * r1; s1[j] = i10 * r0 + i11 * r1;
-        T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0;
         if (live && bus < n && !((roots >> j) & 1u)) {
           const double t00 = i00 * u00 + i01 * u10, t01 = i00 * u01 + i01 * u11, t10 = i10 * u00 + i11 * u10, t11 = i10 * u01 + i11 * u11;
           T00[j] = t00; T01[j] = t01; T10[j] = t10; T11[j] = t11;
@@ -418,6 +433,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           f2_st2(ring3(px[2], 1), make_double2(l10 * t00 + l11 * t10, l10 * t01 + l11 * t11));
           f2_st2(ring3(px[2], 2), make_double2(l00 * s0[j] + l01 * s1[j], l10 * s0[j] + l11 * s1[j]));
         }
+              }
       }
       while (lv < NL) { f2_lds_sync(); ++lv; }
     }
@@ -464,7 +480,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         if (upd && bus < n) {
           const double x0 = s0[j], x1 = s1[j];
           const double2 v = f2_ld2(bufA + f2_slot(bus, l));
-          const double vm0 = sqrt(__builtin_fma(v.x, v.x, v.y * v.y));
+          const double v2 = __builtin_fma(v.x, v.x, v.y * v.y), rvm0 = f2_rsq(v2), vm0 = v2 * rvm0;
           const double dth = C.alpha * x0, vmn = vm0 + C.alpha * x1;
           // V' = (Vm' / Vm) V e^{j dth}: the rectangular voltage scaled and rotated by the increment -- a negative Vm' gives
           // (|Vm'|, angle + pi), what the reference's abs / angle round trip yields.  sin and cos of the increment from
@@ -493,7 +509,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #pragma unroll
             for (int q = 0; q < 3; ++q) { const double c2 = __builtin_fma(cs, cs, -(sn * sn)), s2 = 2.0 * cs * sn; cs = c2; sn = s2; }
           }
-          const double ratio = vmn / vm0;
+          const double ratio = vmn * rvm0;
           const double en = ratio * (v.x * cs - v.y * sn), fn = ratio * (v.x * sn + v.y * cs);
           f2_st2(bufA + f2_slot(bus, l), make_double2(en, fn));
         }
@@ -534,7 +550,16 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     if (hv == 0) { f2_v2 t; t.x = t0r + t1r; t.y = t0i + t1i; tot_lds[wave * 32 + l] = t; }
     f2_lds_sync();
     double br = 0.0, bi = 0.0;                                    // sum of the totals of the waves before this one, in wave order
-    for (int w = 0; w < wave; ++w) { const f2_v2 t = tot_lds[w * 32 + l]; br += t.x; bi += t.y; }
+    {
+#pragma unroll
+      for (int w0 = 0; w0 < NW; w0 += 8) {                        // eight totals per LDS round trip
+        f2_v2 tw[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tw[w] = tot_lds[(w0 + w) * 32 + l];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { if (w0 + w < wave) { br += tw[w].x; bi += tw[w].y; } }
+      }
+    }
     if (hv) { br += t0r; bi += t0i; }
     // Q of position p is filed under the BUS at that position (buffer B shares the slot numbering of buffer A, whose
     // "no ancestor" slot must stay zero); idle positions all file under the DUMMY slot, which nobody reads
@@ -591,12 +616,15 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_lds_sync();
     for (int r = 0; r < R2; ++r) {
       const unsigned rd = (r & 1) ? bufB : bufA, wr = (r & 1) ? bufA : bufB;
+      // the ancestors' slots first, then their sums: two LDS round trips per round for all of the lane's buses together
+      unsigned ao[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int a = anc_lds[r * nsl + ibus[j]];
-        const double2 sa = f2_ld2(rd + f2_slot(a, l));
-        sr[j] += sa.x; si[j] += sa.y;
-      }
+      for (int j = 0; j < NI; ++j) ao[j] = f2_slot(anc_lds[r * nsl + ibus[j]], l);
+      double2 sa[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) sa[j] = f2_ld2(rd + ao[j]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { sr[j] += sa[j].x; si[j] += sa[j].y; }
       if (r + 1 < R2) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) f2_st2(wr + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
@@ -629,7 +657,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // its voltages: its J and V repeat bit for bit while the rest of the group iterates
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const double rd = 1.0 / __builtin_fma(sr[j], sr[j], si[j] * si[j]);
+      const double rd = f2_rcp(__builtin_fma(sr[j], sr[j], si[j] * si[j]));
       if (!st.done && ibus[j] < n) { IR[j] = (Pj[j] * sr[j]) * rd; II[j] = (Pj[j] * si[j]) * rd; }      // (idle positions keep a zero current)
     }
     backward();
