@@ -342,7 +342,7 @@ def main():
         # the device-resident rollout collector (gs_rollout): T steps + bookkeeping + in-place resets,
         # random actions drawn on the device, nothing on the host in between
         try:
-            T = args.steps
+            T = max(args.steps, 64)                                               # a rollout length that amortises the per-call fixed cost (two 45 MB slot copies, host wake-up)
             h.rollout(T, "random", seed=1); h.synchronize()                       # allocation + warm-up
             rates = []
             for r in range(5):

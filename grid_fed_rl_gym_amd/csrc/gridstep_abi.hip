@@ -261,7 +261,7 @@ GsFusedChecks fused_checks_args(gs_handle* h);      // defined with gs_checks be
 
 // obs_out: where the step writes the changing columns of its observation block ([B][obs_dim], constants already in
 // place); NULL = the other one of the handle's two observation buffers
-int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullptr) {
+int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullptr, const GsRolloutStep* rs = nullptr) {
   // one fused launch: actions -> pre-solve dynamics -> load flow -> post-solve dynamics / reward / flags
   { LaunchTimer lt(h, GS_K_SOLVE);
     dim3 grid(h->groups), block(64 * h->W);
@@ -276,23 +276,24 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
     const GsFusedChecks fc = fused_checks_args(h);
+    const GsRolloutStep rsv = rs ? *rs : GsRolloutStep{};
     if (h->nr2) {
       if (fc.enabled)
         hipLaunchKernelGGL(gs_k_stepc_nr_flow2, dim3(2 * h->groups), dim3(64 * GS_F2N_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
       else
         hipLaunchKernelGGL(gs_k_step_nr_flow2, dim3(2 * h->groups), dim3(64 * GS_F2N_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
       HIPCHK(h, hipGetLastError());
       return GS_OK;
     }
     if (h->flow2) {        // two workgroups per 64-instance slab group, each with its own 32 instances
       if (fc.enabled)
         hipLaunchKernelGGL(gs_k_stepc_fbs_flow2, dim3(2 * h->groups), dim3(64 * GS_F2_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
       else
         hipLaunchKernelGGL(gs_k_step_fbs_flow2, dim3(2 * h->groups), dim3(64 * GS_F2_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc);
+                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
       HIPCHK(h, hipGetLastError());
       return GS_OK;
     }
@@ -1112,12 +1113,19 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
   }
   // slot 0 = the observation the environment stands at
   HIPCHK(h, hipMemcpyAsync(ro.obs_seq, h->d_obs2[h->obs_cur], B * D * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  // second-generation step kernels do the bookkeeping themselves (finished instances are reset at the start of the NEXT
+  // step, rewards / flags written at the end of the step): one launch per step, and one small kernel after the last
+  // step for the instances it finished; the other kernels are followed by that small kernel after every step
+  const bool fused = h->flow2 || h->nr2;
   for (int t = 0; t < T; ++t) {
     double* nxt = ro.obs_seq + (size_t)(t + 1) * B * D;
-    if ((rc = step_kernels(h, ro.act + (size_t)t * B * A, nxt))) return rc;
-    GsRolloutPostArgs pa{ro.rew, ro.done, nxt, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, h->B};
-    hipLaunchKernelGGL(gs_k_rollout_post, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, pa);
-    HIPCHK(h, hipGetLastError());
+    GsRolloutStep rs{ro.rew, ro.done, ro.obs_seq + (size_t)t * B * D, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, 1};
+    if ((rc = step_kernels(h, ro.act + (size_t)t * B * A, nxt, fused ? &rs : nullptr))) return rc;
+    if (!fused || t == T - 1) {
+      GsRolloutPostArgs pa{fused ? nullptr : ro.rew, fused ? nullptr : ro.done, nxt, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, h->B};
+      hipLaunchKernelGGL(gs_k_rollout_post, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, pa);
+      HIPCHK(h, hipGetLastError());
+    }
   }
   // the environment now stands at slot T: that is its current observation for gs_download_step / gs_allgather_obs
   if (h->gather_pending[h->obs_cur]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[h->obs_cur], 0)); h->gather_pending[h->obs_cur] = false; }

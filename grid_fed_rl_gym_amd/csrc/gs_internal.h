@@ -334,6 +334,17 @@ struct GsRolloutPostArgs {
   int32_t obs_dim, t, B;
 };
 
+// The rollout collector's bookkeeping when it is fused into the step kernel (kernels_flow2.hip): at the START of step t the
+// kernel files the instances that step t - 1 finished (terminal observation to the side list, in-place reset, fresh
+// observation into slot t), at its end it writes reward and done flags of step t.  active == 0: an ordinary step.
+struct GsRolloutStep {
+  double* rew; uint8_t* done;            // [T][B]
+  double* obs_prev;                      // [B][obs_dim] slot t of the observation sequence (what this step starts from)
+  const int32_t* map; const double* cst; // observation column -> slab row, or -(1 + constant index)
+  int32_t* term_count; int32_t* term_idx; double* term_obs;
+  int32_t term_cap, obs_dim, t, active;
+};
+
 struct GsSolveCfg {
   double tolerance, alpha;
   int32_t max_iterations, jacobian_exact;

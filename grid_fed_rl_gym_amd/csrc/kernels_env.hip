@@ -13,28 +13,6 @@
 #define ROW(r) S[(size_t)(r) * GS_LANES]
 #include "env_device.h"
 
-// reset() of this lane's instance with the given seed (grid_env.py:360-408)
-__device__ __forceinline__ void env_reset_lane(const GsTables& T, const GsRows& R, const GsEnvCfg& E, GsLaneRows S,
-                                               uint64_t inst, uint64_t seed) {
-  ROW(R.SEEDLO) = (double)(uint32_t)seed;
-  ROW(R.SEEDHI) = (double)(uint32_t)(seed >> 32);
-  ROW(R.TIME) = 0.0; ROW(R.STEP) = 0.0; ROW(R.VIOL) = 0.0; ROW(R.TOTLOSS) = 0.0; ROW(R.EPREW) = 0.0;
-  ROW(R.FREQ) = 60.0;                                           // grid_env.py:394
-  ROW(R.IRR) = 0.0; ROW(R.WIND) = 5.0; ROW(R.TEMP) = 25.0; ROW(R.CLOUD) = 0.3;   // grid_env.py:213-218
-  for (int i = 0; i < T.n; ++i) {
-    ROW(R.VM + i) = 1.0; ROW(R.VA + i) = 0.0;
-    ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0; ROW(R.F + i) = 0.0;     // the flat start, for a warm-started sweep solver
-  }
-  for (int k = 0; k < T.m; ++k) { ROW(R.FLOW + k) = 0.0; ROW(R.ENVLOAD + k) = 0.0; ROW(R.LOAD + k) = 0.0; }
-  for (int q = 0; q < T.n_bats; ++q) { ROW(R.SOC + q) = 0.5; ROW(R.BATP + q) = 0.0; }      // grid_env.py:397-399
-  for (int g = 0; g < T.n_gens; ++g) ROW(R.CURT + g) = 1.0;
-  weather_update(R, E, S, inst);                                  // grid_env.py:402
-  for (int g = 0; g < T.n_gens; ++g) ROW(R.GENP + g) = renewable_power(T, R, S, g);
-  ROW(R.REWARD) = 0.0; ROW(R.TERM) = 0.0; ROW(R.TRUNC) = 0.0; ROW(R.VMAX) = 1.0; ROW(R.VMIN) = 1.0;
-  for (int v = 0; v < 4; ++v) ROW(R.VFLAGS + v) = 0.0;
-  ROW(R.LOSSES) = 0.0; ROW(R.MAXMIS) = 0.0; ROW(R.ITERS) = 0.0; ROW(R.CONV) = 0.0; ROW(R.STATUS) = 0.0;
-}
-
 // seeds == NULL: the instance's stream runs on (next_episode_seed of the seed it holds; a handle that was never
 // seeded holds 0), as the reference's reset(seed=None) leaves its global streams running
 extern "C" __global__ void __launch_bounds__(64)
@@ -115,8 +93,10 @@ gs_k_rollout_post(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, G
   if (b >= A.B) return;
   const double rew = ROW(R.REWARD), te = ROW(R.TERM), tr = ROW(R.TRUNC);
   const int d = (te != 0.0 ? 1 : 0) | (tr != 0.0 ? 2 : 0);
-  A.rew[(size_t)A.t * A.B + b] = rew;
-  A.done[(size_t)A.t * A.B + b] = (uint8_t)d;
+  if (A.rew) {                          // (NULL: the step kernel has written them itself)
+    A.rew[(size_t)A.t * A.B + b] = rew;
+    A.done[(size_t)A.t * A.B + b] = (uint8_t)d;
+  }
   if (!d) return;
   double* row = A.obs_next + (size_t)b * A.obs_dim;
   const int k = atomicAdd(A.term_count, 1);

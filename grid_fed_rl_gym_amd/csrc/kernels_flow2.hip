@@ -133,7 +133,7 @@ enum { F2_FBS = 0, F2_NR = 1 };
 template <int SOLVER, int CHK, int NW, int NI>
 __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                         double* __restrict__ slab, int B, const double* __restrict__ actions, double total_load,
-                                        const GsPackArgs& PA, const GsFusedChecks& FC) {
+                                        const GsPackArgs& PA, const GsFusedChecks& FC, const GsRolloutStep& RS) {
   const int lane = threadIdx.x & 63, l = lane & 31, hv = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.x >> 1, hs = blockIdx.x & 1, L = hs * 32 + l;
@@ -169,8 +169,28 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   for (int k = threadIdx.x; k < 5 * 32; k += blockDim.x) cell[k] = (k >= 4 * 32) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
   for (int k = threadIdx.x; k < 16 * 32; k += blockDim.x) icell[k] = 0u;
 
-  // ---- clock; then three independent chains on different waves (grid_env.py:433-477) --------------------------------
+  // ---- inside a rollout: the instances the previous step finished are reset here, where the reference calls env.reset()
+  // (algorithms/base.py:289-290) -- terminal observation to the side list, next seed of the instance's chain, fresh
+  // observation into the slot this step starts from.  Rare (once per episode); the column loops are per lane.
   const uint64_t inst = (uint64_t)(E.first_instance + b);
+  if (RS.active && RS.t > 0) {
+    if (wave == 0 && hv == 0 && valid) {
+      const double te = ROW(R.TERM), tr = ROW(R.TRUNC);
+      if (te != 0.0 || tr != 0.0) {
+        double* row = RS.obs_prev + (size_t)b * RS.obs_dim;
+        const int kx = __hip_atomic_fetch_add(RS.term_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kx < RS.term_cap) {
+          RS.term_idx[2 * kx] = RS.t - 1; RS.term_idx[2 * kx + 1] = b;
+          double* dst = RS.term_obs + (size_t)kx * RS.obs_dim;
+          for (int c = 0; c < RS.obs_dim; ++c) dst[c] = row[c];
+        }
+        env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
+        for (int c = 0; c < RS.obs_dim; ++c) { const int sidx = RS.map[c]; row[c] = (sidx >= 0) ? (double)ROW(sidx) : RS.cst[-sidx - 1]; }
+      }
+    }
+    f2_sync();                       // the other waves read the clock and seed rows next
+  }
+  // ---- clock; then three independent chains on different waves (grid_env.py:433-477) --------------------------------
   const double told = ROW(R.TIME), kold = ROW(R.STEP), tnew = told + E.timestep;
   const uint32_t snew = (uint32_t)(kold + 1.0);
   const uint64_t seed = lane_seed(S, R);
@@ -837,6 +857,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     ROW(R.VMAX) = vmax; ROW(R.VMIN) = vmin;
     ROW(R.VFLAGS + 0) = (double)vhigh; ROW(R.VFLAGS + 1) = (double)vlow;
     ROW(R.VFLAGS + 2) = (double)fhigh; ROW(R.VFLAGS + 3) = (double)flow_;
+    if (RS.active && valid) {        // the rollout's [T][B] arrays: reward, and bit 0 terminated / bit 1 truncated
+      RS.rew[(size_t)RS.t * B + b] = reward;
+      RS.done[(size_t)RS.t * B + b] = (uint8_t)((step0 >= (double)E.episode_length ? 1 : 0) | (trunc != 0.0 ? 2 : 0));
+    }
     // the observation columns that are neither bus nor line pairs: frequency, renewable powers, battery state
     // (grid_env.py:766, 773-781); the static load columns in between are written at reset and never change
     if (PA.out != nullptr && valid) {
@@ -897,13 +921,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #define F2_KERNELS(name, SOLVER, NW, NI)                                                                                   \
   extern "C" __global__ void __launch_bounds__(64 * NW)                                                                    \
   gs_k_step_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,         \
-                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {               \
-    f2_step<SOLVER, 0, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);                                       \
+                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
+    f2_step<SOLVER, 0, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                                   \
   }                                                                                                                        \
   extern "C" __global__ void __launch_bounds__(64 * NW)     /* the step with the post-step checks in its epilogue */       \
   gs_k_stepc_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,        \
-                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {              \
-    f2_step<SOLVER, 1, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC);                                       \
+                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
+    f2_step<SOLVER, 1, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                                   \
   }
 F2_KERNELS(fbs_flow2, F2_FBS, 16, 4)
 F2_KERNELS(nr_flow2, F2_NR, 8, 8)

@@ -6,6 +6,7 @@ TAG=${TAG:-mem}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 i=0
+FAILED=""
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -15,8 +16,13 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ" \
            "TCC_EA0_RDREQ_DRAM TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" \
            "TCC_EA0_RDREQ_LEVEL TCC_EA0_WRREQ_LEVEL TCC_TAG_STALL TCC_BUSY" \
-           "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TD_TD_BUSY" \
+           "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES" \
+           "TA_DATA_STALLED_BY_TC_CYCLES TD_TD_BUSY" \
            "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_REQUEST GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/${TAG}_pmcm_$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $R/gpurun_out/${TAG}_pmcm_$i.log 2>&1 || { tail -3 $R/gpurun_out/${TAG}_pmcm_$i.log; }
+  # (round 1: the four TA / TD counters in one pass made rocprofv3 abort with "Request exceeds the capabilities of the
+  # hardware" and the failure was swallowed; they are two passes now, and a failing pass fails the script)
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/${TAG}_pmcm_$i -- python3 $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-also --no-secondary ${BENCH_ARGS} > $R/gpurun_out/${TAG}_pmcm_$i.log 2>&1 \
+    || { echo "pmc_memory_path: counter set $i ($set) FAILED" >&2; tail -5 $R/gpurun_out/${TAG}_pmcm_$i.log >&2; FAILED="$FAILED $i"; }
 done
+if [ -n "$FAILED" ]; then echo "pmc_memory_path: failed counter sets:$FAILED" >&2; exit 1; fi
