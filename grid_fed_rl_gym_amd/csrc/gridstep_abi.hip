@@ -81,6 +81,7 @@ struct gs_handle {
   // the env step of a handle whose solver is the dataflow sweep runs the second-generation kernel (kernels_flow2.hip:
   // 32 instances per workgroup, half-waves on different buses) when the feeder fits its tables; gs_solve keeps kernel 6
   bool flow2 = false; GsF2Tables F2{}; std::string flow2_why;
+  bool f2_small = false; int f2_iw = 32, f2_nw = 16;     // which member of the family (8 instances per workgroup for small feeders)
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -277,23 +278,17 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
     const GsFusedChecks fc = fused_checks_args(h);
     const GsRolloutStep rsv = rs ? *rs : GsRolloutStep{};
-    if (h->nr2) {
-      if (fc.enabled)
-        hipLaunchKernelGGL(gs_k_stepc_nr_flow2, dim3(2 * h->groups), dim3(64 * GS_F2N_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
-      else
-        hipLaunchKernelGGL(gs_k_step_nr_flow2, dim3(2 * h->groups), dim3(64 * GS_F2N_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
-      HIPCHK(h, hipGetLastError());
-      return GS_OK;
-    }
-    if (h->flow2) {        // two workgroups per 64-instance slab group, each with its own 32 instances
-      if (fc.enabled)
-        hipLaunchKernelGGL(gs_k_stepc_fbs_flow2, dim3(2 * h->groups), dim3(64 * GS_F2_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
-      else
-        hipLaunchKernelGGL(gs_k_step_fbs_flow2, dim3(2 * h->groups), dim3(64 * GS_F2_WAVES), h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC,
-                           h->slab, h->B, d_actions, h->total_load, pa, fc, rsv);
+    if (h->nr2 || h->flow2) {        // 64 / IW workgroups per 64-instance slab group, each with its own IW instances
+      const dim3 g2(h->groups * (64 / h->f2_iw)), b2(64 * h->f2_nw);
+#define GS_F2(k) hipLaunchKernelGGL(k, g2, b2, h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc, rsv)
+      if (h->nr2) {
+        if (h->f2_small) { if (fc.enabled) GS_F2(gs_k_stepc_nr_flow2s); else GS_F2(gs_k_step_nr_flow2s); }
+        else { if (fc.enabled) GS_F2(gs_k_stepc_nr_flow2); else GS_F2(gs_k_step_nr_flow2); }
+      } else {
+        if (h->f2_small) { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2s); else GS_F2(gs_k_step_fbs_flow2s); }
+        else { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2); else GS_F2(gs_k_step_fbs_flow2); }
+      }
+#undef GS_F2
       HIPCHK(h, hipGetLastError());
       return GS_OK;
     }
@@ -444,7 +439,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", max_dyn));
     for (const void* f : {(const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2, (const void*)gs_k_step_nr_flow2,
-                          (const void*)gs_k_stepc_nr_flow2})      // no static LDS in these
+                          (const void*)gs_k_stepc_nr_flow2, (const void*)gs_k_step_fbs_flow2s, (const void*)gs_k_stepc_fbs_flow2s,
+                          (const void*)gs_k_step_nr_flow2s, (const void*)gs_k_stepc_nr_flow2s})      // no static LDS in these
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", 160 * 1024));
   }
@@ -594,12 +590,44 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     wb_ptr[h->W] = (int)wbus.size();
   }
 
-  // ---- second-generation sweep kernel for the env step: one record per position of the forest's preorder ----
+  // ---- second-generation step kernels (kernels_flow2.hip): IW instances per workgroup, NW waves, NI buses per sub-group ----
   std::vector<GsF2Rec> f2recs; std::vector<int32_t> f2anc; std::vector<double> f2z;
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  // LDS carve-up shared by the members of the family; returns the total
+  auto f2_layout = [&](GsF2Tables& F, int NW, int IW, size_t second_region_min, size_t n_table_ints, int zcols) {
+    const int nsl = ht.n + 3;
+    const size_t SB = (size_t)(IW + 1) * 16;
+    size_t off = up16((size_t)nsl * SB);
+    F.off_tile = (int32_t)off;
+    off += up16(std::max<size_t>({(size_t)nsl * SB, second_region_min, (size_t)ht.m * SB, (size_t)(topo->n_loads + 4) * IW * sizeof(double)}));
+    F.off_anc = (int32_t)off; off += up16(n_table_ints * 4);
+    F.off_z = (int32_t)off; off += up16((size_t)nsl * zcols * 8);
+    F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
+    F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * IW * sizeof(double));
+    F.off_red = (int32_t)off; off += 2 * (size_t)NW * IW * sizeof(double);
+    F.off_atom = (int32_t)off; off += 5 * (size_t)IW * sizeof(unsigned long long) + 16 * (size_t)IW * sizeof(uint32_t);
+    F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack;
+    return off;
+  };
+  auto f2_devices = [&](GsF2Rec& r, int i) {
+    r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
+    if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
+    if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
+    if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
+    if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
+    if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
+    if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
+  };
+  int max_dev = 0, max_ch = 0;
+  for (int i = 0; i < ht.n; ++i) {
+    max_dev = std::max({max_dev, ht.bl_ptr[i + 1] - ht.bl_ptr[i], ht.bg_ptr[i + 1] - ht.bg_ptr[i], ht.bb_ptr[i + 1] - ht.bb_ptr[i]});
+    if (ht.is_forest) max_ch = std::max(max_ch, ht.child_ptr[i + 1] - ht.child_ptr[i]);
+  }
+  const int SL_ZERO = ht.n, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2, nsl = ht.n + 3;
+
+  // -- sweep solver: one record per position of the preorder of the tree below the slack
   if (h->solve_kernel == 6) {
     std::string& why = h->flow2_why;
-    const int nsl = ht.n + 3, SL_ZERO = ht.n, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2, NPOS = GS_F2_WAVES * 2 * GS_F2_ITEMS;
-    // preorder of the tree below the slack (children in list order), subtree sizes, depth in edges from the slack
     std::vector<int> order, size(ht.n, 1), depth(ht.n, 0);
     {
       std::vector<std::vector<int>> kids(ht.n);
@@ -621,26 +649,18 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       for (int p = (int)order.size() - 1; p >= 0; --p) { const int i = order[p], fp = ht.fbs_parent[i]; if (fp != ht.slack) size[fp] += size[i]; }
     }
     const int N = (int)order.size();
-    int max_depth = 1, max_dev = 0;
+    int max_depth = 1;
     for (int i : order) max_depth = std::max(max_depth, depth[i]);
-    for (int i = 0; i < ht.n; ++i)
-      max_dev = std::max({max_dev, ht.bl_ptr[i + 1] - ht.bl_ptr[i], ht.bg_ptr[i + 1] - ht.bg_ptr[i], ht.bb_ptr[i + 1] - ht.bb_ptr[i]});
     int n_jump = 0;
     while ((1 << n_jump) < max_depth) ++n_jump;
     n_jump = std::max(2, (n_jump + 1) & ~1);                         // even: the last round then reads the second buffer
-    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    // small feeders: 8 instances per workgroup, the eight sub-groups of a wavefront on eight buses
+    const bool small = N <= GS_F2S_WAVES * (64 / GS_F2S_IW) * GS_F2S_ITEMS && !getenv("GS_NO_FLOW2_SMALL");
+    const int NW = small ? GS_F2S_WAVES : GS_F2_WAVES, NI = small ? GS_F2S_ITEMS : GS_F2_ITEMS, IW = small ? GS_F2S_IW : 32;
+    const int NPOS = NW * (64 / IW) * NI;
     GsF2Tables& F = h->F2;
-    size_t off = up16((size_t)nsl * GS_F2_PITCH * 16);
-    // second buffer: the solver's ping-pong partner / prefix sums (slot numbering of the first), the load powers before,
-    // the line tile of the observation block after
-    F.off_tile = (int32_t)off; off += up16(std::max<size_t>({(size_t)nsl * GS_F2_PITCH * 16, (size_t)ht.m * GS_F2_PITCH * 16, (size_t)(topo->n_loads + 4) * 32 * sizeof(double)}));
-    F.off_anc = (int32_t)off; off += up16((size_t)n_jump * nsl * 4);
-    F.off_z = (int32_t)off; off += up16((size_t)nsl * 16);
-    F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
-    F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * 32 * sizeof(double));
-    F.off_red = (int32_t)off; off += 2 * GS_F2_WAVES * 32 * sizeof(double);
-    F.off_atom = (int32_t)off; off += 5 * 32 * sizeof(unsigned long long) + 16 * 32 * sizeof(uint32_t);
-    F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack; F.n_jump = n_jump;
+    const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl, 2);
+    F.n_jump = n_jump;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
     else if (N > NPOS) why = "more than " + std::to_string(NPOS) + " buses below the slack";
     else if (N != ht.lvl_ptr[ht.n_levels]) why = "part of the forest does not hang off the slack bus";
@@ -648,7 +668,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     else if (off > 160 * 1024) why = "LDS tables do not fit";
     else if (ht.n < 2 || ht.m < 1 || N < 1) why = "trivial network";
     if (why.empty()) {
-      h->flow2 = true;
+      h->flow2 = true; h->f2_small = small; h->f2_iw = IW; h->f2_nw = NW;
       GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY;
       f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 2, 0.0);
@@ -662,71 +682,58 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         r.zr = yr / yd; r.zi = -yi / yd; r.yr = yr; r.yi = yi;
         f2z[2 * (size_t)i] = r.zr; f2z[2 * (size_t)i + 1] = r.zi;
         f2anc[i] = fp == ht.slack ? SL_ZERO : fp;
-        r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
-        if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
-        if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
-        if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
-        if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
-        if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
-        if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
+        f2_devices(r, i);
       }
       for (int r = 1; r < n_jump; ++r)
         for (int sidx = 0; sidx < nsl; ++sidx) f2anc[(size_t)r * nsl + sidx] = f2anc[(size_t)(r - 1) * nsl + f2anc[(size_t)(r - 1) * nsl + sidx]];
     }
   }
 
-  // ---- Newton-Raphson member of the second-generation family: pairs of same-level buses per (wave, item) ----
+  // -- Newton-Raphson: every (wave, item) holds a group of HV = 64 / IW buses of ONE level of the tree
   if (h->solve_kernel == 4 && ht.fbs_ok) {
     std::string& why = h->flow2_why;
-    const int NW = GS_F2N_WAVES, NI = GS_F2N_ITEMS, NPOS = NW * 2 * NI;
-    const int nsl = ht.n + 3, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2, maxw = ht.max_level_width;
-    std::vector<std::vector<std::pair<int, int>>> mine(NW);
-    std::vector<std::vector<int>> mine_lv(NW);
     bool all_pq = true, off_slack = true;
-    for (int lv = 0; lv < ht.n_levels; ++lv)
-      for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; t += 2) {
-        int w = 0;
-        for (int v = 1; v < NW; ++v) if (mine[v].size() < mine[w].size()) w = v;
-        mine[w].push_back({ht.lvl_bus[t], t + 1 < ht.lvl_ptr[lv + 1] ? ht.lvl_bus[t + 1] : -1});
-        mine_lv[w].push_back(lv);
-      }
-    int max_items = 0, max_ch = 0, max_dev = 0;
-    for (auto& v : mine) max_items = std::max<int>(max_items, (int)v.size());
     for (int i = 0; i < ht.n; ++i) {
-      max_ch = std::max(max_ch, ht.child_ptr[i + 1] - ht.child_ptr[i]);
-      max_dev = std::max({max_dev, ht.bl_ptr[i + 1] - ht.bl_ptr[i], ht.bg_ptr[i + 1] - ht.bg_ptr[i], ht.bb_ptr[i + 1] - ht.bb_ptr[i]});
       if (i != ht.slack && ht.lvl_pos[i] >= 0 && !(ht.th_free[i] && ht.vm_free[i])) all_pq = false;
       if (i != ht.slack && ht.lvl_pos[i] < 0) off_slack = false;                       // a bus outside the forest
       if (ht.lvl_pos[i] >= 0 && ht.parent[i] < 0 && ht.fbs_parent[i] != ht.slack) off_slack = false;
     }
-    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    auto deal = [&](int NW, int HV, std::vector<std::vector<std::vector<int>>>& mine, std::vector<std::vector<int>>& mine_lv) {
+      mine.assign(NW, {}); mine_lv.assign(NW, {});
+      for (int lv = 0; lv < ht.n_levels; ++lv)
+        for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; t += HV) {
+          int w = 0;
+          for (int v = 1; v < NW; ++v) if (mine[v].size() < mine[w].size()) w = v;
+          std::vector<int> grp;
+          for (int q = 0; q < HV; ++q) grp.push_back(t + q < ht.lvl_ptr[lv + 1] ? ht.lvl_bus[t + q] : -1);
+          mine[w].push_back(grp); mine_lv[w].push_back(lv);
+        }
+      int mx = 0;
+      for (auto& v : mine) mx = std::max<int>(mx, (int)v.size());
+      return mx;
+    };
+    std::vector<std::vector<std::vector<int>>> mine; std::vector<std::vector<int>> mine_lv;
+    bool small = !getenv("GS_NO_FLOW2_SMALL") && deal(GS_F2NS_WAVES, 64 / GS_F2S_IW, mine, mine_lv) <= GS_F2NS_ITEMS;
+    const int NW = small ? GS_F2NS_WAVES : GS_F2N_WAVES, NI = small ? GS_F2NS_ITEMS : GS_F2N_ITEMS, IW = small ? GS_F2S_IW : 32, HV = 64 / IW;
+    const int max_items = deal(NW, HV, mine, mine_lv);
+    const int NPOS = NW * HV * NI, maxw = ht.max_level_width;
     GsF2Tables& F = h->F2;
-    size_t off = up16((size_t)nsl * GS_F2_PITCH * 16);
-    const size_t ring_bytes = (size_t)2 * maxw * 3 * 32 * 16;
-    F.off_tile = (int32_t)off; off += up16(std::max<size_t>({(size_t)nsl * GS_F2_PITCH * 16, ring_bytes, (size_t)ht.m * GS_F2_PITCH * 16, (size_t)(topo->n_loads + 4) * 32 * sizeof(double)}));
+    const size_t ring_bytes = (size_t)2 * maxw * 3 * IW * 16;
     const int pos_off = (2 * ht.n * GS_F2_CHILDREN + nsl + 3) & ~3;
     const int n_ints = pos_off + NPOS * 4;
-    F.off_anc = (int32_t)off; off += up16((size_t)n_ints * 4);
-    F.off_z = (int32_t)off; off += up16((size_t)nsl * 32);
-    F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
-    F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * 32 * sizeof(double));
-    F.off_red = (int32_t)off; off += 2 * NW * 32 * sizeof(double);
-    F.off_atom = (int32_t)off; off += 5 * 32 * sizeof(unsigned long long) + 16 * 32 * sizeof(uint32_t);
-    F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack; F.n_jump = 0; F.n_levels = ht.n_levels; F.pos_off = pos_off; F.n_anc_ints = n_ints;
+    const size_t off = f2_layout(F, NW, IW, ring_bytes, (size_t)n_ints, 4);
+    F.n_jump = 0; F.n_levels = ht.n_levels; F.pos_off = pos_off; F.n_anc_ints = n_ints;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
     else if (!h->SC.jacobian_exact && cfg->jacobian_mode != GS_JACOBIAN_EXACT) why = "as-coded Jacobian";
     else if (!all_pq) why = "a bus below the slack is not a PQ bus";
     else if (!off_slack) why = "part of the network does not hang off the slack bus";
-    else if (max_items > NI) why = "more than " + std::to_string(NI) + " bus pairs per wave";
-    // a feeder of a dozen buses leaves seven of a wave's eight items empty: the level-synchronous kernel of the first
-    // generation (16 waves on 64 instances) is faster there (IEEE-13, B = 4096: 50 us against 61 us); GS_FORCE_FLOW2 overrides
-    else if (ht.lvl_ptr[ht.n_levels] < 2 * NW * 2 && !getenv("GS_FORCE_FLOW2")) why = "fewer than " + std::to_string(2 * NW * 2) + " buses: first-generation kernel";
+    else if (max_items > NI) why = "more than " + std::to_string(NI) + " bus groups per wave";
     else if (max_ch > GS_F2_CHILDREN) why = "a bus has more than " + std::to_string(GS_F2_CHILDREN) + " children";
     else if (max_dev > 2) why = "more than two devices of a kind at one bus";
     else if (off > 160 * 1024) why = "LDS tables do not fit";
     else if (ht.n < 2 || ht.m < 1) why = "trivial network";
     if (why.empty()) {
-      h->nr2 = true;
+      h->nr2 = true; h->f2_small = small; h->f2_iw = IW; h->f2_nw = NW;
       GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY; idle.level = -1;
       f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 4, 0.0);
@@ -750,24 +757,18 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       for (int p = 0; p < NPOS; ++p) { pos_tab[4 * p] = SL_DUMMY; pos_tab[4 * p + 1] = SL_ONE; pos_tab[4 * p + 2] = 0; pos_tab[4 * p + 3] = 0; }
       for (int w = 0; w < NW; ++w)
         for (int j = 0; j < (int)mine[w].size(); ++j) {
-          const int pair[2] = {mine[w][j].first, mine[w][j].second};
-          for (int hh = 0; hh < 2; ++hh) {
-            const int p = (w * 2 + hh) * NI + j;
+          int grp_maxch = 0;
+          for (int i : mine[w][j]) if (i >= 0) grp_maxch = std::max(grp_maxch, ht.child_ptr[i + 1] - ht.child_ptr[i]);
+          for (int hh = 0; hh < HV; ++hh) {
+            const int p = (w * HV + hh) * NI + j;
             GsF2Rec& r = f2recs[p];
-            r.level = mine_lv[w][j];
-            for (int h2 = 0; h2 < 2; ++h2) if (pair[h2] >= 0) r.pad1 = std::max(r.pad1, ht.child_ptr[pair[h2] + 1] - ht.child_ptr[pair[h2]]);   // most children of the pair
-            const int i = pair[hh];
+            r.level = mine_lv[w][j]; r.pad1 = grp_maxch;        // most children of the group's buses
+            const int i = mine[w][j][hh];
             if (i < 0) continue;
             const int fp = ht.fbs_parent[i];
             r.bus = i; r.parent = fp; r.flags = 1 | (fp == ht.slack ? 2 : 0); r.last = i;
             pos_tab[4 * p] = i; pos_tab[4 * p + 1] = fp; pos_tab[4 * p + 2] = ring_of(i); pos_tab[4 * p + 3] = fp == ht.slack ? 0 : ring_of(fp);
-            r.nl = ht.bl_ptr[i + 1] - ht.bl_ptr[i]; r.ng = ht.bg_ptr[i + 1] - ht.bg_ptr[i]; r.nb = ht.bb_ptr[i + 1] - ht.bb_ptr[i];
-            if (r.nl > 0) r.l0 = ht.bl_idx[ht.bl_ptr[i]];
-            if (r.nl > 1) r.l1 = ht.bl_idx[ht.bl_ptr[i] + 1];
-            if (r.ng > 0) r.g0 = ht.bg_idx[ht.bg_ptr[i]];
-            if (r.ng > 1) r.g1 = ht.bg_idx[ht.bg_ptr[i] + 1];
-            if (r.nb > 0) r.b0 = ht.bb_idx[ht.bb_ptr[i]];
-            if (r.nb > 1) r.b1 = ht.bb_idx[ht.bb_ptr[i] + 1];
+            f2_devices(r, i);
           }
         }
     }
@@ -920,10 +921,10 @@ int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
            "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d, "
            "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"solve_kernel\": \"%s\", \"flow2\": \"%s\"}",
-           h->flow2 ? "fbs_flow2" : h->nr2 ? "nr_flow2" : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
-           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, h->flow2 ? GS_F2_WAVES : h->nr2 ? GS_F2N_WAVES : h->W, h->groups,
+           h->flow2 ? (h->f2_small ? "fbs_flow2s" : "fbs_flow2") : h->nr2 ? (h->f2_small ? "nr_flow2s" : "nr_flow2") : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
+           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, (h->flow2 || h->nr2) ? h->f2_nw : h->W, h->groups,
            h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim,
-           (h->flow2 || h->nr2) ? 32 : 64, (h->flow2 || h->nr2) ? 2 * h->groups : h->groups, (h->flow2 || h->nr2) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576,
+           (h->flow2 || h->nr2) ? h->f2_iw : 64, (h->flow2 || h->nr2) ? (64 / h->f2_iw) * h->groups : h->groups, (h->flow2 || h->nr2) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576,
            kn[h->solve_kernel], (h->flow2 || h->nr2) ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()));
   return GS_OK;
 }

@@ -302,6 +302,11 @@ struct GsPackArgs {
 #define GS_F2_WAVES 16
 #define GS_F2N_WAVES 8            /* the Newton-Raphson member of the family: 8 waves x 2 halves x 8 buses (its bus state needs the registers) */
 #define GS_F2N_ITEMS 8
+#define GS_F2S_IW 8               /* small feeders: 8 instances per workgroup, the eight sub-groups of a wavefront on eight buses */
+#define GS_F2S_WAVES 2            /* sweeps: 2 waves x 8 sub-groups x 1 bus = 16 positions */
+#define GS_F2S_ITEMS 1
+#define GS_F2NS_WAVES 2           /* Newton-Raphson: 2 waves x 2 items, each a group of 8 buses of one level */
+#define GS_F2NS_ITEMS 2
 #define GS_F2_CHILDREN 8          /* children per bus in the Newton-Raphson kernel's LDS child tables */
 struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half) * GS_F2_ITEMS + item); 96 bytes
   int32_t bus, parent, flags, last;         // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); last: the bus at the LAST position of this bus's subtree

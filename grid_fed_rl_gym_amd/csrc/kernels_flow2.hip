@@ -38,7 +38,6 @@
 
 extern __shared__ __attribute__((aligned(16))) char f2_lds[];
 
-#define F2_SLOT_BYTES (GS_F2_PITCH * 16)
 #define F2_SPIN_CAP (1 << 18)
 
 __device__ __forceinline__ void f2_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -49,7 +48,6 @@ __device__ __forceinline__ void f2_lds_sync() { asm volatile("s_waitcnt lgkmcnt(
 #define F2_AS3 __attribute__((address_space(3)))
 #define F2_P(type, off) ((type F2_AS3*)((F2_AS3 char*)f2_lds + (off)))
 #define F2_VP(type, off) ((volatile type F2_AS3*)((F2_AS3 char*)f2_lds + (off)))
-__device__ __forceinline__ unsigned f2_slot(int slot, int l) { return (unsigned)slot * F2_SLOT_BYTES + ((unsigned)l << 4); }
 typedef double f2_v2 __attribute__((ext_vector_type(2)));        // 16 bytes: one ds_read_b128 / ds_write_b128
 typedef int f2_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double2 f2_ld2(unsigned off) { const f2_v2 v = *F2_P(const f2_v2, off); return make_double2(v.x, v.y); }
@@ -66,6 +64,18 @@ __device__ __forceinline__ void f2_st(unsigned off, double v) { *F2_P(double, of
 #define atomicAdd(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define atomicOr(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 __device__ __forceinline__ double f2_xhalf(double v) { return __shfl_xor(v, 32); }      // the same instance's value in the other half
+// the same instance's values in all HV sub-groups of the wave: maximum, and sum in sub-group order (the same on every lane)
+template <int IW> __device__ __forceinline__ double f2_xmax(double v) {
+#pragma unroll
+  for (int o = IW; o < 64; o <<= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+template <int IW> __device__ __forceinline__ double f2_xsum(double v, int l) {
+  double s = __shfl(v, l);
+#pragma unroll
+  for (int k = 1; k < 64 / IW; ++k) s += __shfl(v, k * IW + l);
+  return s;
+}
 __device__ __forceinline__ unsigned long long f2_bits(double v) { return __builtin_bit_cast(unsigned long long, v); }
 __device__ __forceinline__ double f2_dbl(unsigned long long b) { return __builtin_bit_cast(double, b); }
 
@@ -130,13 +140,18 @@ struct F2Stamp {
 // positions): the sweep kernel runs 16 x 4, Newton-Raphson -- whose bus state (voltage, the T and s of the elimination)
 // lives in registers across its two sweeps -- 8 x 8, i.e. twice the registers per wave.
 enum { F2_FBS = 0, F2_NR = 1 };
-template <int SOLVER, int CHK, int NW, int NI>
+template <int SOLVER, int CHK, int NW, int NI, int IW>
 __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                         double* __restrict__ slab, int B, const double* __restrict__ actions, double total_load,
                                         const GsPackArgs& PA, const GsFusedChecks& FC, const GsRolloutStep& RS) {
-  const int lane = threadIdx.x & 63, l = lane & 31, hv = lane >> 5;
+  // IW instances per workgroup (32; 16 or 8 for small feeders, where more of a wavefront's lanes go to different buses):
+  // lane = hv * IW + l, sub-group hv of the wave works on its own bus for instance l
+  constexpr int HV = 64 / IW;                          // sub-groups (buses) per wavefront
+  constexpr unsigned SB = (unsigned)(IW + 1) * 16u;    // bytes of an LDS slot: IW lanes x 16 B + one entry of padding
+  const int lane = threadIdx.x & 63, l = lane & (IW - 1), hv = lane / IW;
+  auto f2_slot = [](int slot, int ll) -> unsigned { return (unsigned)slot * SB + ((unsigned)ll << 4); };
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = blockIdx.x >> 1, hs = blockIdx.x & 1, L = hs * 32 + l;
+  const int g = blockIdx.x / HV, hs = blockIdx.x % HV, L = hs * IW + l;      // HV workgroups share a 64-instance slab group
   const int b = g * GS_LANES + L;
   const bool valid = b < B;
   const GsLaneRows S = gs_lane_rows(slab, g, R.total, L);
@@ -145,15 +160,15 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   double F2_AS3* const env_lds = F2_P(double, F.off_env);                 // [row][32 lanes]
   double F2_AS3* const loadp_lds = F2_P(double, F.off_tile);               // [load][32 lanes], dead before the line tile is written
   double F2_AS3* const red_lsum = F2_P(double, F.off_red);                 // [16 waves][32 lanes]
-  double F2_AS3* const red_dev = red_lsum + NW * 32;
+  double F2_AS3* const red_dev = red_lsum + NW * IW;
   unsigned long long F2_AS3* const cell = F2_P(unsigned long long, F.off_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits
-  unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 5 * 32);                // [16][32] integer counts
+  unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 5 * IW);                // [16][32] integer counts
   F2Stamp stp{C.stamps, 0ull, blockIdx.x == 0 && wave == C.stamp_wave && lane == 0};
   if (C.stamps) stp.t = __builtin_readcyclecounter();
 
   // ---- LDS init: flat start in every slot, ancestor and impedance tables, cells -----------------------------------------------
-  for (int k = threadIdx.x; k < nsl * 32; k += blockDim.x) {
-    const int s = k >> 5, ll = k & 31;
+  for (int k = threadIdx.x; k < nsl * IW; k += blockDim.x) {
+    const int s = k / IW, ll = k & (IW - 1);
     double e = 1.0;
     if (s < n) e = T.fixed_v[s] ? T.v_set[s] : 1.0;
     else if (s == SL_ZERO) e = 0.0;
@@ -166,8 +181,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     for (int k = threadIdx.x; k < F.n_anc_ints; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];          // child tables + per-position indices
     for (int k = threadIdx.x; k < 4 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];             // (G_ip, B_ip, G_ii, B_ii) per bus
   }
-  for (int k = threadIdx.x; k < 5 * 32; k += blockDim.x) cell[k] = (k >= 4 * 32) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
-  for (int k = threadIdx.x; k < 16 * 32; k += blockDim.x) icell[k] = 0u;
+  for (int k = threadIdx.x; k < 5 * IW; k += blockDim.x) cell[k] = (k >= 4 * IW) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
+  for (int k = threadIdx.x; k < 16 * IW; k += blockDim.x) icell[k] = 0u;
 
   // ---- inside a rollout: the instances the previous step finished are reset here, where the reference calls env.reset()
   // (algorithms/base.py:289-290) -- terminal observation to the side list, next seed of the instance's chain, fresh
@@ -200,7 +215,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // _apply_actions (grid_env.py:621-651, dynamics.py:189-220): the halves take alternate batteries / generators
     const double* act = actions + (size_t)(valid ? b : 0) * (nb + ng);
     const double dt = E.timestep;
-    for (int q0 = 0; q0 < nb; q0 += 2) {
+    for (int q0 = 0; q0 < nb; q0 += HV) {
       const int q = q0 + hv; const bool on = q < nb; const int qq = on ? q : 0;
       const double a = act[qq], rating = T.bat_rating[qq], cap = T.bat_cap[qq], eff = T.bat_eff[qq];
       double soc = f2_row(S, R.SOC + qq), bp = f2_row(S, R.BATP + qq);
@@ -219,20 +234,21 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       }
       if (on) {
         if (valid && cmd != 0.0) { f2_row(S, R.SOC + q) = soc; f2_row(S, R.BATP + q) = bp; }
-        env_lds[(F.env_soc + q) * 32 + l] = soc; env_lds[(F.env_batp + q) * 32 + l] = bp;
+        env_lds[(F.env_soc + q) * IW + l] = soc; env_lds[(F.env_batp + q) * IW + l] = bp;
       }
     }
-    for (int g0 = 0; g0 < ng; g0 += 2) {
+    for (int g0 = 0; g0 < ng; g0 += HV) {
       const int gi = g0 + hv; const bool on = gi < ng; const int gg = on ? gi : 0;
       const double c = valid ? (act[nb + gg] + 1.0) / 2.0 : (double)f2_row(S, R.CURT + gg);
-      if (on) { if (valid) f2_row(S, R.CURT + gi) = c; env_lds[(F.env_curt + gi) * 32 + l] = c; }
+      if (on) { if (valid) f2_row(S, R.CURT + gi) = c; env_lds[(F.env_curt + gi) * IW + l] = c; }
     }
     if (valid && hv == 0) { ROW(R.TIME) = told + dt; ROW(R.STEP) = kold + 1.0; }      // grid_env.py:470-471
-  } else if (wave == 1) {
+  }
+  if (wave == (NW >= 2 ? 1 : 0)) {
     // _update_weather + renewable models (grid_env.py:653-681, dynamics.py:120-142, 158-170); the halves take alternate generators
     const GsWeather wx = weather_step(R, E, S, inst, tnew, snew, valid);
     const double elev = solar_elevation(valid ? tnew : told);
-    for (int g0 = 0; g0 < ng; g0 += 2) {
+    for (int g0 = 0; g0 < ng; g0 += HV) {
       const int gi = g0 + hv; const bool on = gi < ng; const int gg = on ? gi : 0;
       const double cap = T.gen_cap[gg], p0 = T.gen_p0[gg], p1 = T.gen_p1[gg], p2 = T.gen_p2[gg];
       double pw;
@@ -243,12 +259,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       } else if (wx.wind < p0 || wx.wind > p2) pw = 0.0;
       else if (wx.wind <= p1) { const double q = (wx.wind - p0) / (p1 - p0); pw = cap * (q * q * q); }
       else pw = cap;
-      if (on) { f2_row(S, R.GENP + gi) = pw; env_lds[(F.env_genp + gi) * 32 + l] = pw; }
+      if (on) { f2_row(S, R.GENP + gi) = pw; env_lds[(F.env_genp + gi) * IW + l] = pw; }
     }
-  } else {
-    // realised load powers (dynamics.py:54-75): loads 4 p .. 4 p + 3 share one Philox call; one quad per HALF wave
+  }
+  if (NW < 3 || wave >= 2) {
+    // realised load powers (dynamics.py:54-75): loads 4 p .. 4 p + 3 share one Philox call; one quad per sub-group of a wave
+    // (workgroups of one or two waves: every wave draws, the first after its two scalar chains)
     const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
-    for (int p = (wave - 2) * 2 + hv; 4 * p < nl_; p += (NW - 2) * 2) {
+    for (int p = (NW < 3 ? wave : wave - 2) * HV + hv; 4 * p < nl_; p += (NW < 3 ? NW : NW - 2) * HV) {
       double z[4] = {0.0, 0.0, 0.0, 0.0};
       if (E.stochastic_loads) rng_normal_quad(seed, inst, snew, DRAW_LOAD0 + p, z);
       const int l0 = 4 * p;
@@ -258,7 +276,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const int li = min(l0 + k, nl_ - 1);
         const double base = T.load_base[li];
         lp[k] = E.stochastic_loads ? fmax(0.0, base * (prof * (1.0 + 0.1 * z[k])) * 1.0) : base;
-        if (l0 + k < nl_) loadp_lds[(l0 + k) * 32 + l] = lp[k];
+        if (l0 + k < nl_) loadp_lds[(l0 + k) * IW + l] = lp[k];
       }
       // LOADP starts on an even row: (l0, l0 + 1) and (l0 + 2, l0 + 3) are row pairs
       if (l0 + 1 < nl_) f2_pair(S, R.LOADP + l0) = make_double2(lp[0], lp[1]); else f2_row(S, R.LOADP + l0) = lp[0];
@@ -270,7 +288,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   stp.hit(F2_ST_PRO_SCALAR);
 
   // ---- the records of this lane's items: position p = ((wave * 2 + half) * NI + j) of the forest's preorder ----
-  const GsF2Rec* const rec0 = F.recs + ((size_t)(wave * 2 + hv) * NI);
+  const GsF2Rec* const rec0 = F.recs + ((size_t)(wave * HV + hv) * NI);
   int ibus[NI], ilast[NI];
   unsigned roots = 0u;                   // bit j: item j hangs off the slack bus
 #pragma unroll
@@ -283,12 +301,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     const GsF2Rec* q = rec0 + j;
     const int nl = q->nl, l0 = q->l0, l1 = q->l1, ngj = q->ng, g0 = q->g0, g1 = q->g1, nbj = q->nb, b0 = q->b0, b1 = q->b1;
     double ls = 0.0, gs = 0.0;
-    if (nl > 0) ls += loadp_lds[l0 * 32 + l];
-    if (nl > 1) ls += loadp_lds[l1 * 32 + l];
-    if (ngj > 0) gs += env_lds[(F.env_genp + g0) * 32 + l] * env_lds[(F.env_curt + g0) * 32 + l];
-    if (ngj > 1) gs += env_lds[(F.env_genp + g1) * 32 + l] * env_lds[(F.env_curt + g1) * 32 + l];
-    if (nbj > 0) { const double bp = env_lds[(F.env_batp + b0) * 32 + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
-    if (nbj > 1) { const double bp = env_lds[(F.env_batp + b1) * 32 + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+    if (nl > 0) ls += loadp_lds[l0 * IW + l];
+    if (nl > 1) ls += loadp_lds[l1 * IW + l];
+    if (ngj > 0) gs += env_lds[(F.env_genp + g0) * IW + l] * env_lds[(F.env_curt + g0) * IW + l];
+    if (ngj > 1) gs += env_lds[(F.env_genp + g1) * IW + l] * env_lds[(F.env_curt + g1) * IW + l];
+    if (nbj > 0) { const double bp = env_lds[(F.env_batp + b0) * IW + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
+    if (nbj > 1) { const double bp = env_lds[(F.env_batp + b1) * IW + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
     Pj[j] = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base);
     IR[j] = 0.0; II[j] = 0.0; JR[j] = 0.0; JI[j] = 0.0;
   }
@@ -304,11 +322,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   auto wg_max = [&](double lmax) -> double {
     const int c0 = check % 3, c1 = (check + 1) % 3;
     ++check;
-    lmax = fmax(lmax, f2_xhalf(lmax));
-    if (wave == 0 && hv == 0) cell[c1 * 32 + l] = 0ull;
-    if (hv == 0) atomicMax(cell + c0 * 32 + l, f2_bits(lmax));
+    lmax = f2_xmax<IW>(lmax);
+    if (wave == 0 && hv == 0) cell[c1 * IW + l] = 0ull;
+    if (hv == 0) atomicMax(cell + c0 * IW + l, f2_bits(lmax));
     f2_lds_sync();
-    return f2_dbl(cell[c0 * 32 + l]);
+    return f2_dbl(cell[c0 * IW + l]);
   };
 
   if constexpr (SOLVER == F2_NR) {
@@ -332,9 +350,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   int imax[NI];                                                     // most children of the pair's two buses, wave-uniform
 #pragma unroll
   for (int j = 0; j < NI; ++j) imax[j] = __builtin_amdgcn_readfirstlane(rec0[j].pad1);
-  const int pos0 = (wave * 2 + hv) * NI;
+  const int pos0 = (wave * HV + hv) * NI;
   const int NL = F.n_levels;
-  auto ring3 = [&](int slot, int part) -> unsigned { return bufB + ((unsigned)(slot * 3 + part) * 32u + (unsigned)l) * 16u; };
+  auto ring3 = [&](int slot, int part) -> unsigned { return bufB + ((unsigned)(slot * 3 + part) * (unsigned)IW + (unsigned)l) * 16u; };
   // flat start: the slots hold it already (every bus below the slack is a PQ bus, the host checks).  |V| and the angle are
   // not kept: |V| = sqrt(e^2 + f^2) where it is needed, corrections rotate (e, f) by the angle increment
   double pcj[NI], qcj[NI];
@@ -459,10 +477,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     }
     stp.hit(F2_ST_BOTTOM_UP);
     {  // exact singularity anywhere in the instance: stop it where it is (status 2), as the reference's LinAlgError break does
-      sing |= __shfl_xor(sing, 32);
-      if (sing && hv == 0) atomicOr(icell + 15 * 32 + l, 1u);
+#pragma unroll
+      for (int o = IW; o < 64; o <<= 1) sing |= __shfl_xor(sing, o);
+      if (sing && hv == 0) atomicOr(icell + 15 * IW + l, 1u);
       f2_lds_sync();
-      const unsigned sa = icell[15 * 32 + l];
+      const unsigned sa = icell[15 * IW + l];
       if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
     }
     const bool upd = !st.done;
@@ -565,22 +584,29 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     double ar = 0.0, ai = 0.0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) { ar += -IR[j]; ai += -II[j]; qr[j] = ar; qi[j] = ai; }      // local inclusive scan
-    const double orr = f2_xhalf(ar), oi = f2_xhalf(ai);
-    const double t0r = hv ? orr : ar, t0i = hv ? oi : ai, t1r = hv ? ar : orr, t1i = hv ? ai : oi;      // half 0's and half 1's totals
-    if (hv == 0) { f2_v2 t; t.x = t0r + t1r; t.y = t0i + t1i; tot_lds[wave * 32 + l] = t; }
+    // totals of the sub-groups before this one inside the wave (in sub-group order), and of the whole wave
+    double pre_r = 0.0, pre_i = 0.0, wt_r = 0.0, wt_i = 0.0;
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      const double tr = __shfl(ar, k * IW + l), ti = __shfl(ai, k * IW + l);
+      if (k < hv) { pre_r += tr; pre_i += ti; }
+      wt_r += tr; wt_i += ti;
+    }
+    if (hv == 0) { f2_v2 t; t.x = wt_r; t.y = wt_i; tot_lds[wave * IW + l] = t; }
     f2_lds_sync();
     double br = 0.0, bi = 0.0;                                    // sum of the totals of the waves before this one, in wave order
     {
+      constexpr int TB = NW < 8 ? NW : 8;
 #pragma unroll
-      for (int w0 = 0; w0 < NW; w0 += 8) {                        // eight totals per LDS round trip
-        f2_v2 tw[8];
+      for (int w0 = 0; w0 < NW; w0 += TB) {                       // eight totals per LDS round trip
+        f2_v2 tw[TB];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) tw[w] = tot_lds[(w0 + w) * 32 + l];
+        for (int w = 0; w < TB; ++w) tw[w] = tot_lds[(w0 + w) * IW + l];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) { if (w0 + w < wave) { br += tw[w].x; bi += tw[w].y; } }
+        for (int w = 0; w < TB; ++w) { if (w0 + w < wave) { br += tw[w].x; bi += tw[w].y; } }
       }
     }
-    if (hv) { br += t0r; bi += t0i; }
+    br += pre_r; bi += pre_i;
     // Q of position p is filed under the BUS at that position (buffer B shares the slot numbering of buffer A, whose
     // "no ancestor" slot must stay zero); idle positions all file under the DUMMY slot, which nobody reads
 #pragma unroll
@@ -699,7 +725,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   double totloss0 = 0.0, f_old = 0.0, viol0 = 0.0, step0 = 0.0, eprew0 = 0.0;
   if (wave == 0) { totloss0 = ROW(R.TOTLOSS); f_old = ROW(R.FREQ); viol0 = ROW(R.VIOL); eprew0 = ROW(R.EPREW); step0 = valid ? kold + 1.0 : kold; }
   const bool chk = CHK && FC.enabled;
-  if (chk && wave == 0 && hv == 0) { cell[l] = 0ull; cell[32 + l] = 0ull; }      // the first two convergence cells take two maxima of the checks
+  if (chk && wave == 0 && hv == 0) { cell[l] = 0ull; cell[IW + l] = 0ull; }      // the first two convergence cells take two maxima of the checks
   const GsChecksCfg& K = FC.C;
   double* Pv = chk ? FC.prev + (size_t)g * (n + 1) * GS_LANES + L : nullptr;
   int k_nlow = 0, k_nhigh = 0, k_mhigh = 0, k_mlow = 0, k_mem = 0, k_cover = 0, k_mover = 0, k_vbad = 0, k_fbad = 0;
@@ -707,7 +733,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 
   // lines (power_flow.py:340-356; Line.update_state, base.py:261-264): two lines per wave instruction
   int over = 0;
-  for (int k0 = wave * 2 + hv; k0 < ((m + 2 * NW - 1) / (2 * NW)) * (2 * NW); k0 += 2 * NW) {
+  for (int k0 = wave * HV + hv; k0 < ((m + HV * NW - 1) / (HV * NW)) * (HV * NW); k0 += HV * NW) {
     const bool on = k0 < m; const int k = on ? k0 : m - 1;
     const int li = T.lfrom[k], lj = T.lto[k];
     const double yr = T.lyr[k], yi = T.lyi[k], rating = T.lrating[k], rinv = T.lrating_inv[k];
@@ -720,7 +746,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     if (on) {
       f2_row(S, R.LOAD + k) = ql;
       f2_pair(S, R.FLOW + k) = make_double2(sr, ld);
-      f2_st2(F.off_tile + (unsigned)k * F2_SLOT_BYTES + ((unsigned)l << 4), make_double2(sr, ld));
+      f2_st2(F.off_tile + (unsigned)k * SB + ((unsigned)l << 4), make_double2(sr, ld));
       over += (ld > 0.8) ? 1 : 0;
       if (chk) {
         const double cld_ = K.stride_cload == 2 ? ld : ql;             // which loading the limits apply to
@@ -737,7 +763,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // buses: (e, f) -> (|V|, angle) in place (the slots become the observation tile), state rows, reward / flag partials
   double dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int vflags = 0;
-  for (int i0 = wave * 2 + hv; i0 < ((n + 2 * NW - 1) / (2 * NW)) * (2 * NW); i0 += 2 * NW) {
+  for (int i0 = wave * HV + hv; i0 < ((n + HV * NW - 1) / (HV * NW)) * (HV * NW); i0 += HV * NW) {
     const bool on = i0 < n; const int i = on ? i0 : n - 1;
     double2 ef = final_ef(i);
     if (!on) ef = make_double2(1.0, 0.0);                     // keep the wave on the series branch of the angle
@@ -766,58 +792,59 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   }
   stp.hit(F2_ST_EPI_BUSES);
   {  // partial results: sums keep per-wave partials (added in wave order below), everything else is an integer atomic
-    const double ls2 = psum + f2_xhalf(psum), dv2 = dev + f2_xhalf(dev);            // half 0 + half 1, the same on both sides
-    if (hv == 0) { red_lsum[wave * 32 + l] = ls2; red_dev[wave * 32 + l] = dv2; }
-    if (vmax == vmax && vmax > -INFINITY) atomicMax(cell + 3 * 32 + l, f2_bits(vmax));       // |V| >= 0: bit patterns order like the values
-    if (vmin == vmin && vmin < INFINITY) atomicMin(cell + 4 * 32 + l, f2_bits(vmin));
-    if (over) atomicAdd(icell + 0 * 32 + l, (unsigned)over);
-    if (vflags) atomicOr(icell + 1 * 32 + l, (unsigned)vflags);
+    const double ls2 = f2_xsum<IW>(psum, l), dv2 = f2_xsum<IW>(dev, l);            // over the wave's sub-groups, in sub-group order
+    if (hv == 0) { red_lsum[wave * IW + l] = ls2; red_dev[wave * IW + l] = dv2; }
+    if (vmax == vmax && vmax > -INFINITY) atomicMax(cell + 3 * IW + l, f2_bits(vmax));       // |V| >= 0: bit patterns order like the values
+    if (vmin == vmin && vmin < INFINITY) atomicMin(cell + 4 * IW + l, f2_bits(vmin));
+    if (over) atomicAdd(icell + 0 * IW + l, (unsigned)over);
+    if (vflags) atomicOr(icell + 1 * IW + l, (unsigned)vflags);
     if (chk) {
-      if (k_nlow) atomicAdd(icell + 2 * 32 + l, (unsigned)k_nlow);
-      if (k_nhigh) atomicAdd(icell + 3 * 32 + l, (unsigned)k_nhigh);
-      if (k_mhigh) atomicAdd(icell + 4 * 32 + l, (unsigned)k_mhigh);
-      if (k_mlow) atomicAdd(icell + 5 * 32 + l, (unsigned)k_mlow);
-      if (k_mem) atomicAdd(icell + 6 * 32 + l, (unsigned)k_mem);
-      if (k_cover) atomicAdd(icell + 7 * 32 + l, (unsigned)k_cover);
-      if (k_mover) atomicAdd(icell + 8 * 32 + l, (unsigned)k_mover);
+      if (k_nlow) atomicAdd(icell + 2 * IW + l, (unsigned)k_nlow);
+      if (k_nhigh) atomicAdd(icell + 3 * IW + l, (unsigned)k_nhigh);
+      if (k_mhigh) atomicAdd(icell + 4 * IW + l, (unsigned)k_mhigh);
+      if (k_mlow) atomicAdd(icell + 5 * IW + l, (unsigned)k_mlow);
+      if (k_mem) atomicAdd(icell + 6 * IW + l, (unsigned)k_mem);
+      if (k_cover) atomicAdd(icell + 7 * IW + l, (unsigned)k_cover);
+      if (k_mover) atomicAdd(icell + 8 * IW + l, (unsigned)k_mover);
       const unsigned fl = (unsigned)(k_vbad | (k_fbad << 1) | (k_dvnan << 2) | (k_qlnan << 3));
-      if (fl) atomicOr(icell + 9 * 32 + l, fl);
+      if (fl) atomicOr(icell + 9 * IW + l, fl);
       // the convergence cells are free by now: [0] max |dV|, [1] max loading (both >= 0)
-      atomicMax(cell + 0 * 32 + l, f2_bits(k_dv));
-      atomicMax(cell + 1 * 32 + l, f2_bits(k_ql));
+      atomicMax(cell + 0 * IW + l, f2_bits(k_dv));
+      atomicMax(cell + 1 * IW + l, f2_bits(k_ql));
     }
   }
   // (the convergence cells [0], [1] were last read before the solver's final barrier; cell [2] is not reused)
   f2_lds_sync();
   stp.hit(F2_ST_EPI_REDUCE);
 
-  if (wave != 0) {
-    // ---- observation block of this workgroup's 32 instances, straight from the two LDS tiles: lane = column pair ----
+  constexpr int WO0 = NW > 1 ? 1 : 0;             // the waves that write the observation block out: all but wave 0 (which has the scalar part)
+  if (wave >= WO0) {
+    // ---- observation block of this workgroup's IW instances, straight from the two LDS tiles: lane = column pair ----
     // (|V|, angle) per bus and (flow, loading) per line are adjacent observation columns (grid_env.py:758-763)
     if (PA.out != nullptr) {
-      for (int r = wave - 1; r < 32; r += NW - 1) {
-        const int br = g * GS_LANES + hs * 32 + r;
+      for (int r = wave - WO0; r < IW; r += NW - WO0) {
+        const int br = g * GS_LANES + hs * IW + r;
         if (br >= B) continue;
         double* o = PA.out + (size_t)br * PA.obs_dim;
         if (!(PA.obs_dim & 1)) {            // every row of the block starts on a 16-byte boundary: one store per column pair
           for (int cp = lane; cp < n; cp += 64) *(double2*)(o + 2 * cp) = f2_ld2(f2_slot(cp, r));
-          for (int cp = lane; cp < m; cp += 64) *(double2*)(o + 2 * n + 2 * cp) = f2_ld2(F.off_tile + (unsigned)cp * F2_SLOT_BYTES + ((unsigned)r << 4));
+          for (int cp = lane; cp < m; cp += 64) *(double2*)(o + 2 * n + 2 * cp) = f2_ld2(F.off_tile + (unsigned)cp * SB + ((unsigned)r << 4));
         } else {
           for (int cp = lane; cp < n; cp += 64) { const double2 v = f2_ld2(f2_slot(cp, r)); o[2 * cp] = v.x; o[2 * cp + 1] = v.y; }
           for (int cp = lane; cp < m; cp += 64) {
-            const double2 v = f2_ld2(F.off_tile + (unsigned)cp * F2_SLOT_BYTES + ((unsigned)r << 4)); o[2 * n + 2 * cp] = v.x; o[2 * n + 2 * cp + 1] = v.y; }
+            const double2 v = f2_ld2(F.off_tile + (unsigned)cp * SB + ((unsigned)r << 4)); o[2 * n + 2 * cp] = v.x; o[2 * n + 2 * cp + 1] = v.y; }
         }
       }
     }
     stp.hit(F2_ST_EPILOGUE);
-    return;
+    if (wave != 0) return;
   }
   // ---- wave 0: everything of step() that follows the load flow, per instance (grid_env.py:553-617) ----
   double losses = 0.0;
   dev = 0.0;
-  for (int w = 0; w < NW; ++w) { losses += red_lsum[w * 32 + l]; dev += red_dev[w * 32 + l]; }
-  vmax = f2_dbl(cell[3 * 32 + l]); vmin = f2_dbl(cell[4 * 32 + l]);
-  over = (int)icell[0 * 32 + l]; vflags = (int)icell[1 * 32 + l];
+  for (int w = 0; w < NW; ++w) { losses += red_lsum[w * IW + l]; dev += red_dev[w * IW + l]; }
+  vmax = f2_dbl(cell[3 * IW + l]); vmin = f2_dbl(cell[4 * IW + l]);
+  over = (int)icell[0 * IW + l]; vflags = (int)icell[1 * IW + l];
   const bool st_lane = hv == 0;                       // both halves hold the same values; half 0 stores
   if (st_lane) {
     ROW(R.LOSSES) = losses; ROW(R.MAXMIS) = st.mm; ROW(R.ITERS) = (double)st.iters; ROW(R.CONV) = (double)st.conv; ROW(R.STATUS) = (double)st.status;
@@ -825,9 +852,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const double dt = E.timestep;
   double total_gen = 0.0, total_curt = 0.0;                            // grid_env.py:744-751, 807-816
   for (int gi = 0; gi < ng; ++gi) {
-    const double p = env_lds[(F.env_genp + gi) * 32 + l];
+    const double p = env_lds[(F.env_genp + gi) * IW + l];
     total_gen += p;
-    total_curt += p * (1.0 - env_lds[(F.env_curt + gi) * 32 + l]);
+    total_curt += p * (1.0 - env_lds[(F.env_curt + gi) * IW + l]);
   }
   const double totloss = totloss0 + losses * dt / 3600.0;              // grid_env.py:739
   const double imbalance = (total_gen - total_load - losses * E.power_base) / 1e6;
@@ -841,7 +868,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   reward -= totloss * 0.1;
   reward += (total_gen - total_curt) * 1e-5;
   for (int q = 0; q < nb; ++q) {
-    const double soc = env_lds[(F.env_soc + q) * 32 + l];
+    const double soc = env_lds[(F.env_soc + q) * IW + l];
     reward += (soc >= 0.2 && soc <= 0.8) ? 1.0 : -5.0;
   }
   const int vhigh = vflags & 1, vlow = (vflags >> 1) & 1, fhigh = f > E.f_max, flow_ = f < E.f_min;
@@ -867,18 +894,18 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       double* o = PA.out + (size_t)b * PA.obs_dim;
       const int c_f = 2 * n + 2 * m, c_g = c_f + 1 + 2 * nl_, c_b = c_g + ng;
       o[c_f] = f;
-      for (int gi = 0; gi < ng; ++gi) o[c_g + gi] = env_lds[(F.env_genp + gi) * 32 + l];
-      for (int q = 0; q < nb; ++q) { o[c_b + 2 * q] = env_lds[(F.env_soc + q) * 32 + l]; o[c_b + 2 * q + 1] = env_lds[(F.env_batp + q) * 32 + l]; }
+      for (int gi = 0; gi < ng; ++gi) o[c_g + gi] = env_lds[(F.env_genp + gi) * IW + l];
+      for (int q = 0; q < nb; ++q) { o[c_b + 2 * q] = env_lds[(F.env_soc + q) * IW + l]; o[c_b + 2 * q + 1] = env_lds[(F.env_batp + q) * IW + l]; }
     }
   }
   if (chk && st_lane && b < (int)FC.Bp && valid) {
     // same finalisation as gs_k_checks (kernels_checks.hip) / the first-generation fused epilogue, on the values of this very step
-    const int c_nlow = (int)icell[2 * 32 + l], c_nhigh = (int)icell[3 * 32 + l], m_nhigh = (int)icell[4 * 32 + l], m_nlow = (int)icell[5 * 32 + l];
-    const int m_nem = (int)icell[6 * 32 + l], c_nover = (int)icell[7 * 32 + l], m_nover = (int)icell[8 * 32 + l];
-    const unsigned fl = icell[9 * 32 + l];
+    const int c_nlow = (int)icell[2 * IW + l], c_nhigh = (int)icell[3 * IW + l], m_nhigh = (int)icell[4 * IW + l], m_nlow = (int)icell[5 * IW + l];
+    const int m_nem = (int)icell[6 * IW + l], c_nover = (int)icell[7 * IW + l], m_nover = (int)icell[8 * IW + l];
+    const unsigned fl = icell[9 * IW + l];
     const int vbad = fl & 1, fbad = (fl >> 1) & 1;
-    k_dv = (fl & 4) ? NAN : f2_dbl(cell[0 * 32 + l]);
-    k_ql = (fl & 8) ? NAN : f2_dbl(cell[1 * 32 + l]);
+    k_dv = (fl & 4) ? NAN : f2_dbl(cell[0 * IW + l]);
+    k_ql = (fl & 8) ? NAN : f2_dbl(cell[1 * IW + l]);
     if (m == 0) k_ql = -INFINITY;
     int32_t* has_prev = FC.state + b; int32_t* consec = FC.state + FC.Bp + b; int32_t* emode = FC.state + 2 * FC.Bp + b;
 #define OI(k) FC.out_i[(size_t)(k) * FC.Bp + b]
@@ -918,16 +945,18 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   stp.hit(F2_ST_EPI_SCALARS);
 }
 
-#define F2_KERNELS(name, SOLVER, NW, NI)                                                                                   \
+#define F2_KERNELS(name, SOLVER, NW, NI, IW)                                                                               \
   extern "C" __global__ void __launch_bounds__(64 * NW)                                                                    \
   gs_k_step_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,         \
                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
-    f2_step<SOLVER, 0, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                                   \
+    f2_step<SOLVER, 0, NW, NI, IW>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                               \
   }                                                                                                                        \
   extern "C" __global__ void __launch_bounds__(64 * NW)     /* the step with the post-step checks in its epilogue */       \
   gs_k_stepc_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,        \
                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
-    f2_step<SOLVER, 1, NW, NI>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                                   \
+    f2_step<SOLVER, 1, NW, NI, IW>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                               \
   }
-F2_KERNELS(fbs_flow2, F2_FBS, 16, 4)
-F2_KERNELS(nr_flow2, F2_NR, 8, 8)
+F2_KERNELS(fbs_flow2, F2_FBS, 16, 4, 32)       // up to 128 buses below the slack
+F2_KERNELS(nr_flow2, F2_NR, 8, 8, 32)
+F2_KERNELS(fbs_flow2s, F2_FBS, 2, 1, 8)        // up to 16 buses: 8 instances per workgroup, eight buses per wavefront
+F2_KERNELS(nr_flow2s, F2_NR, 2, 2, 8)          // up to 4 groups of 8 same-level buses
