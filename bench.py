@@ -357,7 +357,8 @@ def main():
             nbytes = sum(v.nbytes for v in d.values() if isinstance(v, np.ndarray))
             m["rollout"] = {"env_steps_per_s": med, "p10_p90": [p10, p90], "T": T, "policy": "random actions drawn on the device",
                             "what": "gs_rollout: T fused steps, each writing its observation block into the next slot of obs_seq[T+1][B][obs_dim]; "
-                                    "reward / done bookkeeping and in-place resets by a second small kernel per step; no host copy",
+                                    "reward / done arrays, terminal-observation side list and in-place resets of finished instances ride in the same launches "
+                                    "(one kernel per step); random actions end an episode by truncation every 10-20 steps, so resets are part of the figure; no host copy",
                             "finished_episodes": d["n_terminal"],
                             "download_once_at_the_end": {"seconds": dt_dl, "bytes": nbytes, "GB_per_s": nbytes / dt_dl / 1e9}}
         except Exception as e:

@@ -1124,7 +1124,7 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
     if ((rc = step_kernels(h, ro.act + (size_t)t * B * A, nxt, fused ? &rs : nullptr))) return rc;
     if (!fused || t == T - 1) {
       GsRolloutPostArgs pa{fused ? nullptr : ro.rew, fused ? nullptr : ro.done, nxt, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, h->B};
-      hipLaunchKernelGGL(gs_k_rollout_post, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, pa);
+      hipLaunchKernelGGL(gs_k_rollout_post, dim3(h->groups), dim3(256), 0, h->stream, h->T, h->R, h->EC, h->slab, pa);
       HIPCHK(h, hipGetLastError());
     }
   }

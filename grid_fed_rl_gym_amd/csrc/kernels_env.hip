@@ -83,32 +83,59 @@ gs_k_fill_const_columns(double* __restrict__ out, long long rows, int obs_dim, i
 // that finished (terminated or truncated) has its terminal observation -- row b of obs_next, which the step kernel has
 // just written -- moved to the side list, is reset in place with the next seed of its chain (algorithms/base.py:289-290:
 // `obs, _ = env.reset()`), and its fresh observation takes the row's place, so that obs_next is what step t + 1 starts
-// from for every instance.  Finished instances are rare (once per episode); their column loops are per lane.
+// from for every instance.  With random actions an episode lasts 10-20 steps (truncation), so the row moves are done by
+// the whole workgroup, coalesced (per-lane column loops cost 1.5 ms per 8192 finished instances).
 // (arguments: GsRolloutPostArgs, gs_internal.h)
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(256)
 gs_k_rollout_post(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, GsRolloutPostArgs A) {
-  const int lane = threadIdx.x;
+  // 256 threads per 64-instance group: threads 0-63 are the instances (flags, list entries, reset), all of them move the
+  // observation rows, consecutive threads on consecutive columns
+  __shared__ int fin[GS_LANES];          // entry of the side list (>= 0), -1 list full, -2 not finished
+  const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * GS_LANES + lane;
   const GsLaneRows S = gs_lane_rows(slab, blockIdx.x, R.total, lane);
-  if (b >= A.B) return;
-  const double rew = ROW(R.REWARD), te = ROW(R.TERM), tr = ROW(R.TRUNC);
-  const int d = (te != 0.0 ? 1 : 0) | (tr != 0.0 ? 2 : 0);
-  if (A.rew) {                          // (NULL: the step kernel has written them itself)
-    A.rew[(size_t)A.t * A.B + b] = rew;
-    A.done[(size_t)A.t * A.B + b] = (uint8_t)d;
+  const bool mine = threadIdx.x < GS_LANES && b < A.B;
+  if (threadIdx.x < GS_LANES) {
+    int k = -2;
+    if (mine) {
+      const double rew = ROW(R.REWARD), te = ROW(R.TERM), tr = ROW(R.TRUNC);
+      const int d = (te != 0.0 ? 1 : 0) | (tr != 0.0 ? 2 : 0);
+      if (A.rew) {                          // (NULL: the step kernel has written them itself)
+        A.rew[(size_t)A.t * A.B + b] = rew;
+        A.done[(size_t)A.t * A.B + b] = (uint8_t)d;
+      }
+      if (d) {
+        k = atomicAdd(A.term_count, 1);
+        if (k < A.term_cap) { A.term_idx[2 * k] = A.t; A.term_idx[2 * k + 1] = b; }
+        else k = -1;
+      }
+    }
+    fin[lane] = k;
   }
-  if (!d) return;
-  double* row = A.obs_next + (size_t)b * A.obs_dim;
-  const int k = atomicAdd(A.term_count, 1);
-  if (k < A.term_cap) {
-    A.term_idx[2 * k] = A.t; A.term_idx[2 * k + 1] = b;
-    double* dst = A.term_obs + (size_t)k * A.obs_dim;
-    for (int c = 0; c < A.obs_dim; ++c) dst[c] = row[c];
+  __syncthreads();
+  bool any = false;
+  for (int q = 0; q < GS_LANES; ++q) {
+    const int k = fin[q];
+    any |= k != -2;
+    if (k >= 0) {
+      const double* row = A.obs_next + (size_t)(blockIdx.x * GS_LANES + q) * A.obs_dim;
+      double* dst = A.term_obs + (size_t)k * A.obs_dim;
+      for (int c = threadIdx.x; c < A.obs_dim; c += blockDim.x) dst[c] = row[c];
+    }
   }
-  const uint64_t inst = (uint64_t)(E.first_instance + b);
-  env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
-  for (int c = 0; c < A.obs_dim; ++c) {
-    const int s = A.map[c];
-    row[c] = (s >= 0) ? (double)ROW(s) : A.cst[-s - 1];
+  if (!any) return;                       // (uniform: fin is shared)
+  if (mine && fin[lane] != -2) {
+    const uint64_t inst = (uint64_t)(E.first_instance + b);
+    env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the reset rows are in memory before the other waves gather them
+  for (int q = 0; q < GS_LANES; ++q) {
+    if (fin[q] == -2) continue;
+    const GsLaneRows Sq = gs_lane_rows(slab, blockIdx.x, R.total, q);
+    double* row = A.obs_next + (size_t)(blockIdx.x * GS_LANES + q) * A.obs_dim;
+    for (int c = threadIdx.x; c < A.obs_dim; c += blockDim.x) {
+      const int s = A.map[c];
+      row[c] = (s >= 0) ? Sq.lane_row((size_t)s * GS_LANES).get() : A.cst[-s - 1];
+    }
   }
 }

@@ -186,21 +186,44 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 
   // ---- inside a rollout: the instances the previous step finished are reset here, where the reference calls env.reset()
   // (algorithms/base.py:289-290) -- terminal observation to the side list, next seed of the instance's chain, fresh
-  // observation into the slot this step starts from.  Rare (once per episode); the column loops are per lane.
+  // observation into the slot this step starts from.  Not rare under random actions (an episode is truncated after 10-20
+  // steps), so the rows are moved by the whole workgroup.
   const uint64_t inst = (uint64_t)(E.first_instance + b);
   if (RS.active && RS.t > 0) {
-    if (wave == 0 && hv == 0 && valid) {
-      const double te = ROW(R.TERM), tr = ROW(R.TRUNC);
-      if (te != 0.0 || tr != 0.0) {
-        double* row = RS.obs_prev + (size_t)b * RS.obs_dim;
-        const int kx = __hip_atomic_fetch_add(RS.term_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (kx < RS.term_cap) {
-          RS.term_idx[2 * kx] = RS.t - 1; RS.term_idx[2 * kx + 1] = b;
-          double* dst = RS.term_obs + (size_t)kx * RS.obs_dim;
-          for (int c = 0; c < RS.obs_dim; ++c) dst[c] = row[c];
+    int F2_AS3* const fin = F2_P(int, F.off_red);        // [IW] entry of the side list (>= 0), -1 list full, -2 not finished
+    if (wave == 0 && hv == 0) {
+      int kx = -2;
+      if (valid && (ROW(R.TERM) != 0.0 || ROW(R.TRUNC) != 0.0)) {
+        kx = __hip_atomic_fetch_add(RS.term_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kx < RS.term_cap) { RS.term_idx[2 * kx] = RS.t - 1; RS.term_idx[2 * kx + 1] = b; }
+        else kx = -1;
+      }
+      fin[l] = kx;
+    }
+    f2_lds_sync();
+    // the whole workgroup moves the observation rows (obs_dim columns each, consecutive threads on consecutive columns)
+    int any = 0;
+    for (int k = 0; k < IW; ++k) {
+      const int kx = fin[k];
+      any |= (kx != -2) ? 1 : 0;
+      if (kx >= 0) {
+        const double* row = RS.obs_prev + (size_t)(b - l + k) * RS.obs_dim;
+        double* dst = RS.term_obs + (size_t)kx * RS.obs_dim;
+        for (int c = threadIdx.x; c < RS.obs_dim; c += blockDim.x) dst[c] = row[c];
+      }
+    }
+    any = __builtin_amdgcn_readfirstlane(any);
+    if (any) {
+      if (wave == 0 && hv == 0 && fin[l] != -2) env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
+      f2_sync();                     // the reset rows are in memory (vmcnt covers stores) before the other waves gather them
+      for (int k = 0; k < IW; ++k) {
+        if (fin[k] == -2) continue;
+        const GsLaneRows Sk = gs_lane_rows(slab, g, R.total, hs * IW + k);
+        double* row = RS.obs_prev + (size_t)(b - l + k) * RS.obs_dim;
+        for (int c = threadIdx.x; c < RS.obs_dim; c += blockDim.x) {
+          const int sidx = RS.map[c];
+          row[c] = (sidx >= 0) ? Sk.lane_row((size_t)sidx * GS_LANES).get() : RS.cst[-sidx - 1];
         }
-        env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
-        for (int c = 0; c < RS.obs_dim; ++c) { const int sidx = RS.map[c]; row[c] = (sidx >= 0) ? (double)ROW(sidx) : RS.cst[-sidx - 1]; }
       }
     }
     f2_sync();                       // the other waves read the clock and seed rows next

@@ -6,6 +6,8 @@
   per-unit scaling), including stochastic loads / weather on the shared Philox stream,
   ragged batch sizes, masked reset and checkpoint round trips.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -162,6 +164,43 @@ def test_rccl_allgather_single_rank():
     full = env.gather_observations()
     assert full.shape == (48, fs.obs_dim) and np.array_equal(full, obs)
     env.close()
+
+
+def test_rccl_allgather_two_ranks_on_one_device(tmp_path):
+    """The N = 2 data path through RCCL: two processes, file rendezvous, compact all-gather, against one process that
+    owns the whole batch.  A one-GPU box has one device for both ranks; RCCL refuses a communicator with two ranks on one
+    device ("Duplicate GPU detected"), in which case the test SKIPS with RCCL's message -- the multi-GPU runs of
+    bench.py are then the only execution of this path."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_two_rank_worker.py")
+    outs = [str(tmp_path / f"full{r}.npy") for r in range(2)]
+    env = dict(os.environ, NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path / "rdzv"), outs[r]], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    texts, codes = [], []
+    for p in procs:
+        try:
+            t, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            t, _ = p.communicate()
+            t += "\n[killed after 150 s]"
+        texts.append(t); codes.append(p.returncode)
+    if any(c == 77 for c in codes) or any("Duplicate GPU" in t or "invalid usage" in t.lower() for t in texts):
+        reason = next((ln for t in texts for ln in t.splitlines() if "REFUSED" in ln or "Duplicate GPU" in ln), "RCCL refused")
+        pytest.skip("RCCL does not form a 2-rank communicator on one device: " + reason.strip()[:200])
+    assert codes == [0, 0], "\n".join(texts)
+    from grid_fed_rl_gym_amd.sharding import ShardedGridEnvironment
+    fs = P.ieee13_like("epsilon")
+    one = ShardedGridEnvironment(fs, global_num_envs=96, rank=0, world=1, device=0, stochastic_loads=True, weather_variation=True)
+    one.reset(seed=3)
+    acts = np.random.default_rng(1).uniform(-1, 1, (96, fs.action_dim))
+    for _ in range(3):
+        obs, *_ = one.step(acts)
+    one.close()
+    for o in outs:
+        assert np.array_equal(np.load(o), obs)
 
 
 def _oracle_collect(fs, cfg, actions, seeds, first_instance, policy_seed=None):
