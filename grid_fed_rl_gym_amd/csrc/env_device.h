@@ -261,19 +261,16 @@ __device__ __forceinline__ void bus_injection(const GsTables& T, const GsRows& R
   ROW(R.Q + i) = 0.0;
 }
 
-// reset() of this lane's instance with the given seed (grid_env.py:360-408)
-__device__ __forceinline__ void env_reset_lane(const GsTables& T, const GsRows& R, const GsEnvCfg& E, GsLaneRows S,
-                                               uint64_t inst, uint64_t seed) {
+// reset() of this lane's instance with the given seed (grid_env.py:360-408), in two parts so that a workgroup can share
+// the second: the per-instance scalars / devices / weather (one lane per instance), and the per-bus and per-line rows
+// (any thread, any instance: `Sx` addresses the instance, j in [0, n + m) picks the bus or line).
+__device__ __forceinline__ void env_reset_lane_scalars(const GsTables& T, const GsRows& R, const GsEnvCfg& E, GsLaneRows S,
+                                                       uint64_t inst, uint64_t seed) {
   ROW(R.SEEDLO) = (double)(uint32_t)seed;
   ROW(R.SEEDHI) = (double)(uint32_t)(seed >> 32);
   ROW(R.TIME) = 0.0; ROW(R.STEP) = 0.0; ROW(R.VIOL) = 0.0; ROW(R.TOTLOSS) = 0.0; ROW(R.EPREW) = 0.0;
   ROW(R.FREQ) = 60.0;                                           // grid_env.py:394
   ROW(R.IRR) = 0.0; ROW(R.WIND) = 5.0; ROW(R.TEMP) = 25.0; ROW(R.CLOUD) = 0.3;   // grid_env.py:213-218
-  for (int i = 0; i < T.n; ++i) {
-    ROW(R.VM + i) = 1.0; ROW(R.VA + i) = 0.0;
-    ROW(R.E + i) = cld(T.fixed_v, i) ? cld(T.v_set, i) : 1.0; ROW(R.F + i) = 0.0;     // the flat start, for a warm-started sweep solver
-  }
-  for (int k = 0; k < T.m; ++k) { ROW(R.FLOW + k) = 0.0; ROW(R.ENVLOAD + k) = 0.0; ROW(R.LOAD + k) = 0.0; }
   for (int q = 0; q < T.n_bats; ++q) { ROW(R.SOC + q) = 0.5; ROW(R.BATP + q) = 0.0; }      // grid_env.py:397-399
   for (int g = 0; g < T.n_gens; ++g) ROW(R.CURT + g) = 1.0;
   weather_update(R, E, S, inst);                                  // grid_env.py:402
@@ -281,5 +278,21 @@ __device__ __forceinline__ void env_reset_lane(const GsTables& T, const GsRows& 
   ROW(R.REWARD) = 0.0; ROW(R.TERM) = 0.0; ROW(R.TRUNC) = 0.0; ROW(R.VMAX) = 1.0; ROW(R.VMIN) = 1.0;
   for (int v = 0; v < 4; ++v) ROW(R.VFLAGS + v) = 0.0;
   ROW(R.LOSSES) = 0.0; ROW(R.MAXMIS) = 0.0; ROW(R.ITERS) = 0.0; ROW(R.CONV) = 0.0; ROW(R.STATUS) = 0.0;
+}
+__device__ __forceinline__ void env_reset_element(const GsTables& T, const GsRows& R, GsLaneRows Sx, int j) {
+  if (j < T.n) {
+    const double e0 = T.fixed_v[j] ? T.v_set[j] : 1.0;            // the flat start, for a warm-started sweep solver
+    Sx.lane_row((size_t)(R.VM + j) * GS_LANES).put(1.0); Sx.lane_row((size_t)(R.VA + j) * GS_LANES).put(0.0);
+    Sx.lane_row((size_t)(R.E + j) * GS_LANES).put(e0); Sx.lane_row((size_t)(R.F + j) * GS_LANES).put(0.0);
+  } else if (j < T.n + T.m) {
+    const int k = j - T.n;
+    Sx.lane_row((size_t)(R.FLOW + k) * GS_LANES).put(0.0); Sx.lane_row((size_t)(R.ENVLOAD + k) * GS_LANES).put(0.0);
+    Sx.lane_row((size_t)(R.LOAD + k) * GS_LANES).put(0.0);
+  }
+}
+__device__ __forceinline__ void env_reset_lane(const GsTables& T, const GsRows& R, const GsEnvCfg& E, GsLaneRows S,
+                                               uint64_t inst, uint64_t seed) {
+  env_reset_lane_scalars(T, R, E, S, inst, seed);
+  for (int j = 0; j < T.n + T.m; ++j) env_reset_element(T, R, S, j);
 }
 

@@ -126,7 +126,12 @@ gs_k_rollout_post(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, G
   if (!any) return;                       // (uniform: fin is shared)
   if (mine && fin[lane] != -2) {
     const uint64_t inst = (uint64_t)(E.first_instance + b);
-    env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
+    env_reset_lane_scalars(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
+  }
+  for (int q = 0; q < GS_LANES; ++q) {
+    if (fin[q] == -2) continue;
+    const GsLaneRows Sq = gs_lane_rows(slab, blockIdx.x, R.total, q);
+    for (int j = threadIdx.x; j < T.n + T.m; j += blockDim.x) env_reset_element(T, R, Sq, j);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the reset rows are in memory before the other waves gather them
   for (int q = 0; q < GS_LANES; ++q) {

@@ -189,11 +189,15 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // observation into the slot this step starts from.  Not rare under random actions (an episode is truncated after 10-20
   // steps), so the rows are moved by the whole workgroup.
   const uint64_t inst = (uint64_t)(E.first_instance + b);
+  // (the clock and seed rows are asked for here, in the same round trip as the rollout's flags; re-read after a reset)
+  double told = ROW(R.TIME), kold = ROW(R.STEP);
+  uint64_t seed = lane_seed(S, R);
   if (RS.active && RS.t > 0) {
     int F2_AS3* const fin = F2_P(int, F.off_red);        // [IW] entry of the side list (>= 0), -1 list full, -2 not finished
     if (wave == 0 && hv == 0) {
       int kx = -2;
-      if (valid && (ROW(R.TERM) != 0.0 || ROW(R.TRUNC) != 0.0)) {
+      const double te = ROW(R.TERM), tr = ROW(R.TRUNC);
+      if (valid && (te != 0.0 || tr != 0.0)) {
         kx = __hip_atomic_fetch_add(RS.term_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (kx < RS.term_cap) { RS.term_idx[2 * kx] = RS.t - 1; RS.term_idx[2 * kx + 1] = b; }
         else kx = -1;
@@ -214,7 +218,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     }
     any = __builtin_amdgcn_readfirstlane(any);
     if (any) {
-      if (wave == 0 && hv == 0 && fin[l] != -2) env_reset_lane(T, R, E, S, inst, next_episode_seed(lane_seed(S, R), inst));
+      if (wave == 0 && hv == 0 && fin[l] != -2) env_reset_lane_scalars(T, R, E, S, inst, next_episode_seed(seed, inst));
+      for (int k = 0; k < IW; ++k) {           // the per-bus / per-line rows of the finished instances: every thread takes a share
+        if (fin[k] == -2) continue;
+        const GsLaneRows Sk = gs_lane_rows(slab, g, R.total, hs * IW + k);
+        for (int j = threadIdx.x; j < n + m; j += blockDim.x) env_reset_element(T, R, Sk, j);
+      }
       f2_sync();                     // the reset rows are in memory (vmcnt covers stores) before the other waves gather them
       for (int k = 0; k < IW; ++k) {
         if (fin[k] == -2) continue;
@@ -225,14 +234,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           row[c] = (sidx >= 0) ? Sk.lane_row((size_t)sidx * GS_LANES).get() : RS.cst[-sidx - 1];
         }
       }
+      told = ROW(R.TIME); kold = ROW(R.STEP); seed = lane_seed(S, R);      // (behind the barrier that published the reset rows)
     }
-    f2_sync();                       // the other waves read the clock and seed rows next
   }
   // ---- clock; then three independent chains on different waves (grid_env.py:433-477) --------------------------------
-  const double told = ROW(R.TIME), kold = ROW(R.STEP), tnew = told + E.timestep;
+  const double tnew = told + E.timestep;
   const uint32_t snew = (uint32_t)(kold + 1.0);
-  const uint64_t seed = lane_seed(S, R);
-  f2_sync();
+  f2_sync();                         // every wave has read the clock and seed rows before wave 0 moves them on
   const int nb = T.n_bats, ng = T.n_gens, nl_ = T.n_loads;
   if (wave == 0) {
     // _apply_actions (grid_env.py:621-651, dynamics.py:189-220): the halves take alternate batteries / generators
