@@ -49,7 +49,7 @@ WORKLOADS = {
     "ieee8500_3ph_b1024": dict(feeder="ieee8500_like", batch=1024, solver="fbs3"),  # config 5 (solver only)
 }
 KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
-                "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow", "fbs_flow2": "fbs_flow2", "fbs_flow2s": "fbs_flow2s", "nr_flow2s": "nr_flow2s",
+                "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow", "fbs_flow2": "fbs_flow2", "fbs_flow2h": "fbs_flow2h", "fbs_flow2s": "fbs_flow2s", "nr_flow2s": "nr_flow2s",
                 "nr_flow2": "nr_flow2"}
 
 

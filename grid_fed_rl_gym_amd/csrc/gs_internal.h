@@ -303,6 +303,9 @@ struct GsPackArgs {
 #define GS_F2N_WAVES 8            /* the Newton-Raphson member of the family: 8 waves x 2 halves x 8 buses (its bus state needs the registers) */
 #define GS_F2N_ITEMS 8
 #define GS_F2S_IW 8               /* small feeders: 8 instances per workgroup, the eight sub-groups of a wavefront on eight buses */
+#define GS_F2H_IW 16       // half-size member: 16 instances per workgroup, two workgroups per CU
+#define GS_F2H_WAVES 8
+#define GS_F2H_ITEMS 4
 #define GS_F2S_WAVES 2            /* sweeps: 2 waves x 8 sub-groups x 1 bus = 16 positions */
 #define GS_F2S_ITEMS 1
 #define GS_F2NS_WAVES 2           /* Newton-Raphson: 2 waves x 2 items, each a group of 8 buses of one level */

@@ -710,7 +710,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     }
     stp.hit(F2_ST_TOP_DOWN);
     // V = V_slack - S; mismatch and sum of P_calc at the new voltages (power_flow.py:150-168); the voltages go to buffer A
-    // (its last reader was round R2 - 2, a barrier ago), where the epilogue finds those of the last sweep
+    // (its last reader was round R2 - 2, a barrier ago), where the epilogue finds those of the last sweep.  (Publishing them
+    // only when the loop ends -- an LDS store costs three times a load -- was tried: the extra live range or the extra exits
+    // cost 30-80 spilled registers at the 128-VGPR budget, -25 %.)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const double en = vs_r - sr[j], fn = 0.0 - si[j];
@@ -976,18 +978,24 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   stp.hit(F2_ST_EPI_SCALARS);
 }
 
-#define F2_KERNELS(name, SOLVER, NW, NI, IW)                                                                               \
-  extern "C" __global__ void __launch_bounds__(64 * NW)                                                                    \
+#define F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, OCC)                                                                      \
+  extern "C" __global__ void __launch_bounds__(64 * NW) OCC                                                                \
   gs_k_step_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,         \
                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
     f2_step<SOLVER, 0, NW, NI, IW>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                               \
   }                                                                                                                        \
-  extern "C" __global__ void __launch_bounds__(64 * NW)     /* the step with the post-step checks in its epilogue */       \
+  extern "C" __global__ void __launch_bounds__(64 * NW) OCC /* the step with the post-step checks in its epilogue */       \
   gs_k_stepc_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,        \
                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
     f2_step<SOLVER, 1, NW, NI, IW>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                               \
   }
+#define F2_KERNELS(name, SOLVER, NW, NI, IW) F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, )
 F2_KERNELS(fbs_flow2, F2_FBS, 16, 4, 32)       // up to 128 buses below the slack
 F2_KERNELS(nr_flow2, F2_NR, 8, 8, 32)
 F2_KERNELS(fbs_flow2s, F2_FBS, 2, 1, 8)        // up to 16 buses: 8 instances per workgroup, eight buses per wavefront
 F2_KERNELS(nr_flow2s, F2_NR, 2, 2, 8)          // up to 4 groups of 8 same-level buses
+// 16 instances per workgroup, four buses per wavefront, 8 waves: two workgroups share a CU (four waves per SIMD as above),
+// so that one's LDS-bound solver phase runs beside the other's VALU-bound prologue / epilogue: +6 % at B = 8192, +11 % at
+// 16384, +30 % at 4096 over the 32-instance member (the host's default for the sweep solver; 8 instances per workgroup
+// with four workgroups per CU was tried too: -20 %, the per-instance scalar chains then fill an eighth of a wavefront)
+F2_KERNELS_OCC(fbs_flow2h, F2_FBS, GS_F2H_WAVES, GS_F2H_ITEMS, GS_F2H_IW, __attribute__((amdgpu_waves_per_eu(4, 4))))

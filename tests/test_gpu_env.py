@@ -393,8 +393,8 @@ def test_warm_started_sweep_solver_agrees_with_the_cold_start():
                                      (lambda: P.ieee123_like(seed=7, load_seed=5), 96), (lambda: P.ieee123_like(seed=2024, load_seed=9), 64),
                                      (lambda: P.random_meshed(90, 0, seed=3), 64)])          # other tree shapes: depth, fan-out, bus count
 def test_dataflow_sweeps_agree_with_the_level_synchronous_kernel(maker, B, monkeypatch):
-    """`fbs_flow2` (32 instances per workgroup, half-waves on different buses, observation tiles straight from the LDS
-    slots) and `fbs_flow` (64 instances per workgroup; both: per-bus LDS slots + flags, register-resident bus state, no
+    """`fbs_flow2h` / `fbs_flow2` (16 / 32 instances per workgroup, sub-groups of a wavefront on different buses, sweeps
+    as scans, observation tiles straight from the LDS slots) and `fbs_flow` (64 instances per workgroup; both: per-bus LDS slots + flags, register-resident bus state, no
     level barriers) against `fbs_lds` (level barriers): same iteration counts per instance and the same trajectories to
     rounding (they sum children's currents / per-wave partials in different orders).  Several tolerances, so that at
     some of them the instances of one group stop at different iterations and the frozen lanes are exercised."""
@@ -404,25 +404,31 @@ def test_dataflow_sweeps_agree_with_the_level_synchronous_kernel(maker, B, monke
     for tol in (1e-4, 3e-5, 1e-5, 3e-6, 1e-6, 1e-7, 1e-9):
         kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True, tolerance=tol, max_iterations=50)
         flow2 = P.BatchedGridEnvironment(fs, **kw)
+        monkeypatch.setenv("GS_FLOW2_IW", "32")
+        flow2w = P.BatchedGridEnvironment(fs, **kw)
+        monkeypatch.delenv("GS_FLOW2_IW")
         monkeypatch.setenv("GS_NO_FLOW2", "1")
         flow = P.BatchedGridEnvironment(fs, **kw)
         monkeypatch.setenv("GS_NO_FLOW", "1")
         sync = P.BatchedGridEnvironment(fs, **kw)
         monkeypatch.delenv("GS_NO_FLOW"); monkeypatch.delenv("GS_NO_FLOW2")
-        assert flow2.handle.describe()["kernel"] in ("fbs_flow2", "fbs_flow2s"), flow2.handle.describe()["flow2"]
+        assert flow2.handle.describe()["kernel"] in ("fbs_flow2h", "fbs_flow2s"), flow2.handle.describe()["flow2"]
+        assert flow2w.handle.describe()["kernel"] in ("fbs_flow2", "fbs_flow2s"), flow2w.handle.describe()["flow2"]
         assert flow.handle.describe()["kernel"] == "fbs_flow" and sync.handle.describe()["kernel"] in ("fbs_lds", "fbs")
-        for e in (flow2, flow, sync):
+        for e in (flow2, flow2w, flow, sync):
             e.reset(seed=seeds)
         rng = np.random.default_rng(99)
         for t in range(4):
             a = rng.uniform(-1, 1, (B, fs.action_dim))
             o2, r2, t2, c2, in2 = flow2.step(a)
+            ow, rw, tw, cw, inw = flow2w.step(a)
             of, rf, tf, cf, inf_ = flow.step(a)
             os_, rs, ts, cs, ins = sync.step(a)
             assert in2["power_flow_converged"].all() and inf_["power_flow_converged"].all() and ins["power_flow_converged"].all()
             assert np.array_equal(inf_["iterations"], ins["iterations"]) and np.array_equal(in2["iterations"], ins["iterations"]), tol
             spread += len(np.unique(inf_["iterations"][:64])) > 1
-            for o, r in ((of, rf), (o2, r2)):
+            assert np.array_equal(inw["iterations"], ins["iterations"]) and np.array_equal(tw, ts) and np.array_equal(cw, cs)
+            for o, r in ((of, rf), (o2, r2), (ow, rw)):
                 assert np.max(np.abs(o - os_) / np.maximum(1.0, np.abs(os_))) < 1e-12, tol
                 assert np.allclose(r, rs, rtol=1e-12, atol=1e-12)
             assert np.array_equal(tf, ts) and np.array_equal(cf, cs) and np.array_equal(t2, ts) and np.array_equal(c2, cs)
@@ -431,7 +437,7 @@ def test_dataflow_sweeps_agree_with_the_level_synchronous_kernel(maker, B, monke
             assert np.array_equal(in2["constraint_violations_count"], ins["constraint_violations_count"])
         st2, sts = flow2.get_state(), sync.get_state()
         assert np.allclose(st2, sts, rtol=1e-11, atol=1e-11)
-        flow2.close(); flow.close(); sync.close()
+        flow2.close(); flow2w.close(); flow.close(); sync.close()
     if fs.n == 123 and fs.name.endswith("seed42"):
         assert spread > 0        # at some tolerance the first group mixes instances that stop one iteration apart
 
@@ -446,7 +452,7 @@ def test_dataflow_kernel_falls_back_when_a_wave_would_own_too_many_buses(monkeyp
     monkeypatch.setenv("GS_WAVES", "4")
     narrow = P.BatchedGridEnvironment(fs, **kw)
     monkeypatch.delenv("GS_WAVES")
-    assert wide.handle.describe()["kernel"] == "fbs_flow2" and narrow.handle.describe()["kernel"] == "fbs_lds"
+    assert wide.handle.describe()["kernel"] == "fbs_flow2h" and narrow.handle.describe()["kernel"] == "fbs_lds"
     wide.reset(seed=1); narrow.reset(seed=1)
     ow = wide.step(a)[0]; on = narrow.step(a)[0]
     assert np.max(np.abs(ow - on) / np.maximum(1.0, np.abs(on))) < 1e-12
