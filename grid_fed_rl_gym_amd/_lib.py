@@ -110,6 +110,7 @@ SYMBOLS = [
     ("gs_timing_enable", C.c_int, [_H, C.c_int32]),
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
+    ("gs_debug_block_times", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     ("gs_debug_write_rows", C.c_int, [_H, C.c_int32, _dp]),
     ("gs_debug_read_rows", C.c_int, [_H, C.c_int32, _dp]),
     ("gs_fallback_linear", C.c_int, [_H, _dp, _dp, _dp, _dp, _up, _up, C.POINTER(C.c_int32)]),
@@ -438,6 +439,12 @@ class Handle:
         buf = (C.c_uint64 * 16)()
         self._check(self._lib.gs_debug_stamps(self._h, buf, 16))
         return {n: int(buf[k]) for k, n in enumerate(self.STAMP_NAMES)}
+
+    def debug_block_times(self, n_blocks: int) -> np.ndarray:
+        """[n_blocks, 2] (start, end) of the workgroups of the last step launch, 100 MHz ticks (gs_debug_block_times)."""
+        out = np.zeros((int(n_blocks), 2), dtype=np.uint64)
+        self._check(self._lib.gs_debug_block_times(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(n_blocks)))
+        return out
 
     ROW_FAMILIES = {"VM": 0, "LOAD": 1, "ENVLOAD": 2, "FLOW": 3, "FREQ": 4, "CONV": 5, "ITERS": 6, "MAXMIS": 7, "LOADP": 8}
 

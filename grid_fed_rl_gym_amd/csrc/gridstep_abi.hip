@@ -1307,11 +1307,12 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (!h->d_stamps) {
-    int rc = dev_alloc(h, &h->d_stamps, 16);
+    int rc = dev_alloc(h, &h->d_stamps, 16 + 2 * GS_STAMP_BLOCKS);
     if (rc) return rc;
-    HIPCHK(h, hipMemset(h->d_stamps, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_stamps, 0, (16 + 2 * GS_STAMP_BLOCKS) * sizeof(unsigned long long)));
     h->SC.stamps = h->d_stamps;
     h->SC.stamp_wave = getenv("GS_STAMP_WAVE") ? atoi(getenv("GS_STAMP_WAVE")) : 0;
+    h->SC.block_times = getenv("GS_STAMP_BLOCK_TIMES") ? 1 : 0;
     for (int k = 0; k < n; ++k) cycles_out[k] = 0;
     return GS_OK;
   }
@@ -1319,6 +1320,18 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
   HIPCHK(h, hipMemcpy(tmp, h->d_stamps, sizeof tmp, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemset(h->d_stamps, 0, sizeof tmp));
   for (int k = 0; k < n; ++k) cycles_out[k] = tmp[k];
+  return GS_OK;
+}
+
+// (start, end) of every workgroup of the LAST step launch on the 100 MHz real-time clock (flow2 kernels, armed by
+// gs_debug_stamps with GS_STAMP_BLOCK_TIMES set); returns the pairs of the first n_blocks workgroups
+int gs_debug_block_times(gs_handle* h, uint64_t* out, int32_t n_blocks) {
+  if (!h || !out || n_blocks < 1 || n_blocks > GS_STAMP_BLOCKS) return fail(h, GS_E_INVALID, "bad arguments");
+  if (!h->d_stamps) return fail(h, GS_E_STATE, "gs_debug_stamps has not armed the buffer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_stamps + 16, (size_t)n_blocks * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemset(h->d_stamps + 16, 0, (size_t)2 * GS_STAMP_BLOCKS * sizeof(unsigned long long)));
   return GS_OK;
 }
 

@@ -353,11 +353,13 @@ struct GsRolloutStep {
   int32_t term_cap, obs_dim, t, active;
 };
 
+#define GS_STAMP_BLOCKS 2048
 struct GsSolveCfg {
   double tolerance, alpha;
   int32_t max_iterations, jacobian_exact;
-  unsigned long long* stamps;   // diagnostic: per-phase cycle sums of block 0 / wave stamp_wave (NULL = off)
-  int32_t stamp_wave, pad;
+  unsigned long long* stamps;   // diagnostic: per-phase cycle sums of block 0 / wave stamp_wave (NULL = off); behind the 16
+                                // sums, when block_times is set: (start, end) of every workgroup on the 100 MHz real-time clock
+  int32_t stamp_wave, block_times;
 };
 
 struct GsEnvCfg {

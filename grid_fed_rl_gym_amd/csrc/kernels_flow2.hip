@@ -163,8 +163,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   double F2_AS3* const red_dev = red_lsum + NW * IW;
   unsigned long long F2_AS3* const cell = F2_P(unsigned long long, F.off_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits
   unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 5 * IW);                // [16][32] integer counts
+  // (Two workgroups share a CU in the 16-instance members and the instruction arbiter serves the oldest wave first: the
+  // workgroup that arrived first finishes in 32 us, the other in 42 (tools/block_times.py).  Flipping s_setprio at every phase
+  // boundary, the two in opposite states, evens them out -- 38 to 42 us each -- and leaves the launch at 42: the CU's
+  // throughput, not the sharing, sets the time.  Not kept.)
   F2Stamp stp{C.stamps, 0ull, blockIdx.x == 0 && wave == C.stamp_wave && lane == 0};
   if (C.stamps) stp.t = __builtin_readcyclecounter();
+  if (C.stamps && C.block_times && threadIdx.x == 0 && blockIdx.x < GS_STAMP_BLOCKS) C.stamps[16 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
   // ---- LDS init: flat start in every slot, ancestor and impedance tables, cells -----------------------------------------------
   for (int k = threadIdx.x; k < nsl * IW; k += blockDim.x) {
@@ -870,6 +875,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       }
     }
     stp.hit(F2_ST_EPILOGUE);
+    if (C.stamps && C.block_times && lane == 0 && blockIdx.x < GS_STAMP_BLOCKS)
+      atomicMax(&C.stamps[17 + 2 * blockIdx.x], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (wave != 0) return;
   }
   // ---- wave 0: everything of step() that follows the load flow, per instance (grid_env.py:553-617) ----
@@ -976,6 +983,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #undef OF
   }
   stp.hit(F2_ST_EPI_SCALARS);
+  if (C.stamps && C.block_times && lane == 0 && blockIdx.x < GS_STAMP_BLOCKS)
+    atomicMax(&C.stamps[17 + 2 * blockIdx.x], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 #define F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, OCC)                                                                      \

@@ -265,6 +265,9 @@ int gs_timing_enable(gs_handle* h, int32_t on);
  * (block 0 / wave 0; phases: prologue, init, mismatch, bottom-up, flag, top-down, final mismatch,
  * epilogue), later calls return the sums accumulated since the previous call and clear them. */
 int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n);
+/* Diagnostic: (start, end) of each of the first n_blocks workgroups of the last step launch, in ticks of the GPU's 100 MHz
+ * real-time clock (second-generation step kernels; arm with gs_debug_stamps while GS_STAMP_BLOCK_TIMES is set). */
+int gs_debug_block_times(gs_handle* h, uint64_t* out, int32_t n_blocks);
 /* total_ms[GS_K_COUNT], launches[GS_K_COUNT] accumulated since the last call; resets them */
 int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches);
 /* test aid: overwrite one family of device rows with values[B][width] (width = n, m or 1), so that kernels

@@ -18,7 +18,10 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "TCC_EA0_RDREQ_LEVEL TCC_EA0_WRREQ_LEVEL TCC_TAG_STALL TCC_BUSY" \
            "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES" \
            "TA_DATA_STALLED_BY_TC_CYCLES TD_TD_BUSY" \
-           "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_REQUEST GRBM_GUI_ACTIVE"; do
+           "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_REQUEST GRBM_GUI_ACTIVE" \
+           "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_ANY" \
+           "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS SQ_INSTS_VALU_ADD_F64" \
+           "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32"; do
   i=$((i+1))
   # (round 1: the four TA / TD counters in one pass made rocprofv3 abort with "Request exceeds the capabilities of the
   # hardware" and the failure was swallowed; they are two passes now, and a failing pass fails the script)
