@@ -81,7 +81,7 @@ struct gs_handle {
   // the env step of a handle whose solver is the dataflow sweep runs the second-generation kernel (kernels_flow2.hip:
   // 32 instances per workgroup, half-waves on different buses) when the feeder fits its tables; gs_solve keeps kernel 6
   bool flow2 = false; GsF2Tables F2{}; std::string flow2_why;
-  bool f2_small = false, f2_half = false; int f2_iw = 32, f2_nw = 16;     // which member of the family (8 instances per workgroup for small feeders)
+  bool f2_small = false, f2_half = false, f2_wide = false; int f2_iw = 32, f2_nw = 16;     // which member of the family (8 instances per workgroup for small feeders)
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -286,6 +286,7 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
         else { if (fc.enabled) GS_F2(gs_k_stepc_nr_flow2); else GS_F2(gs_k_step_nr_flow2); }
       } else {
         if (h->f2_small) { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2s); else GS_F2(gs_k_step_fbs_flow2s); }
+        else if (h->f2_wide) { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2x); else GS_F2(gs_k_step_fbs_flow2x); }
         else if (h->f2_half) { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2h); else GS_F2(gs_k_step_fbs_flow2h); }
         else { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2); else GS_F2(gs_k_step_fbs_flow2); }
       }
@@ -627,7 +628,10 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   const int SL_ZERO = ht.n, SL_ONE = ht.n + 1, SL_DUMMY = ht.n + 2, nsl = ht.n + 3;
 
   // -- sweep solver: one record per position of the preorder of the tree below the slack
-  if (h->solve_kernel == 6) {
+  // (eligible wherever the first-generation dataflow kernel is, and -- with the number of waves left to the library -- for
+  // feeders beyond its 128 buses)
+  if (h->solve_kernel == 6 || (cfg->solver_kind == GS_SOLVER_FBS && auto_w && !cfg->fbs_warm_start && ht.is_forest && ht.fbs_ok &&
+                               ht.lvl_ptr[ht.n_levels] > 8 * GS_MAX_WAVES && !getenv("GS_NO_FLOW"))) {
     std::string& why = h->flow2_why;
     std::vector<int> order, size(ht.n, 1), depth(ht.n, 0);
     {
@@ -658,9 +662,11 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     // small feeders: 8 instances per workgroup, the eight sub-groups of a wavefront on eight buses
     const bool small = N <= GS_F2S_WAVES * (64 / GS_F2S_IW) * GS_F2S_ITEMS && !getenv("GS_NO_FLOW2_SMALL");
     // default: 16 instances per workgroup, two workgroups per CU (GS_FLOW2_IW=32 asks for the 32-instance member, one per CU)
-    const bool half = !small && !(getenv("GS_FLOW2_IW") && atoi(getenv("GS_FLOW2_IW")) == 32);
-    const int NW = small ? GS_F2S_WAVES : half ? GS_F2H_WAVES : GS_F2_WAVES, NI = small ? GS_F2S_ITEMS : half ? GS_F2H_ITEMS : GS_F2_ITEMS,
-              IW = small ? GS_F2S_IW : half ? GS_F2H_IW : 32;
+    const bool wide = !small && N > GS_F2_WAVES * 2 * GS_F2_ITEMS;          // 129 ... 256 buses: eight buses per sub-group
+    const bool half = !small && !wide && !(getenv("GS_FLOW2_IW") && atoi(getenv("GS_FLOW2_IW")) == 32);
+    const int NW = small ? GS_F2S_WAVES : wide ? GS_F2X_WAVES : half ? GS_F2H_WAVES : GS_F2_WAVES,
+              NI = small ? GS_F2S_ITEMS : wide ? GS_F2X_ITEMS : half ? GS_F2H_ITEMS : GS_F2_ITEMS,
+              IW = small ? GS_F2S_IW : (wide || half) ? GS_F2H_IW : 32;
     const int NPOS = NW * (64 / IW) * NI;
     GsF2Tables& F = h->F2;
     const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl, 2);
@@ -672,7 +678,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     else if (off > 160 * 1024) why = "LDS tables do not fit";
     else if (ht.n < 2 || ht.m < 1 || N < 1) why = "trivial network";
     if (why.empty()) {
-      h->flow2 = true; h->f2_small = small; h->f2_half = half; h->f2_iw = IW; h->f2_nw = NW;
+      h->flow2 = true; h->f2_small = small; h->f2_half = half; h->f2_wide = wide; h->f2_iw = IW; h->f2_nw = NW;
       GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY;
       f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 2, 0.0);
@@ -925,7 +931,7 @@ int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
            "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d, "
            "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"solve_kernel\": \"%s\", \"flow2\": \"%s\"}",
-           h->flow2 ? (h->f2_small ? "fbs_flow2s" : h->f2_half ? "fbs_flow2h" : "fbs_flow2") : h->nr2 ? (h->f2_small ? "nr_flow2s" : "nr_flow2") : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
+           h->flow2 ? (h->f2_small ? "fbs_flow2s" : h->f2_wide ? "fbs_flow2x" : h->f2_half ? "fbs_flow2h" : "fbs_flow2") : h->nr2 ? (h->f2_small ? "nr_flow2s" : "nr_flow2") : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
            h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, (h->flow2 || h->nr2) ? h->f2_nw : h->W, h->groups,
            h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim,
            (h->flow2 || h->nr2) ? h->f2_iw : 64, (h->flow2 || h->nr2) ? (64 / h->f2_iw) * h->groups : h->groups, (h->flow2 || h->nr2) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576,

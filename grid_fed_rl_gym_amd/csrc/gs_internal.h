@@ -306,6 +306,8 @@ struct GsPackArgs {
 #define GS_F2H_IW 16       // half-size member: 16 instances per workgroup, two workgroups per CU
 #define GS_F2H_WAVES 8
 #define GS_F2H_ITEMS 4
+#define GS_F2X_WAVES 8        // wide member: 16 instances per workgroup, eight buses per sub-group (up to 256 buses)
+#define GS_F2X_ITEMS 8
 #define GS_F2S_WAVES 2            /* sweeps: 2 waves x 8 sub-groups x 1 bus = 16 positions */
 #define GS_F2S_ITEMS 1
 #define GS_F2NS_WAVES 2           /* Newton-Raphson: 2 waves x 2 items, each a group of 8 buses of one level */

@@ -1008,3 +1008,5 @@ F2_KERNELS(nr_flow2s, F2_NR, 2, 2, 8)          // up to 4 groups of 8 same-level
 // 16384, +30 % at 4096 over the 32-instance member (the host's default for the sweep solver; 8 instances per workgroup
 // with four workgroups per CU was tried too: -20 %, the per-instance scalar chains then fill an eighth of a wavefront)
 F2_KERNELS_OCC(fbs_flow2h, F2_FBS, GS_F2H_WAVES, GS_F2H_ITEMS, GS_F2H_IW, __attribute__((amdgpu_waves_per_eu(4, 4))))
+// up to 256 buses below the slack: eight buses per sub-group (twice the registers: two waves per SIMD), one workgroup per CU
+F2_KERNELS(fbs_flow2x, F2_FBS, GS_F2X_WAVES, GS_F2X_ITEMS, GS_F2H_IW)

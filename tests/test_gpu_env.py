@@ -391,7 +391,9 @@ def test_warm_started_sweep_solver_agrees_with_the_cold_start():
 
 @pytest.mark.parametrize("maker,B", [(P.ieee123_like, 130), (lambda: P.ieee13_like("epsilon"), 70),
                                      (lambda: P.ieee123_like(seed=7, load_seed=5), 96), (lambda: P.ieee123_like(seed=2024, load_seed=9), 64),
-                                     (lambda: P.random_meshed(90, 0, seed=3), 64)])          # other tree shapes: depth, fan-out, bus count
+                                     (lambda: P.random_meshed(90, 0, seed=3), 64),           # other tree shapes: depth, fan-out, bus count
+                                     (lambda: P.random_meshed(200, 0, seed=5), 48),          # 129 ... 256 buses: the eight-buses-per-sub-group member
+                                     (lambda: P.random_meshed(256, 0, seed=6), 20)])
 def test_dataflow_sweeps_agree_with_the_level_synchronous_kernel(maker, B, monkeypatch):
     """`fbs_flow2h` / `fbs_flow2` (16 / 32 instances per workgroup, sub-groups of a wavefront on different buses, sweeps
     as scans, observation tiles straight from the LDS slots) and `fbs_flow` (64 instances per workgroup; both: per-bus LDS slots + flags, register-resident bus state, no
@@ -412,9 +414,10 @@ def test_dataflow_sweeps_agree_with_the_level_synchronous_kernel(maker, B, monke
         monkeypatch.setenv("GS_NO_FLOW", "1")
         sync = P.BatchedGridEnvironment(fs, **kw)
         monkeypatch.delenv("GS_NO_FLOW"); monkeypatch.delenv("GS_NO_FLOW2")
-        assert flow2.handle.describe()["kernel"] in ("fbs_flow2h", "fbs_flow2s"), flow2.handle.describe()["flow2"]
-        assert flow2w.handle.describe()["kernel"] in ("fbs_flow2", "fbs_flow2s"), flow2w.handle.describe()["flow2"]
-        assert flow.handle.describe()["kernel"] == "fbs_flow" and sync.handle.describe()["kernel"] in ("fbs_lds", "fbs")
+        wide = fs.n - 1 > 128
+        assert flow2.handle.describe()["kernel"] in (("fbs_flow2x",) if wide else ("fbs_flow2h", "fbs_flow2s")), flow2.handle.describe()["flow2"]
+        assert flow2w.handle.describe()["kernel"] in (("fbs_flow2x",) if wide else ("fbs_flow2", "fbs_flow2s")), flow2w.handle.describe()["flow2"]
+        assert flow.handle.describe()["kernel"] in (("fbs_lds", "fbs") if wide else ("fbs_flow",)) and sync.handle.describe()["kernel"] in ("fbs_lds", "fbs")
         for e in (flow2, flow2w, flow, sync):
             e.reset(seed=seeds)
         rng = np.random.default_rng(99)
