@@ -433,7 +433,7 @@ class Handle:
         self._check(self._lib.gs_timing_enable(self._h, (2 if span else 1) if on else 0))
 
     STAMP_NAMES = ["prologue_inject", "init", "mismatch", "bottom_up", "flag", "top_down", "final_mismatch", "epilogue_pack",
-                   "prologue_scalars_rng", "spare", "epi_buses", "epi_lines", "epi_reduce", "epi_scalars", "nr_apply", "spare2"]
+                   "prologue_scalars_rng", "prologue_chains", "epi_buses", "epi_lines", "epi_reduce", "epi_scalars", "nr_apply", "startup"]
 
     def debug_stamps(self) -> dict:
         buf = (C.c_uint64 * 16)()

@@ -310,8 +310,8 @@ struct GsPackArgs {
 #define GS_F2X_ITEMS 8
 #define GS_F2S_WAVES 2            /* sweeps: 2 waves x 8 sub-groups x 1 bus = 16 positions */
 #define GS_F2S_ITEMS 1
-#define GS_F2NS_WAVES 2           /* Newton-Raphson: 2 waves x 2 items, each a group of 8 buses of one level */
-#define GS_F2NS_ITEMS 2
+#define GS_F2NS_WAVES 4           /* Newton-Raphson: 4 waves x 1 item, each a group of 8 buses of one level (2 x 2: 124 M env-steps/s on config 2; 4 x 1: 147 M -- the load draws get waves of their own) */
+#define GS_F2NS_ITEMS 1
 #define GS_F2_CHILDREN 8          /* children per bus in the Newton-Raphson kernel's LDS child tables */
 struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half) * GS_F2_ITEMS + item); 96 bytes
   int32_t bus, parent, flags, last;         // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); last: the bus at the LAST position of this bus's subtree

@@ -246,6 +246,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const double tnew = told + E.timestep;
   const uint32_t snew = (uint32_t)(kold + 1.0);
   f2_sync();                         // every wave has read the clock and seed rows before wave 0 moves them on
+  stp.hit(15);                       // (kernel start, LDS tables, clock round trip)
   const int nb = T.n_bats, ng = T.n_gens, nl_ = T.n_loads;
   if (wave == 0) {
     // _apply_actions (grid_env.py:621-651, dynamics.py:189-220): the halves take alternate batteries / generators
@@ -1001,8 +1002,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #define F2_KERNELS(name, SOLVER, NW, NI, IW) F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, )
 F2_KERNELS(fbs_flow2, F2_FBS, 16, 4, 32)       // up to 128 buses below the slack
 F2_KERNELS(nr_flow2, F2_NR, 8, 8, 32)
-F2_KERNELS(fbs_flow2s, F2_FBS, 2, 1, 8)        // up to 16 buses: 8 instances per workgroup, eight buses per wavefront
-F2_KERNELS(nr_flow2s, F2_NR, 2, 2, 8)          // up to 4 groups of 8 same-level buses
+F2_KERNELS(fbs_flow2s, F2_FBS, GS_F2S_WAVES, GS_F2S_ITEMS, GS_F2S_IW)        // up to 16 buses: 8 instances per workgroup, eight buses per wavefront
+F2_KERNELS(nr_flow2s, F2_NR, GS_F2NS_WAVES, GS_F2NS_ITEMS, GS_F2S_IW)          // up to 4 groups of 8 same-level buses
 // 16 instances per workgroup, four buses per wavefront, 8 waves: two workgroups share a CU (four waves per SIMD as above),
 // so that one's LDS-bound solver phase runs beside the other's VALU-bound prologue / epilogue: +6 % at B = 8192, +11 % at
 // 16384, +30 % at 4096 over the 32-instance member (the host's default for the sweep solver; 8 instances per workgroup
