@@ -813,8 +813,16 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
 #undef UP
-  if ((h->flow2 || h->nr2) && ((rc = dev_upload(h, &h->F2.recs, f2recs)) || (rc = dev_upload(h, &h->F2.anc, f2anc)) ||
-                   (rc = dev_upload(h, &h->F2.zbus, f2z)))) return bail(rc);
+  if (h->flow2 || h->nr2) {
+    // buses with a voltage set point, for the kernels' flat start (the slack; the first entry travels inside the argument block)
+    std::vector<int32_t> fs_slot; std::vector<double> fs_val;
+    for (int i = 0; i < ht.n; ++i) if (ht.fixed_v[i]) { fs_slot.push_back(i); fs_val.push_back(ht.v_set[i]); }
+    h->F2.n_fixed = (int32_t)fs_slot.size();
+    h->F2.fixed_slot0 = fs_slot.empty() ? 0 : fs_slot[0]; h->F2.fixed_val0 = fs_val.empty() ? 1.0 : fs_val[0];
+    h->F2.fixed_slot = nullptr; h->F2.fixed_val = nullptr;
+    if ((rc = dev_upload(h, &h->F2.recs, f2recs)) || (rc = dev_upload(h, &h->F2.anc, f2anc)) || (rc = dev_upload(h, &h->F2.zbus, f2z)) ||
+        (fs_slot.size() > 1 && ((rc = dev_upload(h, &h->F2.fixed_slot, fs_slot)) || (rc = dev_upload(h, &h->F2.fixed_val, fs_val))))) return bail(rc);
+  }
 
   // ---- configs ----
   h->SC.tolerance = cfg->tolerance; h->SC.alpha = cfg->acceleration_factor;

@@ -333,6 +333,10 @@ struct GsF2Tables {
   int32_t n_levels, pos_off, n_anc_ints, pad0;   // Newton-Raphson: levels of the tree below the slack; layout of `anc`
   int32_t off_tile, off_anc, off_z, off_env, off_red, off_atom, lds_bytes;     // LDS byte offsets (slots at 0)
   int32_t env_genp, env_curt, env_batp, env_soc;      // row indices inside the env area ([row][32 lanes] doubles)
+  // buses with a voltage set point (normally the slack alone): slot and |V|; the first inline, the rest through the arrays
+  int32_t n_fixed, fixed_slot0;
+  double fixed_val0;
+  const int32_t* fixed_slot; const double* fixed_val;
 };
 
 // gs_k_rollout_post (kernels_env.hip): bookkeeping after step t of gs_rollout

@@ -171,32 +171,40 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   if (C.stamps) stp.t = __builtin_readcyclecounter();
   if (C.stamps && C.block_times && threadIdx.x == 0 && blockIdx.x < GS_STAMP_BLOCKS) C.stamps[16 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
-  // ---- LDS init: flat start in every slot, ancestor and impedance tables, cells -----------------------------------------------
+  // ---- start-up: every global load the prologue's first barrier waits for is asked for FIRST -- the clock and seed rows, the
+  // first blockDim entries of the two tables that go to LDS -- and the LDS-only initialisation runs while they fly (the
+  // first version loaded a bus-type flag per slot inside the flat-start loop and the tables after it: four to six
+  // round trips in a row, 9 k cycles = 13 % of the launch before the first useful instruction)
+  double told = ROW(R.TIME), kold = ROW(R.STEP);
+  uint64_t seed = lane_seed(S, R);
+  const int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl : F.n_anc_ints;      // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
+  const int n_z = (SOLVER == F2_FBS ? 2 : 4) * nsl;                        // z per bus; Newton-Raphson (G_ip, B_ip, G_ii, B_ii) per bus
+  const int tab0 = (int)threadIdx.x < n_tab ? F.anc[threadIdx.x] : 0;
+  const double z0 = (int)threadIdx.x < n_z ? F.zbus[threadIdx.x] : 0.0;
+  // flat start in every slot: 1 + 0j, the ZERO slot 0, buses with a voltage set point (the slack; F.fixed_*) their set point
   for (int k = threadIdx.x; k < nsl * IW; k += blockDim.x) {
     const int s = k / IW, ll = k & (IW - 1);
-    double e = 1.0;
-    if (s < n) e = T.fixed_v[s] ? T.v_set[s] : 1.0;
-    else if (s == SL_ZERO) e = 0.0;
-    f2_st2(f2_slot(s, ll), make_double2(e, 0.0));
-  }
-  if (SOLVER == F2_FBS) {
-    for (int k = threadIdx.x; k < F.n_jump * nsl; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];
-    for (int k = threadIdx.x; k < 2 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];
-  } else {
-    for (int k = threadIdx.x; k < F.n_anc_ints; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];          // child tables + per-position indices
-    for (int k = threadIdx.x; k < 4 * nsl; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];             // (G_ip, B_ip, G_ii, B_ii) per bus
+    f2_st2(f2_slot(s, ll), make_double2(s == SL_ZERO ? 0.0 : 1.0, 0.0));
   }
   for (int k = threadIdx.x; k < 5 * IW; k += blockDim.x) cell[k] = (k >= 4 * IW) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
   for (int k = threadIdx.x; k < 16 * IW; k += blockDim.x) icell[k] = 0u;
+  if ((int)threadIdx.x < n_tab) F2_P(int, F.off_anc)[threadIdx.x] = tab0;
+  for (int k = threadIdx.x + blockDim.x; k < n_tab; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];
+  if ((int)threadIdx.x < n_z) F2_P(double, F.off_z)[threadIdx.x] = z0;
+  for (int k = threadIdx.x + blockDim.x; k < n_z; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];
+  f2_lds_sync();                      // (the set points below overwrite slots other threads have just initialised)
+  for (int q = 0; q < F.n_fixed; ++q) {
+    const int s = q == 0 ? F.fixed_slot0 : F.fixed_slot[q];
+    const double e = q == 0 ? F.fixed_val0 : F.fixed_val[q];
+    if ((int)threadIdx.x < IW) f2_st2(f2_slot(s, threadIdx.x), make_double2(e, 0.0));
+  }
 
   // ---- inside a rollout: the instances the previous step finished are reset here, where the reference calls env.reset()
   // (algorithms/base.py:289-290) -- terminal observation to the side list, next seed of the instance's chain, fresh
   // observation into the slot this step starts from.  Not rare under random actions (an episode is truncated after 10-20
   // steps), so the rows are moved by the whole workgroup.
   const uint64_t inst = (uint64_t)(E.first_instance + b);
-  // (the clock and seed rows are asked for here, in the same round trip as the rollout's flags; re-read after a reset)
-  double told = ROW(R.TIME), kold = ROW(R.STEP);
-  uint64_t seed = lane_seed(S, R);
+  // (the clock and seed rows were asked for at the top, in the same round trip as the rollout's flags; re-read after a reset)
   if (RS.active && RS.t > 0) {
     int F2_AS3* const fin = F2_P(int, F.off_red);        // [IW] entry of the side list (>= 0), -1 list full, -2 not finished
     if (wave == 0 && hv == 0) {
