@@ -442,7 +442,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", max_dyn));
     for (const void* f : {(const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2, (const void*)gs_k_step_nr_flow2,
                           (const void*)gs_k_stepc_nr_flow2, (const void*)gs_k_step_fbs_flow2s, (const void*)gs_k_stepc_fbs_flow2s,
-                          (const void*)gs_k_step_nr_flow2s, (const void*)gs_k_stepc_nr_flow2s})      // no static LDS in these
+                          (const void*)gs_k_step_nr_flow2s, (const void*)gs_k_stepc_nr_flow2s, (const void*)gs_k_step_fbs_flow2h,
+                          (const void*)gs_k_stepc_fbs_flow2h, (const void*)gs_k_step_fbs_flow2x, (const void*)gs_k_stepc_fbs_flow2x})      // no static LDS in these
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", 160 * 1024));
   }
@@ -1135,6 +1136,10 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
   // second-generation step kernels do the bookkeeping themselves (finished instances are reset at the start of the NEXT
   // step, rewards / flags written at the end of the step): one launch per step, and one small kernel after the last
   // step for the instances it finished; the other kernels are followed by that small kernel after every step
+  // (The whole rollout as ONE launch -- each workgroup looping over the T steps by itself, no workgroup needs another --
+  // was built in round 2 and is bit-identical, but slower: inlined into a loop the step's ~1 KB argument block stays live
+  // across iterations (230 spilled registers); as an out-of-line call reading its arguments from memory the block lands in
+  // scratch (59 M env-steps/s against 150 M for a launch per step).)
   const bool fused = h->flow2 || h->nr2;
   for (int t = 0; t < T; ++t) {
     double* nxt = ro.obs_seq + (size_t)(t + 1) * B * D;
