@@ -379,6 +379,23 @@ def main():
                                                    "pageable NumPy memory on the host side"}
         except Exception as e:
             m["with_host_io"] = {"error": str(e)}
+        # the same call with the output arrays in page-locked memory (BatchedGridEnvironment(pinned_host_buffers=True):
+        # step() returns views of two rotating pinned buffer sets instead of fresh arrays)
+        try:
+            h.use_pinned_outputs()
+            for k in range(4):
+                env.step(actions[k % n_act])
+            ts = []
+            for k in range(10):
+                t1 = time.perf_counter()
+                env.step(actions[k % n_act])
+                ts.append(time.perf_counter() - t1)
+            med, p10, p90 = quantiles(ts)
+            m["with_host_io_pinned"] = {"env_steps_per_s": B / med, "ms_per_step": 1e3 * med, "ms_per_step_p10_p90": [1e3 * p10, 1e3 * p90],
+                                        "GB_per_s_of_observations": B * fs.obs_dim * 8 / med / 1e9,
+                                        "what": "as with_host_io, outputs in page-locked host buffers (gs_host_alloc), reused every other step"}
+        except Exception as e:
+            m["with_host_io_pinned"] = {"error": str(e)}
         return m
 
     def accuracy(fs, solver):
@@ -481,7 +498,7 @@ def main():
             "converged_fraction": head_m["converged_fraction"],
             "host": host_description(),
         }
-        for k in ("post_step_checks", "rollout", "with_host_io"):
+        for k in ("post_step_checks", "rollout", "with_host_io", "with_host_io_pinned"):
             if k in main_m:
                 result[k] = main_m[k]
         if world > 1:

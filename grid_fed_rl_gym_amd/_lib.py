@@ -109,6 +109,8 @@ SYMBOLS = [
     ("gs_comm_destroy", C.c_int, [_H]),
     ("gs_timing_enable", C.c_int, [_H, C.c_int32]),
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
+    ("gs_host_alloc", C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    ("gs_host_free", C.c_int, [C.c_void_p]),
     ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     ("gs_debug_block_times", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     ("gs_debug_write_rows", C.c_int, [_H, C.c_int32, _dp]),
@@ -219,6 +221,7 @@ class Handle:
                 child.close()
             self._lib.gs_destroy(self._h)
             self._h = _H()
+            self._free_pinned()
 
     def last_error(self) -> str:
         return self._lib.gs_last_error(self._h).decode()
@@ -318,14 +321,50 @@ class Handle:
         self._check(self._lib.gs_reset(self._h, _ptr(s, C.POINTER(C.c_uint64)), _ptr(k, _up), _ptr(obs, _dp)))
         return obs
 
-    def _step_buffers(self, want_obs=True):
+    # -- page-locked output buffers (opt-in) ----------------------------------------------------
+    def use_pinned_outputs(self, sets: int = 2) -> None:
+        """From now on step() / download_step() return arrays that live in ``sets`` rotating sets of page-locked host
+        buffers (gs_host_alloc): the device-to-host copy runs at the link's rate and no 45 MB array is page-faulted in
+        per step.  The price is the reference's "fresh arrays every step": what step() returned is overwritten ``sets``
+        steps later -- copy what has to live longer (a replay buffer does that anyway)."""
+        if getattr(self, "_pinned", None):
+            return
+        self._pinned, self._pinned_ptrs, self._pinned_turn = [], [], 0
+        for _ in range(max(2, int(sets))):
+            self._pinned.append(self._alloc_step_set(self._pinned_array))
+
+    def _pinned_array(self, shape, dtype=np.float64):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        rc = self._lib.gs_host_alloc(C.byref(p), max(n, 8))
+        if rc != GS_OK:
+            raise PowerFlowError(f"gs_host_alloc({n}) failed ({rc}): {self._lib.gs_last_error(None).decode()}")
+        self._pinned_ptrs.append(p)
+        return np.frombuffer((C.c_char * max(n, 8)).from_address(p.value), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def _alloc_step_set(self, new, want_obs=True):
         B = self.B
-        out = dict(obs=np.empty((B, self.obs_dim)) if want_obs else None, reward=np.empty(B),
-                   terminated=np.empty(B, dtype=np.uint8), truncated=np.empty(B, dtype=np.uint8),
-                   power_flow_converged=np.empty(B, dtype=np.uint8), max_voltage=np.empty(B), min_voltage=np.empty(B),
-                   total_losses=np.empty(B), violations=np.empty((B, 4), dtype=np.uint8),
-                   constraint_violations=np.empty(B, dtype=np.int32), current_step=np.empty(B, dtype=np.int32),
-                   episode_reward=np.empty(B), iterations=np.empty(B, dtype=np.int32), status=np.empty(B, dtype=np.int32))
+        return dict(obs=new((B, self.obs_dim)) if want_obs else None, reward=new((B,)),
+                    terminated=new((B,), np.uint8), truncated=new((B,), np.uint8),
+                    power_flow_converged=new((B,), np.uint8), max_voltage=new((B,)), min_voltage=new((B,)),
+                    total_losses=new((B,)), violations=new((B, 4), np.uint8),
+                    constraint_violations=new((B,), np.int32), current_step=new((B,), np.int32),
+                    episode_reward=new((B,)), iterations=new((B,), np.int32), status=new((B,), np.int32))
+
+    def _free_pinned(self) -> None:
+        self._pinned = None
+        for p in getattr(self, "_pinned_ptrs", []):
+            self._lib.gs_host_free(p)
+        self._pinned_ptrs = []
+
+    def _step_buffers(self, want_obs=True):
+        if getattr(self, "_pinned", None):
+            out = dict(self._pinned[self._pinned_turn])
+            self._pinned_turn = (self._pinned_turn + 1) % len(self._pinned)
+            if not want_obs:
+                out["obs"] = None
+        else:
+            out = self._alloc_step_set(lambda shape, dtype=np.float64: np.empty(shape, dtype=dtype), want_obs)
         info = gs_info_view(_ptr(out["power_flow_converged"], _up), _ptr(out["max_voltage"], _dp),
                             _ptr(out["min_voltage"], _dp), _ptr(out["total_losses"], _dp), _ptr(out["violations"], _up),
                             _ptr(out["constraint_violations"], _ip), _ptr(out["current_step"], _ip),

@@ -1025,6 +1025,22 @@ int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* o
   return GS_OK;
 }
 
+int gs_host_alloc(void** out, size_t bytes) {
+  if (!out || bytes == 0) return fail(nullptr, GS_E_INVALID, "gs_host_alloc: out is NULL or bytes == 0");
+  *out = nullptr;
+  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, GS_E_NOMEM, "hipHostMalloc(%zu bytes) failed", bytes);
+  }
+  return GS_OK;
+}
+
+int gs_host_free(void* p) {
+  if (!p) return GS_OK;
+  if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, GS_E_INVALID, "gs_host_free: not a gs_host_alloc pointer"); }
+  return GS_OK;
+}
+
 int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
                      const gs_info_view* info) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");

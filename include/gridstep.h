@@ -194,6 +194,14 @@ int gs_fallback_linear(gs_handle* h, const double* load_w, const double* gen_w, 
 int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* obs_out);
 int gs_step(gs_handle* h, const double* actions, double* obs, double* reward,
             uint8_t* terminated, uint8_t* truncated, const gs_info_view* info);
+/* Page-locked host memory for the arrays gs_step / gs_download_step / gs_reset / gs_rollout_download fill.  The reference's
+ * step() returns fresh NumPy arrays every call (grid_env.py:563-619); at [8192][684] doubles that is 45 MB of first-touch
+ * page faults plus a staged copy per step.  A caller that hands gs_step buffers from gs_host_alloc gets the copy at the
+ * link's rate and asynchronously (measured: DESIGN.md section 5, `with_host_io`).  Plain host allocations, owned by the
+ * caller: gs_host_free releases them; they outlive any handle. */
+int gs_host_alloc(void** out, size_t bytes);
+int gs_host_free(void* p);
+
 /* device-resident variant: K action batches [K][B][action_dim] staged in HBM, stepped by index */
 int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches);
 int gs_step_device(gs_handle* h, int32_t action_batch_index);

@@ -319,6 +319,30 @@ def test_set_state_on_a_fresh_handle_restores_the_whole_observation():
     a.close(); b.close()
 
 
+def test_pinned_host_buffers_give_the_same_arrays_and_rotate():
+    """`pinned_host_buffers=True`: step() returns views of two rotating page-locked buffer sets (gs_host_alloc) -- same
+    numbers as the fresh-array path, an array stays intact through the next step and is reused by the one after."""
+    fs = P.ieee13_like("epsilon"); B = 70
+    kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True)
+    plain, pinned = P.BatchedGridEnvironment(fs, **kw), P.BatchedGridEnvironment(fs, pinned_host_buffers=True, **kw)
+    plain.reset(seed=5); pinned.reset(seed=5)
+    rng = np.random.default_rng(2)
+    kept = []
+    for t in range(4):
+        a = rng.uniform(-1, 1, (B, fs.action_dim))
+        o0, r0, te0, tr0, i0 = plain.step(a)
+        o1, r1, te1, tr1, i1 = pinned.step(a)
+        assert np.array_equal(o0, o1) and np.array_equal(r0, r1) and np.array_equal(te0, te1) and np.array_equal(tr0, tr1)
+        for k in ("max_voltage", "total_losses", "iterations", "episode_reward"):
+            assert np.array_equal(i0[k], i1[k]), k
+        kept.append((o1, o0.copy()))
+        if t >= 1:
+            assert np.array_equal(kept[t - 1][0], kept[t - 1][1])          # the previous step's array is still intact
+        if t >= 2:
+            assert np.shares_memory(kept[t - 2][0], o1)      # ... and the one before that is being reused
+    plain.close(); pinned.close()
+
+
 def test_handles_with_different_lds_footprints_coexist():
     """A 123-bus NR handle (120 KB of dynamic LDS) keeps working after a small FBS handle was created."""
     big = P.BatchedGridEnvironment(P.ieee123_like(), num_envs=4, stochastic_loads=False, weather_variation=False)
