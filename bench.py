@@ -399,7 +399,10 @@ def main():
         return m
 
     def accuracy(fs, solver):
-        """max |V|, angle and line-flow error of the HIP path against the CPU oracle on a 64-instance, 3-step sample of the workload."""
+        """Voltage, angle and line-flow differences of the HIP path on a 64-instance, 3-step sample of the workload against
+        (1) the reference's algorithm at the reference's own settings -- Newton-Raphson, tolerance 1e-6 (power_flow.py:81):
+        the figure north_star's 1e-6 pu bar is about --, (2) the same algorithm converged to 1e-10 (what the tolerance
+        leaves behind, for both), (3) the GPU's own algorithm at the GPU's own tolerance (the implementation alone)."""
         try:
             from oracle import oracle_c as OC
             if not OC.available():
@@ -414,34 +417,36 @@ def main():
         st = env.get_state(); st[:, env.state_column("time")] = 11.5 * 3600.0; env.set_state(st)
         net = OC.Net(fs)
         kw = env_kwargs_of(solver)
-        # the oracle always runs Newton-Raphson (the reference's solver), tightly converged
-        cfg = OC.config(solver="nr", jacobian="exact", max_iterations=50, tolerance=1e-10, stochastic_loads=True,
-                        weather_variation=True, power_base=fs.base_power_va, threads=8)
-        _, cst = OC.env_reset(net, cfg, b, np.arange(b, dtype=np.uint64)); cst[:, 0] = 11.5 * 3600.0
-        # ... and, beside it, the GPU's own algorithm at the GPU's own tolerance: what is left then is the implementation,
-        # not the tolerance (two solvers that both stop at a 1e-6 mismatch differ by about that much in the flows)
-        cfg2 = OC.config(solver=solver, jacobian="exact", max_iterations=kw["max_iterations"], tolerance=kw["tolerance"], stochastic_loads=True,
-                         weather_variation=True, power_base=fs.base_power_va, threads=8)
-        _, cst2 = OC.env_reset(net, cfg2, b, np.arange(b, dtype=np.uint64)); cst2[:, 0] = 11.5 * 3600.0
-        dv = da = df = dv2 = da2 = df2 = fmax = 0.0
+        common = dict(jacobian="exact", stochastic_loads=True, weather_variation=True, power_base=fs.base_power_va, threads=8)
+        cfgs = {"ref": OC.config(solver="nr", max_iterations=50, tolerance=1e-6, **common),
+                "exact": OC.config(solver="nr", max_iterations=50, tolerance=1e-10, **common),
+                "same": OC.config(solver=solver, max_iterations=kw["max_iterations"], tolerance=kw["tolerance"], **common)}
+        states = {}
+        for k, c in cfgs.items():
+            _, cs = OC.env_reset(net, c, b, np.arange(b, dtype=np.uint64)); cs[:, 0] = 11.5 * 3600.0
+            states[k] = cs
         o_f = 2 * fs.n
-        for k in range(3):
-            obs, *_ = env.step(actions[k])
-            ref = OC.env_step(net, cfg, cst, actions[k])["obs"]
-            ref2 = OC.env_step(net, cfg2, cst2, actions[k])["obs"]
-            dv = max(dv, float(np.max(np.abs(obs[:, 0:2 * fs.n:2] - ref[:, 0:2 * fs.n:2]))))
-            da = max(da, float(np.max(np.abs(obs[:, 1:2 * fs.n:2] - ref[:, 1:2 * fs.n:2]))))
-            df = max(df, float(np.max(np.abs(obs[:, o_f:o_f + 2 * fs.m:2] - ref[:, o_f:o_f + 2 * fs.m:2]))))
-            dv2 = max(dv2, float(np.max(np.abs(obs[:, 0:2 * fs.n:2] - ref2[:, 0:2 * fs.n:2]))))
-            da2 = max(da2, float(np.max(np.abs(obs[:, 1:2 * fs.n:2] - ref2[:, 1:2 * fs.n:2]))))
-            df2 = max(df2, float(np.max(np.abs(obs[:, o_f:o_f + 2 * fs.m:2] - ref2[:, o_f:o_f + 2 * fs.m:2]))))
-            fmax = max(fmax, float(np.max(np.abs(ref[:, o_f:o_f + 2 * fs.m:2]))))
+        cols = {"Vm": slice(0, 2 * fs.n, 2), "Va": slice(1, 2 * fs.n, 2), "flow": slice(o_f, o_f + 2 * fs.m, 2)}
+        worst = {k: {q: 0.0 for q in cols} for k in ("ref", "exact", "same", "ref_vs_exact")}
+        fmax = 0.0
+        for t in range(3):
+            obs, *_ = env.step(actions[t])
+            o = {k: OC.env_step(net, cfgs[k], states[k], actions[t])["obs"] for k in cfgs}
+            for q, sl in cols.items():
+                for k in cfgs:
+                    worst[k][q] = max(worst[k][q], float(np.max(np.abs(obs[:, sl] - o[k][:, sl]))))
+                worst["ref_vs_exact"][q] = max(worst["ref_vs_exact"][q], float(np.max(np.abs(o["ref"][:, sl] - o["exact"][:, sl]))))
+            fmax = max(fmax, float(np.max(np.abs(o["exact"][:, cols["flow"]]))))
         env.close()
-        return {"max_abs_dVm_pu": dv, "max_abs_dVa_rad": da, "max_abs_dflow_pu": df, "largest_flow_pu": fmax, "max_dflow_relative_to_largest_flow": df / fmax if fmax else None,
-                "against": "C oracle, Newton-Raphson (reference algorithm) converged to 1e-10",
-                "same_algorithm_same_tolerance": {"max_abs_dVm_pu": dv2, "max_abs_dVa_rad": da2, "max_abs_dflow_pu": df2,
-                                                  "against": f"C oracle running the GPU's solver ({solver}) at the GPU's tolerance"},
-                "sample": f"{b} instances x 3 steps of the workload", "gpu_tolerance": kw["tolerance"]}
+        fmt = lambda w: {"max_abs_dVm_pu": w["Vm"], "max_abs_dVa_rad": w["Va"], "max_abs_dflow_pu": w["flow"]}
+        out = fmt(worst["ref"])
+        out.update(against="C oracle running the reference's algorithm at the reference's settings: Newton-Raphson, tolerance 1e-6 (power_flow.py:81)",
+                   bar_pu=1e-6, largest_flow_pu=fmax,
+                   against_converged_solution=dict(fmt(worst["exact"]), against="C oracle, Newton-Raphson converged to 1e-10",
+                                                   reference_settings_vs_converged=fmt(worst["ref_vs_exact"])),
+                   same_algorithm_same_tolerance=dict(fmt(worst["same"]), against=f"C oracle running the GPU's solver ({solver}) at the GPU's tolerance"),
+                   sample=f"{b} instances x 3 steps of the workload", gpu_tolerance=kw["tolerance"])
+        return out
 
     def summarize(m, n_ranks):
         med, p10, p90 = quantiles(m["regions"])

@@ -117,3 +117,45 @@ def test_full_size_three_phase_batch_properties():
     sub = s.solve_batch(spec, lam[100:164, None, None] * Pn[None], lam[100:164, None, None] * Qn[None])
     np.testing.assert_array_equal(sub.voltages, sol.voltages[100:164])
     s.close()
+
+
+@pytest.mark.parametrize("maker,solver,bar", [(lambda: P.ieee123_like(), "fbs", 1e-6),            # BASELINE config 3 (headline)
+                                              (lambda: P.ieee123_like(), "nr", 1e-6),
+                                              (lambda: P.ieee13_like("epsilon"), "nr", 1e-6),      # BASELINE config 2
+                                              (lambda: P.ieee13_like("epsilon"), "fbs", 5e-6)])    # not a BASELINE config, see below
+def test_north_star_accuracy_bar_against_the_reference_algorithm_at_its_own_settings(maker, solver, bar):
+    """north_star: "bus voltages and line flows within 1e-6 pu of the reference NumPy/CPU solver".  The reference's solver
+    is Newton-Raphson stopping at a 1e-6 mismatch (power_flow.py:81, 168-171); the oracle runs exactly that, the GPU runs
+    the benchmark's configuration (either solver, tolerance 1e-6) on the same instances, steps and draws.  Same algorithm:
+    1e-13.  The sweep solver on the headline feeder: 4.5e-7.  What is NOT asserted at 1e-6: against the CONVERGED solution
+    the reference itself, at its own tolerance, sits 1.3e-6 away in the flows, and two different algorithms that both stop
+    at a 1e-6 mismatch can differ by a few 1e-6 -- the sweep solver on the more heavily loaded 13-bus feeder: 2.8e-6 in
+    the flows (held to 5e-6 here; a caller who needs 1e-6 there sets tolerance <= 3e-8, one sweep more: DESIGN.md section 2)."""
+    spec = maker(); B = 48
+    env = P.BatchedGridEnvironment(spec, num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True, jacobian="exact",
+                                   tolerance=1e-6, max_iterations=100 if solver == "fbs" else 50)
+    seeds = np.arange(B, dtype=np.uint64) + 77
+    env.reset(seed=seeds)
+    st = env.get_state(); st[:, env.state_column("time")] = 11.5 * 3600.0; env.set_state(st)
+    from tests.helpers import oracle_spec
+    ospec = oracle_spec(spec, solver="nr", jacobian_mode="exact", zero_z="open", tolerance=1e-6, max_iterations=50, stochastic_loads=True,
+                        weather_variation=True, power_base=spec.base_power_va)
+    states = []
+    for b in range(B):
+        _, s = O.env_reset(ospec, seed=int(seeds[b]), instance=b)
+        s.time = 11.5 * 3600.0
+        states.append(s)
+    rng = np.random.default_rng(4)
+    n, m = spec.n, spec.m
+    worst = dict(Vm=0.0, Va=0.0, flow=0.0)
+    for t in range(2):
+        a = rng.uniform(-1, 1, (B, spec.action_dim))
+        obs, *_ = env.step(a)
+        for b in range(B):
+            ref, *_ = O.env_step(ospec, states[b], a[b])
+            ref = np.asarray(ref)
+            worst["Vm"] = max(worst["Vm"], np.abs(obs[b, 0:2 * n:2] - ref[0:2 * n:2]).max())
+            worst["Va"] = max(worst["Va"], np.abs(obs[b, 1:2 * n:2] - ref[1:2 * n:2]).max())
+            worst["flow"] = max(worst["flow"], np.abs(obs[b, 2 * n:2 * n + 2 * m:2] - ref[2 * n:2 * n + 2 * m:2]).max())
+    env.close()
+    assert worst["Vm"] < bar and worst["Va"] < bar and worst["flow"] < bar, worst
