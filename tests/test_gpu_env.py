@@ -102,6 +102,36 @@ def test_seeded_rollouts_against_oracle(maker, B, T, solver, stoch):
     env.close()
 
 
+@pytest.mark.parametrize("maker,B,solver,cap", [(lambda: P.ieee123_like(), 37, "fbs", 2), (lambda: P.ieee123_like(), 37, "nr", 1),
+                                                (lambda: P.ieee123_like(), 1, "nr", 2), (lambda: P.ieee13_like("epsilon"), 9, "fbs", 3),
+                                                (lambda: P.ieee13_like("epsilon"), 1, "nr", 2), (lambda: P.random_meshed(200, 0, seed=5), 5, "fbs", 2)])
+def test_iteration_cap_in_the_fused_step_kernels_matches_the_oracle(maker, B, solver, cap):
+    """power_flow.py:143-211 under an iteration cap: the solve stops after `cap` checks, reports converged = False, the
+    iteration count and the last mismatch, and the step goes on with the voltages it has (the reference's behaviour; the
+    environment then counts whatever limits they break).  Also the smallest batches (one instance, one partial workgroup)."""
+    fs = maker()
+    rng = np.random.default_rng(11)
+    T = 2
+    actions = rng.uniform(-1, 1, (T, B, fs.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 5
+    env = P.BatchedGridEnvironment(fs, num_envs=B, stochastic_loads=True, weather_variation=True, solver=solver, jacobian="exact",
+                                   tolerance=1e-9, max_iterations=cap, first_instance=40)
+    assert env.handle.describe()["kernel"] in ("fbs_flow2h", "fbs_flow2s", "fbs_flow2x", "nr_flow2", "nr_flow2s")
+    env.reset(seed=seeds)
+    cfg = dict(stochastic_loads=True, weather_variation=True, power_base=fs.base_power_va, solver=solver, tolerance=1e-9,
+               max_iterations=cap, jacobian_mode="exact", zero_z="open")
+    ref = _oracle_rollout(fs, cfg, actions, seeds, first_instance=40)
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(actions[t])
+        assert not info["power_flow_converged"].any() and (info["iterations"] == cap).all() and (info["status"] == 1).all()
+        for b in range(B):
+            o, r, te, tr, inf = ref[b][t]
+            assert np.max(np.abs(obs[b] - o) / np.maximum(1.0, np.abs(o))) < 1e-9, (t, b)
+            assert abs(rew[b] - r) <= 1e-8 * max(1.0, abs(r)) and bool(term[b]) == te and bool(trunc[b]) == tr
+            assert inf["power_flow_converged"] is False or not inf["power_flow_converged"]
+    env.close()
+
+
 def test_masked_reset_checkpoint_and_list_adapter():
     fs = P.ieee13_like("epsilon")
     B = 9
