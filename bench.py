@@ -296,6 +296,24 @@ def main():
                  mean_iterations=float(out["iterations"].mean()))
         if extras and rank == 0:
             m.update(side_measurements(env, fs, B, actions, solver))
+        if desc.get("step_launches", 1) > 1 and rank == 0 and not use_gather:
+            # how long ONE of the step's two dispatches runs (what rocprofv3 --kernel-trace reports per dispatch), from the
+            # workgroups' own start / end stamps on the GPU's 100 MHz clock; armed only now, after everything that is timed
+            try:
+                os.environ["GS_STAMP_BLOCK_TIMES"] = "1"
+                h.debug_stamps()
+                for k in range(12):
+                    h.step_device(k % n_act)
+                nwg = int(desc["workgroups"]); t = h.debug_block_times(nwg).astype(np.int64); half = nwg // 2
+                spans = [float(t[q, 1].max() - t[q, 0].min()) / 100.0 for q in (slice(0, half), slice(half, nwg))]
+                m["dispatch"] = {"in_kernel_us": spans, "second_starts_after_first_us": float(t[half:, 0].min() - t[:half, 0].min()) / 100.0,
+                                 "workgroups": [half, nwg - half], "algorithmic_bytes": [algorithmic_bytes_per_step(fs) * B * half // nwg,
+                                                                                        algorithmic_bytes_per_step(fs) * B * (nwg - half) // nwg],
+                                 "how": "first workgroup start to last workgroup end of each dispatch, last of 12 steps (gs_debug_block_times)"}
+            except Exception as e:
+                m["dispatch"] = {"error": str(e)}
+            finally:
+                os.environ.pop("GS_STAMP_BLOCK_TIMES", None)
         if use_gather:
             h.comm_destroy()
         env.close()
@@ -468,6 +486,13 @@ def main():
                 "kernel": "gs_k_step_" + KERNEL_NAMES.get(m["desc"]["kernel"], m["desc"]["kernel"]),
                 "avg_launch_ms": avg, "avg_launch_method": "one HIP event pair on the kernel's stream around the K launches of each timed region / K, mean over the regions",
                 "algorithmic_bytes_per_launch": bytes_step * B,
+                **({} if m["desc"].get("step_launches", 1) == 1 else {
+                    "dispatches_per_launch": m["desc"]["step_launches"],
+                    "note": "one step = TWO concurrent dispatches of the kernel, each half of the workgroups, on two streams that run about half a "
+                            "step out of phase (one half's LDS-bound solver beside the other's VALU-bound prologue / epilogue); `avg_launch_ms`, "
+                            "`achieved` and `algorithmic_bytes_per_launch` are per STEP (both dispatches); rocprofv3 --kernel-trace lists the "
+                            "dispatches separately, each longer than half a step because they overlap (`per_dispatch`)",
+                    "per_dispatch": m.get("dispatch")}),
                 "fp64_valu": {"achieved_tflops": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                               "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "mean_iterations": m["mean_iterations"]}}
 

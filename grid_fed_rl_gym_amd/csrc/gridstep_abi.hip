@@ -81,7 +81,14 @@ struct gs_handle {
   // the env step of a handle whose solver is the dataflow sweep runs the second-generation kernel (kernels_flow2.hip:
   // 32 instances per workgroup, half-waves on different buses) when the feeder fits its tables; gs_solve keeps kernel 6
   bool flow2 = false; GsF2Tables F2{}; std::string flow2_why;
-  bool f2_small = false, f2_half = false, f2_wide = false; int f2_iw = 32, f2_nw = 16;     // which member of the family (8 instances per workgroup for small feeders)
+  bool f2_small = false, f2_half = false, f2_wide = false; int f2_iw = 32, f2_nw = 16;
+  // A step of the 16-instance sweep kernel goes out as TWO launches, each half of the workgroups, on two streams: consecutive
+  // steps of one half need nothing from the other half, so the second stream's kernels slide into the launch gaps and the
+  // uneven tails of the first's (two handles of 4096 instances on two streams: 205 M env-steps/s against 186 M for one of
+  // 8192).  `forked`: stream2 holds step launches the main stream has not waited for yet; every entry point other than the
+  // step itself joins first (GS_ENTER).
+  bool split_ok = false, forked = false;
+  hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // which member of the family (8 instances per workgroup for small feeders)
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -141,6 +148,18 @@ int fail(gs_handle* h, int code, const char* fmt, ...) {
 #define HIPCHK(h, expr)                                                                           \
   do { hipError_t e_ = (expr);                                                                    \
        if (e_ != hipSuccess) return fail((h), GS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// Work of the second step stream joins the main stream (see gs_handle::forked)
+static int join_streams(gs_handle* h) {
+  if (!h->forked) return GS_OK;
+  HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  h->forked = false;
+  return GS_OK;
+}
+#define GS_ENTER(h)                                                                               \
+  do { HIPCHK((h), hipSetDevice((h)->device));                                                    \
+       if ((h)->forked) { int rc_ = join_streams(h); if (rc_) return rc_; } } while (0)
 
 template <typename X>
 int dev_alloc(gs_handle* h, X** p, size_t count) {
@@ -279,8 +298,19 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     const GsFusedChecks fc = fused_checks_args(h);
     const GsRolloutStep rsv = rs ? *rs : GsRolloutStep{};
     if (h->nr2 || h->flow2) {        // 64 / IW workgroups per 64-instance slab group, each with its own IW instances
-      const dim3 g2(h->groups * (64 / h->f2_iw)), b2(64 * h->f2_nw);
-#define GS_F2(k) hipLaunchKernelGGL(k, g2, b2, h->F2.lds_bytes, h->stream, h->T, h->F2, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc, rsv)
+      const int per_group = 64 / h->f2_iw, n_wg = h->groups * per_group;
+      const dim3 b2(64 * h->f2_nw);
+      // (two half-grid launches on two streams, see gs_handle::split_ok; the halves are whole 64-instance slab groups)
+      const int n_first = h->split_ok ? (h->groups / 2) * per_group : n_wg;
+      if (h->split_ok && !h->forked) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        h->forked = true;
+      }
+      GsF2Tables f2a = h->F2, f2b = h->F2;
+      f2a.wg_offset = 0; f2b.wg_offset = n_first;
+#define GS_F2(k) do { hipLaunchKernelGGL(k, dim3(n_first), b2, h->F2.lds_bytes, h->stream, h->T, f2a, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc, rsv); \
+                      if (n_first < n_wg) hipLaunchKernelGGL(k, dim3(n_wg - n_first), b2, h->F2.lds_bytes, h->stream2, h->T, f2b, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc, rsv); } while (0)
       if (h->nr2) {
         if (h->f2_small) { if (fc.enabled) GS_F2(gs_k_stepc_nr_flow2s); else GS_F2(gs_k_step_nr_flow2s); }
         else { if (fc.enabled) GS_F2(gs_k_stepc_nr_flow2); else GS_F2(gs_k_step_nr_flow2); }
@@ -814,6 +844,16 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
 #undef UP
+  // a step as two half-grid launches on two streams: only where each half still gives every CU a workgroup
+  if ((h->flow2 || h->nr2) && 2 * (size_t)h->F2.lds_bytes <= 160 * 1024 && !getenv("GS_NO_SPLIT") && h->groups * (64 / h->f2_iw) >= 512 &&
+      h->groups >= 2) {
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+      return bail(fail(nullptr, GS_E_HIP, "second step stream: hipStreamCreate / hipEventCreate failed"));
+    h->split_ok = true;
+  }
+
   if (h->flow2 || h->nr2) {
     // buses with a voltage set point, for the kernels' flat start (the slack; the first entry travels inside the argument block)
     std::vector<int32_t> fs_slot; std::vector<double> fs_val;
@@ -904,8 +944,10 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
 void gs_destroy(gs_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  if (h->stream2) { (void)hipStreamDestroy(h->stream2); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   if (h->ev_step) (void)hipEventDestroy(h->ev_step);
   for (int k = 0; k < 2; ++k) if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
@@ -939,18 +981,18 @@ int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
            "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d, "
-           "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"solve_kernel\": \"%s\", \"flow2\": \"%s\"}",
+           "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"step_launches\": %d, \"solve_kernel\": \"%s\", \"flow2\": \"%s\"}",
            h->flow2 ? (h->f2_small ? "fbs_flow2s" : h->f2_wide ? "fbs_flow2x" : h->f2_half ? "fbs_flow2h" : "fbs_flow2") : h->nr2 ? (h->f2_small ? "nr_flow2s" : "nr_flow2") : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
            h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, (h->flow2 || h->nr2) ? h->f2_nw : h->W, h->groups,
            h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim,
-           (h->flow2 || h->nr2) ? h->f2_iw : 64, (h->flow2 || h->nr2) ? (64 / h->f2_iw) * h->groups : h->groups, (h->flow2 || h->nr2) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576,
+           (h->flow2 || h->nr2) ? h->f2_iw : 64, (h->flow2 || h->nr2) ? (64 / h->f2_iw) * h->groups : h->groups, (h->flow2 || h->nr2) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576, h->split_ok ? 2 : 1,
            kn[h->solve_kernel], (h->flow2 || h->nr2) ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()));
   return GS_OK;
 }
 
 int gs_synchronize(gs_handle* h) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   return GS_OK;
@@ -959,7 +1001,7 @@ int gs_synchronize(gs_handle* h) {
 // ---- solver -------------------------------------------------------------------------------
 int gs_upload_injections(gs_handle* h, const double* P_spec, const double* Q_spec) {
   if (!h || !P_spec) return fail(h, GS_E_INVALID, "handle / P_spec is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   int rc = unpack_from_host(h, h->map_p, h->n, P_spec);
   if (rc) return rc;
   if (Q_spec) {
@@ -976,13 +1018,13 @@ int gs_upload_injections(gs_handle* h, const double* P_spec, const double* Q_spe
 
 int gs_solve_device(gs_handle* h) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   return launch_solve(h);
 }
 
 int gs_download_solution(gs_handle* h, const gs_solution_view* out) {
   if (!h || !out) return fail(h, GS_E_INVALID, "handle / view is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   int rc;
   if ((rc = pack_to_host(h, h->map_vm, h->n, out->bus_voltages))) return rc;
   if ((rc = pack_to_host(h, h->map_va, h->n, out->bus_angles))) return rc;
@@ -1008,7 +1050,7 @@ int gs_solve(gs_handle* h, const double* P_spec, const double* Q_spec, const gs_
 // ---- environment ----------------------------------------------------------------------------
 int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* obs_out) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   if (seeds) HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)h->B * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   if (mask) HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->B, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(gs_k_env_reset, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, h->B,
@@ -1044,7 +1086,7 @@ int gs_host_free(void* p) {
 int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
                      const gs_info_view* info) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   if (obs) {
     HIPCHK(h, hipMemcpyAsync(obs, h->d_obs2[h->obs_cur], (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
@@ -1058,7 +1100,7 @@ int gs_step(gs_handle* h, const double* actions, double* obs, double* reward, ui
             uint8_t* truncated, const gs_info_view* info) {
   if (!h || (!actions && h->action_dim > 0)) return fail(h, GS_E_INVALID, "handle / actions is NULL");
   if (!h->was_reset) return fail(h, GS_E_STATE, "gs_step before gs_reset");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   if (h->action_dim > 0)
     HIPCHK(h, hipMemcpyAsync(h->d_in, actions, (size_t)h->B * h->action_dim * sizeof(double), hipMemcpyHostToDevice, h->stream));
   int rc = step_kernels(h, h->d_in);
@@ -1068,7 +1110,7 @@ int gs_step(gs_handle* h, const double* actions, double* obs, double* reward, ui
 
 int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches) {
   if (!h || !actions || n_batches <= 0) return fail(h, GS_E_INVALID, "bad arguments");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->d_actions) { (void)hipFree(h->d_actions); h->d_actions = nullptr; }
   const size_t bytes = (size_t)n_batches * h->B * std::max(h->action_dim, 1) * sizeof(double);
@@ -1130,7 +1172,7 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
   if (policy != GS_POLICY_UPLOADED && policy != GS_POLICY_RANDOM) return fail(h, GS_E_INVALID, "unknown policy %d", policy);
   if (policy == GS_POLICY_UPLOADED && !actions && h->action_dim > 0) return fail(h, GS_E_INVALID, "GS_POLICY_UPLOADED needs actions[T][B][action_dim]");
   if (!h->was_reset) return fail(h, GS_E_STATE, "gs_rollout before gs_reset");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   int rc = rollout_ensure(h, T);
   if (rc) return rc;
   gs_handle::Rollout& ro = h->ro;
@@ -1162,11 +1204,13 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
     GsRolloutStep rs{ro.rew, ro.done, ro.obs_seq + (size_t)t * B * D, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, 1};
     if ((rc = step_kernels(h, ro.act + (size_t)t * B * A, nxt, fused ? &rs : nullptr))) return rc;
     if (!fused || t == T - 1) {
+      if ((rc = join_streams(h))) return rc;
       GsRolloutPostArgs pa{fused ? nullptr : ro.rew, fused ? nullptr : ro.done, nxt, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, h->B};
       hipLaunchKernelGGL(gs_k_rollout_post, dim3(h->groups), dim3(256), 0, h->stream, h->T, h->R, h->EC, h->slab, pa);
       HIPCHK(h, hipGetLastError());
     }
   }
+  if ((rc = join_streams(h))) return rc;
   // the environment now stands at slot T: that is its current observation for gs_download_step / gs_allgather_obs
   if (h->gather_pending[h->obs_cur]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[h->obs_cur], 0)); h->gather_pending[h->obs_cur] = false; }
   HIPCHK(h, hipMemcpyAsync(h->d_obs2[h->obs_cur], ro.obs_seq + (size_t)T * B * D, B * D * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1177,7 +1221,7 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
 static int rollout_finish(gs_handle* h) {
   gs_handle::Rollout& ro = h->ro;
   if (ro.T <= 0) return fail(h, GS_E_STATE, "no rollout has been collected on this handle");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   if (ro.n_term < 0) {
     int32_t n = 0;
     HIPCHK(h, hipMemcpyAsync(&n, ro.term_count, sizeof n, hipMemcpyDeviceToHost, h->stream));
@@ -1229,13 +1273,13 @@ int gs_rollout_download(gs_handle* h, const gs_rollout_view* out) {
 // ---- checkpoint ---------------------------------------------------------------------------------
 int gs_get_state(gs_handle* h, double* state) {
   if (!h || !state) return fail(h, GS_E_INVALID, "handle / state is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   return pack_to_host(h, h->map_state, h->state_dim, state);
 }
 
 int gs_set_state(gs_handle* h, const double* state) {
   if (!h || !state) return fail(h, GS_E_INVALID, "handle / state is NULL");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   int rc = unpack_from_host(h, h->map_state, h->state_dim, state);
   if (rc) return rc;
   // rows that follow from the checkpoint: the rectangular voltages (what a warm-started sweep solver resumes from) and
@@ -1268,7 +1312,7 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
   if (!h || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, GS_E_INVALID, "bad arguments");
   std::string why;
   if (!load_rccl(why)) return fail(h, GS_E_COMM, "%s", why.c_str());
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   gs_ncclUniqueId uid; memcpy(uid.internal, id, 128);
   int rc = g_rccl.CommInitRank(&h->comm, world_size, uid, rank);
   if (rc != 0) return fail(h, GS_E_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
@@ -1297,7 +1341,7 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
 int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   if (!h->comm) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   const int D = h->obs_dim, nd = D - (h->obs_skip1 - h->obs_skip0);
   const size_t count = (size_t)h->B * nd;
   // On its own stream, behind the step that produced the current observation buffer.  Only the columns that change
@@ -1339,7 +1383,7 @@ int gs_comm_destroy(gs_handle* h) {
 // ---- measurement ------------------------------------------------------------------------------------
 int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
   if (!h || !cycles_out || n < 1 || n > 16) return fail(h, GS_E_INVALID, "bad arguments");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (!h->d_stamps) {
     int rc = dev_alloc(h, &h->d_stamps, 16 + 2 * GS_STAMP_BLOCKS);
@@ -1363,7 +1407,7 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
 int gs_debug_block_times(gs_handle* h, uint64_t* out, int32_t n_blocks) {
   if (!h || !out || n_blocks < 1 || n_blocks > GS_STAMP_BLOCKS) return fail(h, GS_E_INVALID, "bad arguments");
   if (!h->d_stamps) return fail(h, GS_E_STATE, "gs_debug_stamps has not armed the buffer");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_stamps + 16, (size_t)n_blocks * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemset(h->d_stamps + 16, 0, (size_t)2 * GS_STAMP_BLOCKS * sizeof(unsigned long long)));
@@ -1382,7 +1426,7 @@ int gs_timing_enable(gs_handle* h, int32_t on) {
 
 int gs_timing_read(gs_handle* h, double* total_ms, int64_t* launches) {
   if (!h || !total_ms || !launches) return fail(h, GS_E_INVALID, "bad arguments");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   if (h->timing_span) {           // call right after the last launch of the region: the closing event goes behind it on the stream
     for (int k = 0; k < GS_K_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; }
     if (h->span_open) {
@@ -1425,7 +1469,7 @@ static int debug_rows_map(gs_handle* h, int32_t which, std::vector<int32_t>& map
 
 int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
   if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   std::vector<int32_t> map;
   const int C = debug_rows_map(h, which, map);
   if (C <= 0) return GS_OK;
@@ -1443,7 +1487,7 @@ int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
 
 int gs_debug_read_rows(gs_handle* h, int32_t which, double* values) {
   if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   std::vector<int32_t> map;
   const int C = debug_rows_map(h, which, map);
   if (C <= 0) return GS_OK;
@@ -1466,7 +1510,7 @@ int gs_fallback_linear(gs_handle* h, const double* load_w, const double* gen_w, 
   if ((total_load == nullptr) != (total_gen == nullptr)) return fail(h, GS_E_INVALID, "total_load and total_gen go together");
   if (!load_w && total_load) return fail(h, GS_E_INVALID, "totals without per-bus arrays: with the device state the sums are formed on the device");
   if (!load_w && !h->was_reset) return fail(h, GS_E_STATE, "no environment state on the device: call gs_reset first or pass load_w / gen_w");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   const int B = h->B, n = h->n;
   int rc = GS_OK;
   if (!h->fb_ready) {
@@ -1546,7 +1590,7 @@ int gs_checks_set_fused(gs_checks* c, int32_t on, int32_t want_masks) {
   gs_handle* h = c->h;
   if (on && (h->n >= 65536 || h->m >= 65536)) return fail(h, GS_E_INVALID, "fused checks count in 16 bits: fewer than 65536 buses and lines");
   if (on && h->fused && h->fused != c) return fail(h, GS_E_STATE, "another checks object is already fused into this handle's step");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   c->want_masks = want_masks != 0;
   if (on) h->fused = c; else if (h->fused == c) h->fused = nullptr;
@@ -1559,7 +1603,7 @@ int gs_checks_create(gs_handle* h, const gs_checks_config* cfg, gs_checks** out)
   if (cfg->struct_size != (int32_t)sizeof(gs_checks_config)) return fail(h, GS_E_INVALID, "gs_checks_config.struct_size mismatch");
   if (!(cfg->timestep > 0.0)) return fail(h, GS_E_INVALID, "timestep must be positive");
   if (cfg->loading_source != 0 && cfg->loading_source != 1) return fail(h, GS_E_INVALID, "loading_source must be 0 or 1");
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   gs_checks* c = new gs_checks();
   c->h = h;
   GsChecksCfg& C = c->C;
@@ -1603,7 +1647,7 @@ void gs_checks_destroy(gs_checks* c) {
 int gs_checks_set_frequency(gs_checks* c, const double* f) {
   if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
   gs_handle* h = c->h;
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   c->use_freq = f != nullptr;
   if (f) { HIPCHK(h, hipMemcpyAsync(c->freq, f, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   return GS_OK;
@@ -1612,7 +1656,7 @@ int gs_checks_set_frequency(gs_checks* c, const double* f) {
 int gs_checks_run(gs_checks* c) {
   if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
   gs_handle* h = c->h;
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   // HIP events only while somebody reads them (gs_checks_timing_enable), and never more than GS_CHECKS_MAX_EVENTS pairs:
   // a per-step safety check over a long run must not grow an event list without bound
   std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
@@ -1635,7 +1679,7 @@ int gs_checks_run(gs_checks* c) {
 int gs_checks_download(gs_checks* c, const gs_checks_view* out) {
   if (!c || !out) return fail(c ? c->h : nullptr, GS_E_INVALID, "checks object / view is NULL");
   gs_handle* h = c->h;
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   const size_t Bp = h->Bp, B = h->B;
   std::vector<int32_t> ti; std::vector<double> tf; std::vector<uint8_t> tb, tl;
   if (out->ints) { ti.resize((size_t)GS_CI_COUNT * Bp); HIPCHK(h, hipMemcpyAsync(ti.data(), c->out_i, ti.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)); }
@@ -1659,7 +1703,7 @@ int gs_checks_download(gs_checks* c, const gs_checks_view* out) {
 int gs_checks_reset(gs_checks* c, const uint8_t* mask) {
   if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
   gs_handle* h = c->h;
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   uint8_t* dmask = nullptr;
   if (mask) {
     HIPCHK(h, hipMalloc((void**)&dmask, h->B));
@@ -1674,7 +1718,7 @@ int gs_checks_reset(gs_checks* c, const uint8_t* mask) {
 
 int gs_checks_timing_enable(gs_checks* c, int32_t on) {
   if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
-  HIPCHK(c->h, hipSetDevice(c->h->device));
+  GS_ENTER(c->h);
   HIPCHK(c->h, hipStreamSynchronize(c->h->stream));
   c->timing = on != 0; c->ev_used = 0;
   return GS_OK;
@@ -1683,7 +1727,7 @@ int gs_checks_timing_enable(gs_checks* c, int32_t on) {
 int gs_checks_timing_read(gs_checks* c, double* total_ms, int64_t* launches) {
   if (!c || !total_ms || !launches) return fail(c ? c->h : nullptr, GS_E_INVALID, "bad arguments");
   gs_handle* h = c->h;
-  HIPCHK(h, hipSetDevice(h->device));
+  GS_ENTER(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   *total_ms = 0.0; *launches = 0;
   for (size_t k = 0; k < c->ev_used; ++k) {

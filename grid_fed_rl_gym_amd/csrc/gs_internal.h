@@ -330,7 +330,7 @@ struct GsF2Tables {
   int32_t n_slots;                // n + 3: buses, then ZERO (0, 0), ONE (1, 0), DUMMY
   int32_t slack;                  // slot of the slack bus
   int32_t n_jump;                 // rounds of the forward sweep's pointer jumping: ceil(log2(depth)), rounded up to even
-  int32_t n_levels, pos_off, n_anc_ints, pad0;   // Newton-Raphson: levels of the tree below the slack; layout of `anc`
+  int32_t n_levels, pos_off, n_anc_ints, wg_offset;   // Newton-Raphson: levels of the tree below the slack; layout of `anc`
   int32_t off_tile, off_anc, off_z, off_env, off_red, off_atom, lds_bytes;     // LDS byte offsets (slots at 0)
   int32_t env_genp, env_curt, env_batp, env_soc;      // row indices inside the env area ([row][32 lanes] doubles)
   // buses with a voltage set point (normally the slack alone): slot and |V|; the first inline, the rest through the arrays

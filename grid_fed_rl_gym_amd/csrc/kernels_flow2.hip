@@ -151,7 +151,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const int lane = threadIdx.x & 63, l = lane & (IW - 1), hv = lane / IW;
   auto f2_slot = [](int slot, int ll) -> unsigned { return (unsigned)slot * SB + ((unsigned)ll << 4); };
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = blockIdx.x / HV, hs = blockIdx.x % HV, L = hs * IW + l;      // HV workgroups share a 64-instance slab group
+  // (a step may be launched as two halves of the grid on two streams, gs_internal.h GsF2Tables::wg_offset: bid is the
+  // workgroup's index in the whole grid)
+  const int bid = (int)blockIdx.x + F.wg_offset;
+  const int g = bid / HV, hs = bid % HV, L = hs * IW + l;      // HV workgroups share a 64-instance slab group
   const int b = g * GS_LANES + L;
   const bool valid = b < B;
   const GsLaneRows S = gs_lane_rows(slab, g, R.total, L);
@@ -167,9 +170,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // workgroup that arrived first finishes in 32 us, the other in 42 (tools/block_times.py).  Flipping s_setprio at every phase
   // boundary, the two in opposite states, evens them out -- 38 to 42 us each -- and leaves the launch at 42: the CU's
   // throughput, not the sharing, sets the time.  Not kept.)
-  F2Stamp stp{C.stamps, 0ull, blockIdx.x == 0 && wave == C.stamp_wave && lane == 0};
+  F2Stamp stp{C.stamps, 0ull, bid == 0 && wave == C.stamp_wave && lane == 0};
   if (C.stamps) stp.t = __builtin_readcyclecounter();
-  if (C.stamps && C.block_times && threadIdx.x == 0 && blockIdx.x < GS_STAMP_BLOCKS) C.stamps[16 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  if (C.stamps && C.block_times && threadIdx.x == 0 && bid < GS_STAMP_BLOCKS) C.stamps[16 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
 
   // ---- start-up: every global load the prologue's first barrier waits for is asked for FIRST -- the clock and seed rows, the
   // first blockDim entries of the two tables that go to LDS -- and the LDS-only initialisation runs while they fly (the
@@ -884,8 +887,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       }
     }
     stp.hit(F2_ST_EPILOGUE);
-    if (C.stamps && C.block_times && lane == 0 && blockIdx.x < GS_STAMP_BLOCKS)
-      atomicMax(&C.stamps[17 + 2 * blockIdx.x], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (C.stamps && C.block_times && lane == 0 && bid < GS_STAMP_BLOCKS)
+      atomicMax(&C.stamps[17 + 2 * bid], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (wave != 0) return;
   }
   // ---- wave 0: everything of step() that follows the load flow, per instance (grid_env.py:553-617) ----
@@ -992,8 +995,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #undef OF
   }
   stp.hit(F2_ST_EPI_SCALARS);
-  if (C.stamps && C.block_times && lane == 0 && blockIdx.x < GS_STAMP_BLOCKS)
-    atomicMax(&C.stamps[17 + 2 * blockIdx.x], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (C.stamps && C.block_times && lane == 0 && bid < GS_STAMP_BLOCKS)
+    atomicMax(&C.stamps[17 + 2 * bid], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 #define F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, OCC)                                                                      \

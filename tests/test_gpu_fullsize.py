@@ -159,3 +159,53 @@ def test_north_star_accuracy_bar_against_the_reference_algorithm_at_its_own_sett
             worst["flow"] = max(worst["flow"], np.abs(obs[b, 2 * n:2 * n + 2 * m:2] - ref[2 * n:2 * n + 2 * m:2]).max())
     env.close()
     assert worst["Vm"] < bar and worst["Va"] < bar and worst["flow"] < bar, worst
+
+
+def test_step_as_two_half_launches_on_two_streams_changes_nothing(monkeypatch):
+    """At 512 or more workgroups the sweep kernel's step goes out as two half-grid launches on two streams that run out
+    of phase (gridstep_abi.hip, gs_handle::split_ok).  Every entry point other than the step joins the streams first: the
+    same sequence of calls -- device steps, downloads, host-array steps, checkpoints, a masked reset, a rollout with
+    resets, the RCCL gather -- gives bit-identical arrays with and without the split."""
+    spec = P.ieee123_like(); B = 8192
+    kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True)
+    split = P.BatchedGridEnvironment(spec, **kw)
+    monkeypatch.setenv("GS_NO_SPLIT", "1")
+    plain = P.BatchedGridEnvironment(spec, **kw)
+    monkeypatch.delenv("GS_NO_SPLIT")
+    assert split.handle.describe()["step_launches"] == 2 and plain.handle.describe()["step_launches"] == 1
+    rng = np.random.default_rng(8)
+    acts = rng.uniform(-1, 1, (8, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) * 3 + 1
+    outs = []
+    for env in (split, plain):
+        h = env.handle
+        got = []
+        env.reset(seed=seeds)
+        h.upload_actions(acts)
+        for k in range(5):
+            h.step_device(k)
+        got.append(h.download_step())
+        o, r, te, tr, info = env.step(acts[5])
+        got.append(dict(obs=o, reward=r, truncated=tr, losses=info["total_losses"], iterations=info["iterations"]))
+        got.append(dict(state=env.get_state()))
+        mask = np.zeros(B, dtype=np.uint8); mask[::3] = 1
+        got.append(dict(obs_after_masked_reset=h.reset(seeds + np.uint64(7), mask)))
+        for k in range(3):
+            h.step_device(k)
+        st = env.get_state()
+        env.set_state(st)
+        h.step_device(3)
+        got.append(h.download_step())
+        h.rollout(24, "random", seed=4)
+        got.append(h.rollout_download())
+        for k in range(2):
+            h.step_device(k)
+        got.append(h.download_step())
+        outs.append(got)
+    for a, b in zip(*outs):
+        for k in a:
+            if isinstance(a[k], np.ndarray):
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                assert a[k] == b[k], k
+    split.close(); plain.close()

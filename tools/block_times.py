@@ -29,6 +29,10 @@ for rep in range(5):
     t = h.debug_block_times(nb).astype(np.int64)
     t0 = t[:, 0].min()
     start, dur = (t[:, 0] - t0) / 100.0, (t[:, 1] - t[:, 0]) / 100.0           # microseconds
+    if nb >= 4:
+        half = nb // 2
+        print(json.dumps({"median_start_us_first_half": float(np.median(start[:half])), "median_start_us_second_half": float(np.median(start[half:])),
+                          "median_end_us_first_half": float(np.median(start[:half] + dur[:half])), "median_end_us_second_half": float(np.median(start[half:] + dur[half:]))}))
     if rep == 4:
         by_xcd = [round(float(np.median(dur[x::8])), 2) for x in range(8)]
         order = np.argsort(dur)

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("tag"); ap.add_argument("out_prefix")
     ap.add_argument("--traffic-key", default=""); ap.add_argument("--kernel", default="")
     ap.add_argument("--note", default="")
+    ap.add_argument("--dispatches-per-step", type=int, default=1,
+                    help="a step that goes out as N dispatches of the kernel (two half-grid launches on two streams): the traffic entry is per STEP")
     a = ap.parse_args()
     prof = os.path.join(ROOT, "profiles")
     stats = find(a.tag + "_trace", "_kernel_stats.csv")
@@ -67,13 +69,14 @@ def main():
         fe, wr = per_kernel.get((a.kernel, "FETCH_SIZE")), per_kernel.get((a.kernel, "WRITE_SIZE"))
         if not fe or not wr:
             print("no counters for", a.kernel, file=sys.stderr); sys.exit(1)
-        fe_kb, wr_kb = sum(fe) / len(fe), sum(wr) / len(wr)
+        fe_kb, wr_kb = a.dispatches_per_step * sum(fe) / len(fe), a.dispatches_per_step * sum(wr) / len(wr)
         tfile = os.path.join(prof, "hbm_traffic.json")
         d = json.load(open(tfile)) if os.path.exists(tfile) else {}
         d[a.traffic_key] = {"kernel": a.kernel, "fetch_size_kb_raw": fe_kb, "write_size_kb": wr_kb,
                             "solve_bytes_per_launch": int((2 * fe_kb + wr_kb) * 1024),
                             "note": "fabric-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per the gfx950 correction "
-                                    "(MI355X_MICROARCH.md, HBM) | " + (a.note or a.out_prefix + " counters")}
+                                    "(MI355X_MICROARCH.md, HBM) | " + (a.note or a.out_prefix + " counters") +
+                                    (f" | per step = {a.dispatches_per_step} dispatches of the kernel" if a.dispatches_per_step > 1 else "")}
         json.dump(d, open(tfile, "w"), indent=1)
         print(a.traffic_key, d[a.traffic_key]["solve_bytes_per_launch"] / 1e6, "MB per launch (fetch x2 %.1f MB, write %.1f MB)" % (2 * fe_kb / 1024 * 1.048576, wr_kb / 1024 * 1.048576))
 
