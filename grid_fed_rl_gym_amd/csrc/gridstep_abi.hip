@@ -287,7 +287,11 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     dim3 grid(h->groups), block(64 * h->W);
     if (!obs_out) {
       const int next = h->obs_cur ^ 1;
-      if (h->gather_pending[next]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[next], 0)); h->gather_pending[next] = false; }
+      if (h->gather_pending[next]) {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[next], 0));
+        if (h->split_ok) HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_gather[next], 0));     // (the second half writes the same buffer)
+        h->gather_pending[next] = false;
+      }
       h->obs_cur = next;
       obs_out = h->d_obs2[next];
     }
