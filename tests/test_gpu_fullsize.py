@@ -201,6 +201,15 @@ def test_step_as_two_half_launches_on_two_streams_changes_nothing(monkeypatch):
         for k in range(2):
             h.step_device(k)
         got.append(h.download_step())
+        # the RCCL gather (world of one) between device steps: it reads the buffer the step wrote, two steps later that buffer is rewritten
+        from grid_fed_rl_gym_amd._lib import Handle
+        h.comm_init(Handle.comm_unique_id(), 0, 1)
+        for k in range(4):
+            h.step_device(k)
+            full = h.allgather_obs(to_host=(k == 3))
+        got.append(dict(gathered=full, after_gather=h.download_step()["obs"]))
+        assert np.array_equal(got[-1]["gathered"], got[-1]["after_gather"])
+        h.comm_destroy()
         outs.append(got)
     for a, b in zip(*outs):
         for k in a:
