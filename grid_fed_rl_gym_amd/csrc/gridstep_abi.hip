@@ -305,8 +305,10 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
       const int per_group = 64 / h->f2_iw, n_wg = h->groups * per_group;
       const dim3 b2(64 * h->f2_nw);
       // (two half-grid launches on two streams, see gs_handle::split_ok; the halves are whole 64-instance slab groups)
-      const int n_first = h->split_ok ? (h->groups / 2) * per_group : n_wg;
-      if (h->split_ok && !h->forked) {
+      // (per-launch event pairs, gs_timing_enable(1), bracket ONE launch on the main stream: the step stays whole then)
+      const bool split = h->split_ok && !h->timing;
+      const int n_first = split ? (h->groups / 2) * per_group : n_wg;
+      if (split && !h->forked) {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         h->forked = true;
