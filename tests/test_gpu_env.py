@@ -554,3 +554,8 @@ def test_store_data_hazard_reproducer_is_clean_with_one_wait_state(tmp_path):
     lines = {int(l.split()[2].rstrip(":")): int(l.split()[3]) for l in out.splitlines() if l.startswith("wait states")}
     assert set(lines) == {0, 1, 2, 4}, out
     assert lines[1] == 0 and lines[2] == 0 and lines[4] == 0, out        # lines[0] is > 0 on gfx950 (the hazard itself); not asserted
+    # the other store forms with zero wait states: the 8-byte stores (GsRowRef::put and plain global stores) are not affected;
+    # the bare 16-byte global store is (heavily) -- the compiler never emits it bare, tools/check_store_hazard.py watches that
+    forms = {l.split()[1].rstrip(","): int(l.split()[5]) for l in out.splitlines() if l.startswith("form ")}
+    assert set(forms) == {"global_store_dwordx4_saddr", "buffer_store_dwordx2_soffset", "global_store_dwordx2_saddr"}, out
+    assert forms["buffer_store_dwordx2_soffset"] == 0 and forms["global_store_dwordx2_saddr"] == 0, out

@@ -6,6 +6,13 @@
 //                               wait states 1, 2, 4: 0 wrong
 // The compiler's hazard recogniser inserts that wait state for 16-byte stores EXCEPT when soffset is a register.
 // (The same experiment with buffer_store_dwordx2, 8 bytes per lane: 0 of 16777216 wrong -- only the wide store is affected.)
+// Round 2, the other store forms with ZERO wait states (k2 below; same box, ROCm 7.2):
+//   buffer_store_dwordx4, soffset in an SGPR    111200 of 16777216 slots wrong, lanes 12-15 of every 16      <- the one the compiler leaves unprotected
+//   global_store_dwordx4 ... saddr              4004048 of 16777216 slots wrong (the compiler pads this form itself: never emitted bare)
+//   buffer_store_dwordx2, soffset in an SGPR    0 wrong
+//   global_store_dwordx2 ... saddr              0 wrong
+// tools/check_store_hazard.py checks every 12- / 16-byte buffer and global store of the shipped library for a VALU write of
+// its data registers in the next instruction.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -50,10 +57,10 @@ __global__ void __launch_bounds__(1024) k(unsigned* buf, unsigned long long byte
 }
 
 template <int NOPS> void run(unsigned* d, size_t bytes_per_group, int groups, int iters, const double* pr, double* sink, std::vector<unsigned>& h) {
-  hipMemset(d, 0xff, bytes_per_group * groups);
+  (void)hipMemset(d, 0xff, bytes_per_group * groups);
   hipLaunchKernelGGL(k<NOPS>, dim3(groups), dim3(1024), 0, 0, d, (unsigned long long)bytes_per_group, iters, pr, sink);
-  hipDeviceSynchronize();
-  hipMemcpy(h.data(), d, bytes_per_group * groups, hipMemcpyDeviceToHost);
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(h.data(), d, bytes_per_group * groups, hipMemcpyDeviceToHost);
   long bad = 0, total = 0; long by_lane[16] = {0};
   for (int g = 0; g < groups; ++g)
     for (int row = 0; row < iters * 16; ++row)
@@ -108,10 +115,10 @@ __global__ void __launch_bounds__(1024) k2(unsigned* buf, unsigned long long byt
 }
 
 template <int FORM> void run2(const char* what, unsigned* d, size_t bytes_per_group, int groups, int iters, const double* pr, double* sink, std::vector<unsigned>& h) {
-  hipMemset(d, 0xff, bytes_per_group * groups);
+  (void)hipMemset(d, 0xff, bytes_per_group * groups);
   hipLaunchKernelGGL(k2<FORM>, dim3(groups), dim3(1024), 0, 0, d, (unsigned long long)bytes_per_group, iters, pr, sink);
-  hipDeviceSynchronize();
-  hipMemcpy(h.data(), d, bytes_per_group * groups, hipMemcpyDeviceToHost);
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(h.data(), d, bytes_per_group * groups, hipMemcpyDeviceToHost);
   long bad = 0, total = 0;
   const int words = FORM == 0 ? 4 : 2;
   for (int g = 0; g < groups; ++g)
@@ -130,8 +137,8 @@ template <int FORM> void run2(const char* what, unsigned* d, size_t bytes_per_gr
 int main() {
   const int groups = 256, iters = 64;
   const size_t bytes_per_group = (size_t)iters * 16 * 1024;
-  unsigned* d; hipMalloc(&d, bytes_per_group * groups);
-  double *pr, *sink; hipMalloc(&pr, (1 << 20) * 8); hipMemset(pr, 0, (1 << 20) * 8); hipMalloc(&sink, 8);
+  unsigned* d; (void)hipMalloc(&d, bytes_per_group * groups);
+  double *pr, *sink; (void)hipMalloc(&pr, (1 << 20) * 8); (void)hipMemset(pr, 0, (1 << 20) * 8); (void)hipMalloc(&sink, 8);
   std::vector<unsigned> h(bytes_per_group * groups / 4);
   run<0>(d, bytes_per_group, groups, iters, pr, sink, h);
   run<1>(d, bytes_per_group, groups, iters, pr, sink, h);
