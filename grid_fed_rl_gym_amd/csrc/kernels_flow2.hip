@@ -1,5 +1,9 @@
-// kernels_flow2.hip -- the fused env.step() with the forward/backward sweep load flow for small radial feeders,
-// second generation: 32 instances per workgroup, the two halves of every wavefront on DIFFERENT buses.
+// kernels_flow2.hip -- the fused env.step() for radial feeders, second generation: IW instances per workgroup (16 by
+// default; 32, or 8 for small feeders), the 64 / IW sub-groups of every wavefront on DIFFERENT buses; the sweep load flow
+// as a prefix sum + pointer jumping, Newton-Raphson as a level-by-level 2x2-block elimination with its state in registers
+// and LDS.  One template (f2_step), the members at the end of the file; the host (gridstep_abi.hip) picks one by feeder
+// size, and launches a step of the two-workgroups-per-CU members as two half grids on two streams (gs_handle::split_ok).
+// The text below describes the 32-instance sweep member the family started from.
 //
 // Why: the dataflow sweep kernel of kernels_solve.hip (gs_k_step_fbs_flow) gives a 64-instance group a whole compute
 // unit (its per-bus LDS slots fill it), so BASELINE.json's config 3 -- 8192 instances -- ran on 128 of the chip's 256
