@@ -109,6 +109,8 @@ SYMBOLS = [
     ("gs_comm_destroy", C.c_int, [_H]),
     ("gs_timing_enable", C.c_int, [_H, C.c_int32]),
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
+    ("gs_step_device_ptr", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("gs_step_device_view", C.c_int, [_H, C.c_void_p, C.c_void_p]),
     ("gs_host_alloc", C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     ("gs_host_free", C.c_int, [C.c_void_p]),
     ("gs_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
@@ -171,6 +173,43 @@ def make_config(**kw) -> gs_config:
     for k, v in d.items():
         setattr(cfg, k, v)
     return cfg
+
+
+class gs_step_device_out(C.Structure):
+    _fields_ = [("observations", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
+                ("B", C.c_int32), ("obs_dim", C.c_int32)]
+
+
+class DeviceArray:
+    """A view of device memory owned by a handle: address, shape, dtype, exposed through ``__cuda_array_interface__`` (which
+    PyTorch-ROCm and CuPy read as well) so that a consumer on the GPU wraps it without a copy."""
+
+    def __init__(self, ptr: int, shape, typestr: str) -> None:
+        self.ptr, self.shape, self.typestr = int(ptr or 0), tuple(int(x) for x in shape), typestr
+
+    @property
+    def __cuda_array_interface__(self) -> dict:
+        return {"shape": self.shape, "typestr": self.typestr, "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def __repr__(self) -> str:
+        return f"DeviceArray(0x{self.ptr:x}, shape={self.shape}, typestr={self.typestr!r})"
+
+
+def _device_address(x, shape) -> int:
+    """Device address of a float64 C-contiguous array of ``shape`` given as an int, a torch tensor or anything with
+    ``__cuda_array_interface__``."""
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):                      # torch
+        if tuple(x.shape) != tuple(shape) or str(x.dtype) not in ("torch.float64",) or not x.is_contiguous():
+            raise PowerFlowError(f"device actions must be a contiguous float64 tensor of shape {tuple(shape)}, got {tuple(x.shape)} {x.dtype}")
+        return int(x.data_ptr())
+    cai = getattr(x, "__cuda_array_interface__", None)
+    if cai is None:
+        raise PowerFlowError("device actions: an address, a torch tensor or an object with __cuda_array_interface__")
+    if tuple(cai["shape"]) != tuple(shape) or cai["typestr"] not in ("<f8", "=f8") or cai.get("strides") not in (None,):
+        raise PowerFlowError(f"device actions must be C-contiguous float64 of shape {tuple(shape)}")
+    return int(cai["data"][0])
 
 
 class Handle:
@@ -388,6 +427,26 @@ class Handle:
 
     def step_device(self, k: int) -> None:
         self._check(self._lib.gs_step_device(self._h, int(k)))
+
+    # -- a consumer on the same GPU: device pointers in, device pointers out -------------------------
+    def step_device_ptr(self, actions, stream=None) -> None:
+        """gs_step_device_ptr: one step with ``actions`` [B, action_dim] float64 in DEVICE memory -- an integer address, or
+        any object with ``__cuda_array_interface__`` / ``data_ptr()`` (a torch tensor on this GPU).  ``stream``: the
+        producer's ``hipStream_t`` as an integer (torch: ``torch.cuda.current_stream().cuda_stream``); the step then waits
+        on the device for what is queued there.  None: the caller has synchronised."""
+        self._check(self._lib.gs_step_device_ptr(self._h, C.c_void_p(_device_address(actions, (self.B, self.action_dim))),
+                                                 C.c_void_p(int(stream)) if stream else None))
+
+    def step_device_view(self, stream=None) -> dict:
+        """gs_step_device_view: the last step's observation block, rewards and flags as ``DeviceArray`` objects (zero-copy:
+        ``torch.as_tensor(x, device="cuda")`` / ``cupy.asarray(x)``).  ``stream``: the consumer's stream, made to wait on the
+        device for the step; None: the call returns when the step has finished.  The observation block is one of the handle's
+        two buffers (valid until the next-but-one step), the other arrays are refreshed by every call."""
+        out = gs_step_device_out()
+        self._check(self._lib.gs_step_device_view(self._h, C.byref(out), C.c_void_p(int(stream)) if stream else None))
+        B = int(out.B)
+        return dict(obs=DeviceArray(out.observations, (B, int(out.obs_dim)), "<f8"), reward=DeviceArray(out.reward, (B,), "<f8"),
+                    terminated=DeviceArray(out.terminated, (B,), "|u1"), truncated=DeviceArray(out.truncated, (B,), "|u1"))
 
     def download_step(self, want_obs: bool = True) -> dict:
         out, info = self._step_buffers(want_obs)

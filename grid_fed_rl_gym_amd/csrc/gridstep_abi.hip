@@ -88,7 +88,7 @@ struct gs_handle {
   // 8192).  `forked`: stream2 holds step launches the main stream has not waited for yet; every entry point other than the
   // step itself joins first (GS_ENTER).
   bool split_ok = false, forked = false;
-  hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // which member of the family (8 instances per workgroup for small feeders)
+  hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_peer = nullptr, ev_peer2 = nullptr;     // which member of the family (8 instances per workgroup for small feeders)
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -954,6 +954,8 @@ void gs_destroy(gs_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->stream2) { (void)hipStreamDestroy(h->stream2); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
+  if (h->ev_peer) (void)hipEventDestroy(h->ev_peer);
+  if (h->ev_peer2) (void)hipEventDestroy(h->ev_peer2);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   if (h->ev_step) (void)hipEventDestroy(h->ev_step);
   for (int k = 0; k < 2; ++k) if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
@@ -1112,6 +1114,41 @@ int gs_step(gs_handle* h, const double* actions, double* obs, double* reward, ui
   int rc = step_kernels(h, h->d_in);
   if (rc) return rc;
   return gs_download_step(h, obs, reward, terminated, truncated, info);
+}
+
+int gs_step_device_ptr(gs_handle* h, const double* d_actions, void* producer_stream) {
+  if (!h || (!d_actions && h->action_dim > 0)) return fail(h, GS_E_INVALID, "handle / d_actions is NULL");
+  if (!h->was_reset) return fail(h, GS_E_STATE, "gs_step_device_ptr before gs_reset");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (producer_stream) {             // the step waits, on the device, for what the producer has queued so far
+    if (!h->ev_peer) HIPCHK(h, hipEventCreateWithFlags(&h->ev_peer, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_peer, (hipStream_t)producer_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_peer, 0));
+    if (h->forked) HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_peer, 0));
+  }
+  return step_kernels(h, d_actions);
+}
+
+int gs_step_device_view(gs_handle* h, gs_step_device_out* out, void* consumer_stream) {
+  if (!h || !out) return fail(h, GS_E_INVALID, "handle / out is NULL");
+  if (!h->was_reset) return fail(h, GS_E_STATE, "gs_step_device_view before gs_reset");
+  GS_ENTER(h);
+  hipLaunchKernelGGL(gs_k_scalars, dim3(h->groups), dim3(64), 0, h->stream, h->rows_f, (int)SF_COUNT, h->rows_i,
+                     (int)SI_COUNT, h->rows_u, (int)SU_COUNT, h->R.total, h->slab, h->sc_f, h->sc_i, h->sc_u, h->Bp);
+  HIPCHK(h, hipGetLastError());
+  if (consumer_stream) {
+    if (!h->ev_peer2) HIPCHK(h, hipEventCreateWithFlags(&h->ev_peer2, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_peer2, h->stream));
+    HIPCHK(h, hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_peer2, 0));
+  } else {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  out->observations = h->d_obs2[h->obs_cur];
+  out->reward = h->sc_f + (size_t)SF_REWARD * h->Bp;
+  out->terminated = h->sc_u + (size_t)SU_TERM * h->Bp;
+  out->truncated = h->sc_u + (size_t)SU_TRUNC * h->Bp;
+  out->B = h->B; out->obs_dim = h->obs_dim;
+  return GS_OK;
 }
 
 int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches) {

@@ -161,6 +161,19 @@ class BatchedGridEnvironment:
                     iterations=out["iterations"], status=out["status"], action_invalid=bad)
         return out["obs"], out["reward"], out["terminated"].astype(bool), out["truncated"].astype(bool), info
 
+    def step_device(self, actions, stream=None):
+        """``step()`` for a policy that lives on the same GPU: ``actions`` is a float64 [num_envs, action_dim] array in
+        device memory (a torch tensor, anything with ``__cuda_array_interface__``, or an address), the result is
+        ``(obs, reward, terminated, truncated)`` as zero-copy ``DeviceArray`` views (``torch.as_tensor(obs, device="cuda")``).
+        ``stream``: the caller's ``hipStream_t`` (torch: ``torch.cuda.current_stream().cuda_stream``) -- the step waits on
+        the device for the actions queued there, and the stream waits for the step before it reads the results; None: the
+        caller synchronises.  No host copy, no validation of the action values (non-finite actions are the caller's)."""
+        if self._needs_reset:
+            raise RuntimeError("reset() before step_device()")
+        self._h.step_device_ptr(actions, stream)
+        out = self._h.step_device_view(stream)
+        return out["obs"], out["reward"], out["terminated"], out["truncated"]
+
     def _base_info(self, step, ep_reward, viol) -> Dict[str, Any]:
         # get_info(), base.py:169-176
         return {"current_step": step, "episode_reward": ep_reward, "constraint_violations_count": viol,

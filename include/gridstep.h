@@ -208,6 +208,25 @@ int gs_step_device(gs_handle* h, int32_t action_batch_index);
 int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated,
                      uint8_t* truncated, const gs_info_view* info);
 
+/* A consumer that lives on the same GPU (a policy network) steps the environment without any host copy: it reads the
+ * observation block and the reward / flag arrays through device pointers and hands back a device pointer to its actions.
+ * Streams are passed as `hipStream_t` cast to `void*`; NULL means "the caller synchronises itself".
+ *   gs_step_device_ptr   one env step with actions[B][action_dim] (float64, C order) in DEVICE memory of the handle's GPU; when
+ *                        `producer_stream` is given, the step waits (on the device) for the work queued on it so far.
+ *   gs_step_device_view  device pointers to what the last step left: observations[B][obs_dim] (one of the handle's two
+ *                        observation buffers: valid until the next-but-one step), reward[B], terminated[B], truncated[B]
+ *                        (refreshed by this call; valid until the next call); when `consumer_stream` is given it is made to
+ *                        wait (on the device) for the step, otherwise the call returns after the step has finished. */
+typedef struct gs_step_device_out {
+  double* observations;
+  double* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  int32_t B, obs_dim;
+} gs_step_device_out;
+int gs_step_device_ptr(gs_handle* h, const double* d_actions, void* producer_stream);
+int gs_step_device_view(gs_handle* h, gs_step_device_out* out, void* consumer_stream);
+
 /* ---- device-resident rollout collection: collect_random_data(env, num_steps) and the five arrays GridDataset is
  * built from (algorithms/base.py:268-298, 180-205) ------------------------------------------------------------
  * T env steps back to back on the device -- no host round trip between them: the step kernel of step t writes its
