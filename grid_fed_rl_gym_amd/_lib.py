@@ -491,6 +491,18 @@ class Handle:
         self._check(self._lib.gs_rollout_device_view(self._h, C.byref(v)))
         return v
 
+    def rollout_device_arrays(self) -> dict:
+        """The last rollout as zero-copy ``DeviceArray`` views (``torch.as_tensor(x, device="cuda")``): ``obs_seq`` [T + 1, B, obs_dim]
+        (slot t = what step t started from; ``obs_seq[1:]`` are the next observations except where an episode ended),
+        ``actions`` [T, B, A], ``rewards`` [T, B], ``terminals`` [T, B] uint8 (bit 0 terminated, bit 1 truncated), and for the
+        transitions that ended an episode ``terminal_index`` [n, 2] int32 (t, b) with their ``terminal_obs`` [n, obs_dim].
+        Valid until the next rollout on the handle."""
+        v = self.rollout_device_view()
+        T, B, D, A, n = int(v.T), int(v.B), int(v.obs_dim), int(v.action_dim), int(v.n_terminal)
+        return dict(obs_seq=DeviceArray(v.obs_seq, (T + 1, B, D), "<f8"), actions=DeviceArray(v.actions, (T, B, A), "<f8"),
+                    rewards=DeviceArray(v.rewards, (T, B), "<f8"), terminals=DeviceArray(v.terminals, (T, B), "|u1"),
+                    terminal_index=DeviceArray(v.terminal_index, (n, 2), "<i4"), terminal_obs=DeviceArray(v.terminal_obs, (n, D), "<f8"))
+
     def get_state(self) -> np.ndarray:
         st = np.empty((self.B, self.state_dim))
         self._check(self._lib.gs_get_state(self._h, _ptr(st, _dp)))

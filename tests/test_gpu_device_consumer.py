@@ -40,3 +40,27 @@ def test_a_policy_on_the_gpu_steps_the_environment_without_host_copies(B, use_st
         assert np.array_equal(rew_t.cpu().numpy(), r) and np.array_equal(term_t.cpu().numpy().astype(bool), te)
         assert np.array_equal(trunc_t.cpu().numpy().astype(bool), tr)
     dev_env.close(); host_env.close()
+
+
+def test_rollout_buffers_are_readable_on_the_gpu_without_a_copy():
+    """`rollout_device_arrays`: the [T + 1, B, obs_dim] observation sequence, actions, rewards, flags and the terminal-observation
+    side list as torch tensors over the library's own device memory; equal to what `rollout_download` copies to the host
+    (next_observations = obs_seq[1:] with the terminal observations scattered in)."""
+    if not torch.cuda.is_available():
+        pytest.skip("torch without a GPU")
+    fs = P.ieee123_like(); B, T = 96, 30
+    env = P.BatchedGridEnvironment(fs, num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True, episode_length=7)   # episodes end inside the rollout
+    env.reset(seed=np.arange(B, dtype=np.uint64) + 2)
+    h = env.handle
+    h.rollout(T, "random", seed=9)
+    dev = {k: torch.as_tensor(v, device="cuda") for k, v in h.rollout_device_arrays().items() if v.shape[0] > 0}
+    host = h.rollout_download()
+    assert host["n_terminal"] > 0 and dev["terminal_index"].shape[0] == host["n_terminal"]
+    assert np.array_equal(dev["obs_seq"][:-1].cpu().numpy(), host["observations"])
+    assert np.array_equal(dev["actions"].cpu().numpy(), host["actions"]) and np.array_equal(dev["rewards"].cpu().numpy(), host["rewards"])
+    assert np.array_equal(dev["terminals"].cpu().numpy(), host["terminals"])
+    nxt = dev["obs_seq"][1:].clone()
+    idx = dev["terminal_index"].long()
+    nxt[idx[:, 0], idx[:, 1]] = dev["terminal_obs"]                  # what gs_rollout_download does on the host
+    assert np.array_equal(nxt.cpu().numpy(), host["next_observations"])
+    env.close()
