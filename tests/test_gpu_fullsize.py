@@ -218,3 +218,32 @@ def test_step_as_two_half_launches_on_two_streams_changes_nothing(monkeypatch):
             else:
                 assert a[k] == b[k], k
     split.close(); plain.close()
+
+
+def test_three_thousand_steps_with_and_without_the_split_end_in_the_same_state(monkeypatch):
+    """A soak of the two-stream step: 3000 device steps of the full batch (the halves drift half a step apart and stay
+    there), state and observation compared bit for bit with the single-launch form every 1000 steps -- a lost cross-wave
+    write, a torn row or a race between the halves would show as a difference."""
+    spec = P.ieee123_like(); B = 8192
+    kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True, episode_length=700)    # episodes end and restart on the way
+    split = P.BatchedGridEnvironment(spec, **kw)
+    monkeypatch.setenv("GS_NO_SPLIT", "1")
+    plain = P.BatchedGridEnvironment(spec, **kw)
+    monkeypatch.delenv("GS_NO_SPLIT")
+    acts = np.random.default_rng(12).uniform(-0.3, 0.3, (8, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 1000
+    for env in (split, plain):
+        env.reset(seed=seeds); env.handle.upload_actions(acts)
+    for chunk in range(3):
+        for env in (split, plain):
+            for k in range(1000):
+                env.handle.step_device(k % 8)
+        a, b = split.handle.download_step(), plain.handle.download_step()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (chunk, k)
+        assert np.array_equal(split.get_state(), plain.get_state()), chunk
+        done = (a["terminated"] != 0)
+        if done.any():                                             # the reference resets finished environments; so does the caller here
+            for env in (split, plain):
+                env.handle.reset(seeds + np.uint64(chunk + 1), done.astype(np.uint8), want_obs=False)
+    split.close(); plain.close()
