@@ -79,3 +79,29 @@ def test_feeder_generators_and_flattening():
     assert P.with_reference_env_renewables(P.reference_env_network(), ["solar", "wind"]).obs_dim == 19
     p = P.injections_from_dicts(e, {2: 0.2, 3: 0.15, 99: 7.0}, {3: 0.05})
     assert np.allclose(p, [0.0, -0.2, -0.1])
+
+
+def test_device_array_interface_and_device_address_validation():
+    """`DeviceArray` speaks `__cuda_array_interface__` (what PyTorch-ROCm / CuPy read); `_device_address` accepts an address, an object
+    with that interface or a `data_ptr()` and refuses wrong shapes / dtypes / strides before anything reaches the GPU."""
+    from grid_fed_rl_gym_amd._lib import DeviceArray, _device_address
+    from grid_fed_rl_gym_amd.components import PowerFlowError
+    a = DeviceArray(0x7f0000001000, (4, 3), "<f8")
+    cai = a.__cuda_array_interface__
+    assert cai["shape"] == (4, 3) and cai["typestr"] == "<f8" and cai["data"] == (0x7f0000001000, False) and cai["version"] == 3
+    assert _device_address(a, (4, 3)) == 0x7f0000001000 and _device_address(12345, (1, 1)) == 12345
+    with pytest.raises(PowerFlowError):
+        _device_address(a, (3, 4))
+    with pytest.raises(PowerFlowError):
+        _device_address(DeviceArray(1, (4, 3), "<f4"), (4, 3))
+    with pytest.raises(PowerFlowError):
+        _device_address(object(), (4, 3))
+
+    class FakeTensor:                      # what a torch tensor exposes
+        shape, dtype = (4, 3), "torch.float64"
+        def is_contiguous(self): return True
+        def data_ptr(self): return 4096
+    assert _device_address(FakeTensor(), (4, 3)) == 4096
+    FakeTensor.dtype = "torch.float32"
+    with pytest.raises(PowerFlowError):
+        _device_address(FakeTensor(), (4, 3))
