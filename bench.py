@@ -239,7 +239,11 @@ def main():
     wl = WORKLOADS[args.workload]
     solver0 = args.solver or wl["solver"]
     n_act = 8
-    want_gather = world > 1 and not args.no_allgather and n_dev >= world
+    # fewer GPUs than ranks (a rehearsal of N > 1 on a smaller box): RCCL refuses two ranks on one device, so rank 0 holds
+    # every rank's shard itself and the exchange runs through the in-process transport (gs_comm_init_loopback) -- the same
+    # device code with device-to-device copies where ncclAllGather would cross xGMI.  Flagged, never a config-4 number.
+    rehearsal = world > 1 and n_dev < world
+    want_gather = world > 1 and not args.no_allgather and not rehearsal
 
     def env_kwargs_of(solver):
         return dict(stochastic_loads=True, weather_variation=True, solver=solver, tolerance=args.tolerance,
@@ -320,6 +324,67 @@ def main():
             h.comm_destroy()
         env.close()
         return m
+
+    def measure_loopback(fs, B, solver, W, repeats, warmup, steps):
+        """Every one of W ranks' shards on THIS device in this process; returns the rates with and without the exchange."""
+        envs, hs = [], []
+        for r in range(W):
+            rng = np.random.default_rng(5678 + r)
+            env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=device,
+                                           first_instance=r * B, waves_per_group=args.waves, **env_kwargs_of(solver))
+            env.handle.upload_actions(rng.uniform(-1, 1, (n_act, B, fs.action_dim)))
+            env.reset(seed=np.arange(r * B, (r + 1) * B, dtype=np.uint64))
+            st = env.get_state(); st[:, env.state_column("time")] = 11.5 * 3600.0; env.set_state(st)
+            envs.append(env); hs.append(env.handle)
+        _lib.Handle.comm_init_loopback(hs)
+
+        def run(with_gather):
+            def one_step(k):
+                for h in hs:
+                    h.step_device(k % n_act)
+                if with_gather:
+                    _lib.Handle.allgather_obs_shards(hs)
+            for k in range(warmup):
+                one_step(k)
+            regions = []
+            for _ in range(repeats):
+                for h in hs:
+                    h.synchronize()
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    one_step(k)
+                for h in hs:
+                    h.synchronize()
+                regions.append(time.perf_counter() - t0)
+            return regions
+        plain, gathered = run(False), run(True)
+        out = hs[0].download_step(want_obs=False)
+        # the exchanged block against the members' own observations, once, outside the timing
+        full = _lib.Handle.allgather_obs_shards(hs, to_host=True)
+        same = all(np.array_equal(full[r * B:(r + 1) * B], hs[r].download_step()["obs"]) for r in range(W))
+        desc = hs[0].describe()
+        for env in envs:
+            env.close()
+        return dict(plain=plain, gathered=gathered, desc=desc, converged_fraction=float(out["power_flow_converged"].mean()),
+                    gathered_block_equals_member_observations=bool(same))
+
+    def loopback_summary(fs, B, W, m, steps):
+        obs_bytes = B * (fs.obs_dim - 2 * fs.n_loads) * 8
+        gp, gg = quantiles(m["plain"]), quantiles(m["gathered"])
+        rate = lambda t: W * B * steps / t
+        d_ms = 1e3 * (gg[0] - gp[0]) / steps
+        return {"transport": "loopback", "world": W, "devices_used": 1, "batch_per_rank": B,
+                "value": rate(gg[0]), "unit": "env_steps/s", "ms_per_step": 1e3 * gg[0] / steps,
+                "value_p10_p90": [rate(gg[2]), rate(gg[1])],
+                "without_obs_allgather": {"value": rate(gp[0]), "ms_per_step": 1e3 * gp[0] / steps},
+                "exchange_ms_per_step": d_ms, "bytes_sent_per_rank_per_step": obs_bytes,
+                "bytes_copied_on_the_device_per_step": W * W * obs_bytes,
+                "gathered_block_equals_member_observations": m["gathered_block_equals_member_observations"],
+                "converged_fraction": m["converged_fraction"],
+                "note": f"all {W} ranks' shards are handles of ONE process on ONE GPU; the exchange is the RCCL transport's device code "
+                        "(compaction, slot offsets, expansion, constant columns, double-buffer events) with device-to-device copies in "
+                        "place of ncclAllGather -- a rehearsal of the N-rank data path, NOT a BASELINE config 4 measurement: there is no "
+                        "xGMI in it and one GPU does every rank's work"}
 
     def side_measurements(env, fs, B, actions, solver):
         """Outside the timed regions: post-step checks, the rollout collector, plain env.step() with its host copies."""
@@ -500,6 +565,21 @@ def main():
 
     fs = make_feeder(wl["feeder"])
     B = args.batch or wl["batch"]
+    if rehearsal:
+        if rank == 0:
+            m = measure_loopback(fs, B, solver0, world, max(3, args.repeats // 2), min(args.warmup, 50), args.steps)
+            lb = loopback_summary(fs, B, world, m, args.steps)
+            result = {"metric": "env steps/sec (batched feeders)", "value": lb["value"], "unit": "env_steps/s", "n_gpus": world,
+                      "steps": args.steps, "warmup": min(args.warmup, 50), "ms_per_step": lb["ms_per_step"], "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "transport": "loopback", "rehearsal": True,
+                      "config": {"workload": f"{fs.name}, batch={B} per rank, REHEARSAL of {world} ranks on {n_dev} device(s) through the in-process transport",
+                                 "batch_per_gpu": B, "global_batch": world * B, "solver": solver0, "kernel": m["desc"]["kernel"],
+                                 "obs_allgather_in_value": True, "parallelism": f"batch-sharded x{world} (loopback)"},
+                      "loopback": lb, "roofline": None, "cpu_baseline": None, "host": host_description()}
+            print(json.dumps(result), flush=True)
+        rz.barrier()
+        rz.close()
+        return
     main_m = measure(fs, B, solver0, False, args.repeats, extras=(world == 1))
     gather_m = measure(fs, B, solver0, True, args.repeats) if want_gather else None
     other = None
@@ -573,6 +653,16 @@ def main():
                 result["also_config5"] = {k: r5[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "converged_fraction")}
             except Exception as e:
                 result["also_config5"] = {"error": str(e)}
+        if world == 1 and not args.no_also and args.workload == "ieee123_b8192":
+            # BASELINE config 4's data path rehearsed on this one GPU: W ranks' shards in this process, the exchange through
+            # the in-process transport (what an 8-GPU run adds to this is ncclAllGather itself)
+            try:
+                result["also_config4_loopback"] = {}
+                for W in (2, 8):
+                    m4 = measure_loopback(fs, B, solver0, W, 3, 20, min(args.steps, 20))
+                    result["also_config4_loopback"][f"world_{W}"] = loopback_summary(fs, B, W, m4, min(args.steps, 20))
+            except Exception as e:
+                result["also_config4_loopback"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             result["accuracy"] = accuracy(fs, solver0)
             # the reference's CPU path is dense Newton-Raphson: that port is THE baseline; the CPU port of

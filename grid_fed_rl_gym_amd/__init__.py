@@ -17,7 +17,7 @@ from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoup
                      injections_from_dicts)
 from .env import BatchedGridEnvironment, VectorizedEnvironment, Box
 from .rollout import collect_random_data, GridDataset
-from .sharding import ShardedGridEnvironment, shard_range
+from .sharding import LoopbackShards, ShardedGridEnvironment, shard_range
 from .multi_agent import AgentConfig, BatchedMultiAgentWrapper
 from .feeders import feeder_from_dict, feeder_to_dict, network_dict_normalized
 from .safety import BatchedSafetyChecker, BatchedSafetyMonitor, PostStepChecks, device_quality_score
@@ -27,7 +27,7 @@ __all__ = [
     "BatchedNewtonRaphsonSolver", "NewtonRaphsonSolver", "FastDecoupledSolver",
     "BatchedForwardBackwardSweepSolver", "BatchedRobustPowerFlowSolver", "DistributionPowerFlow", "parallel_power_flow_batch",
     "injections_from_dicts", "BatchedGridEnvironment", "VectorizedEnvironment", "Box",
-    "collect_random_data", "GridDataset", "ShardedGridEnvironment", "shard_range",
+    "collect_random_data", "GridDataset", "ShardedGridEnvironment", "LoopbackShards", "shard_range",
     "AgentConfig", "BatchedMultiAgentWrapper", "feeder_from_dict", "feeder_to_dict", "network_dict_normalized",
     "BatchedSafetyChecker", "BatchedSafetyMonitor", "PostStepChecks", "device_quality_score",
     "UnbalancedPowerFlow", "UnbalancedFeederSpec", "UnbalancedSolution", "unbalanced_from_single_phase", "ieee8500_like",

@@ -107,6 +107,10 @@ SYMBOLS = [
     ("gs_comm_init", C.c_int, [_H, _up, C.c_int32, C.c_int32]),
     ("gs_allgather_obs", C.c_int, [_H, _dp]),
     ("gs_comm_destroy", C.c_int, [_H]),
+    ("gs_comm_init_loopback", C.c_int, [C.POINTER(_H), C.c_int32]),
+    ("gs_allgather_obs_shards", C.c_int, [C.POINTER(_H), C.c_int32, _dp]),
+    ("gs_allgather_obs_view", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("gs_allgather_obs_download", C.c_int, [_H, _dp]),
     ("gs_timing_enable", C.c_int, [_H, C.c_int32]),
     ("gs_timing_read", C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     ("gs_step_device_ptr", C.c_int, [_H, C.c_void_p, C.c_void_p]),
@@ -173,6 +177,11 @@ def make_config(**kw) -> gs_config:
     for k, v in d.items():
         setattr(cfg, k, v)
     return cfg
+
+
+class gs_gathered_obs(C.Structure):
+    _fields_ = [("observations", C.c_void_p), ("rows", C.c_int64), ("obs_dim", C.c_int32), ("rank", C.c_int32),
+                ("world", C.c_int32), ("reserved", C.c_int32)]
 
 
 class gs_step_device_out(C.Structure):
@@ -536,6 +545,40 @@ class Handle:
 
     def comm_destroy(self) -> None:
         self._check(self._lib.gs_comm_destroy(self._h))
+
+    @staticmethod
+    def comm_init_loopback(handles) -> None:
+        """gs_comm_init_loopback: the handles of this process (shard r built with first_instance = r * B) become ranks
+        0 .. len - 1 of an in-process communicator whose all-gather moves the blocks by device-to-device copies."""
+        lib = load()
+        arr = (_H * len(handles))(*[h._h for h in handles])
+        rc = lib.gs_comm_init_loopback(arr, len(handles))
+        if rc != GS_OK:
+            raise PowerFlowError(f"gs_comm_init_loopback failed ({rc}): {lib.gs_last_error(None).decode()}")
+        for h in handles:
+            h.world = len(handles)
+
+    @staticmethod
+    def allgather_obs_shards(handles, to_host: bool = False):
+        """gs_allgather_obs_shards: one gather for every member; returns the [world * B, obs_dim] block (to_host) or None."""
+        lib = load()
+        arr = (_H * len(handles))(*[h._h for h in handles])
+        full = np.empty((len(handles) * handles[0].B, handles[0].obs_dim)) if to_host else None
+        rc = lib.gs_allgather_obs_shards(arr, len(handles), _ptr(full, _dp))
+        if rc != GS_OK:
+            raise PowerFlowError(f"gs_allgather_obs_shards failed ({rc}): {lib.gs_last_error(None).decode()} / {handles[0].last_error()}")
+        return full
+
+    def allgather_obs_view(self, stream=None) -> "DeviceArray":
+        """gs_allgather_obs_view: this member's gathered block [world * B, obs_dim] as a zero-copy ``DeviceArray``."""
+        v = gs_gathered_obs()
+        self._check(self._lib.gs_allgather_obs_view(self._h, C.byref(v), C.c_void_p(int(stream)) if stream else None))
+        return DeviceArray(v.observations, (int(v.rows), int(v.obs_dim)), "<f8")
+
+    def allgather_obs_download(self) -> np.ndarray:
+        full = np.empty((self.world * self.B, self.obs_dim))
+        self._check(self._lib.gs_allgather_obs_download(self._h, _ptr(full, _dp)))
+        return full
 
     # -- measurement ----------------------------------------------------------------------
     def timing_enable(self, on: bool = True, span: bool = False) -> None:

@@ -36,6 +36,8 @@ struct RcclApi {
   int (*CommInitRank)(gs_ncclComm_t*, int, gs_ncclUniqueId, int) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, gs_ncclComm_t, hipStream_t) = nullptr;
   int (*CommDestroy)(gs_ncclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -51,6 +53,8 @@ bool load_rccl(std::string& why) {
   a.CommInitRank = (int (*)(gs_ncclComm_t*, int, gs_ncclUniqueId, int))dlsym(lib, "ncclCommInitRank");
   a.AllGather = (int (*)(const void*, void*, size_t, int, gs_ncclComm_t, hipStream_t))dlsym(lib, "ncclAllGather");
   a.CommDestroy = (int (*)(gs_ncclComm_t))dlsym(lib, "ncclCommDestroy");
+  a.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+  a.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
   a.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
   if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) { why = "librccl lacks a required symbol"; return false; }
   g_rccl = a;
@@ -128,6 +132,8 @@ struct gs_handle {
   // comm
   gs_ncclComm_t comm = nullptr; int rank = 0, world = 1; double* d_obs_full = nullptr;
   double *d_gather_send = nullptr, *d_gather_recv = nullptr;     // compact observation blocks (changing columns only): [B][nd], [world * B][nd]
+  struct GsLoopComm* loop = nullptr;                              // the in-process transport (gs_comm_init_loopback) instead of RCCL
+  hipEvent_t ev_full = nullptr;                                   // gs_allgather_obs_view: the gathered block is complete
   mutable std::string err;
 };
 
@@ -953,11 +959,12 @@ void gs_destroy(gs_handle* h) {
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  if (h->loop || h->comm) (void)gs_comm_destroy(h);
   if (h->stream2) { (void)hipStreamDestroy(h->stream2); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
   if (h->ev_peer) (void)hipEventDestroy(h->ev_peer);
   if (h->ev_peer2) (void)hipEventDestroy(h->ev_peer2);
-  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   if (h->ev_step) (void)hipEventDestroy(h->ev_step);
+  if (h->ev_full) (void)hipEventDestroy(h->ev_full);
   for (int k = 0; k < 2; ++k) if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   for (auto& t : h->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1351,14 +1358,9 @@ int gs_comm_unique_id(uint8_t id_out[128]) {
   return GS_OK;
 }
 
-int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t world_size) {
-  if (!h || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, GS_E_INVALID, "bad arguments");
-  std::string why;
-  if (!load_rccl(why)) return fail(h, GS_E_COMM, "%s", why.c_str());
-  GS_ENTER(h);
-  gs_ncclUniqueId uid; memcpy(uid.internal, id, 128);
-  int rc = g_rccl.CommInitRank(&h->comm, world_size, uid, rank);
-  if (rc != 0) return fail(h, GS_E_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+// What both transports need on a member: the gathered block [world * B][obs_dim] with its constant columns in place,
+// the compact send / receive blocks, the exchange stream and its events.
+static int comm_buffers(gs_handle* h, int rank, int world_size) {
   h->rank = rank; h->world = world_size;
   HIPCHK(h, hipMalloc((void**)&h->d_obs_full, (size_t)world_size * h->B * h->obs_dim * sizeof(double)));
   const int nd = h->obs_dim - (h->obs_skip1 - h->obs_skip0);
@@ -1367,6 +1369,7 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
   if (!h->comm_stream) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_full, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather[k], hipEventDisableTiming));
   }
   // the constant columns of the gathered block do not depend on the rank (static load powers of the shared feeder):
@@ -1381,9 +1384,105 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
   return GS_OK;
 }
 
+int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t world_size) {
+  if (!h || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, GS_E_INVALID, "bad arguments");
+  if (h->comm || h->loop) return fail(h, GS_E_STATE, "the handle already belongs to a communicator");
+  std::string why;
+  if (!load_rccl(why)) return fail(h, GS_E_COMM, "%s", why.c_str());
+  GS_ENTER(h);
+  gs_ncclUniqueId uid; memcpy(uid.internal, id, 128);
+  int rc = g_rccl.CommInitRank(&h->comm, world_size, uid, rank);
+  if (rc != 0) return fail(h, GS_E_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+  return comm_buffers(h, rank, world_size);
+}
+
+// ---- the in-process transport ----------------------------------------------------------------------
+// `world` handles of ONE process form the communicator; rank r's compact block reaches rank q by a device-to-device
+// copy on q's exchange stream where RCCL would move it over xGMI.  Everything either side of that copy -- compaction,
+// slot offsets, expansion into [world * B][obs_dim], constant columns, the double-buffered observation buffers and
+// their events -- is the code the RCCL transport runs.  The collective completes when the last member has called
+// (the semantics of a grouped RCCL call): that call queues every member's copies.
+struct GsLoopComm {
+  int world = 0, n_live = 0, n_arrived = 0;
+  std::vector<gs_handle*> member;
+  std::vector<hipEvent_t> ev_sent;      // rank r's send block is complete (recorded on r's exchange stream)
+  std::vector<hipEvent_t> ev_taken;     // rank r has copied every send block of the round (before anyone refills one)
+  std::vector<uint8_t> arrived, taken_valid;
+  std::vector<double*> host_out;
+};
+
+static int loop_complete(GsLoopComm* lc) {
+  const gs_handle* h0 = lc->member[0];
+  const int D = h0->obs_dim, nd = D - (h0->obs_skip1 - h0->obs_skip0);
+  const size_t count = (size_t)h0->B * nd;
+  for (int r = 0; r < lc->world; ++r) {
+    gs_handle* q = lc->member[r];
+    HIPCHK(q, hipSetDevice(q->device));
+    for (int p = 0; p < lc->world; ++p) {
+      if (p != r) HIPCHK(q, hipStreamWaitEvent(q->comm_stream, lc->ev_sent[p], 0));
+      HIPCHK(q, hipMemcpyAsync(q->d_gather_recv + (size_t)p * count, lc->member[p]->d_gather_send, count * sizeof(double),
+                               hipMemcpyDeviceToDevice, q->comm_stream));
+    }
+    HIPCHK(q, hipEventRecord(lc->ev_taken[r], q->comm_stream));
+    lc->taken_valid[r] = 1;
+    const size_t total = count * lc->world;
+    hipLaunchKernelGGL(gs_k_obs_compact, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, q->comm_stream, q->d_gather_recv, q->d_obs_full,
+                       (long long)lc->world * q->B, D, q->obs_skip0, q->obs_skip1, 1);
+    HIPCHK(q, hipGetLastError());
+    if (lc->host_out[r])
+      HIPCHK(q, hipMemcpyAsync(lc->host_out[r], q->d_obs_full, (size_t)q->B * D * lc->world * sizeof(double), hipMemcpyDeviceToHost, q->comm_stream));
+  }
+  for (int r = 0; r < lc->world; ++r) {
+    if (lc->host_out[r]) HIPCHK(lc->member[r], hipStreamSynchronize(lc->member[r]->comm_stream));
+    lc->host_out[r] = nullptr; lc->arrived[r] = 0;
+  }
+  lc->n_arrived = 0;
+  return GS_OK;
+}
+
+int gs_comm_init_loopback(gs_handle* const* shards, int32_t nshards) {
+  if (!shards || nshards < 1) return fail(nullptr, GS_E_INVALID, "bad arguments");
+  for (int r = 0; r < nshards; ++r) {
+    gs_handle* h = shards[r];
+    if (!h) return fail(nullptr, GS_E_INVALID, "shard %d is NULL", r);
+    if (h->comm || h->loop) return fail(h, GS_E_STATE, "shard %d already belongs to a communicator", r);
+    if (h->B != shards[0]->B || h->obs_dim != shards[0]->obs_dim || h->obs_skip0 != shards[0]->obs_skip0 || h->obs_skip1 != shards[0]->obs_skip1)
+      return fail(h, GS_E_INVALID, "shard %d: batch / observation layout differs from shard 0 (the all-gather needs equal shards)", r);
+    for (int q = 0; q < r; ++q) if (shards[q] == h) return fail(h, GS_E_INVALID, "shard %d is shard %d again", r, q);
+  }
+  GsLoopComm* lc = new GsLoopComm();
+  lc->world = lc->n_live = nshards;
+  lc->member.assign(shards, shards + nshards);
+  lc->ev_sent.assign(nshards, nullptr); lc->ev_taken.assign(nshards, nullptr);
+  lc->arrived.assign(nshards, 0); lc->taken_valid.assign(nshards, 0); lc->host_out.assign(nshards, nullptr);
+  for (int r = 0; r < nshards; ++r) {
+    gs_handle* h = shards[r];
+    int rc = GS_OK;
+    do {
+      hipError_t e = hipSetDevice(h->device);
+      if (e == hipSuccess && h->forked) { rc = join_streams(h); if (rc) break; }
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&lc->ev_sent[r], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&lc->ev_taken[r], hipEventDisableTiming);
+      if (e != hipSuccess) { rc = fail(h, GS_E_HIP, "loopback communicator set-up failed: %s", hipGetErrorString(e)); break; }
+      rc = comm_buffers(h, r, nshards);
+    } while (0);
+    if (rc) {       // undo: members attached so far go back to "no communicator"
+      for (int q = 0; q <= r; ++q) { shards[q]->loop = nullptr; (void)gs_comm_destroy(shards[q]); }
+      for (int q = 0; q < nshards; ++q) { if (lc->ev_sent[q]) (void)hipEventDestroy(lc->ev_sent[q]); if (lc->ev_taken[q]) (void)hipEventDestroy(lc->ev_taken[q]); }
+      delete lc;
+      return rc;
+    }
+    h->loop = lc;
+  }
+  return GS_OK;
+}
+
 int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
-  if (!h->comm) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init");
+  if (!h->comm && !h->loop) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init / gs_comm_init_loopback");
+  GsLoopComm* lc = h->loop;
+  if (lc && lc->n_live != lc->world) return fail(h, GS_E_STATE, "a member of the loopback communicator has left");
+  if (lc && lc->arrived[h->rank]) return fail(h, GS_E_STATE, "rank %d called gs_allgather_obs twice before every member had called once", h->rank);
   GS_ENTER(h);
   const int D = h->obs_dim, nd = D - (h->obs_skip1 - h->obs_skip0);
   const size_t count = (size_t)h->B * nd;
@@ -1394,11 +1493,20 @@ int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   const int cur = h->obs_cur;
   HIPCHK(h, hipEventRecord(h->ev_step, h->stream));
   HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step, 0));
+  if (lc)       // loopback only: the peers copy OUT of this send block on their own streams (RCCL reads it on this one)
+    for (int r = 0; r < lc->world; ++r)
+      if (r != h->rank && lc->taken_valid[r]) HIPCHK(h, hipStreamWaitEvent(h->comm_stream, lc->ev_taken[r], 0));
   hipLaunchKernelGGL(gs_k_obs_compact, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->comm_stream, h->d_obs2[cur], h->d_gather_send,
                      (long long)h->B, D, h->obs_skip0, h->obs_skip1, 0);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev_gather[cur], h->comm_stream));
   h->gather_pending[cur] = true;
+  if (lc) {
+    HIPCHK(h, hipEventRecord(lc->ev_sent[h->rank], h->comm_stream));
+    lc->arrived[h->rank] = 1; lc->host_out[h->rank] = obs_full_host;
+    if (++lc->n_arrived == lc->world) return loop_complete(lc);
+    return GS_OK;
+  }
   int rc = g_rccl.AllGather(h->d_gather_send, h->d_gather_recv, count, /*ncclFloat64*/ 8, h->comm, h->comm_stream);
   if (rc != 0) return fail(h, GS_E_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
   const size_t total = count * h->world;
@@ -1412,14 +1520,78 @@ int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   return GS_OK;
 }
 
+int gs_allgather_obs_shards(gs_handle* const* shards, int32_t nshards, double* obs_full_host) {
+  if (!shards || nshards < 1 || !shards[0]) return fail(nullptr, GS_E_INVALID, "bad arguments");
+  GsLoopComm* lc = shards[0]->loop;
+  for (int r = 0; r < nshards; ++r) {
+    if (!shards[r]) return fail(nullptr, GS_E_INVALID, "shard %d is NULL", r);
+    if (shards[r]->loop != lc || (!lc && !shards[r]->comm)) return fail(shards[r], GS_E_STATE, "shard %d is not in the communicator of shard 0", r);
+  }
+  if (lc && (nshards != lc->world || lc->n_arrived != 0)) return fail(shards[0], GS_E_STATE, "the call must name every member of the loopback communicator once, with no gather half-way");
+  if (!lc) {      // one process driving several GPUs through RCCL: the members' calls form one group
+    if (!g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(shards[0], GS_E_COMM, "librccl lacks ncclGroupStart / ncclGroupEnd");
+    g_rccl.GroupStart();
+    int rc = GS_OK;
+    for (int r = 0; r < nshards && !rc; ++r) rc = gs_allgather_obs(shards[r], nullptr);
+    const int rg = g_rccl.GroupEnd();
+    if (rc) return rc;
+    if (rg != 0) return fail(shards[0], GS_E_COMM, "ncclGroupEnd: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rg) : "error");
+    return obs_full_host ? gs_allgather_obs_download(shards[0], obs_full_host) : GS_OK;
+  }
+  for (int r = 0; r < nshards; ++r) {
+    int rc = gs_allgather_obs(shards[r], r == 0 ? obs_full_host : nullptr);
+    if (rc) return rc;
+  }
+  return GS_OK;
+}
+
+int gs_allgather_obs_view(gs_handle* h, gs_gathered_obs* out, void* consumer_stream) {
+  if (!h || !out) return fail(h, GS_E_INVALID, "handle / out is NULL");
+  if (!h->d_obs_full) return fail(h, GS_E_STATE, "no communicator on this handle");
+  if (h->loop && h->loop->arrived[h->rank]) return fail(h, GS_E_STATE, "the gather of this round is not complete: not every member has called gs_allgather_obs");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (consumer_stream) {
+    HIPCHK(h, hipEventRecord(h->ev_full, h->comm_stream));
+    HIPCHK(h, hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_full, 0));
+  } else {
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  }
+  out->observations = h->d_obs_full; out->rows = (int64_t)h->world * h->B; out->obs_dim = h->obs_dim;
+  out->rank = h->rank; out->world = h->world; out->reserved = 0;
+  return GS_OK;
+}
+
+int gs_allgather_obs_download(gs_handle* h, double* obs_full_host) {
+  if (!h || !obs_full_host) return fail(h, GS_E_INVALID, "handle / obs_full_host is NULL");
+  gs_gathered_obs v;
+  int rc = gs_allgather_obs_view(h, &v, nullptr);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(obs_full_host, v.observations, (size_t)v.rows * v.obs_dim * sizeof(double), hipMemcpyDeviceToHost));
+  return GS_OK;
+}
+
 int gs_comm_destroy(gs_handle* h) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  (void)hipSetDevice(h->device);
+  if (h->loop) {      // nobody may still be copying out of this member's send block
+    GsLoopComm* lc = h->loop;
+    for (gs_handle* q : lc->member)
+      if (q && q->comm_stream) { (void)hipSetDevice(q->device); (void)hipStreamSynchronize(q->comm_stream); }
+    (void)hipSetDevice(h->device);
+    lc->member[h->rank] = nullptr; h->loop = nullptr;
+    if (--lc->n_live == 0) {
+      for (hipEvent_t e : lc->ev_sent) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : lc->ev_taken) if (e) (void)hipEventDestroy(e);
+      delete lc;
+    }
+  }
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   h->gather_pending[0] = h->gather_pending[1] = false;
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   if (h->d_obs_full) { (void)hipFree(h->d_obs_full); h->d_obs_full = nullptr; }
   if (h->d_gather_send) { (void)hipFree(h->d_gather_send); h->d_gather_send = nullptr; }
   if (h->d_gather_recv) { (void)hipFree(h->d_gather_recv); h->d_gather_recv = nullptr; }
+  h->rank = 0; h->world = 1;
   return GS_OK;
 }
 

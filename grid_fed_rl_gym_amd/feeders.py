@@ -367,6 +367,68 @@ def random_meshed(n: int, extra_lines: int, seed: int = 0) -> FeederSpec:
         load_bus=_i32(lb), load_base=rng.uniform(10e3, 200e3, n - 1), load_pf=np.full(n - 1, 0.95))
 
 
+def scalable_like(num_buses: int = 123, seed: int = 1, connectivity: Optional[float] = None) -> FeederSpec:
+    """Seeded MESHED feeder following the recipe of the reference's ``ScalableFeeder(num_buses, seed)``
+    (feeders/synthetic.py:233-251 on top of ``SyntheticFeeder``, :65-214), drawn from a private
+    ``default_rng(seed)`` instead of the process-global NumPy generator: random spanning tree grown from bus 1
+    (:75-94), then random extra lines towards ``tree + connectivity * (all pairs - tree)`` with the reference's
+    cap of 1000 attempts (:96-124; connectivity = clip(20 / n, 0.1, 0.6), i.e. ~1000 lines at n = 123 -- a graph
+    whose block LU fills in almost completely), per-km impedances 0.2-0.5 / 0.3-0.7 ohm over 0.05-1.5 km on the
+    12.47 kV / 10 MVA base, ratings 2-10 MVA (:126-155), loads with probability min(0.9, 0.5 + 0.01 n) of 20-300 kW at
+    power factor 0.85-1.0 (:157-177), DG with probability min(0.4, 0.1 + 0.005 n), a third each solar / wind / battery
+    (:179-213).  ``connectivity`` overrides the recipe's value (0.0 = the spanning tree alone)."""
+    n = int(num_buses)
+    rng = np.random.default_rng(seed)
+    conn = max(0.1, min(0.6, 20.0 / n)) if connectivity is None else float(connectivity)
+    base_z = 12.47 ** 2 / 10.0
+    frm, to, r, x, rating = [], [], [], [], []
+
+    def add_line(a, b):
+        length = 0.05 + 1.45 * rng.random()
+        frm.append(a); to.append(b)
+        r.append((0.2 + 0.3 * rng.random()) * length / base_z); x.append((0.3 + 0.4 * rng.random()) * length / base_z)
+        rating.append((2 + 8 * rng.random()) * 1e6)
+
+    connected, unconnected = [0], list(range(1, n))
+    while unconnected:
+        a = connected[int(rng.integers(0, len(connected)))]
+        b = unconnected.pop(int(rng.integers(0, len(unconnected))))
+        add_line(a, b); connected.append(b)
+    have = {(a, b) for a, b in zip(frm, to)} | {(b, a) for a, b in zip(frm, to)}
+    target = int(len(frm) + conn * (n * (n - 1) // 2 - len(frm)))
+    attempts = 0
+    while len(frm) < target and attempts < 1000:
+        a, b = int(rng.integers(0, n)), int(rng.integers(0, n)); attempts += 1
+        if a != b and (a, b) not in have:
+            add_line(a, b); have.add((a, b)); have.add((b, a))
+    lb, lp, lpf = [], [], []
+    p_load = min(0.9, 0.5 + 0.01 * n)
+    for b in range(1, n):
+        if rng.random() < p_load:
+            lb.append(b); lp.append((20 + 280 * rng.random()) * 1000.0); lpf.append(0.85 + 0.15 * rng.random())
+    gb, gk, gc, g0, g1, g2, bb, bc, br, be = [], [], [], [], [], [], [], [], [], []
+    p_dg = min(0.4, 0.1 + 0.005 * n)
+    for b in range(1, n):
+        if rng.random() < p_dg:
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                cap = (100 + 400 * rng.random()) * 1000.0; eff = 0.15 + 0.10 * rng.random()
+                gb.append(b); gk.append(GEN_SOLAR); gc.append(cap); g0.append(eff); g1.append(cap / (eff * 1000.0)); g2.append(0.0)
+            elif kind == 1:
+                gb.append(b); gk.append(GEN_WIND); gc.append((500 + 1500 * rng.random()) * 1000.0)
+                g0.append(2.5 + rng.random()); g1.append(10 + 5 * rng.random()); g2.append(20 + 10 * rng.random())
+            else:
+                kwh = 200 + 800 * rng.random()
+                bb.append(b); bc.append(kwh * 1000.0); br.append(0.5 * kwh * 1000.0); be.append(0.85 + 0.10 * rng.random())
+    return FeederSpec(
+        name=f"scalable_like_{n}_seed{seed}_m{len(frm)}", bus_ids=list(range(1, n + 1)),
+        bus_type=np.array([SLACK] + [PQ] * (n - 1), dtype=np.uint8), v_set=np.ones(n),
+        frm=_i32(frm), to=_i32(to), r=_f64(r), x=_f64(x), rating=_f64(rating),
+        load_bus=_i32(lb), load_base=_f64(lp), load_pf=_f64(lpf),
+        gen_bus=_i32(gb), gen_kind=_i32(gk), gen_cap=_f64(gc), gen_p0=_f64(g0), gen_p1=_f64(g1), gen_p2=_f64(g2),
+        bat_bus=_i32(bb), bat_cap=_f64(bc), bat_rating=_f64(br), bat_eff=_f64(be), base_power_va=10e6)
+
+
 # ----------------------------------------------------------------------------------------
 # dictionary (JSON) network format: CustomFeeder.from_dict / to_dict, feeders/base.py:170-253
 # ----------------------------------------------------------------------------------------

@@ -6,7 +6,9 @@ instances splits into contiguous blocks, rank r owning ``shard_range(B_total, r,
 Seeds and RNG counters are keyed by the GLOBAL instance index, so results do not depend on the
 number of ranks.  The only exchange is optional and happens after the step: an all-gather of
 the observation block so that every rank (or a host-side learner) sees all observations --
-RCCL over xGMI through libgridstep (``transport="rccl"``, device buffers, equal shards) or host
+RCCL over xGMI through libgridstep (``transport="rccl"``, device buffers, equal shards), the same device-side
+exchange with every rank's shard held by ONE process (``LoopbackShards``: device-to-device copies where RCCL would
+cross xGMI -- the rehearsal of N ranks on a box with fewer GPUs), or host
 arrays (``transport="host"``, uneven shards allowed) through a framework-free file rendezvous
 (``rendezvous.FileRendezvous``) or any ``torch.distributed`` process group (what the world_size-2
 gloo tests exercise).  Nothing here imports torch unless a torch group is what the caller hands in.
@@ -61,7 +63,8 @@ class ShardedGridEnvironment:
     """This rank's block of a ``global_num_envs``-instance batched environment.
 
     ``transport`` is "rccl" (all-gather of device-resident observations through libgridstep;
-    needs equal shards and a 128-byte RCCL unique id shared by the ranks) or "host".
+    needs equal shards and a 128-byte RCCL unique id shared by the ranks), "loopback" (a member of a
+    ``LoopbackShards`` group) or "host".
     """
 
     def __init__(self, feeder: Any, global_num_envs: int, rank: int, world: int, device: Optional[int] = None,
@@ -69,7 +72,7 @@ class ShardedGridEnvironment:
         self.global_num_envs, self.rank, self.world = int(global_num_envs), int(rank), int(world)
         self.start, self.stop = shard_range(self.global_num_envs, self.rank, self.world)
         self.transport, self.group = transport, group
-        if transport == "rccl" and self.global_num_envs % self.world != 0:
+        if transport in ("rccl", "loopback") and self.global_num_envs % self.world != 0:
             raise ValueError("the RCCL all-gather needs equal shards (global_num_envs % world == 0)")
         self.env = BatchedGridEnvironment(feeder, num_envs=self.stop - self.start,
                                           device=self.rank if device is None else device,
@@ -98,6 +101,8 @@ class ShardedGridEnvironment:
             if not self._comm:
                 raise RuntimeError("init_rccl() first")
             return self.env.handle.allgather_obs(to_host=True)
+        if self.transport == "loopback":
+            raise RuntimeError("a loopback member gathers through its LoopbackShards group")
         if local_obs is None:
             raise ValueError("host transport gathers the array it is given")
         return host_all_gather(local_obs, self.global_num_envs, self.rank, self.world, self.group)
@@ -106,3 +111,42 @@ class ShardedGridEnvironment:
         if self._comm:
             self.env.handle.comm_destroy()
         self.env.close()
+
+
+class LoopbackShards:
+    """All ``world`` shards of a ``global_num_envs``-instance environment in THIS process (``gs_comm_init_loopback``):
+    shard r is exactly what rank r of an N-GPU job builds (``first_instance = r * B``, global-index seeds), and the
+    observation exchange runs the RCCL transport's device code with in-process copies in place of ``ncclAllGather``.
+    For rehearsing / testing N ranks on fewer GPUs; ``devices`` maps shard -> device (default: all on device 0)."""
+
+    def __init__(self, feeder: Any, global_num_envs: int, world: int, devices: Optional[list] = None, **env_kwargs: Any) -> None:
+        if global_num_envs % world != 0:
+            raise ValueError("the device all-gather needs equal shards (global_num_envs % world == 0)")
+        self.global_num_envs, self.world = int(global_num_envs), int(world)
+        self.shards = [ShardedGridEnvironment(feeder, global_num_envs, r, world, device=(devices[r] if devices else 0),
+                                              transport="loopback", **env_kwargs) for r in range(world)]
+        from ._lib import Handle
+        Handle.comm_init_loopback([s.env.handle for s in self.shards])
+        for s in self.shards:
+            s._comm = True
+
+    @property
+    def handles(self):
+        return [s.env.handle for s in self.shards]
+
+    def reset(self, seed: int = 0):
+        return [s.reset(seed) for s in self.shards]
+
+    def step(self, global_actions):
+        """``global_actions`` [global_num_envs, action_dim]; every shard steps its block.  Returns the shards' step tuples."""
+        a = np.asarray(global_actions)
+        return [s.step(a[s.start:s.stop]) for s in self.shards]
+
+    def gather_observations(self, to_host: bool = True):
+        """One exchange for every member (``gs_allgather_obs_shards``); [global_num_envs, obs_dim] from shard 0's block."""
+        from ._lib import Handle
+        return Handle.allgather_obs_shards(self.handles, to_host=to_host)
+
+    def close(self) -> None:
+        for s in self.shards:
+            s.close()

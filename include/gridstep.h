@@ -281,6 +281,29 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
  * buffer [world*B][obs_dim]; obs_full_host may be NULL (stay on device) */
 int gs_allgather_obs(gs_handle* h, double* obs_full_host);
 int gs_comm_destroy(gs_handle* h);
+/* The in-process transport: `nshards` handles of ONE process (shard r built with first_instance = r * B; normally all on
+ * one device) form the communicator, rank = position in `shards`.  A member's compact block reaches the others by
+ * device-to-device copies on their exchange streams where RCCL would move it over xGMI; compaction, slot offsets,
+ * expansion, constant columns, the double-buffered observation buffers and their events are the code the RCCL transport
+ * runs.  With this transport gs_allgather_obs completes when the LAST member has called (a grouped call): earlier callers
+ * return at once, their obs_full_host (if any) is filled by that last call.  What it is for: rehearsing and testing the
+ * N > 1 exchange on a box with fewer GPUs than ranks (tests/test_gpu_loopback.py; bench.py flags such a run
+ * "transport": "loopback"), and a single process that keeps several shards on one GPU. */
+int gs_comm_init_loopback(gs_handle* const* shards, int32_t nshards);
+/* The form SURVEY.md section 8(b) specified: one call gathers for every member (all members of one loopback communicator,
+ * or the RCCL ranks one process drives, issued as one ncclGroup); obs_full_host: NULL or [nshards * B][obs_dim], filled
+ * from shard 0's gathered block (every member's is the same). */
+int gs_allgather_obs_shards(gs_handle* const* shards, int32_t nshards, double* obs_full_host);
+/* The gathered block where it lies, [world * B][obs_dim] in rank order, for a learner on the GPU (valid until the member's
+ * next gather completes).  consumer_stream (hipStream_t as void*): made to wait on the device for the gather; NULL: the
+ * call returns when the gather has finished.  gs_allgather_obs_download is the host copy of the same block. */
+typedef struct gs_gathered_obs {
+  const double* observations;
+  int64_t rows;                   /* world * B */
+  int32_t obs_dim, rank, world, reserved;
+} gs_gathered_obs;
+int gs_allgather_obs_view(gs_handle* h, gs_gathered_obs* out, void* consumer_stream);
+int gs_allgather_obs_download(gs_handle* h, double* obs_full_host);
 
 /* ---- measurement: HIP-event timing of every kernel launched on the handle's stream ------ */
 enum { GS_K_UNPACK = 0, GS_K_ENV_PRE = 1, GS_K_SOLVE = 2, GS_K_ENV_POST = 3, GS_K_PACK = 4, GS_K_COUNT = 5 };
