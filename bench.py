@@ -249,13 +249,16 @@ def main():
         return dict(stochastic_loads=True, weather_variation=True, solver=solver, tolerance=args.tolerance,
                     max_iterations=args.max_iterations or (50 if solver == "nr" else 100))
 
-    def measure(fs, B, solver, use_gather, repeats, extras=False):
+    def measure(fs, B, solver, use_gather, repeats, extras=False, warmup=None, steps=None, linear_solver=None):
         """W untimed + R x K timed batched steps of one solver; returns the measurement as a dict."""
+        warmup = args.warmup if warmup is None else warmup
+        steps = args.steps if steps is None else steps
+        more = {} if linear_solver is None else {"linear_solver": linear_solver}
         rng = np.random.default_rng(5678 + rank)
         actions = rng.uniform(-1, 1, (n_act, B, fs.action_dim))
         seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.uint64)
         env = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=device,
-                                       first_instance=rank * B, waves_per_group=args.waves, **env_kwargs_of(solver))
+                                       first_instance=rank * B, waves_per_group=args.waves, **env_kwargs_of(solver), **more)
         h = env.handle
         desc = h.describe()
         h.upload_actions(actions)                               # inputs resident in HBM before the timed region
@@ -277,7 +280,7 @@ def main():
             if rz is not None:
                 rz.barrier()
 
-        for k in range(args.warmup):
+        for k in range(warmup):
             one_step(k)
         regions, kernel_ms, kernel_launches = [], 0.0, 0
         for r in range(repeats):
@@ -286,8 +289,8 @@ def main():
             h.timing_enable(True, span=True)
             barrier()
             t0 = time.perf_counter()
-            for k in range(args.steps):
-                one_step(args.warmup + k)
+            for k in range(steps):
+                one_step(warmup + k)
             timing = h.timing_read()                            # closing event behind the last launch; waits for it
             h.synchronize()
             elapsed = time.perf_counter() - t0
@@ -297,7 +300,7 @@ def main():
             regions.append(elapsed)
             kernel_ms += timing["solve"]["total_ms"]; kernel_launches += timing["solve"]["launches"]
         out = h.download_step(want_obs=False)                    # sanity of the timed work: every instance solved
-        m = dict(solver=solver, regions=regions, kernel_ms=kernel_ms, kernel_launches=kernel_launches, desc=desc, B=B, fs=fs,
+        m = dict(solver=solver, regions=regions, kernel_ms=kernel_ms, kernel_launches=kernel_launches, desc=desc, B=B, fs=fs, steps=steps,
                  converged_fraction=float(out["power_flow_converged"].mean()),
                  mean_iterations=float(out["iterations"].mean()))
         if extras and rank == 0:
@@ -535,10 +538,11 @@ def main():
 
     def summarize(m, n_ranks):
         med, p10, p90 = quantiles(m["regions"])
-        sps = [n_ranks * m["B"] * args.steps / t for t in m["regions"]]
+        K = m.get("steps", args.steps)
+        sps = [n_ranks * m["B"] * K / t for t in m["regions"]]
         s_med, s_p10, s_p90 = quantiles(sps)
-        return dict(value=s_med, value_p10_p90=[s_p10, s_p90], ms_per_step=1e3 * med / args.steps,
-                    ms_per_step_p10_p90=[1e3 * p10 / args.steps, 1e3 * p90 / args.steps],
+        return dict(value=s_med, value_p10_p90=[s_p10, s_p90], ms_per_step=1e3 * med / K,
+                    ms_per_step_p10_p90=[1e3 * p10 / K, 1e3 * p90 / K],
                     avg_launch_ms=m["kernel_ms"] / max(m["kernel_launches"], 1))
 
     def roofline_of(m, s, workload_key):
@@ -549,7 +553,7 @@ def main():
         flops_it = algorithmic_flops_per_iteration(fs) if m["solver"] == "nr" else 30 * fs.n
         tflops = flops_it * m["mean_iterations"] * B / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_of(f"{workload_key}:{m['solver']}") if B == WORKLOADS[workload_key]["batch"] else None,
+                "traffic": traffic_of(f"{workload_key}:{m['solver']}") if B == WORKLOADS.get(workload_key, {}).get("batch") else None,
                 "kernel": "gs_k_step_" + KERNEL_NAMES.get(m["desc"]["kernel"], m["desc"]["kernel"]),
                 "avg_launch_ms": avg, "avg_launch_method": "one HIP event pair on the kernel's stream around the K launches of each timed region / K, mean over the regions",
                 "algorithmic_bytes_per_launch": bytes_step * B,
@@ -654,6 +658,38 @@ def main():
             except Exception as e:
                 result["also_config5"] = {"error": str(e)}
         if world == 1 and not args.no_also and args.workload == "ieee123_b8192":
+            # Meshed feeders: Newton-Raphson with a sparse block LU (north_star: "Jacobian build, sparse LU/Cholesky solve";
+            # the reference solves them densely, power_flow.py:186-190).  Two graphs of the reference's own generators' kind:
+            # 123 buses with 26 loops (IEEE123Bus's cycle count, feeders/ieee_feeders.py:236-330) and the ScalableFeeder(123)
+            # recipe (feeders/synthetic.py:233: ~1000 lines, a graph whose block LU fills in almost completely).
+            result["also_meshed"] = {}
+            for key, mk, Bm, K, W_ in (("loops26_123", lambda: P.random_meshed(123, 26, seed=1), B, min(args.steps, 20), min(args.warmup, 20)),
+                                       ("scalable_123", lambda: P.scalable_like(123, seed=1), B, 3, 1)):
+                try:
+                    fsm = mk()
+                    mm = measure(fsm, Bm, "nr", False, 3, warmup=W_, steps=K)
+                    sm = summarize(mm, 1)
+                    rl = roofline_of(mm, sm, "meshed")
+                    pairs = int(mm["desc"].get("lu_pairs", 0))
+                    # per Newton iteration and instance: one 2x2 (A_ik D^-1) A_kj product and subtraction per scheduled pair
+                    # (2 x 12 + 4 flops), one 2x2 inverse per pivot, the Jacobian blocks (~40 flops per Ybus entry)
+                    fl_it = 28 * pairs + 30 * fsm.n + 40 * int(mm["desc"]["nnz"])
+                    tf = fl_it * mm["mean_iterations"] * Bm / (sm["avg_launch_ms"] * 1e-3) / 1e12 if sm["avg_launch_ms"] > 0 else 0.0
+                    rl["fp64_valu"] = {"achieved_tflops": tf, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                                       "flops_per_iteration_per_instance": fl_it, "mean_iterations": mm["mean_iterations"],
+                                       "how": "28 flops per scheduled pair update (host schedule, gs_describe lu_pairs) + 30 per pivot + 40 per Ybus entry"}
+                    rl["traffic"] = traffic_of(f"meshed_{key}:nr") if Bm == B else None
+                    entry = {"workload": f"{fsm.name}, batch={Bm}, Newton-Raphson (exact Jacobian), stochastic loads + weather",
+                             "feeder_sha256": fsm.sha256(), "n_buses": fsm.n, "n_lines": fsm.m, "obs_dim": fsm.obs_dim, "action_dim": fsm.action_dim,
+                             "value": sm["value"], "unit": "env_steps/s", "ms_per_step": sm["ms_per_step"], "value_p10_p90": sm["value_p10_p90"],
+                             "steps": K, "kernel": "gs_k_step_" + KERNEL_NAMES.get(mm["desc"]["kernel"], mm["desc"]["kernel"]),
+                             "lu_slots": mm["desc"].get("lu_slots"), "lu_original_blocks": mm["desc"].get("lu_orig"), "lu_pair_updates": pairs,
+                             "mean_iterations": mm["mean_iterations"], "converged_fraction": mm["converged_fraction"], "roofline": rl}
+                    if not args.no_cpu_baseline:
+                        entry["cpu_baseline"] = cpu_baseline(fsm, env_kwargs_of("nr"), budget_s=5.0)
+                    result["also_meshed"][key] = entry
+                except Exception as e:
+                    result["also_meshed"][key] = {"error": str(e)}
             # BASELINE config 4's data path rehearsed on this one GPU: W ranks' shards in this process, the exchange through
             # the in-process transport (what an 8-GPU run adds to this is ncclAllGather itself)
             try:
@@ -669,6 +705,8 @@ def main():
             # the solver the GPU ran is reported next to it when it differs; and the same on ONE core
             result["cpu_baseline"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=10.0)
             result["cpu_baseline_1core"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=6.0, threads=1)
+            # every CPU in this process's affinity mask (the 16-thread figure above is the share of the host one GPU gets)
+            result["cpu_baseline_all_cores"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=6.0, threads="all")
             if solver0 != "nr":
                 result["cpu_baseline_same_solver"] = cpu_baseline(fs, env_kwargs_of(solver0), budget_s=6.0)
                 result["cpu_baseline_same_solver_1core"] = cpu_baseline(fs, env_kwargs_of(solver0), budget_s=4.0, threads=1)

@@ -10,7 +10,7 @@ from .components import (Bus, Line, Load, PowerFlowSolution, BatchedPowerFlowSol
                          PowerFlowError, InvalidActionError)
 from .feeders import (FeederSpec, flatten_feeder, flatten_network, to_objects, reference_env_network,
                       with_reference_env_renewables, simple_radial, ieee13_like, ieee123_like,
-                      random_meshed)
+                      random_meshed, scalable_like)
 
 from .solver import (BatchedNewtonRaphsonSolver, NewtonRaphsonSolver, FastDecoupledSolver,
                      BatchedForwardBackwardSweepSolver, BatchedRobustPowerFlowSolver, DistributionPowerFlow, parallel_power_flow_batch,
@@ -34,6 +34,6 @@ __all__ = [
     "Bus", "Line", "Load", "PowerFlowSolution", "BatchedPowerFlowSolution", "PowerFlowError",
     "InvalidActionError", "FeederSpec", "flatten_feeder", "flatten_network", "to_objects",
     "reference_env_network", "with_reference_env_renewables", "simple_radial", "ieee13_like",
-    "ieee123_like", "random_meshed",
+    "ieee123_like", "random_meshed", "scalable_like",
 ]
 __version__ = "0.1.0"

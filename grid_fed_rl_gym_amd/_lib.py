@@ -204,6 +204,17 @@ class DeviceArray:
         return f"DeviceArray(0x{self.ptr:x}, shape={self.shape}, typestr={self.typestr!r})"
 
 
+def _stream_arg(stream):
+    """A consumer's / producer's ``hipStream_t`` for the C ABI: ``None`` = no stream (the caller synchronises itself); an
+    integer handle otherwise.  Handle 0 is the LEGACY DEFAULT stream -- what ``torch.cuda.current_stream().cuda_stream`` is
+    unless the caller made a stream of its own -- and goes over as ``hipStreamLegacy`` (1), since NULL means "no stream" at
+    the boundary.  (Round 3: 0 used to be taken for "no stream", which left a step free to read its actions before the
+    default stream had written them.)"""
+    if stream is None:
+        return None
+    return C.c_void_p(int(stream) if int(stream) != 0 else 1)
+
+
 def _device_address(x, shape) -> int:
     """Device address of a float64 C-contiguous array of ``shape`` given as an int, a torch tensor or anything with
     ``__cuda_array_interface__``."""
@@ -444,7 +455,7 @@ class Handle:
         producer's ``hipStream_t`` as an integer (torch: ``torch.cuda.current_stream().cuda_stream``); the step then waits
         on the device for what is queued there.  None: the caller has synchronised."""
         self._check(self._lib.gs_step_device_ptr(self._h, C.c_void_p(_device_address(actions, (self.B, self.action_dim))),
-                                                 C.c_void_p(int(stream)) if stream else None))
+                                                 _stream_arg(stream)))
 
     def step_device_view(self, stream=None) -> dict:
         """gs_step_device_view: the last step's observation block, rewards and flags as ``DeviceArray`` objects (zero-copy:
@@ -452,7 +463,7 @@ class Handle:
         device for the step; None: the call returns when the step has finished.  The observation block is one of the handle's
         two buffers (valid until the next-but-one step), the other arrays are refreshed by every call."""
         out = gs_step_device_out()
-        self._check(self._lib.gs_step_device_view(self._h, C.byref(out), C.c_void_p(int(stream)) if stream else None))
+        self._check(self._lib.gs_step_device_view(self._h, C.byref(out), _stream_arg(stream)))
         B = int(out.B)
         return dict(obs=DeviceArray(out.observations, (B, int(out.obs_dim)), "<f8"), reward=DeviceArray(out.reward, (B,), "<f8"),
                     terminated=DeviceArray(out.terminated, (B,), "|u1"), truncated=DeviceArray(out.truncated, (B,), "|u1"))
@@ -572,7 +583,7 @@ class Handle:
     def allgather_obs_view(self, stream=None) -> "DeviceArray":
         """gs_allgather_obs_view: this member's gathered block [world * B, obs_dim] as a zero-copy ``DeviceArray``."""
         v = gs_gathered_obs()
-        self._check(self._lib.gs_allgather_obs_view(self._h, C.byref(v), C.c_void_p(int(stream)) if stream else None))
+        self._check(self._lib.gs_allgather_obs_view(self._h, C.byref(v), _stream_arg(stream)))
         return DeviceArray(v.observations, (int(v.rows), int(v.obs_dim)), "<f8")
 
     def allgather_obs_download(self) -> np.ndarray:

@@ -93,6 +93,10 @@ struct gs_handle {
   // step itself joins first (GS_ENTER).
   bool split_ok = false, forked = false;
   hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_peer = nullptr, ev_peer2 = nullptr;     // which member of the family (8 instances per workgroup for small feeders)
+  // The second-generation step kernels do not write the (|V|, angle) / (flow, |P| / rating) row pairs: those are the first
+  // 2 n + 2 m columns of the observation block the step writes anyway.  `rows_stale`: the rows lag behind `last_obs`, the block
+  // of the last step; every entry point that reads or partly rewrites them restores them first (ensure_rows).
+  bool lean = false, rows_stale = false; const double* last_obs = nullptr;
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -150,6 +154,9 @@ int fail(gs_handle* h, int code, const char* fmt, ...) {
   if (h) h->err = buf;
   return code;
 }
+
+// A peer's stream as it crosses the C ABI: NULL = none; hipStreamLegacy (1) = the legacy default stream, i.e. handle 0
+static inline hipStream_t peer_stream(void* s) { return s == (void*)hipStreamLegacy ? (hipStream_t)nullptr : (hipStream_t)s; }
 
 #define HIPCHK(h, expr)                                                                           \
   do { hipError_t e_ = (expr);                                                                    \
@@ -232,13 +239,21 @@ int launch_pack(gs_handle* h, const int32_t* map, int C, double* dst) {
   return GS_OK;
 }
 
-int launch_unpack(gs_handle* h, const int32_t* map, int C, const double* src) {
+int launch_unpack(gs_handle* h, const int32_t* map, int C, const double* src, int stride = 0) {
   if (C <= 0) return GS_OK;
   LaunchTimer lt(h, GS_K_UNPACK);
   dim3 grid(h->groups, (C + 63) / 64);
-  hipLaunchKernelGGL(gs_k_unpack, grid, dim3(256), 0, h->stream, map, C, h->R.total, h->slab, src, h->B);
+  hipLaunchKernelGGL(gs_k_unpack, grid, dim3(256), 0, h->stream, map, C, h->R.total, h->slab, src, h->B, stride ? stride : C);
   HIPCHK(h, hipGetLastError());
   return GS_OK;
+}
+
+// The result rows a lean step left behind (gs_handle::lean), copied back from the observation block it wrote: exact (the
+// block's first 2 n + 2 m columns ARE those rows' values).  Called, after GS_ENTER, by whatever reads or partly rewrites them.
+int ensure_rows(gs_handle* h) {
+  if (!h->rows_stale) return GS_OK;
+  h->rows_stale = false;
+  return launch_unpack(h, h->map_obs, 2 * h->n + 2 * h->m, h->last_obs, h->obs_dim);
 }
 
 int pack_to_host(gs_handle* h, const int32_t* map, int C, double* host) {
@@ -305,6 +320,8 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
                   h->obs_skip0, h->obs_skip1};
     pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
+    pa.lean = h->lean ? 1 : 0;
+    if (h->lean) { h->rows_stale = true; h->last_obs = obs_out; }
     const GsFusedChecks fc = fused_checks_args(h);
     const GsRolloutStep rsv = rs ? *rs : GsRolloutStep{};
     if (h->nr2 || h->flow2) {        // 64 / IW workgroups per 64-instance slab group, each with its own IW instances
@@ -650,7 +667,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
     F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * IW * sizeof(double));
     F.off_red = (int32_t)off; off += 2 * (size_t)NW * IW * sizeof(double);
-    F.off_atom = (int32_t)off; off += 5 * (size_t)IW * sizeof(unsigned long long) + 16 * (size_t)IW * sizeof(uint32_t);
+    F.off_atom = (int32_t)off; off += 8 * (size_t)IW * sizeof(unsigned long long) + 16 * (size_t)IW * sizeof(uint32_t);
     F.lds_bytes = (int32_t)off; F.n_slots = nsl; F.slack = ht.slack;
     return off;
   };
@@ -857,6 +874,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
 #undef UP
   // a step as two half-grid launches on two streams: only where each half still gives every CU a workgroup
+  h->lean = (h->flow2 || h->nr2) && !getenv("GS_EAGER_ROWS");
   if ((h->flow2 || h->nr2) && 2 * (size_t)h->F2.lds_bytes <= 160 * 1024 && !getenv("GS_NO_SPLIT") && h->groups * (64 / h->f2_iw) >= 512 &&
       h->groups >= 2) {
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -1034,6 +1052,7 @@ int gs_upload_injections(gs_handle* h, const double* P_spec, const double* Q_spe
 int gs_solve_device(gs_handle* h) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   GS_ENTER(h);
+  h->rows_stale = false;            // the solve writes every result row
   return launch_solve(h);
 }
 
@@ -1041,6 +1060,7 @@ int gs_download_solution(gs_handle* h, const gs_solution_view* out) {
   if (!h || !out) return fail(h, GS_E_INVALID, "handle / view is NULL");
   GS_ENTER(h);
   int rc;
+  if ((rc = ensure_rows(h))) return rc;
   if ((rc = pack_to_host(h, h->map_vm, h->n, out->bus_voltages))) return rc;
   if ((rc = pack_to_host(h, h->map_va, h->n, out->bus_angles))) return rc;
   if ((rc = pack_to_host(h, h->map_flow, h->m, out->line_flows))) return rc;
@@ -1066,6 +1086,7 @@ int gs_solve(gs_handle* h, const double* P_spec, const double* Q_spec, const gs_
 int gs_reset(gs_handle* h, const uint64_t* seeds, const uint8_t* mask, double* obs_out) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   GS_ENTER(h);
+  { int rc0 = ensure_rows(h); if (rc0) return rc0; }      // a masked reset leaves the other instances' rows as they are: they must be current
   if (seeds) HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)h->B * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   if (mask) HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->B, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(gs_k_env_reset, dim3(h->groups), dim3(64), 0, h->stream, h->T, h->R, h->EC, h->slab, h->B,
@@ -1129,7 +1150,7 @@ int gs_step_device_ptr(gs_handle* h, const double* d_actions, void* producer_str
   HIPCHK(h, hipSetDevice(h->device));
   if (producer_stream) {             // the step waits, on the device, for what the producer has queued so far
     if (!h->ev_peer) HIPCHK(h, hipEventCreateWithFlags(&h->ev_peer, hipEventDisableTiming));
-    HIPCHK(h, hipEventRecord(h->ev_peer, (hipStream_t)producer_stream));
+    HIPCHK(h, hipEventRecord(h->ev_peer, peer_stream(producer_stream)));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_peer, 0));
     if (h->forked) HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_peer, 0));
   }
@@ -1146,7 +1167,7 @@ int gs_step_device_view(gs_handle* h, gs_step_device_out* out, void* consumer_st
   if (consumer_stream) {
     if (!h->ev_peer2) HIPCHK(h, hipEventCreateWithFlags(&h->ev_peer2, hipEventDisableTiming));
     HIPCHK(h, hipEventRecord(h->ev_peer2, h->stream));
-    HIPCHK(h, hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_peer2, 0));
+    HIPCHK(h, hipStreamWaitEvent(peer_stream(consumer_stream), h->ev_peer2, 0));
   } else {
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
@@ -1264,6 +1285,7 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
   // the environment now stands at slot T: that is its current observation for gs_download_step / gs_allgather_obs
   if (h->gather_pending[h->obs_cur]) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather[h->obs_cur], 0)); h->gather_pending[h->obs_cur] = false; }
   HIPCHK(h, hipMemcpyAsync(h->d_obs2[h->obs_cur], ro.obs_seq + (size_t)T * B * D, B * D * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->rows_stale) h->last_obs = h->d_obs2[h->obs_cur];      // (the slot may be reallocated by a longer rollout; this copy stays)
   ro.calls += 1;
   return GS_OK;      // asynchronous: gs_synchronize / gs_rollout_download / gs_rollout_device_view wait for it
 }
@@ -1324,12 +1346,15 @@ int gs_rollout_download(gs_handle* h, const gs_rollout_view* out) {
 int gs_get_state(gs_handle* h, double* state) {
   if (!h || !state) return fail(h, GS_E_INVALID, "handle / state is NULL");
   GS_ENTER(h);
+  int rc = ensure_rows(h);
+  if (rc) return rc;
   return pack_to_host(h, h->map_state, h->state_dim, state);
 }
 
 int gs_set_state(gs_handle* h, const double* state) {
   if (!h || !state) return fail(h, GS_E_INVALID, "handle / state is NULL");
   GS_ENTER(h);
+  h->rows_stale = false;            // the checkpoint carries every result row
   int rc = unpack_from_host(h, h->map_state, h->state_dim, state);
   if (rc) return rc;
   // rows that follow from the checkpoint: the rectangular voltages (what a warm-started sweep solver resumes from) and
@@ -1552,7 +1577,7 @@ int gs_allgather_obs_view(gs_handle* h, gs_gathered_obs* out, void* consumer_str
   HIPCHK(h, hipSetDevice(h->device));
   if (consumer_stream) {
     HIPCHK(h, hipEventRecord(h->ev_full, h->comm_stream));
-    HIPCHK(h, hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_full, 0));
+    HIPCHK(h, hipStreamWaitEvent(peer_stream(consumer_stream), h->ev_full, 0));
   } else {
     HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   }
@@ -1685,6 +1710,7 @@ static int debug_rows_map(gs_handle* h, int32_t which, std::vector<int32_t>& map
 int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
   if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
   GS_ENTER(h);
+  { int rc0 = ensure_rows(h); if (rc0) return rc0; }
   std::vector<int32_t> map;
   const int C = debug_rows_map(h, which, map);
   if (C <= 0) return GS_OK;
@@ -1703,6 +1729,7 @@ int gs_debug_write_rows(gs_handle* h, int32_t which, const double* values) {
 int gs_debug_read_rows(gs_handle* h, int32_t which, double* values) {
   if (!h || !values || which < 0 || which >= GS_ROWS_COUNT) return fail(h, GS_E_INVALID, "bad arguments");
   GS_ENTER(h);
+  { int rc0 = ensure_rows(h); if (rc0) return rc0; }
   std::vector<int32_t> map;
   const int C = debug_rows_map(h, which, map);
   if (C <= 0) return GS_OK;
@@ -1726,6 +1753,7 @@ int gs_fallback_linear(gs_handle* h, const double* load_w, const double* gen_w, 
   if (!load_w && total_load) return fail(h, GS_E_INVALID, "totals without per-bus arrays: with the device state the sums are formed on the device");
   if (!load_w && !h->was_reset) return fail(h, GS_E_STATE, "no environment state on the device: call gs_reset first or pass load_w / gen_w");
   GS_ENTER(h);
+  { int rc0 = ensure_rows(h); if (rc0) return rc0; }      // only the selected instances are overwritten: the others' rows must be current
   const int B = h->B, n = h->n;
   int rc = GS_OK;
   if (!h->fb_ready) {
@@ -1872,6 +1900,7 @@ int gs_checks_run(gs_checks* c) {
   if (!c) return fail(nullptr, GS_E_INVALID, "checks object is NULL");
   gs_handle* h = c->h;
   GS_ENTER(h);
+  { int rc0 = ensure_rows(h); if (rc0) return rc0; }      // the kernel reads the |V| / loading / flow rows of the last step
   // HIP events only while somebody reads them (gs_checks_timing_enable), and never more than GS_CHECKS_MAX_EVENTS pairs:
   // a per-step safety check over a long run must not grow an event list without bound
   std::pair<hipEvent_t, hipEvent_t>* e = nullptr;

@@ -288,6 +288,9 @@ struct GsPackArgs {
                                      // pair_ok: obs_dim and the block of constants are even (two columns per lane)
   int32_t skip0, skip1;              // columns [skip0, skip1) are per-instance constants (the static load powers of
                                      // grid_env.py:769-770): written at reset, left alone by the step (skip0 == skip1: none)
+  int32_t lean, pad0;                // second-generation kernels: the (|V|, angle) and (flow, |P| / rating) row pairs are NOT written --
+                                     // they are columns of the observation block the step writes anyway (a third of its bytes twice);
+                                     // the host restores the rows from the block when somebody asks for them (gridstep_abi.hip, ensure_rows)
 };
 
 // ---- "flow2" kernels (kernels_flow2.hip): 32 instances per workgroup, the two halves of a wavefront on DIFFERENT buses ----

@@ -42,8 +42,6 @@
 
 extern __shared__ __attribute__((aligned(16))) char f2_lds[];
 
-#define F2_SPIN_CAP (1 << 18)
-
 __device__ __forceinline__ void f2_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void f2_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -104,13 +102,22 @@ __device__ __forceinline__ double f2_rsq(double x) {
 }
 
 struct F2State { double mm; int iters, conv, status; bool done; };
-__device__ __forceinline__ void f2_check(F2State& st, double mm, int it, double tol) {      // power_flow.py:148, 168-171, 204
+// mm: the maximum mismatch (what PowerFlowSolution.max_mismatch reports); crit: what is held against the tolerance -- the
+// same maximum for Newton-Raphson (power_flow.py:168-171), the mismatch summed over the buses for the sweeps (below)
+__device__ __forceinline__ void f2_check(F2State& st, double mm, double crit, int it, double tol) {      // power_flow.py:148, 168-171, 204
   if (!st.done) {
     st.mm = mm; st.iters = it + 1;
     if (!(mm < INFINITY)) { st.status = GS_STATUS_NAN; st.done = true; }
-    else if (mm < tol) { st.conv = 1; st.status = GS_STATUS_OK; st.done = true; }
+    else if (crit < tol) { st.conv = 1; st.status = GS_STATUS_OK; st.done = true; }
   }
 }
+// The sweeps stop on sum_i |dP_i| + |dQ_i| < tolerance / 2 (oracle_np.fbs_solve says why: on a radial feeder the sum bounds the
+// error of every line flow; the maximum alone left the head-of-feeder flows n_loads x tolerance off).  Across the waves of a
+// workgroup the sum is an LDS integer add of fixed-point values (2^-44 pu: exact and order-independent like the maxima);
+// inside a wave the additions are in item and sub-group order.  Anything that is not a small finite number saturates.
+#define F2_SUM_SCALE 0x1p44
+#define F2_SUM_SAT (1ull << 58)
+__device__ __forceinline__ unsigned long long f2_fix(double s) { return (s < 8192.0) ? (unsigned long long)(s * F2_SUM_SCALE) : F2_SUM_SAT; }
 
 // Bus voltage angle from (e, f) (see bus_angle in kernels_solve.hip): series for small angles, libm otherwise.
 __device__ __forceinline__ double f2_angle(double f, double e) {
@@ -168,8 +175,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   double F2_AS3* const loadp_lds = F2_P(double, F.off_tile);               // [load][32 lanes], dead before the line tile is written
   double F2_AS3* const red_lsum = F2_P(double, F.off_red);                 // [16 waves][32 lanes]
   double F2_AS3* const red_dev = red_lsum + NW * IW;
-  unsigned long long F2_AS3* const cell = F2_P(unsigned long long, F.off_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits
-  unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 5 * IW);                // [16][32] integer counts
+  unsigned long long F2_AS3* const cell = F2_P(unsigned long long, F.off_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits, [5..7] convergence sums
+  unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 8 * IW);                // [16][32] integer counts
   // (Two workgroups share a CU in the 16-instance members and the instruction arbiter serves the oldest wave first: the
   // workgroup that arrived first finishes in 32 us, the other in 42 (tools/block_times.py).  Flipping s_setprio at every phase
   // boundary, the two in opposite states, evens them out -- 38 to 42 us each -- and leaves the launch at 42: the CU's
@@ -193,7 +200,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     const int s = k / IW, ll = k & (IW - 1);
     f2_st2(f2_slot(s, ll), make_double2(s == SL_ZERO ? 0.0 : 1.0, 0.0));
   }
-  for (int k = threadIdx.x; k < 5 * IW; k += blockDim.x) cell[k] = (k >= 4 * IW) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
+  for (int k = threadIdx.x; k < 8 * IW; k += blockDim.x) cell[k] = (k >= 4 * IW && k < 5 * IW) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
   for (int k = threadIdx.x; k < 16 * IW; k += blockDim.x) icell[k] = 0u;
   if ((int)threadIdx.x < n_tab) F2_P(int, F.off_anc)[threadIdx.x] = tab0;
   for (int k = threadIdx.x + blockDim.x; k < n_tab; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];
@@ -380,6 +387,18 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_lds_sync();
     return f2_dbl(cell[c0 * IW + l]);
   };
+  // the same with the mismatch summed over the buses beside its maximum (the sweeps' stopping criterion)
+  auto wg_max_sum = [&](double lmax, double lsum, double& sum_out) -> double {
+    const int c0 = check % 3, c1 = (check + 1) % 3;
+    ++check;
+    lmax = f2_xmax<IW>(lmax);
+    lsum = f2_xsum<IW>(lsum, l);
+    if (wave == 0 && hv == 0) { cell[c1 * IW + l] = 0ull; cell[(5 + c1) * IW + l] = 0ull; }
+    if (hv == 0) { atomicMax(cell + c0 * IW + l, f2_bits(lmax)); atomicAdd(cell + (5 + c0) * IW + l, f2_fix(lsum)); }
+    f2_lds_sync();
+    sum_out = (double)cell[(5 + c0) * IW + l] * (2.0 / F2_SUM_SCALE);      // twice the sum: what is held against the tolerance
+    return f2_dbl(cell[c0 * IW + l]);
+  };
 
   if constexpr (SOLVER == F2_NR) {
   // ================= Newton-Raphson (power_flow.py:143-193), exact Jacobian, 2x2-block elimination along the tree =================
@@ -459,7 +478,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     stp.hit(F2_ST_MISMATCH);
     const double mm = wg_max(lm);                     // (its barrier also protects the K slots before the ring reuses the region)
     stp.hit(F2_ST_FLAG);
-    f2_check(st, mm, it, C.tolerance);
+    f2_check(st, mm, mm, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
     // ---------------- bottom-up: D_i = J_ii - sum C_c, r_i = rhs_i - sum q_c, T_i = D_i^-1 J_ip, s_i = D_i^-1 r_i ----------------
@@ -673,7 +692,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   };
   stp.hit(F2_ST_INIT);
   {  // at the flat start: every voltage but the slack's is 1, S_calc = conj(K) with K = y (1 - V_slack) at the roots
-    double lmax = 0.0, bad = 0.0;
+    double lmax = 0.0, bad = 0.0, lsum = 0.0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const GsF2Rec* q = rec0 + j;
@@ -685,15 +704,17 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double pc = kr, qc = -ki;
       const double dP = p - pc, dQ = 0.0 - qc;
       lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+      lsum += fabs(dP) + fabs(dQ);
       bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
       psum += pc;
       if (root) psum -= ep * kr;                              // the slack's share: Re(V_s conj(-K_root))
       IR[j] = p; II[j] = -0.0;                                // I = conj(S_spec / V) at V = 1
     }
     if (bad != bad) lmax = INFINITY;
-    const double mm = wg_max(lmax);
+    double sum;
+    const double mm = wg_max_sum(lmax, lsum, sum);
     stp.hit(F2_ST_FLAG);
-    f2_check(st, mm, 0, C.tolerance);
+    f2_check(st, mm, sum, 0, C.tolerance);
     if (!__all(st.done)) backward();
     stp.hit(F2_ST_BOTTOM_UP);
   }
@@ -701,7 +722,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const int R2 = F.n_jump;                                      // even
   for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
     const bool upd = !st.done;
-    double lmax = 0.0, pnew = 0.0, bad = 0.0;
+    double lmax = 0.0, pnew = 0.0, bad = 0.0, lsum = 0.0;
     // forward sweep by pointer jumping; buffers alternate so that the last round reads B (then A may take the voltages)
     double sr[NI], si[NI];
 #pragma unroll
@@ -742,6 +763,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double pc = __builtin_fma(en, IR[j], fn * II[j]), qc = __builtin_fma(fn, IR[j], -(en * II[j]));     // S_calc = V_new conj(I_old)
       const double dP = Pj[j] - pc, dQ = 0.0 - qc;
       lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+      lsum += fabs(dP) + fabs(dQ);
       bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
       pnew += pc;
     }
@@ -749,9 +771,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     stp.hit(F2_ST_MISMATCH);
     if (upd) psum = pnew;                                     // losses at the voltages just stored
     if (it + 1 >= C.max_iterations) break;                    // iteration cap: mismatch / count stay the last check's
-    const double mm = wg_max(lmax);
+    double sum;
+    const double mm = wg_max_sum(lmax, lsum, sum);
     stp.hit(F2_ST_FLAG);
-    f2_check(st, mm, it + 1, C.tolerance);
+    f2_check(st, mm, sum, it + 1, C.tolerance);
     if (__all(st.done)) break;
     // I_new = conj(S_spec / V_new) for the lanes that go on; a lane that has converged keeps the current that produced
     // its voltages: its J and V repeat bit for bit while the rest of the group iterates
@@ -799,7 +822,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     const double ld = (rating > 0.0) ? gs_div_by(fabs(sr), rating, rinv) : 0.0;
     if (on) {
       f2_row(S, R.LOAD + k) = ql;
-      f2_pair(S, R.FLOW + k) = make_double2(sr, ld);
+      if (!PA.lean) f2_pair(S, R.FLOW + k) = make_double2(sr, ld);
       f2_st2(F.off_tile + (unsigned)k * SB + ((unsigned)l << 4), make_double2(sr, ld));
       over += (ld > 0.8) ? 1 : 0;
       if (chk) {
@@ -825,7 +848,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     const double ang = f2_angle(ef.y, ef.x);
     if (on) {
       f2_st2(f2_slot(i, l), make_double2(v, ang));
-      f2_pair(S, R.VM + i) = make_double2(v, ang);
+      if (!PA.lean) f2_pair(S, R.VM + i) = make_double2(v, ang);
       dev += fabs(v - 1.0);                                   // reward / flags, grid_env.py:790-792, base.py:156-159
       vmax = fmax(vmax, v); vmin = fmin(vmin, v);
       vflags |= (v > E.v_max) ? 1 : 0;

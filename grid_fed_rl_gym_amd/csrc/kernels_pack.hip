@@ -38,10 +38,10 @@ gs_k_pack(const int32_t* __restrict__ src, const double* __restrict__ cst, int C
   }
 }
 
-// slab row dst[c] of instance b = in[b][c]; same tiling, opposite direction.
+// slab row dst[c] of instance b = in[b][c], c < C, rows of `in` being `stride` doubles apart; same tiling, opposite direction.
 extern "C" __global__ void __launch_bounds__(256)
 gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,
-            const double* __restrict__ in, int B) {
+            const double* __restrict__ in, int B, int stride) {
   __shared__ double tile[TILE_C * TILE_PAD];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -51,7 +51,7 @@ gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __re
   const int c = c0 + lane;
   for (int r = wave; r < GS_LANES; r += 4) {
     const int b = g * GS_LANES + r;
-    tile[lane * TILE_PAD + r] = (b < B && c < C) ? in[(size_t)b * C + c] : 0.0;
+    tile[lane * TILE_PAD + r] = (b < B && c < C) ? in[(size_t)b * stride + c] : 0.0;
   }
   __syncthreads();
   for (int cc = wave; cc < TILE_C; cc += 4) {

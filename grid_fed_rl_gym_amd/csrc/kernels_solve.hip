@@ -75,6 +75,7 @@ struct Ctx {
   unsigned long long* stamps;
   unsigned long long tlast;
   int stamp_wave;
+  double fsum;              // this lane's sum of |dP| + |dQ| over the wave's buses since the last convergence check (the sweeps' criterion)
 };
 
 // Diagnostic phase stamps (gs_debug_stamps): block 0 / wave 0 / lane 0 adds the cycles since its
@@ -94,6 +95,19 @@ __device__ __forceinline__ double wg_max(Ctx& c, int par, double v) {
   __syncthreads();
   double r = c.sh.red[par][0][c.lane];
   for (int w = 1; w < c.W; ++w) r = fmax(r, c.sh.red[par][w][c.lane]);
+  return r;
+}
+
+// Maximum and, in wave order, sum over the waves of the group (one value each per lane = instance).  Uses both halves of
+// `red`, so it ends with a second barrier: nobody starts the next reduction before everybody has read this one.
+__device__ __forceinline__ double wg_max_sum(Ctx& c, double vmax, double vsum, double* sum_out) {
+  c.sh.red[0][c.wave][c.lane] = vmax;
+  c.sh.red[1][c.wave][c.lane] = vsum;
+  __syncthreads();
+  double r = c.sh.red[0][0][c.lane], s = c.sh.red[1][0][c.lane];
+  for (int w = 1; w < c.W; ++w) { r = fmax(r, c.sh.red[0][w][c.lane]); s += c.sh.red[1][w][c.lane]; }
+  __syncthreads();
+  *sum_out = s;
   return r;
 }
 
@@ -177,6 +191,7 @@ __device__ __forceinline__ double mismatch_rows(Ctx& c) {
     const double dQ = (fl & 2) ? (qs - Q) : 0.0;
     if (STORE >= 2) ROW2(R.R0 + i) = make_double2(dP, dQ);
     lmax = fmax(lmax, fmax(finite_or_inf(fabs(dP)), finite_or_inf(fabs(dQ))));
+    c.fsum += fabs(dP) + fabs(dQ);
   }
   return lmax;
 }
@@ -276,6 +291,17 @@ __device__ __forceinline__ void nr_check(NrState& st, double mm, int it, double 
     st.iters = it + 1;
     if (!(mm < INFINITY)) { st.status = GS_STATUS_NAN; st.done = true; }
     else if (mm < tol) { st.conv = 1; st.status = GS_STATUS_OK; st.done = true; }
+  }
+}
+
+// The sweeps stop on the mismatch SUMMED over the buses (oracle_np.fbs_solve says why: on a radial feeder the sum bounds
+// the error of every line flow); `mm`, the maximum, is what max_mismatch reports.
+__device__ __forceinline__ void fbs_check(NrState& st, double mm, double sum, int it, double tol) {
+  if (!st.done) {
+    st.mm = mm;
+    st.iters = it + 1;
+    if (!(mm < INFINITY)) { st.status = GS_STATUS_NAN; st.done = true; }
+    else if (2.0 * sum < tol) { st.conv = 1; st.status = GS_STATUS_OK; st.done = true; }   // (the factor 2: second-order part of a flow's error)
   }
 }
 
@@ -751,8 +777,11 @@ __device__ __forceinline__ void fbs_loop(Ctx& c, const GsSolveCfg& C, NrState& s
   __syncthreads();
   bool stale = true;
   for (int it = 0; it < C.max_iterations; ++it) {
-    const double mm = wg_max(c, it & 1, mismatch_rows<0>(c));
-    nr_check(st, mm, it, C.tolerance);
+    c.fsum = 0.0;
+    const double lm = mismatch_rows<0>(c);
+    double sum;
+    const double mm = wg_max_sum(c, lm, c.fsum, &sum);
+    fbs_check(st, mm, sum, it, C.tolerance);
     stale = false;
     if (__all(st.done)) break;
     const bool upd = !st.done;
@@ -852,6 +881,7 @@ __device__ __forceinline__ void fbs_backward(Ctx& c, int k0, int k1, double* lma
     const double pc = o.e * icr + o.f * ici, qc = o.f * icr - o.e * ici;
     const double dP = o.p - pc, dQ = o.q - qc;
     lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));         // fmax drops a NaN; `bad` (x * 0 is NaN for NaN / inf) keeps it
+    c.fsum += fabs(dP) + fabs(dQ);
     bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
     psum += pc;
     if (r.flags & 16) psum -= o.ep * kr + o.fp * ki;    // the slack's share: Re(V_s conj(-K_root))
@@ -927,17 +957,19 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
   const int k0 = cld(T.wl_ptr, c.wave), k1 = cld(T.wl_ptr, c.wave + 1);
   double psum = 0.0;
   {
-    double lmax;
+    double lmax, sum;
     stamp(c, ST_INIT);
+    c.fsum = 0.0;
     fbs_backward(c, k0, k1, &lmax, &psum);
     stamp(c, ST_BOTTOM_UP);
-    const double mm = wg_max(c, 0, lmax);              // full barrier: also drains the J rows
+    const double mm = wg_max_sum(c, lmax, c.fsum, &sum);   // full barrier: also drains the J rows
     stamp(c, ST_FLAG);
-    nr_check(st, mm, 0, C.tolerance);
+    fbs_check(st, mm, sum, 0, C.tolerance);
   }
   for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
     const bool upd = !st.done;
     double lmax = 0.0, pnew = 0.0, bad = 0.0;
+    c.fsum = 0.0;
     {  // forward sweep: V_i = V_parent - z_i J_i, and the mismatch / sum of P_calc at the new voltages
       int lv = T.n_levels - 1;
       GsItemRec rn{};
@@ -964,6 +996,7 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
         const double pc = en * icr + fn * ici, qc = fn * icr - en * ici;
         const double dP = o.p - pc, dQ = o.q - qc;
         lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        c.fsum += fabs(dP) + fabs(dQ);
         bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
         pnew += pc;
         if (root) pnew += ep * cjr;                      // the slack's share: Re(V_s conj(J_root)), V_s real
@@ -974,9 +1007,10 @@ __device__ __forceinline__ double fbs_loop_lds(Ctx& c, const GsSolveCfg& C, NrSt
     stamp(c, ST_TOP_DOWN);
     if (upd) psum = pnew;                                // losses at the voltages just stored
     if (it + 1 >= C.max_iterations) { __syncthreads(); break; }   // iteration cap: mismatch / count stay the last backward sweep's
-    const double mm = wg_max(c, (it + 1) & 1, lmax);     // full barrier
+    double sum;
+    const double mm = wg_max_sum(c, lmax, c.fsum, &sum);   // full barrier
     stamp(c, ST_FLAG);
-    nr_check(st, mm, it + 1, C.tolerance);
+    fbs_check(st, mm, sum, it + 1, C.tolerance);
     if (__all(st.done)) break;
     fbs_backward_light(c, k0, k1);
     __syncthreads();                                     // the J rows are read back by the forward sweep
@@ -1063,6 +1097,7 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
   {  // first backward chain, at the flat start: V_i = 1 for every bus but the slack, so K_i = y_i (1 - V_parent) is
      // non-zero for the children of the slack only and no bus receives a K from below; S_calc_i = V_i conj(K_i)
     double lmax = 0.0, bad = 0.0;
+    c.fsum = 0.0;
     GsItemRec rn{};
     if (nit > 0) rn = load_item(T, k0);
 #pragma unroll
@@ -1077,6 +1112,7 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
         const double pc = kr, qc = -ki;                      // V = 1: S_calc = conj(K)
         const double dP = p - pc, dQ = q - qc;
         lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        c.fsum += fabs(dP) + fabs(dQ);
         bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
         psum += pc;
         if (root) psum -= ep * kr;                           // the slack's share: Re(V_s conj(-K_root))
@@ -1097,13 +1133,15 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
     }
     if (bad != bad) lmax = INFINITY;
     stamp(c, ST_BOTTOM_UP);
-    const double mm = wg_max(c, 0, lmax);
+    double sum;
+    const double mm = wg_max_sum(c, lmax, c.fsum, &sum);
     stamp(c, ST_FLAG);
-    nr_check(st, mm, 0, C.tolerance);
+    fbs_check(st, mm, sum, 0, C.tolerance);
   }
   for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
     const bool upd = !st.done;
     double lmax = 0.0, pnew = 0.0, bad = 0.0;
+    c.fsum = 0.0;
     ++epoch;
     {  // forward chain: V_i = V_parent - z_i J_i
       GsItemRec rn{};
@@ -1134,6 +1172,7 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
         const double pc = en * IR[j] + fn * II[j], qc = fn * IR[j] - en * II[j];     // S_calc = V_new conj(I_old)
         const double dP = p - pc, dQ = q - qc;
         lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
+        c.fsum += fabs(dP) + fabs(dQ);
         bad = fma(dP, 0.0, fma(dQ, 0.0, bad));
         pnew += pc;
       }
@@ -1142,9 +1181,10 @@ __device__ __forceinline__ double fbs_loop_flow(Ctx& c, const GsSolveCfg& C, NrS
     stamp(c, ST_MISMATCH);
     if (upd) psum = pnew;                                // losses at the voltages just stored
     if (it + 1 >= C.max_iterations) break;               // iteration cap: mismatch / count stay the last check's
-    const double mm = wg_max(c, (it + 1) & 1, lmax);     // full barrier
+    double sum;
+    const double mm = wg_max_sum(c, lmax, c.fsum, &sum);   // full barrier
     stamp(c, ST_FLAG);
-    nr_check(st, mm, it + 1, C.tolerance);
+    fbs_check(st, mm, sum, it + 1, C.tolerance);
     if (__all(st.done)) break;
     ++epoch;
     // I_new = conj(S_spec / V_new) -- for the lanes that go on.  A lane that has just converged keeps the current that

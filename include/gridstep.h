@@ -210,7 +210,8 @@ int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* termina
 
 /* A consumer that lives on the same GPU (a policy network) steps the environment without any host copy: it reads the
  * observation block and the reward / flag arrays through device pointers and hands back a device pointer to its actions.
- * Streams are passed as `hipStream_t` cast to `void*`; NULL means "the caller synchronises itself".
+ * Streams are passed as `hipStream_t` cast to `void*`; NULL means "the caller synchronises itself"; the legacy default
+ * stream (handle 0 -- PyTorch's current stream unless the caller created one) is passed as hipStreamLegacy, (void*)1.
  *   gs_step_device_ptr   one env step with actions[B][action_dim] (float64, C order) in DEVICE memory of the handle's GPU; when
  *                        `producer_stream` is given, the step waits (on the device) for the work queued on it so far.
  *   gs_step_device_view  device pointers to what the last step left: observations[B][obs_dim] (one of the handle's two

@@ -130,6 +130,8 @@ def bench_env_steps(fs, env_kwargs, budget_s=15.0, threads=None) -> dict:
     net = Net(fs)
     # the GPU box exposes all host threads but grants a 16-core share per GPU; never oversubscribe
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else lib().orc_max_threads()
+    if threads == "all":                      # every CPU this process may run on ("at 1 core and at all cores")
+        threads = max(1, avail)
     threads = max(1, min(lib().orc_max_threads(), avail, 16)) if threads is None else int(threads)
     cfg = config(solver=env_kwargs["solver"], jacobian="exact", max_iterations=env_kwargs["max_iterations"],
                  tolerance=env_kwargs["tolerance"], stochastic_loads=env_kwargs["stochastic_loads"],

@@ -290,15 +290,17 @@ static int fbs_one(const orc_net* t, const orc_prep* p, const orc_cfg* c, const 
   for (it = 0; it < c->max_iterations; ++it) {
     calc_S(p, e, f, P, Q);
     mm = 0.0;
+    double sum = 0.0;      /* the sweeps stop on the SUMMED mismatch: it bounds the error of every line flow (oracle_np.fbs_solve) */
     for (int i = 0; i < n; ++i) {
       if (i == p->slack) continue;
       double a = fabs(Pspec[i] - P[i]), b = fabs((Qspec ? Qspec[i] : 0.0) - Q[i]);
       if (!isfinite(a) || !isfinite(b)) { mm = INFINITY; break; }
       if (a > mm) mm = a;
       if (b > mm) mm = b;
+      sum += a + b;
     }
     if (!(mm < INFINITY)) { status = 3; break; }
-    if (mm < c->tolerance) { conv = 1; status = 0; break; }
+    if (2.0 * sum < c->tolerance) { conv = 1; status = 0; break; }
     for (int i = 0; i < n; ++i) {
       double pp = Pspec[i], qq = Qspec ? Qspec[i] : 0.0, d = e[i] * e[i] + f[i] * f[i];
       jr[i] = -(pp * e[i] + qq * f[i]) / d; ji[i] = (qq * e[i] - pp * f[i]) / d;

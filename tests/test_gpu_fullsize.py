@@ -94,6 +94,28 @@ def test_full_size_newton_raphson_batch_satisfies_the_power_flow_equations():
         solver.close()
 
 
+@pytest.mark.parametrize("maker,B", [(lambda: P.random_meshed(123, 26, seed=1), 8192),      # 26 loops: IEEE123Bus's cycle count (ieee_feeders.py:236-330)
+                                     (lambda: P.scalable_like(123, seed=1), 2048)])          # ScalableFeeder(123) recipe (synthetic.py:233): ~1000 lines
+def test_full_size_meshed_newton_raphson_satisfies_the_power_flow_equations(maker, B):
+    """Meshed networks at bench size: the sparse block LU's answer re-evaluated with the oracle's dense Ybus
+    (S = V conj(Y V)), the loss identity, and an instance's independence of its batch."""
+    spec = maker()
+    assert not spec.is_radial()
+    base = np.zeros(spec.n)
+    np.add.at(base, spec.load_bus, -spec.load_base / spec.base_power_va)
+    lam = np.random.default_rng(5).uniform(0.5, 1.5, B)
+    Pb = lam[:, None] * base[None, :]
+    solver = P.BatchedNewtonRaphsonSolver(tolerance=1e-8, max_iterations=30, jacobian="exact")
+    sol = solver.solve_batch(spec, Pb)
+    d = dict(bus_voltages=sol.bus_voltages, bus_angles=sol.bus_angles, converged=sol.converged, losses=sol.losses)
+    _check_solution_against_power_flow_equations(spec, d, Pb, 1e-8)
+    assert sol.iterations.max() <= 6
+    sub = solver.solve_batch(spec, np.vstack([Pb[B - 70:], Pb[:58]]))          # other neighbours, other lanes
+    np.testing.assert_array_equal(sub.bus_voltages[:70], sol.bus_voltages[B - 70:])
+    np.testing.assert_array_equal(sub.bus_angles[70:], sol.bus_angles[:58])
+    solver.close()
+
+
 def test_full_size_three_phase_batch_properties():
     """BASELINE config 5: 8500 nodes, three-phase, B = 1024."""
     from grid_fed_rl_gym_amd.unbalanced import UnbalancedPowerFlow, ieee8500_like
@@ -122,15 +144,20 @@ def test_full_size_three_phase_batch_properties():
 @pytest.mark.parametrize("maker,solver,bar", [(lambda: P.ieee123_like(), "fbs", 1e-6),            # BASELINE config 3 (headline)
                                               (lambda: P.ieee123_like(), "nr", 1e-6),
                                               (lambda: P.ieee13_like("epsilon"), "nr", 1e-6),      # BASELINE config 2
-                                              (lambda: P.ieee13_like("epsilon"), "fbs", 5e-6)])    # not a BASELINE config, see below
+                                              (lambda: P.ieee13_like("epsilon"), "fbs", 1e-6)])
 def test_north_star_accuracy_bar_against_the_reference_algorithm_at_its_own_settings(maker, solver, bar):
     """north_star: "bus voltages and line flows within 1e-6 pu of the reference NumPy/CPU solver".  The reference's solver
     is Newton-Raphson stopping at a 1e-6 mismatch (power_flow.py:81, 168-171); the oracle runs exactly that, the GPU runs
-    the benchmark's configuration (either solver, tolerance 1e-6) on the same instances, steps and draws.  Same algorithm:
-    1e-13.  The sweep solver on the headline feeder: 4.5e-7.  What is NOT asserted at 1e-6: against the CONVERGED solution
-    the reference itself, at its own tolerance, sits 1.3e-6 away in the flows, and two different algorithms that both stop
-    at a 1e-6 mismatch can differ by a few 1e-6 -- the sweep solver on the more heavily loaded 13-bus feeder: 2.8e-6 in
-    the flows (held to 5e-6 here; a caller who needs 1e-6 there sets tolerance <= 3e-8, one sweep more: DESIGN.md section 2)."""
+    the benchmark's configuration (either solver, tolerance 1e-6) on the same instances, steps and draws.
+
+    Newton-Raphson (the reference's algorithm): the same iterates, 1e-13 -- held to the bar against the reference's own output.
+
+    The sweep solver is a different algorithm, and the reference's output at ITS tolerance is an unconverged iterate: in
+    this workload (midday peak) its line flows sit 1.3e-6 pu from the solution of the power-flow equations, so no other
+    algorithm can be promised to land within 1e-6 of it.  What the sweep solver is held to: (1) within the bar of the
+    CONVERGED solution (oracle Newton-Raphson at 1e-12) in |V|, angle and flows -- it stops on the summed mismatch, which
+    bounds every line flow's error (round 3; with the maximum alone it stopped up to 6.7e-6 away) --, and (2) within the bar
+    PLUS the reference's own distance from convergence of the reference's output."""
     spec = maker(); B = 48
     env = P.BatchedGridEnvironment(spec, num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True, jacobian="exact",
                                    tolerance=1e-6, max_iterations=100 if solver == "fbs" else 50)
@@ -138,27 +165,65 @@ def test_north_star_accuracy_bar_against_the_reference_algorithm_at_its_own_sett
     env.reset(seed=seeds)
     st = env.get_state(); st[:, env.state_column("time")] = 11.5 * 3600.0; env.set_state(st)
     from tests.helpers import oracle_spec
-    ospec = oracle_spec(spec, solver="nr", jacobian_mode="exact", zero_z="open", tolerance=1e-6, max_iterations=50, stochastic_loads=True,
-                        weather_variation=True, power_base=spec.base_power_va)
-    states = []
-    for b in range(B):
-        _, s = O.env_reset(ospec, seed=int(seeds[b]), instance=b)
-        s.time = 11.5 * 3600.0
-        states.append(s)
+    common = dict(solver="nr", jacobian_mode="exact", zero_z="open", max_iterations=50, stochastic_loads=True, weather_variation=True,
+                  power_base=spec.base_power_va)
+    ospecs = {"ref": oracle_spec(spec, tolerance=1e-6, **common)}
+    if solver == "fbs":
+        ospecs["exact"] = oracle_spec(spec, tolerance=1e-12, **common)
+    states = {k: [] for k in ospecs}
+    for k, osp in ospecs.items():
+        for b in range(B):
+            _, s = O.env_reset(osp, seed=int(seeds[b]), instance=b)
+            s.time = 11.5 * 3600.0
+            states[k].append(s)
     rng = np.random.default_rng(4)
     n, m = spec.n, spec.m
-    worst = dict(Vm=0.0, Va=0.0, flow=0.0)
+    cols = dict(Vm=slice(0, 2 * n, 2), Va=slice(1, 2 * n, 2), flow=slice(2 * n, 2 * n + 2 * m, 2))
+    worst = {k: dict(Vm=0.0, Va=0.0, flow=0.0) for k in list(ospecs) + ["ref_vs_exact"]}
     for t in range(2):
         a = rng.uniform(-1, 1, (B, spec.action_dim))
         obs, *_ = env.step(a)
         for b in range(B):
-            ref, *_ = O.env_step(ospec, states[b], a[b])
-            ref = np.asarray(ref)
-            worst["Vm"] = max(worst["Vm"], np.abs(obs[b, 0:2 * n:2] - ref[0:2 * n:2]).max())
-            worst["Va"] = max(worst["Va"], np.abs(obs[b, 1:2 * n:2] - ref[1:2 * n:2]).max())
-            worst["flow"] = max(worst["flow"], np.abs(obs[b, 2 * n:2 * n + 2 * m:2] - ref[2 * n:2 * n + 2 * m:2]).max())
+            o = {k: np.asarray(O.env_step(ospecs[k], states[k][b], a[b])[0]) for k in ospecs}
+            for q, sl in cols.items():
+                for k in ospecs:
+                    worst[k][q] = max(worst[k][q], np.abs(obs[b, sl] - o[k][sl]).max())
+                if "exact" in o:
+                    worst["ref_vs_exact"][q] = max(worst["ref_vs_exact"][q], np.abs(o["ref"][sl] - o["exact"][sl]).max())
     env.close()
-    assert worst["Vm"] < bar and worst["Va"] < bar and worst["flow"] < bar, worst
+    if solver == "nr":
+        assert max(worst["ref"].values()) < bar, worst
+    else:
+        assert max(worst["exact"].values()) < bar, worst
+        for q in cols:
+            assert worst["ref"][q] < bar + worst["ref_vs_exact"][q], worst
+
+
+@pytest.mark.parametrize("maker", [lambda: P.ieee123_like(), lambda: P.ieee13_like("epsilon")])
+def test_sweep_solver_at_the_default_tolerance_meets_the_bar_over_a_loading_sweep(maker):
+    """The sweep solver at tolerance 1e-6 against (a) the reference's algorithm at its own settings (Newton-Raphson, 1e-6)
+    and (b) the solution converged to 1e-12, for loading levels 0.5 / 1.0 / 1.5 with 10 % noise on every load: |V| and
+    line flows within 1e-6 pu of both."""
+    spec = maker(); reps = 12
+    base = np.zeros(spec.n)
+    np.add.at(base, spec.load_bus, -spec.load_base / spec.base_power_va)
+    rng = np.random.default_rng(21)
+    lam = np.repeat([0.5, 1.0, 1.5], reps)
+    Pb = lam[:, None] * base[None, :] * (1.0 + 0.1 * rng.standard_normal((len(lam), spec.n)))
+    s = P.BatchedForwardBackwardSweepSolver(tolerance=1e-6, max_iterations=100)
+    sol = s.solve_batch(spec, Pb)
+    s.close()
+    assert sol.converged.all()
+    worst = dict(v_ref=0.0, f_ref=0.0, v_exact=0.0, f_exact=0.0)
+    for b in range(len(lam)):
+        a = (spec.n, spec.frm, spec.to, spec.r, spec.x, spec.rating, spec.bus_type, spec.v_set, Pb[b])
+        ref = O.nr_solve(*a, tolerance=1e-6, max_iterations=50, jacobian_mode="exact")
+        ex = O.nr_solve(*a, tolerance=1e-12, max_iterations=50, jacobian_mode="exact")
+        worst["v_ref"] = max(worst["v_ref"], np.abs(sol.bus_voltages[b] - ref["bus_voltages"]).max())
+        worst["f_ref"] = max(worst["f_ref"], np.abs(sol.line_flows[b] - ref["line_flows"]).max())
+        worst["v_exact"] = max(worst["v_exact"], np.abs(sol.bus_voltages[b] - ex["bus_voltages"]).max())
+        worst["f_exact"] = max(worst["f_exact"], np.abs(sol.line_flows[b] - ex["line_flows"]).max())
+    assert max(worst.values()) < 1e-6, worst
 
 
 def test_step_as_two_half_launches_on_two_streams_changes_nothing(monkeypatch):
