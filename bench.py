@@ -200,7 +200,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=500,
                     help="untimed steps before the first timed region (default 500 = 20 ms: the GPU's clocks take that long to settle "
                          "under this load -- with 5 warm-up steps the median over the regions reads 5 %% low and the p10 10 %% low)")
-    ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each; median / p10 / p90 are reported")
+    ap.add_argument("--repeats", type=int, default=40,
+                    help="timed regions of exactly --steps steps each, every one bracketed by barrier + device synchronisation; median / p10 / p90 "
+                         "are reported.  40 regions (round 3; 10 before): with the driver's `--steps 20 --warmup 5` ten regions of 0.9 ms all fall "
+                         "into the ~20 ms the GPU's clocks take to settle under this load, and the median read 10 %% below the sustained rate")
     ap.add_argument("--workload", default="ieee123_b8192", choices=sorted(WORKLOADS))
     ap.add_argument("--solver", default="", choices=["", "nr", "fbs"],
                     help="fbs = BASELINE.json config 3 (DistributionPowerFlow); nr = the reference's Newton-Raphson; default: the workload's")

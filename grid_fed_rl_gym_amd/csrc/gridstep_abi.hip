@@ -716,8 +716,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const int N = (int)order.size();
     int max_depth = 1;
     for (int i : order) max_depth = std::max(max_depth, depth[i]);
+    // forward sweep by pointer jumping, radix 4: round r adds the partial sums of the ancestors 4^r, 2 * 4^r and 3 * 4^r up
     int n_jump = 0;
-    while ((1 << n_jump) < max_depth) ++n_jump;
+    while ((1 << (2 * n_jump)) < max_depth) ++n_jump;
     n_jump = std::max(2, (n_jump + 1) & ~1);                         // even: the last round then reads the second buffer
     // small feeders: 8 instances per workgroup, the eight sub-groups of a wavefront on eight buses
     const bool small = N <= GS_F2S_WAVES * (64 / GS_F2S_IW) * GS_F2S_ITEMS && !getenv("GS_NO_FLOW2_SMALL");
@@ -729,7 +730,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
               IW = small ? GS_F2S_IW : (wide || half) ? GS_F2H_IW : 32;
     const int NPOS = NW * (64 / IW) * NI;
     GsF2Tables& F = h->F2;
-    const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl, 2);
+    const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl * 4, 2);
     F.n_jump = n_jump;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
     else if (N > NPOS) why = "more than " + std::to_string(NPOS) + " buses below the slack";
@@ -742,7 +743,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY;
       f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 2, 0.0);
-      f2anc.assign((size_t)n_jump * nsl, SL_ZERO);
+      f2anc.assign((size_t)n_jump * nsl * 4, SL_ZERO);            // [round][slot][4]: the slot's ancestors 1, 2, 3 steps of 4^round up (no ancestor: ZERO)
+      std::vector<int> up1((size_t)nsl, SL_ZERO);                    // parent slot of every slot (the slack's children: ZERO)
       for (int p = 0; p < N; ++p) {
         GsF2Rec& r = f2recs[p];
         const int i = order[p];
@@ -751,11 +753,21 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         r.bus = i; r.parent = fp; r.flags = 1 | (fp == ht.slack ? 2 : 0); r.last = order[p + size[i] - 1]; r.level = depth[i];
         r.zr = yr / yd; r.zi = -yi / yd; r.yr = yr; r.yi = yi;
         f2z[2 * (size_t)i] = r.zr; f2z[2 * (size_t)i + 1] = r.zi;
-        f2anc[i] = fp == ht.slack ? SL_ZERO : fp;
+        up1[i] = fp == ht.slack ? SL_ZERO : fp;
         f2_devices(r, i);
       }
-      for (int r = 1; r < n_jump; ++r)
-        for (int sidx = 0; sidx < nsl; ++sidx) f2anc[(size_t)r * nsl + sidx] = f2anc[(size_t)(r - 1) * nsl + f2anc[(size_t)(r - 1) * nsl + sidx]];
+      {
+        std::vector<int> step = up1;                                 // ancestor 4^round steps up
+        for (int r = 0; r < n_jump; ++r) {
+          for (int sidx = 0; sidx < nsl; ++sidx) {
+            int a = sidx;
+            for (int k = 0; k < 3; ++k) { a = step[a]; f2anc[((size_t)r * nsl + sidx) * 4 + k] = a; }
+          }
+          std::vector<int> nxt((size_t)nsl);
+          for (int sidx = 0; sidx < nsl; ++sidx) nxt[sidx] = step[step[step[step[sidx]]]];
+          step.swap(nxt);
+        }
+      }
     }
   }
 

@@ -66,17 +66,55 @@ __device__ __forceinline__ void f2_st(unsigned off, double v) { *F2_P(double, of
 #define atomicAdd(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define atomicOr(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 __device__ __forceinline__ double f2_xhalf(double v) { return __shfl_xor(v, 32); }      // the same instance's value in the other half
-// the same instance's values in all HV sub-groups of the wave: maximum, and sum in sub-group order (the same on every lane)
+// Cross-sub-group exchanges without the LDS pipe (a __shfl of a double is two ds_bpermute_b32; the sweeps are bound by LDS
+// instruction issue).  gfx950's swaps, with both operands the same register (tools/permlane_probe.hip checks this on the GPU):
+//   f2_halves32(x) = (x of lane i mod 32, x of lane 32 + i mod 32)                        v_permlane32_swap
+//   f2_rows16(x)   = (x of the EVEN 16-lane row of this lane's row pair, x of the ODD row) v_permlane16_swap
+struct F2Two { double a, b; };
+__device__ __forceinline__ F2Two f2_halves32(double x) {
+  const uint2 u = __builtin_bit_cast(uint2, x);
+  const auto lo = __builtin_amdgcn_permlane32_swap(u.x, u.x, false, false), hi = __builtin_amdgcn_permlane32_swap(u.y, u.y, false, false);
+  return F2Two{__builtin_bit_cast(double, make_uint2(lo[0], hi[0])), __builtin_bit_cast(double, make_uint2(lo[1], hi[1]))};
+}
+__device__ __forceinline__ F2Two f2_rows16(double x) {
+  const uint2 u = __builtin_bit_cast(uint2, x);
+  const auto lo = __builtin_amdgcn_permlane16_swap(u.x, u.x, false, false), hi = __builtin_amdgcn_permlane16_swap(u.y, u.y, false, false);
+  return F2Two{__builtin_bit_cast(double, make_uint2(lo[0], hi[0])), __builtin_bit_cast(double, make_uint2(lo[1], hi[1]))};
+}
+// the same instance's values in all HV sub-groups of the wave: maximum, and sum in a fixed order (the same on every lane:
+// sub-group order for IW = 32 and 8, (0 + 1) + (2 + 3) for the four sub-groups of IW = 16)
 template <int IW> __device__ __forceinline__ double f2_xmax(double v) {
+  if constexpr (IW == 32) { const F2Two t = f2_halves32(v); return fmax(t.a, t.b); }
+  else if constexpr (IW == 16) { const F2Two r = f2_rows16(v); const F2Two t = f2_halves32(fmax(r.a, r.b)); return fmax(t.a, t.b); }
+  else {
 #pragma unroll
-  for (int o = IW; o < 64; o <<= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+    for (int o = IW; o < 64; o <<= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+  }
 }
 template <int IW> __device__ __forceinline__ double f2_xsum(double v, int l) {
-  double s = __shfl(v, l);
+  if constexpr (IW == 32) { const F2Two t = f2_halves32(v); return t.a + t.b; }
+  else if constexpr (IW == 16) { const F2Two r = f2_rows16(v); const F2Two t = f2_halves32(r.a + r.b); return t.a + t.b; }
+  else {
+    double s = __shfl(v, l);
 #pragma unroll
-  for (int k = 1; k < 64 / IW; ++k) s += __shfl(v, k * IW + l);
-  return s;
+    for (int k = 1; k < 64 / IW; ++k) s += __shfl(v, k * IW + l);
+    return s;
+  }
+}
+// exclusive prefix over the sub-groups before this one (in sub-group order) and the total of all of them
+template <int IW> __device__ __forceinline__ void f2_xscan(double v, int l, int hv, double& pre, double& tot) {
+  if constexpr (IW == 32) { const F2Two t = f2_halves32(v); pre = hv ? t.a : 0.0; tot = t.a + t.b; }
+  else if constexpr (IW == 16) {
+    const F2Two r = f2_rows16(v);                      // (sub-group 0 | 2, sub-group 1 | 3) of this lane's pair
+    const F2Two t = f2_halves32(r.a + r.b);            // (0 + 1, 2 + 3)
+    pre = ((hv & 2) ? t.a : 0.0) + ((hv & 1) ? r.a : 0.0);
+    tot = t.a + t.b;
+  } else {
+    pre = 0.0; tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 64 / IW; ++k) { const double x = __shfl(v, k * IW + l); if (k < hv) pre += x; tot += x; }
+  }
 }
 __device__ __forceinline__ unsigned long long f2_bits(double v) { return __builtin_bit_cast(unsigned long long, v); }
 __device__ __forceinline__ double f2_dbl(unsigned long long b) { return __builtin_bit_cast(double, b); }
@@ -191,7 +229,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // round trips in a row, 9 k cycles = 13 % of the launch before the first useful instruction)
   double told = ROW(R.TIME), kold = ROW(R.STEP);
   uint64_t seed = lane_seed(S, R);
-  const int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl : F.n_anc_ints;      // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
+  const int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl * 4 : F.n_anc_ints;  // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
   const int n_z = (SOLVER == F2_FBS ? 2 : 4) * nsl;                        // z per bus; Newton-Raphson (G_ip, B_ip, G_ii, B_ii) per bus
   const int tab0 = (int)threadIdx.x < n_tab ? F.anc[threadIdx.x] : 0;
   const double z0 = (int)threadIdx.x < n_z ? F.zbus[threadIdx.x] : 0.0;
@@ -641,14 +679,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   //             a subtree is the contiguous range [p_i, last_i], so J_i = Q[last_i] - Q[p_i - 1] with Q the inclusive
   //             prefix sums of -I: a scan of <= 128 values per instance = local scan of a lane's items, the 16 wave
   //             totals through LDS, one barrier, offsets, Q to LDS, one barrier, one read.
-  //   forward   V_i = V_slack - sum of z_k J_k over the PATH root .. i.  Pointer jumping: S_i starts as D_i = z_i J_i
-  //             and in round r adds the S of the 2^r-th ancestor (ancestor tables from the host); ceil(log2 depth)
-  //             rounds, two LDS buffers in turn, a barrier per round.
+  //   forward   V_i = V_slack - sum of z_k J_k over the PATH root .. i.  Pointer jumping, radix 4: S_i starts as D_i = z_i J_i
+  //             and in round r adds the S of the ancestors 4^r, 2 * 4^r, 3 * 4^r steps up (ancestor tables from the host);
+  //             ceil(log4 depth) rounds, two LDS buffers in turn, a barrier per round.  (Round 2 jumped by powers of two:
+  //             four rounds for the IEEE-123 tree = three more LDS stores and two more barriers per bus and sweep.)
   // The sums associate differently from the sequential recurrences: results agree with them to a few ulp of |V|
   // (absolute ~1e-16 in J, ~1e-15 in V; the tests compare at 1e-12).
   const unsigned bufA = 0u, bufB = (unsigned)F.off_tile;
   f2_v2 F2_AS3* const tot_lds = F2_P(f2_v2, F.off_red);            // [16 waves][32 lanes] wave totals of the scan
-  const int F2_AS3* const anc_lds = F2_P(const int, F.off_anc);    // [n_jump][n_slots]
   // backward sweep: J of this lane's buses from the injection currents of all buses
   auto backward = [&]() {
     double qr[NI], qi[NI];
@@ -656,13 +694,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #pragma unroll
     for (int j = 0; j < NI; ++j) { ar += -IR[j]; ai += -II[j]; qr[j] = ar; qi[j] = ai; }      // local inclusive scan
     // totals of the sub-groups before this one inside the wave (in sub-group order), and of the whole wave
-    double pre_r = 0.0, pre_i = 0.0, wt_r = 0.0, wt_i = 0.0;
-#pragma unroll
-    for (int k = 0; k < HV; ++k) {
-      const double tr = __shfl(ar, k * IW + l), ti = __shfl(ai, k * IW + l);
-      if (k < hv) { pre_r += tr; pre_i += ti; }
-      wt_r += tr; wt_i += ti;
-    }
+    double pre_r, pre_i, wt_r, wt_i;
+    f2_xscan<IW>(ar, l, hv, pre_r, wt_r);
+    f2_xscan<IW>(ai, l, hv, pre_i, wt_i);
     if (hv == 0) { f2_v2 t; t.x = wt_r; t.y = wt_i; tot_lds[wave * IW + l] = t; }
     f2_lds_sync();
     double br = 0.0, bi = 0.0;                                    // sum of the totals of the waves before this one, in wave order
@@ -735,15 +769,19 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_lds_sync();
     for (int r = 0; r < R2; ++r) {
       const unsigned rd = (r & 1) ? bufB : bufA, wr = (r & 1) ? bufA : bufB;
-      // the ancestors' slots first, then their sums: two LDS round trips per round for all of the lane's buses together
-      unsigned ao[NI];
+      // radix 4: the partial sums of the ancestors 4^r, 2 * 4^r and 3 * 4^r steps up (one 16-byte table entry per bus and
+      // round), added in that order -- depth 16 in two rounds, one LDS store per bus between them
+      f2_i4 aq[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) ao[j] = f2_slot(anc_lds[r * nsl + ibus[j]], l);
-      double2 sa[NI];
+      for (int j = 0; j < NI; ++j) aq[j] = *F2_P(const f2_i4, (unsigned)F.off_anc + 16u * (unsigned)(r * nsl + ibus[j]));
 #pragma unroll
-      for (int j = 0; j < NI; ++j) sa[j] = f2_ld2(rd + ao[j]);
+      for (int k = 0; k < 3; ++k) {
+        double2 sa[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) { sr[j] += sa[j].x; si[j] += sa[j].y; }
+        for (int j = 0; j < NI; ++j) sa[j] = f2_ld2(rd + f2_slot(aq[j][k], l));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { sr[j] += sa[j].x; si[j] += sa[j].y; }
+      }
       if (r + 1 < R2) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) f2_st2(wr + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
