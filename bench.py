@@ -47,6 +47,9 @@ WORKLOADS = {
     "ieee123_b8192": dict(feeder="ieee123_like", batch=8192, solver="fbs"),       # BASELINE.json config 3 (and 4 for N > 1)
     "ieee13_b4096": dict(feeder="ieee13_like", batch=4096, solver="nr"),          # config 2
     "ieee8500_3ph_b1024": dict(feeder="ieee8500_like", batch=1024, solver="fbs3"),  # config 5 (solver only)
+    # meshed feeders (Newton-Raphson through the sparse block LU): 123 buses with 26 loops, and the ScalableFeeder(123) recipe
+    "meshed_loops26_b8192": dict(feeder="meshed_loops26", batch=8192, solver="nr"),
+    "meshed_scalable_b8192": dict(feeder="meshed_scalable", batch=8192, solver="nr"),
 }
 KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
                 "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow", "fbs_flow2": "fbs_flow2", "fbs_flow2h": "fbs_flow2h", "fbs_flow2s": "fbs_flow2s", "nr_flow2s": "nr_flow2s",
@@ -54,7 +57,22 @@ KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr
 
 
 def make_feeder(name):
+    if name == "meshed_loops26":
+        return P.random_meshed(123, 26, seed=1)       # 26 loops: the cycle count of the reference's IEEE123Bus (feeders/ieee_feeders.py:236-330)
+    if name == "meshed_scalable":
+        return P.scalable_like(123, seed=1)           # the recipe of ScalableFeeder(123) (feeders/synthetic.py:233): ~1000 lines
     return P.ieee123_like() if name == "ieee123_like" else P.ieee13_like("epsilon")
+
+
+def csrc_hash():
+    """SHA-256 over the kernel sources: what a counter measurement under profiles/ was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "grid_fed_rl_gym_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes_per_step(fs):
@@ -82,8 +100,22 @@ def host_description():
 
 
 def traffic_of(key):
+    """Fabric-side bytes per launch of the workload's step kernel from the PMC passes under profiles/ (tools/profile.sh,
+    tools/collect_profile.py) -- a constant this run did not measure, so it is only reported while the kernel sources are the
+    ones it was measured on (`csrc_sha` recorded with the entry); otherwise null."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key, {}).get("solve_bytes_per_launch")
+        e = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key, {})
+        return e.get("solve_bytes_per_launch") if e.get("csrc_sha") == csrc_hash() else None
+    except Exception:
+        return None
+
+
+def traffic_source(key):
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key, {})
+        cur = csrc_hash()
+        return {"profile": e.get("profile"), "measured_on_csrc_sha": e.get("csrc_sha"), "this_build_csrc_sha": cur,
+                "stale": e.get("csrc_sha") != cur, "bytes_when_measured": e.get("solve_bytes_per_launch")}
     except Exception:
         return None
 
@@ -557,6 +589,7 @@ def main():
         tflops = flops_it * m["mean_iterations"] * B / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic_of(f"{workload_key}:{m['solver']}") if B == WORKLOADS.get(workload_key, {}).get("batch") else None,
+                "traffic_source": traffic_source(f"{workload_key}:{m['solver']}"),
                 "kernel": "gs_k_step_" + KERNEL_NAMES.get(m["desc"]["kernel"], m["desc"]["kernel"]),
                 "avg_launch_ms": avg, "avg_launch_method": "one HIP event pair on the kernel's stream around the K launches of each timed region / K, mean over the regions",
                 "algorithmic_bytes_per_launch": bytes_step * B,
@@ -666,13 +699,13 @@ def main():
             # 123 buses with 26 loops (IEEE123Bus's cycle count, feeders/ieee_feeders.py:236-330) and the ScalableFeeder(123)
             # recipe (feeders/synthetic.py:233: ~1000 lines, a graph whose block LU fills in almost completely).
             result["also_meshed"] = {}
-            for key, mk, Bm, K, W_ in (("loops26_123", lambda: P.random_meshed(123, 26, seed=1), B, min(args.steps, 20), min(args.warmup, 20)),
-                                       ("scalable_123", lambda: P.scalable_like(123, seed=1), B, 3, 1)):
+            for key, mk, Bm, K, W_ in (("loops26", lambda: make_feeder("meshed_loops26"), B, min(args.steps, 20), min(args.warmup, 20)),
+                                       ("scalable", lambda: make_feeder("meshed_scalable"), B, 3, 1)):
                 try:
                     fsm = mk()
                     mm = measure(fsm, Bm, "nr", False, 3, warmup=W_, steps=K)
                     sm = summarize(mm, 1)
-                    rl = roofline_of(mm, sm, "meshed")
+                    rl = roofline_of(mm, sm, f"meshed_{key}_b8192")
                     pairs = int(mm["desc"].get("lu_pairs", 0))
                     # per Newton iteration and instance: one 2x2 (A_ik D^-1) A_kj product and subtraction per scheduled pair
                     # (2 x 12 + 4 flops), one 2x2 inverse per pivot, the Jacobian blocks (~40 flops per Ybus entry)
@@ -681,7 +714,8 @@ def main():
                     rl["fp64_valu"] = {"achieved_tflops": tf, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
                                        "flops_per_iteration_per_instance": fl_it, "mean_iterations": mm["mean_iterations"],
                                        "how": "28 flops per scheduled pair update (host schedule, gs_describe lu_pairs) + 30 per pivot + 40 per Ybus entry"}
-                    rl["traffic"] = traffic_of(f"meshed_{key}:nr") if Bm == B else None
+                    rl["traffic"] = traffic_of(f"meshed_{key}_b8192:nr") if Bm == 8192 else None
+                    rl["traffic_source"] = traffic_source(f"meshed_{key}_b8192:nr")
                     entry = {"workload": f"{fsm.name}, batch={Bm}, Newton-Raphson (exact Jacobian), stochastic loads + weather",
                              "feeder_sha256": fsm.sha256(), "n_buses": fsm.n, "n_lines": fsm.m, "obs_dim": fsm.obs_dim, "action_dim": fsm.action_dim,
                              "value": sm["value"], "unit": "env_steps/s", "ms_per_step": sm["ms_per_step"], "value_p10_p90": sm["value_p10_p90"],

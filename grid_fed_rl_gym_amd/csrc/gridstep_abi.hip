@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -856,11 +857,56 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     }
   }
 
+  // ---- level schedule of the sparse block LU for this handle's W waves (kernels_solve.hip, linsolve_lu) ----
+  std::vector<int32_t> lu_a_ptr, lu_a, lu_b_ptr, lu_b, lu_c_ptr, lu_c;
+  if (ht.has_lu) {
+    const int NL = ht.lu_n_levels, Wn = h->W;
+    std::vector<std::vector<std::vector<int32_t>>> A(Wn, std::vector<std::vector<int32_t>>(NL)), Bs(Wn, std::vector<std::vector<int32_t>>(NL)),
+        Cs(Wn, std::vector<std::vector<int32_t>>(NL));
+    for (int L = 0; L < NL; ++L) {
+      // phase A: one item per (pivot, neighbour), plus one per pivot for the singularity test; dealt round-robin
+      int turn = 0;
+      std::map<int32_t, std::vector<std::pair<int32_t, int32_t>>> tgt;        // target code -> updates
+      for (int t = 0; t < ht.lu_n_piv; ++t) {
+        if (ht.lu_piv_level[t] != L) continue;
+        const int k = ht.lu_piv_bus[t];
+        { auto& a = A[turn++ % Wn][L]; a.push_back(k); a.push_back(-1); }
+        for (int q = ht.lu_nb_ptr[t]; q < ht.lu_nb_ptr[t + 1]; ++q) {
+          auto& a = A[turn++ % Wn][L]; a.push_back(k); a.push_back(ht.lu_nb_jk[q]);
+          tgt[-(1 + ht.n + ht.lu_nb_bus[q])].push_back({ht.lu_nb_jk[q], k});          // r_i -= (A_ik D_k^-1) r_k
+        }
+        for (int q = ht.lu_pair_ptr[t]; q < ht.lu_pair_ptr[t + 1]; ++q) tgt[ht.lu_pair_ij[q]].push_back({ht.lu_pair_ik[q], ht.lu_pair_kj[q]});
+      }
+      // phase B: targets dealt to the wave with the fewest updates so far in this level
+      std::vector<int> load(Wn, 0);
+      std::vector<std::pair<int32_t, std::vector<std::pair<int32_t, int32_t>>>> order(tgt.begin(), tgt.end());
+      std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.second.size() > y.second.size(); });
+      for (auto& e : order) {
+        int w = 0;
+        for (int v = 1; v < Wn; ++v) if (load[v] < load[w]) w = v;
+        load[w] += (int)e.second.size() + 1;
+        auto& b = Bs[w][L];
+        b.push_back(e.first); b.push_back((int32_t)e.second.size());
+        for (auto& u : e.second) { b.push_back(u.first); b.push_back(u.second); }
+      }
+      // phase C: the level's pivots, round-robin
+      int tc = 0;
+      for (int t = 0; t < ht.lu_n_piv; ++t) if (ht.lu_piv_level[t] == L) Cs[tc++ % Wn][L].push_back(t);
+    }
+    auto flatten = [&](std::vector<std::vector<std::vector<int32_t>>>& X, std::vector<int32_t>& ptr, std::vector<int32_t>& flat, int unit) {
+      for (int w = 0; w < Wn; ++w) {
+        for (int L = 0; L < NL; ++L) { ptr.push_back((int32_t)flat.size() / unit); flat.insert(flat.end(), X[w][L].begin(), X[w][L].end()); }
+        ptr.push_back((int32_t)flat.size() / unit);
+      }
+    };
+    flatten(A, lu_a_ptr, lu_a, 2); flatten(Bs, lu_b_ptr, lu_b, 1); flatten(Cs, lu_c_ptr, lu_c, 1);
+  }
+
   // ---- tables ----
   GsTables& T = h->T;
   T.n = n; T.m = m; T.nnz = ht.nnz; T.n_levels = ht.n_levels;
   T.n_loads = h->n_loads; T.n_gens = h->n_gens; T.n_bats = h->n_bats;
-  T.lu_n_piv = ht.lu_n_piv; T.lu_n_slots = ht.lu_n_slots; T.lu_n_orig = ht.lu_n_orig;
+  T.lu_n_piv = ht.lu_n_piv; T.lu_n_slots = ht.lu_n_slots; T.lu_n_orig = ht.lu_n_orig; T.lu_n_levels = ht.lu_n_levels;
   T.dn_N = ht.dn_N;
   int rc = 0;
 #define UP(field, vec) if ((rc = dev_upload(h, &T.field, ht.vec))) return bail(rc)
@@ -880,6 +926,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(lu_nb_jk, lu_nb_jk); UP(lu_pair_ptr, lu_pair_ptr); UP(lu_pair_ik, lu_pair_ik); UP(lu_pair_kj, lu_pair_kj);
   UP(lu_pair_ij, lu_pair_ij); UP(lu_orig_slot, lu_orig_slot); UP(lu_orig_i, lu_orig_i); UP(lu_orig_j, lu_orig_j);
   UP(lu_orig_pos, lu_orig_pos);
+  if ((rc = dev_upload(h, &T.lu_a_ptr, lu_a_ptr)) || (rc = dev_upload(h, &T.lu_a, lu_a)) || (rc = dev_upload(h, &T.lu_b_ptr, lu_b_ptr)) ||
+      (rc = dev_upload(h, &T.lu_b, lu_b)) || (rc = dev_upload(h, &T.lu_c_ptr, lu_c_ptr)) || (rc = dev_upload(h, &T.lu_c, lu_c))) return bail(rc);
   UP(dn_th_idx, dn_th_idx); UP(dn_vm_idx, dn_vm_idx);
   UP(bl_ptr, bl_ptr); UP(bl_idx, bl_idx); UP(bg_ptr, bg_ptr); UP(bg_idx, bg_idx); UP(bb_ptr, bb_ptr); UP(bb_idx, bb_idx);
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);

@@ -209,6 +209,19 @@ struct GsTables {
   const int32_t* lu_orig_i;      // ... their (i, j) ...
   const int32_t* lu_orig_j;
   const int32_t* lu_orig_pos;    // ... and CSR position of (i, j)
+  // the same elimination as a LEVEL schedule (pivots of a level commute): per wave and level,
+  //   phase A  items (pivot bus, slot of (i, pivot) or -1): A_ik <- A_ik D_k^-1 in place (slot -1: only the singularity test of D_k)
+  //   phase B  a stream of target records [target, count, count x (slot of (i, k), slot of (k, j) | pivot bus k)]: the wave owns the
+  //            target for the level and subtracts all of the level's updates from it in registers -- target >= 0 an off-diagonal
+  //            slot, -(1 + i) the diagonal block of bus i, -(1 + n + i) the right-hand side of bus i (second entry = pivot BUS)
+  //   phase C  (back substitution, levels in descending order) pivot indices t into lu_piv_bus / lu_nb_*
+  int32_t lu_n_levels, pad4;
+  const int32_t* lu_a_ptr;       // [W * (lu_n_levels + 1)]
+  const int32_t* lu_a;           // [.][2]
+  const int32_t* lu_b_ptr;       // [W * (lu_n_levels + 1)] offsets into lu_b
+  const int32_t* lu_b;
+  const int32_t* lu_c_ptr;       // [W * (lu_n_levels + 1)]
+  const int32_t* lu_c;
   // dense partial-pivoting LU (reference-faithful linear solve, power_flow.py:187): unknown
   // order [theta(non-slack, ascending) ; Vm(pq, ascending)] exactly as power_flow.py:232-240
   int32_t dn_N, pad2;

@@ -569,9 +569,14 @@ __device__ __forceinline__ void linsolve_tree_lds(Ctx& c, const GsSolveCfg& C, N
 }
 
 // ---- meshed Jacobian: statically scheduled 2x2-block sparse LU ------------------------------------
-// The host ordered the active buses by minimum degree and listed, for every pivot, its remaining
-// neighbours and every (i, j) block its elimination touches; fill blocks own slots.  Waves split
-// the pair updates of a pivot; pivots are sequential (one barrier each).
+// The host ordered the active buses by minimum degree, listed for every pivot its remaining neighbours and every (i, j)
+// block its elimination touches (fill blocks own slots), and grouped the pivots into the LEVELS of the elimination DAG:
+// pivots of one level are not adjacent in the filled graph, so they are eliminated together (round 3; one pivot per
+// barrier before: 122 dependent steps for a 123-bus feeder with 26 loops that has 18 levels).  Per level:
+//   phase A  every block of a pivot's column is scaled in place, A_ik <- A_ik D_k^-1 (one item per block, dealt over the waves);
+//   phase B  every block the level touches is owned by ONE wave, which subtracts all of the level's updates
+//            (A_ik D_k^-1) A_kj from it in registers and stores it once; the right-hand side is one more column.
+// Back substitution walks the levels the other way, the pivots of a level dealt over the waves.
 __device__ __forceinline__ void linsolve_lu(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
   const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
   for (int t = c.wave; t < T.lu_n_piv; t += c.W) {
@@ -589,44 +594,67 @@ __device__ __forceinline__ void linsolve_lu(Ctx& c, const GsSolveCfg& C, NrState
   }
   __syncthreads();
   int sing = 0;
-  for (int t = 0; t < T.lu_n_piv; ++t) {
-    const int k = cld(T.lu_piv_bus, t);
-    const Blk inv = inv2(load_blk(S, R.LUD + 4 * k), &sing);
-    const double rk0 = ROW(R.R0 + k), rk1 = ROW(R.R1 + k);
-    const double s0 = inv.a00 * rk0 + inv.a01 * rk1, s1 = inv.a10 * rk0 + inv.a11 * rk1;
-    const int q1 = cld(T.lu_pair_ptr, t + 1);
-    for (int q = cld(T.lu_pair_ptr, t) + c.wave; q < q1; q += c.W) {
-      const Blk aik = load_blk(S, R.LU + 4 * cld(T.lu_pair_ik, q));
-      const Blk akj = load_blk(S, R.LU + 4 * cld(T.lu_pair_kj, q));
-      const Blk upd = mul(mul(aik, inv), akj);
-      const int tgt = cld(T.lu_pair_ij, q);
-      const int row = (tgt >= 0) ? (R.LU + 4 * tgt) : (R.LUD + 4 * (-tgt - 1));
-      Blk a = load_blk(S, row);
-      a.a00 -= upd.a00; a.a01 -= upd.a01; a.a10 -= upd.a10; a.a11 -= upd.a11;
-      store_blk(S, row, a);
+  const int NL = T.lu_n_levels, pw = c.wave * (NL + 1);
+  for (int L = 0; L < NL; ++L) {
+    {  // phase A, two items at a time: the four block loads of a pair are in flight together (an item is one memory latency)
+      const int q1 = cld(T.lu_a_ptr, pw + L + 1);
+      for (int q = cld(T.lu_a_ptr, pw + L); q < q1; q += 2) {
+        const bool two = q + 1 < q1;
+        const int qb = two ? q + 1 : q;
+        const int k0 = cld(T.lu_a, 2 * q), s0 = cld(T.lu_a, 2 * q + 1), k1 = cld(T.lu_a, 2 * qb), s1 = cld(T.lu_a, 2 * qb + 1);
+        const Blk d0 = load_blk(S, R.LUD + 4 * k0), d1 = load_blk(S, R.LUD + 4 * k1);
+        const Blk a0 = load_blk(S, R.LU + 4 * (s0 >= 0 ? s0 : 0)), a1 = load_blk(S, R.LU + 4 * (s1 >= 0 ? s1 : 0));
+        const Blk i0 = inv2(d0, &sing);
+        if (s0 >= 0) store_blk(S, R.LU + 4 * s0, mul(a0, i0));
+        if (two) { const Blk i1 = inv2(d1, &sing); if (s1 >= 0) store_blk(S, R.LU + 4 * s1, mul(a1, i1)); }
+      }
     }
-    const int n1 = cld(T.lu_nb_ptr, t + 1);
-    for (int q = cld(T.lu_nb_ptr, t) + c.wave; q < n1; q += c.W) {
-      const int i = cld(T.lu_nb_bus, q);
-      const Blk aik = load_blk(S, R.LU + 4 * cld(T.lu_nb_jk, q));
-      ROW(R.R0 + i) -= aik.a00 * s0 + aik.a01 * s1;
-      ROW(R.R1 + i) -= aik.a10 * s0 + aik.a11 * s1;
+    __syncthreads();
+    {  // phase B
+      int p = cld(T.lu_b_ptr, pw + L);
+      const int p1 = cld(T.lu_b_ptr, pw + L + 1);
+      while (p < p1) {
+        const int tgt = cld(T.lu_b, p), cnt = cld(T.lu_b, p + 1);
+        p += 2;
+        if (tgt < -T.n) {                                 // right-hand side of bus i: r_i -= (A_ik D_k^-1) r_k
+          const int i = -tgt - 1 - T.n;
+          double r0 = ROW(R.R0 + i), r1 = ROW(R.R1 + i);
+          for (int u = 0; u < cnt; ++u, p += 2) {
+            const Blk l = load_blk(S, R.LU + 4 * cld(T.lu_b, p));
+            const int k = cld(T.lu_b, p + 1);
+            const double rk0 = ROW(R.R0 + k), rk1 = ROW(R.R1 + k);
+            r0 -= l.a00 * rk0 + l.a01 * rk1;
+            r1 -= l.a10 * rk0 + l.a11 * rk1;
+          }
+          ROW(R.R0 + i) = r0; ROW(R.R1 + i) = r1;
+        } else {
+          const int row = (tgt >= 0) ? (R.LU + 4 * tgt) : (R.LUD + 4 * (-tgt - 1));
+          Blk a = load_blk(S, row);
+          for (int u = 0; u < cnt; ++u, p += 2) {
+            const Blk upd = mul(load_blk(S, R.LU + 4 * cld(T.lu_b, p)), load_blk(S, R.LU + 4 * cld(T.lu_b, p + 1)));
+            a.a00 -= upd.a00; a.a01 -= upd.a01; a.a10 -= upd.a10; a.a11 -= upd.a11;
+          }
+          store_blk(S, row, a);
+        }
+      }
     }
     __syncthreads();
   }
+  stamp(c, ST_BOTTOM_UP);
   const int sing_all = wg_or(c, par, sing);
   if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
   const bool upd = !st.done;
-  if (c.wave == 0) {   // back substitution: sequential in reverse pivot order
-    for (int t = T.lu_n_piv - 1; t >= 0; --t) {
-      const int k = cld(T.lu_piv_bus, t);
+  for (int L = NL - 1; L >= 0; --L) {      // back substitution: x_k = D_k^-1 (r_k - sum_j A_kj x_j), every j in a higher level
+    const int q1 = cld(T.lu_c_ptr, pw + L + 1);
+    for (int q = cld(T.lu_c_ptr, pw + L); q < q1; ++q) {
+      const int t = cld(T.lu_c, q), k = cld(T.lu_piv_bus, t);
       int dummy = 0;
       const Blk inv = inv2(load_blk(S, R.LUD + 4 * k), &dummy);
       double r0 = ROW(R.R0 + k), r1 = ROW(R.R1 + k);
       const int n1 = cld(T.lu_nb_ptr, t + 1);
-      for (int q = cld(T.lu_nb_ptr, t); q < n1; ++q) {
-        const int j = cld(T.lu_nb_bus, q);
-        const Blk akj = load_blk(S, R.LU + 4 * cld(T.lu_nb_kj, q));
+      for (int u = cld(T.lu_nb_ptr, t); u < n1; ++u) {
+        const int j = cld(T.lu_nb_bus, u);
+        const Blk akj = load_blk(S, R.LU + 4 * cld(T.lu_nb_kj, u));
         const double xj0 = ROW(R.X0 + j), xj1 = ROW(R.X1 + j);
         r0 -= akj.a00 * xj0 + akj.a01 * xj1;
         r1 -= akj.a10 * xj0 + akj.a11 * xj1;
@@ -635,8 +663,9 @@ __device__ __forceinline__ void linsolve_lu(Ctx& c, const GsSolveCfg& C, NrState
       ROW(R.X1 + k) = inv.a10 * r0 + inv.a11 * r1;
       apply_step(c, k, C.alpha, upd);
     }
+    __syncthreads();
   }
-  __syncthreads();
+  stamp(c, ST_TOP_DOWN);
 }
 
 // ---- dense, partially pivoted LU per instance: the reference-faithful linear solve -------------

@@ -254,6 +254,16 @@ std::string gs_compile_topology(const gs_topology& t, int zero_z_mode, bool want
     o.lu_n_piv = o.n_active;
     o.lu_n_slots = (int)slot.size();
     o.lu_n_pairs = (int64_t)o.lu_pair_ik.size();
+    {
+      std::vector<int> dep(n, 0);
+      o.lu_piv_level.assign(o.lu_n_piv, 0);
+      for (int t = 0; t < o.lu_n_piv; ++t) {
+        const int lv = dep[o.lu_piv_bus[t]];
+        o.lu_piv_level[t] = lv;
+        o.lu_n_levels = std::max(o.lu_n_levels, lv + 1);
+        for (int q = o.lu_nb_ptr[t]; q < o.lu_nb_ptr[t + 1]; ++q) dep[o.lu_nb_bus[q]] = std::max(dep[o.lu_nb_bus[q]], lv + 1);
+      }
+    }
   }
 
   // ---- dense unknown numbering (power_flow.py:232-240, 291) -----------------------------------

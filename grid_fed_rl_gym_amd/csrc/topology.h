@@ -36,6 +36,11 @@ struct HostTopology {
   std::vector<int32_t> lu_piv_bus, lu_nb_ptr, lu_nb_bus, lu_nb_kj, lu_nb_jk;
   std::vector<int32_t> lu_pair_ptr, lu_pair_ik, lu_pair_kj, lu_pair_ij;
   std::vector<int32_t> lu_orig_slot, lu_orig_i, lu_orig_j, lu_orig_pos;
+  // level of every pivot in the elimination DAG: 0 if no earlier pivot touched it, else 1 + the highest level among the
+  // earlier pivots it was a neighbour of.  Pivots of one level are mutually non-adjacent in the filled graph, so their
+  // eliminations commute and their updates never target each other's rows or columns.
+  int lu_n_levels = 0;
+  std::vector<int32_t> lu_piv_level;
   // dense LU unknown numbering
   int dn_N = 0;
   std::vector<int32_t> dn_th_idx, dn_vm_idx;
