@@ -621,6 +621,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     stp.hit(F2_ST_TOP_DOWN);
     // corrections (power_flow.py:315-327): theta += alpha dtheta, |V| += alpha d|V|, as a rotation and scaling of (e, f)
     if (__any(upd)) {
+      // the sixteen series coefficients once per pass, in scalar registers (a load per use and item before round 3:
+      // 128 scalar loads per wave and iteration on the pass's critical path)
+      double kcs[16];
+      {
+        const GS_CONST double* kc0 = (const GS_CONST double*)kF2Series;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) kcs[q] = kc0[q];
+      }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         __builtin_amdgcn_sched_barrier(0);
@@ -643,7 +651,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
             h = __builtin_fma(-k, 2.4492935982947064e-16, h);
             h *= 0.125;
           }
-          const GS_CONST double* kc = (const GS_CONST double*)kF2Series;
+          const double* kc = kcs;
           const double z = h * h;
           double sp = kc[0];
           sp = __builtin_fma(sp, z, kc[1]); sp = __builtin_fma(sp, z, kc[2]); sp = __builtin_fma(sp, z, kc[3]);
