@@ -51,7 +51,7 @@ WORKLOADS = {
     "meshed_loops26_b8192": dict(feeder="meshed_loops26", batch=8192, solver="nr"),
     "meshed_scalable_b8192": dict(feeder="meshed_scalable", batch=8192, solver="nr"),
 }
-KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
+KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "nr_dense_mfma": "nr_dense_mfma", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
                 "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow", "fbs_flow2": "fbs_flow2", "fbs_flow2h": "fbs_flow2h", "fbs_flow2s": "fbs_flow2s", "nr_flow2s": "nr_flow2s",
                 "nr_flow2": "nr_flow2"}
 

@@ -98,6 +98,9 @@ struct gs_handle {
   // 2 n + 2 m columns of the observation block the step writes anyway.  `rows_stale`: the rows lag behind `last_obs`, the block
   // of the last step; every entry point that reads or partly rewrites them restores them first (ensure_rows).
   bool lean = false, rows_stale = false; const double* last_obs = nullptr;
+  // solve_kernel 7: Newton-Raphson with the dense block LU on the matrix cores (kernels_dense.hip), a launch of its own between
+  // the two halves of the step / solve
+  GsDenseArgs DA{}; int dense_grid = 0; size_t dense_lds = 0;
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -291,6 +294,10 @@ int launch_solve(gs_handle* h) {
   else if (h->solve_kernel == 4) GS_SOLVE(gs_k_nr_tree_lds);
   else if (h->solve_kernel == 1) GS_SOLVE(gs_k_nr_lu);
   else if (h->solve_kernel == 3) GS_SOLVE(gs_k_nr_dense);
+  else if (h->solve_kernel == 7) {
+    hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
+    hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
+  }
   else if (h->solve_kernel == 5) GS_SOLVE(gs_k_fbs_lds);
   else if (h->solve_kernel == 6) GS_SOLVE(gs_k_fbs_flow);
   else GS_SOLVE(gs_k_fbs);
@@ -355,6 +362,11 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
       return GS_OK;
     }
 #define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc)
+    if (h->solve_kernel == 7) {      // prologue | dense Newton-Raphson, one workgroup per instance | epilogue + observation pack
+      GS_STEP(gs_k_pre_nr_dmfma);
+      hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
+      if (fc.enabled) GS_STEP(gs_k_postc_nr_dmfma); else GS_STEP(gs_k_post_nr_dmfma);
+    } else
     if (fc.enabled) {
       if (h->solve_kernel == 0) GS_STEP(gs_k_stepc_nr_tree);
       else if (h->solve_kernel == 4) GS_STEP(gs_k_stepc_nr_tree_lds);
@@ -468,7 +480,14 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     if (ls == GS_LINSOLVE_AUTO)
       ls = (cfg->jacobian_mode == GS_JACOBIAN_AS_CODED) ? GS_LINSOLVE_DENSE_PIVOT
                                                        : (ht.is_forest ? GS_LINSOLVE_TREE : GS_LINSOLVE_SPARSE_LU);
-    h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : 3;
+    // meshed network whose sparse block LU would fill in (more than a quarter of all blocks): dense LU on the matrix cores
+    const int na_ = ht.n_active;
+    const bool mfma_fits = cfg->jacobian_mode == GS_JACOBIAN_EXACT && na_ >= 1 && 2 * na_ <= 256 && !getenv("GS_NO_DENSE_MFMA");
+    if (ls == GS_LINSOLVE_DENSE_MFMA && !mfma_fits) {
+      int rc = fail(nullptr, GS_E_TOPOLOGY, "dense_mfma needs the exact Jacobian and at most 128 non-slack buses (have %d)", na_); delete h; return rc; }
+    if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && mfma_fits && (long long)ht.lu_n_slots * 4 > (long long)na_ * na_)
+      ls = GS_LINSOLVE_DENSE_MFMA;
+    h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : (ls == GS_LINSOLVE_DENSE_MFMA) ? 7 : 3;
     // forest sweeps through LDS messages when two adjacent levels fit next to the 24 KB static block
     const size_t msg_bytes = (size_t)2 * ht.max_level_width * 6 * GS_LANES * sizeof(double);
     if (h->solve_kernel == 0 && msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) h->solve_kernel = 4;
@@ -493,7 +512,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
                          (const void*)gs_k_step_fbs, (const void*)gs_k_fbs_lds, (const void*)gs_k_step_fbs_lds,
                          (const void*)gs_k_stepc_nr_tree, (const void*)gs_k_stepc_nr_tree_lds, (const void*)gs_k_stepc_nr_lu,
                          (const void*)gs_k_stepc_nr_dense, (const void*)gs_k_stepc_fbs, (const void*)gs_k_stepc_fbs_lds,
-                         (const void*)gs_k_fbs_flow, (const void*)gs_k_step_fbs_flow, (const void*)gs_k_stepc_fbs_flow};
+                         (const void*)gs_k_fbs_flow, (const void*)gs_k_step_fbs_flow, (const void*)gs_k_stepc_fbs_flow,
+                         (const void*)gs_k_pre_nr_dmfma, (const void*)gs_k_post_nr_dmfma, (const void*)gs_k_postc_nr_dmfma,
+                         (const void*)gs_k_posts_nr_dmfma};
     // the attribute is per function, i.e. shared by every handle of the process: always raise it to
     // the most any handle may ask for (160 KB per workgroup minus the 24 KB static block)
     const int max_dyn = 160 * 1024 - 24576;
@@ -506,6 +527,11 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
                           (const void*)gs_k_stepc_fbs_flow2h, (const void*)gs_k_step_fbs_flow2x, (const void*)gs_k_stepc_fbs_flow2x})      // no static LDS in these
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", 160 * 1024));
+  }
+
+  {
+    const hipError_t e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(gs_k_nr_dense_mfma): %s", hipGetErrorString(e)));
   }
 
   // ---- rows ----
@@ -933,6 +959,54 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
   UP(gen_p1, gen_p1); UP(gen_p2, gen_p2); UP(bat_cap, bat_cap); UP(bat_rating, bat_rating); UP(bat_eff, bat_eff);
 #undef UP
+  // ---- dense block LU on the matrix cores (kernels_dense.hip): unknown numbering, Jacobian blocks by column panel, scratch ----
+  if (h->solve_kernel == 7) {
+    GsDenseArgs& D = h->DA;
+    std::vector<int32_t> act_bus, act_of(ht.n, -1);
+    for (int i = 0; i < ht.n; ++i) if (ht.th_free[i] || ht.vm_free[i]) { act_of[i] = (int32_t)act_bus.size(); act_bus.push_back(i); }
+    const int na = (int)act_bus.size(), NB = (2 * na + 63) / 64;
+    std::vector<int32_t> ent_ptr(NB + 1, 0), ent;
+    for (int pnl = 0; pnl < NB; ++pnl) {
+      ent_ptr[pnl] = (int32_t)ent.size() / 3;
+      for (int i = 0; i < ht.n; ++i) {
+        if (act_of[i] < 0) continue;
+        for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+          const int j = ht.col[q];
+          if (act_of[j] < 0 || (2 * act_of[j]) / 64 != pnl) continue;
+          ent.push_back(i); ent.push_back(j); ent.push_back(q);
+        }
+      }
+    }
+    ent_ptr[NB] = (int32_t)ent.size() / 3;
+    D.n = ht.n; D.na = na; D.NB = NB; D.max_it = cfg->max_iterations; D.jacobian_exact = 1; D.rows_total = h->R.total;
+    D.tol = cfg->tolerance; D.alpha = cfg->acceleration_factor;
+    if ((rc = dev_upload(h, &D.act_bus, act_bus)) || (rc = dev_upload(h, &D.act_of, act_of)) || (rc = dev_upload(h, &D.ent_ptr, ent_ptr)) ||
+        (rc = dev_upload(h, &D.ent, ent))) return bail(rc);
+    D.row_ptr = T.row_ptr; D.col = T.col; D.G = T.G; D.Bv = T.Bv; D.Gd = T.Gd; D.Bd = T.Bd;
+    D.th_free = T.th_free; D.vm_free = T.vm_free; D.fixed_v = T.fixed_v; D.v_set = T.v_set;
+    D.R = h->R;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    h->dense_grid = std::max(1, std::min(h->B, cus));             // persistent: one workgroup per CU, instances strided over the grid
+    const size_t NP = (size_t)64 * NB;
+    h->dense_lds = (NP * 66 + NP + (size_t)8 * ((ht.n + 1) & ~1) + 2 * 528 + 8) * sizeof(double);
+    if (h->dense_lds > 160 * 1024 - 256) return bail(fail(nullptr, GS_E_TOPOLOGY, "dense_mfma: %zu bytes of LDS needed", h->dense_lds));
+    double* scratch = nullptr;
+    if ((rc = dev_alloc(h, &scratch, (size_t)h->dense_grid * NB * NB * 64 * 64))) return bail(rc);
+    D.scratch = scratch;
+    // the flat-start Jacobian is the same for every instance: factor it once, here, with the solver kernel itself
+    // (bit-identical to what iteration 0 of every solve would compute; GS_DENSE_NO_FLAT=1 keeps it per solve)
+    if (!getenv("GS_DENSE_NO_FLAT")) {
+      double* flat = nullptr;
+      if ((rc = dev_alloc(h, &flat, (size_t)NB * NB * 64 * 64 + 8))) return bail(rc);
+      GsDenseArgs once = D;
+      once.flat = flat; once.mode = 1; once.max_it = 1;
+      hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(1), dim3(256), h->dense_lds, h->stream, once, h->slab, 1);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return bail(fail(nullptr, GS_E_HIP, "dense_mfma: factorisation of the flat-start Jacobian failed"));
+      D.flat = flat;
+    }
+  }
   // a step as two half-grid launches on two streams: only where each half still gives every CU a workgroup
   h->lean = (h->flow2 || h->nr2) && !getenv("GS_EAGER_ROWS");
   if ((h->flow2 || h->nr2) && 2 * (size_t)h->F2.lds_bytes <= 160 * 1024 && !getenv("GS_NO_SPLIT") && h->groups * (64 / h->f2_iw) >= 512 &&
@@ -1069,7 +1143,7 @@ int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_
 
 int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail(nullptr, GS_E_INVALID, "bad arguments");
-  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds", "fbs_lds", "fbs_flow"};
+  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds", "fbs_lds", "fbs_flow", "nr_dense_mfma"};
   snprintf(buf, buflen,
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
@@ -1690,6 +1764,7 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
     if (rc) return rc;
     HIPCHK(h, hipMemset(h->d_stamps, 0, (16 + 2 * GS_STAMP_BLOCKS) * sizeof(unsigned long long)));
     h->SC.stamps = h->d_stamps;
+    h->DA.stamps = h->d_stamps;
     h->SC.stamp_wave = getenv("GS_STAMP_WAVE") ? atoi(getenv("GS_STAMP_WAVE")) : 0;
     h->SC.block_times = getenv("GS_STAMP_BLOCK_TIMES") ? 1 : 0;
     for (int k = 0; k < n; ++k) cycles_out[k] = 0;

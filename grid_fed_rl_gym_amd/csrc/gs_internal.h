@@ -292,6 +292,28 @@ struct GsRows {
   int32_t LOADP;             // [n_loads] realised load power of this step
 };
 
+// gs_k_nr_dense_mfma (kernels_dense.hip): Newton-Raphson with a dense block LU on the matrix cores, one workgroup per instance
+struct GsDenseArgs {
+  int32_t n, na, NB, max_it;                 // buses, active (non-slack) buses, 64-wide panels (NP = 64 NB >= 2 na), iteration cap
+  int32_t jacobian_exact, rows_total, pad0, pad1;
+  double tol, alpha;
+  const int32_t* act_bus;                    // [na] bus of active index a
+  const int32_t* act_of;                     // [n] active index of a bus, -1 for the slack
+  const int32_t* row_ptr; const int32_t* col; const double* G; const double* Bv; const double* Gd; const double* Bd;   // Ybus rows (GsTables)
+  const int32_t* th_free; const int32_t* vm_free; const int32_t* fixed_v; const double* v_set;
+  const int32_t* ent_ptr;                    // [NB + 1] Jacobian blocks whose COLUMN bus lies in panel p ...
+  const int32_t* ent;                        // ... as (row bus i, column bus j, Ybus position of (i, j)) triples
+  double* scratch;                           // [grid][(NB (NB - 1) / 2 L blocks + NB (NB - 1) / 2 U blocks + NB inverses) x 64 x 64]
+  // The first Newton iteration starts from the flat start, where the Jacobian is the same for every instance: its block factors
+  // are computed ONCE per handle (mode 1: one workgroup runs the factorisation below into `flat`) and iteration 0 of every solve
+  // only substitutes with them -- a third of the factorisations of a typical three-iteration solve.
+  double* flat;                              // [NB * NB blocks + 1 flag] or NULL
+  int32_t mode, pad2;                        // 0 solve, 1 factor the flat-start Jacobian into `flat`
+  unsigned long long* stamps;                // diagnostic (gs_debug_stamps): cycles per phase of workgroup 0, NULL = off
+  GsRows R;
+};
+
+
 struct GsPackArgs {
   const int32_t* map;      // obs column -> slab row, or -(1 + constant index)
   const double* cst;

@@ -46,6 +46,14 @@ __global__ void gs_k_step_nr_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCf
                                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS);
 __global__ void gs_k_stepc_nr_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
                                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS);
+__global__ void gs_k_pre_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                                  const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC);
+__global__ void gs_k_post_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC);
+__global__ void gs_k_postc_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC);
+__global__ void gs_k_posts_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
+__global__ void gs_k_nr_dense_mfma(GsDenseArgs A, double* __restrict__ slab, int B);
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);
 __global__ void gs_k_polar_to_rect(GsTables T, GsRows R, double* __restrict__ slab, int B);

@@ -1767,7 +1767,10 @@ __device__ __forceinline__ void prologue_env(Ctx& c, const GsEnvCfg& E, const do
   if (!FLOW_REGS) __syncthreads();          // FLOW_REGS: nothing of this pass is read by another wave
 }
 
-template <int KIND, int ENV, int CHK>
+// PHASE 0: the whole step / solve in one launch.  PHASE 1 / 2: what comes before / after the load flow, for a solver that is
+// its own kernel (kernels_dense.hip: one workgroup per instance around MFMA tiles; it leaves |V| / angle, (e, f), P / Q
+// calculated and the convergence record in the rows, exactly where newton_loop leaves them).
+template <int KIND, int ENV, int CHK, int PHASE = 0>
 __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                           double* __restrict__ slab, int B, const double* __restrict__ actions,
                                           double total_load, const GsPackArgs& PA, const GsFusedChecks& FC) {
@@ -1793,10 +1796,14 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   }
   double Pinj[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // KIND_FBS_FLOW + ENV: S_spec of the wave's own buses
   constexpr bool kNewton = KIND == KIND_TREE || KIND == KIND_TREE_LDS || KIND == KIND_LU || KIND == KIND_DENSE;
-  if (ENV) prologue_env<KIND == KIND_FBS_LDS, KIND == KIND_FBS_FLOW, kNewton>(c, E, actions, b, valid, Pinj);
+  if (ENV && PHASE != 2) prologue_env<KIND == KIND_FBS_LDS, KIND == KIND_FBS_FLOW, kNewton>(c, E, actions, b, valid, Pinj);
   stamp(c, ST_PROLOGUE);
+  if (PHASE == 1) return;
   NrState st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
+  if (PHASE == 2) {          // the convergence record the solver kernel left
+    st.mm = ROW(R.MAXMIS); st.iters = (int)ROW(R.ITERS); st.conv = ROW(R.CONV) != 0.0 ? 1 : 0; st.status = (int)ROW(R.STATUS); st.done = true;
+  } else
   if (KIND == KIND_FBS) fbs_loop(c, C, st);
   else if (KIND == KIND_FBS_LDS) psum = fbs_loop_lds<ENV != 0>(c, C, st);
   else if (KIND == KIND_FBS_FLOW) psum = fbs_loop_flow<ENV != 0>(c, C, st, Pinj);
@@ -1825,6 +1832,28 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) { \
     main_body<KIND, 1, 1>(T, R, C, E, slab, B, actions, total_load, PA, FC);                                  \
   }
+
+// the two halves of a step / solve around the dense MFMA Newton-Raphson kernel (kernels_dense.hip)
+extern "C" __global__ void __launch_bounds__(1024)
+gs_k_pre_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                  const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
+  main_body<KIND_LU, 1, 0, 1>(T, R, C, E, slab, B, actions, total_load, PA, FC);
+}
+extern "C" __global__ void __launch_bounds__(1024)
+gs_k_post_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
+  main_body<KIND_LU, 1, 0, 2>(T, R, C, E, slab, B, actions, total_load, PA, FC);
+}
+extern "C" __global__ void __launch_bounds__(1024)
+gs_k_postc_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
+  main_body<KIND_LU, 1, 1, 2>(T, R, C, E, slab, B, actions, total_load, PA, FC);
+}
+extern "C" __global__ void __launch_bounds__(1024)       // solver-only API (gs_solve): line flows, losses, wrapped angles
+gs_k_posts_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
+  GsEnvCfg E{}; GsPackArgs PA{}; GsFusedChecks FC{};
+  main_body<KIND_LU, 0, 0, 2>(T, R, C, E, slab, B, nullptr, 0.0, PA, FC);
+}
 
 GS_DEFINE_KERNELS(nr_tree, KIND_TREE)
 GS_DEFINE_KERNELS(nr_tree_lds, KIND_TREE_LDS)

@@ -47,7 +47,10 @@ enum { GS_SOLVER_NR = 0, GS_SOLVER_FBS = 1 };
  * no row exchanges: safe because the exact diagonal blocks are rotation-like);
  * as-coded Jacobian -> DENSE_PIVOT (partial pivoting like LAPACK dgesv, power_flow.py:187),
  * because the as-coded diagonal blocks can be exactly singular (e.g. a leaf fed through r = x). */
-enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2, GS_LINSOLVE_DENSE_PIVOT = 3 };
+enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2, GS_LINSOLVE_DENSE_PIVOT = 3,
+       /* dense block LU on the matrix cores, one workgroup per instance (exact Jacobian, at most 128 non-slack buses);
+        * what AUTO takes for a meshed network whose sparse LU would fill in (more than a quarter of all blocks) */
+       GS_LINSOLVE_DENSE_MFMA = 4 };
 enum { GS_GEN_SOLAR = 0, GS_GEN_WIND = 1 };
 enum { GS_STATUS_OK = 0, GS_STATUS_MAX_ITER = 1, GS_STATUS_SINGULAR = 2, GS_STATUS_NAN = 3,
        GS_STATUS_FALLBACK_LINEAR = 4 /* answer replaced by gs_fallback_linear; converged = 1 as the reference's linear solver reports */ };

@@ -171,26 +171,98 @@ def test_reference_plug_point_signature_and_batch_helper():
     s.close(); ex.close()
 
 
-@pytest.mark.parametrize("name", ["solve_env3", "solve_radial13", "solve_tree123", "solve_meshed30", "solve_pv12"])
+@pytest.mark.parametrize("name", ["solve_env3", "solve_radial13", "solve_tree123", "solve_meshed30", "solve_pv12", "solve_scal20", "solve_scal123"])
 def test_linear_solver_paths_agree(name):
-    """tree elimination, sparse block LU and dense partial-pivot LU are three routes to the same
-    Newton step: identical iteration counts, solutions within 1e-10."""
+    """tree elimination, sparse block LU, dense partial-pivot LU and the dense block LU on the matrix cores (one workgroup per
+    instance, kernels_dense.hip) are four routes to the same Newton step: identical iteration counts, solutions within 1e-10."""
     d = golden(name)
     spec = spec_of(d, name)
     Pb = np.stack([d["P_spec"] * lam for lam in d["exact_scales"]])
     sols = {}
-    for ls in ("tree", "sparse_lu", "dense_pivot"):
+    for ls in ("tree", "sparse_lu", "dense_pivot", "dense_mfma"):
         if ls == "tree" and not spec.is_radial():
             continue
+        if ls == "dense_pivot" and spec.n > 100 and not spec.is_radial():
+            continue                                     # (the lane-per-instance pivoted LU on a 244 x 244 matrix: minutes)
         s = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, jacobian="exact", linear_solver=ls)
         sols[ls] = s.solve_batch(spec, Pb)
+        if ls == "dense_mfma":
+            assert s.handle_for(spec, len(Pb)).describe()["solve_kernel"] == "nr_dense_mfma"
         s.close()
-    base = sols["dense_pivot"]
+    base = sols.get("dense_pivot", sols["sparse_lu"])
     for ls, sol in sols.items():
         assert np.array_equal(sol.iterations, base.iterations), ls
         assert np.max(np.abs(sol.bus_voltages - base.bus_voltages)) < 1e-10, ls
         assert np.max(np.abs(sol.bus_angles - base.bus_angles)) < 1e-10, ls
+        assert np.max(np.abs(sol.line_flows - base.line_flows)) < 1e-9, ls
+        assert np.max(np.abs(sol.losses - base.losses)) < 1e-10 and np.max(np.abs(sol.max_mismatch - base.max_mismatch)) < 1e-10, ls
         assert sol.converged.all()
+
+
+def test_dense_mfma_flat_start_factors_shared_by_the_handle_change_nothing(monkeypatch):
+    """Iteration 0 of every solve starts from the flat start, where the Jacobian does not depend on the instance: its block
+    factors are computed once per handle (by the solver kernel itself) and only substituted with.  The same iterates as every
+    solve factoring for itself (GS_DENSE_NO_FLAT=1) up to the order of the additions in the forward substitution (1e-13)."""
+    d = golden("solve_scal123")
+    spec = spec_of(d)
+    rng = np.random.default_rng(5)
+    Pb = d["P_spec"][None, :] * rng.uniform(0.3, 1.6, (40, 1)) * (1.0 + 0.1 * rng.standard_normal((40, spec.n)))
+    outs = []
+    for flag in (None, "1"):
+        if flag:
+            monkeypatch.setenv("GS_DENSE_NO_FLAT", flag)
+        s = P.BatchedNewtonRaphsonSolver(tolerance=1e-10, max_iterations=30, linear_solver="dense_mfma")
+        outs.append(s.solve_batch(spec, Pb))
+        s.close()
+    monkeypatch.delenv("GS_DENSE_NO_FLAT")
+    a, b = outs
+    assert a.converged.all() and np.array_equal(a.iterations, b.iterations)
+    for f, tol in (("bus_voltages", 1e-13), ("bus_angles", 1e-13), ("line_flows", 1e-11), ("losses", 1e-11), ("max_mismatch", 1e-11)):
+        assert np.max(np.abs(getattr(a, f) - getattr(b, f))) < tol, f      # (flows: voltage differences times admittances of ~1e3)
+
+
+def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_the_edge_cases():
+    """AUTO: the ScalableFeeder-like graph goes to the dense block LU on the matrix cores, the 26-loop feeder stays sparse.  Edge
+    cases through the dense kernel: a ragged batch (more instances than workgroups of the persistent grid would be B > 256; here
+    B = 70 with a zero-load instance that converges at the first check), the iteration cap (status 1, iterates equal to the
+    other routes'), a non-finite injection (status 3) and PV buses."""
+    dense, sparse = P.scalable_like(40, seed=3), P.random_meshed(40, 6, seed=2)
+    s = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30)
+    rng = np.random.default_rng(0)
+    B = 70
+    Pd = -rng.uniform(0.0, 0.03, (B, dense.n)); Pd[:, 0] = 0.0; Pd[5] = 0.0
+    a = s.solve_batch(dense, Pd)
+    assert s.handle_for(dense, B).describe()["solve_kernel"] == "nr_dense_mfma"
+    s.solve_batch(sparse, np.zeros((2, sparse.n)))
+    assert s.handle_for(sparse, 2).describe()["solve_kernel"] == "nr_sparse_lu"
+    s.close()
+    ref = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, linear_solver="sparse_lu")
+    b = ref.solve_batch(dense, Pd)
+    ref.close()
+    assert a.converged.all() and np.array_equal(a.iterations, b.iterations) and a.iterations[5] == 1
+    assert np.all(a.bus_voltages[5] == 1.0) and np.max(np.abs(a.bus_voltages - b.bus_voltages)) < 1e-11
+    assert np.max(np.abs(a.bus_angles - b.bus_angles)) < 1e-11 and np.max(np.abs(a.line_flows - b.line_flows)) < 1e-10
+    for cap in (1, 2):
+        outs = []
+        for ls in ("dense_mfma", "sparse_lu"):
+            q = P.BatchedNewtonRaphsonSolver(tolerance=1e-12, max_iterations=cap, linear_solver=ls)
+            outs.append(q.solve_batch(dense, Pd[:9]))
+            q.close()
+        assert np.array_equal(outs[0].status, outs[1].status) and np.array_equal(outs[0].iterations, outs[1].iterations)
+        assert np.max(np.abs(outs[0].bus_voltages - outs[1].bus_voltages)) < 1e-11
+        assert np.max(np.abs(outs[0].max_mismatch - outs[1].max_mismatch)) < 1e-11
+    bad = Pd[:4].copy(); bad[2, 7] = np.nan
+    q = P.BatchedNewtonRaphsonSolver(linear_solver="dense_mfma")
+    o = q.solve_batch(dense, bad)
+    q.close()
+    assert o.status[2] == 3 and not o.converged[2] and o.converged[[0, 1, 3]].all()
+    d = golden("solve_pv12")
+    spec = spec_of(d)
+    q = P.BatchedNewtonRaphsonSolver(tolerance=1e-6, max_iterations=50, linear_solver="dense_mfma")
+    sol = q.solve_batch(spec, np.stack([d["P_spec"] * lam for lam in d["exact_scales"]]))
+    q.close()
+    for k in range(len(d["exact_scales"])):
+        check(sol, k, d, f"B{k}_", 1e-9)
 
 
 def test_block_elimination_as_coded_where_its_pivots_are_regular():
