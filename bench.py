@@ -700,7 +700,7 @@ def main():
             # recipe (feeders/synthetic.py:233: ~1000 lines, a graph whose block LU fills in almost completely).
             result["also_meshed"] = {}
             for key, mk, Bm, K, W_ in (("loops26", lambda: make_feeder("meshed_loops26"), B, min(args.steps, 20), min(args.warmup, 20)),
-                                       ("scalable", lambda: make_feeder("meshed_scalable"), B, 3, 1)):
+                                       ("scalable", lambda: make_feeder("meshed_scalable"), B, 5, 2)):
                 try:
                     fsm = mk()
                     mm = measure(fsm, Bm, "nr", False, 3, warmup=W_, steps=K)
@@ -714,6 +714,20 @@ def main():
                     rl["fp64_valu"] = {"achieved_tflops": tf, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
                                        "flops_per_iteration_per_instance": fl_it, "mean_iterations": mm["mean_iterations"],
                                        "how": "28 flops per scheduled pair update (host schedule, gs_describe lu_pairs) + 30 per pivot + 40 per Ybus entry"}
+                    if mm["desc"]["kernel"] == "nr_dense_mfma":
+                        # dense block LU on the matrix cores: the roofline that binds is FP64 MFMA.  Algorithmic flops:
+                        # (2/3) N^3 + 2 N^2 per Newton solve, N = 2 (n - 1), one solve per iteration but the last (the converged check)
+                        N_ = 2 * (fsm.n - 1)
+                        fl_solve = (2.0 / 3.0) * N_ ** 3 + 2.0 * N_ ** 2
+                        solves = max(mm["mean_iterations"] - 1.0, 0.0)
+                        tfm = fl_solve * solves * Bm / (sm["avg_launch_ms"] * 1e-3) / 1e12 if sm["avg_launch_ms"] > 0 else 0.0
+                        rl = {"bound": "mfma", "achieved": tfm, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfm / FP64_VECTOR_PEAK_TFLOPS,
+                              "traffic": None, "kernel": "gs_k_nr_dense_mfma (between gs_k_pre_nr_dmfma and gs_k_post_nr_dmfma)",
+                              "avg_launch_ms": sm["avg_launch_ms"], "avg_launch_method": rl["avg_launch_method"] + "; a step here is three launches (prologue, dense Newton-Raphson, epilogue): the span covers all three",
+                              "algorithmic_flops_per_launch": fl_solve * solves * Bm,
+                              "how": f"(2/3) N^3 + 2 N^2 = {fl_solve:.3g} flops per Newton solve at N = {N_}, {solves:.2f} solves per step (iterations - 1); the peak is the dense FP64 "
+                                     "MFMA rate (= the FP64 vector rate on this part); the first solve of a step reuses the handle's flat-start factors, so the executed flops are about half",
+                              "hbm_view": {"achieved_GB_per_s": rl["achieved"], "frac": rl["frac"], "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"]}}
                     rl["traffic"] = traffic_of(f"meshed_{key}_b8192:nr") if Bm == 8192 else None
                     rl["traffic_source"] = traffic_source(f"meshed_{key}_b8192:nr")
                     entry = {"workload": f"{fsm.name}, batch={Bm}, Newton-Raphson (exact Jacobian), stochastic loads + weather",

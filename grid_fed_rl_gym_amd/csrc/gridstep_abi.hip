@@ -884,11 +884,11 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   }
 
   // ---- level schedule of the sparse block LU for this handle's W waves (kernels_solve.hip, linsolve_lu) ----
-  std::vector<int32_t> lu_a_ptr, lu_a, lu_b_ptr, lu_b, lu_c_ptr, lu_c;
+  std::vector<int32_t> lu_a_ptr, lu_a, lu_b_ptr, lu_b, lu_c_ptr, lu_c, lu_r_ptr, lu_r;
   if (ht.has_lu) {
     const int NL = ht.lu_n_levels, Wn = h->W;
     std::vector<std::vector<std::vector<int32_t>>> A(Wn, std::vector<std::vector<int32_t>>(NL)), Bs(Wn, std::vector<std::vector<int32_t>>(NL)),
-        Cs(Wn, std::vector<std::vector<int32_t>>(NL));
+        Cs(Wn, std::vector<std::vector<int32_t>>(NL)), Rs(Wn, std::vector<std::vector<int32_t>>(NL));
     for (int L = 0; L < NL; ++L) {
       // phase A: one item per (pivot, neighbour), plus one per pivot for the singularity test; dealt round-robin
       int turn = 0;
@@ -914,6 +914,11 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         auto& b = Bs[w][L];
         b.push_back(e.first); b.push_back((int32_t)e.second.size());
         for (auto& u : e.second) { b.push_back(u.first); b.push_back(u.second); }
+        if (e.first < -ht.n) {      // the right-hand-side records alone: all iteration 0 needs (GsTables::lu_flat)
+          auto& rr = Rs[w][L];
+          rr.push_back(e.first); rr.push_back((int32_t)e.second.size());
+          for (auto& u : e.second) { rr.push_back(u.first); rr.push_back(u.second); }
+        }
       }
       // phase C: the level's pivots, round-robin
       int tc = 0;
@@ -925,7 +930,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         ptr.push_back((int32_t)flat.size() / unit);
       }
     };
-    flatten(A, lu_a_ptr, lu_a, 2); flatten(Bs, lu_b_ptr, lu_b, 1); flatten(Cs, lu_c_ptr, lu_c, 1);
+    flatten(A, lu_a_ptr, lu_a, 2); flatten(Bs, lu_b_ptr, lu_b, 1); flatten(Cs, lu_c_ptr, lu_c, 1); flatten(Rs, lu_r_ptr, lu_r, 1);
   }
 
   // ---- tables ----
@@ -953,7 +958,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   UP(lu_pair_ij, lu_pair_ij); UP(lu_orig_slot, lu_orig_slot); UP(lu_orig_i, lu_orig_i); UP(lu_orig_j, lu_orig_j);
   UP(lu_orig_pos, lu_orig_pos);
   if ((rc = dev_upload(h, &T.lu_a_ptr, lu_a_ptr)) || (rc = dev_upload(h, &T.lu_a, lu_a)) || (rc = dev_upload(h, &T.lu_b_ptr, lu_b_ptr)) ||
-      (rc = dev_upload(h, &T.lu_b, lu_b)) || (rc = dev_upload(h, &T.lu_c_ptr, lu_c_ptr)) || (rc = dev_upload(h, &T.lu_c, lu_c))) return bail(rc);
+      (rc = dev_upload(h, &T.lu_b, lu_b)) || (rc = dev_upload(h, &T.lu_c_ptr, lu_c_ptr)) || (rc = dev_upload(h, &T.lu_c, lu_c)) ||
+      (rc = dev_upload(h, &T.lu_r_ptr, lu_r_ptr)) || (rc = dev_upload(h, &T.lu_r, lu_r))) return bail(rc);
   UP(dn_th_idx, dn_th_idx); UP(dn_vm_idx, dn_vm_idx);
   UP(bl_ptr, bl_ptr); UP(bl_idx, bl_idx); UP(bg_ptr, bg_ptr); UP(bg_idx, bg_idx); UP(bb_ptr, bb_ptr); UP(bb_idx, bb_idx);
   UP(load_base, load_base); UP(load_q, load_q); UP(gen_kind, gen_kind); UP(gen_cap, gen_cap); UP(gen_p0, gen_p0);
@@ -1100,6 +1106,31 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       (rc = dev_alloc(h, &h->d_mask, (size_t)h->B)))
     return bail(rc);
   h->h_f.resize((size_t)SF_COUNT * h->Bp); h->h_i.resize((size_t)SI_COUNT * h->Bp); h->h_u.resize((size_t)SU_COUNT * h->Bp);
+  // Sparse block LU: iteration 0 of every solve factors the flat-start Jacobian, which is the same for every instance.  One
+  // ordinary solve of group 0, capped at one iteration, leaves those factors in the rows of lane 0; they are kept as a table
+  // of wave-uniform scalars (GsTables::lu_flat) and iteration 0 then only carries its right-hand side through
+  // (kernels_solve.hip, linsolve_lu_flat: bit-identical -- the same blocks, the same operations).  GS_LU_NO_FLAT=1: off.
+  if (h->solve_kernel == 1 && ht.lu_n_piv > 0 && !getenv("GS_LU_NO_FLAT")) {
+    double* tab = nullptr;
+    const int nblk = ht.lu_n_slots + ht.n;
+    if ((rc = dev_alloc(h, &tab, (size_t)4 * nblk + 4))) return bail(rc);
+    hipLaunchKernelGGL(gs_k_fill_rows, dim3(1), dim3(64), 0, h->stream, R.P.base, 2, ht.n, R.total, h->slab, -0.01);
+    hipLaunchKernelGGL(gs_k_fill_rows, dim3(1), dim3(64), 0, h->stream, R.Q.base, 2, ht.n, R.total, h->slab, 0.0);
+    GsSolveCfg once = h->SC; once.max_iterations = 1; once.stamps = nullptr;
+    hipLaunchKernelGGL(gs_k_nr_lu, dim3(1), dim3(64 * h->W), h->dyn_lds, h->stream, h->T, h->R, once, h->slab, 1);
+    if (ht.lu_n_slots > 0)
+      hipLaunchKernelGGL(gs_k_gather_lane, dim3((4 * ht.lu_n_slots + 255) / 256), dim3(256), 0, h->stream, R.LU, 4 * ht.lu_n_slots, 0, h->slab, tab);
+    hipLaunchKernelGGL(gs_k_gather_lane, dim3((4 * ht.n + 255) / 256), dim3(256), 0, h->stream, R.LUD, 4 * ht.n, 0, h->slab, tab + (size_t)4 * ht.lu_n_slots);
+    double status = 0.0;
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(&status, h->slab + GS_ELEM(R.STATUS, 0), sizeof status, hipMemcpyDeviceToHost) != hipSuccess)
+      return bail(fail(nullptr, GS_E_HIP, "sparse LU: factorisation of the flat-start Jacobian failed"));
+    const double flag = status == (double)GS_STATUS_SINGULAR ? 1.0 : 0.0;
+    if (hipMemcpy(tab + (size_t)4 * nblk, &flag, sizeof flag, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->slab, 0, (size_t)R.total * GS_LANES * sizeof(double)) != hipSuccess)      // group 0 as gs_create leaves every group
+      return bail(fail(nullptr, GS_E_HIP, "sparse LU: flat-start table"));
+    h->T.lu_flat = tab;
+  }
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipDeviceSynchronize failed"));
   *out = h;
   return GS_OK;

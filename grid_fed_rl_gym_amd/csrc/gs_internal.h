@@ -222,6 +222,14 @@ struct GsTables {
   const int32_t* lu_b;
   const int32_t* lu_c_ptr;       // [W * (lu_n_levels + 1)]
   const int32_t* lu_c;
+  // Iteration 0 of every Newton-Raphson solve starts from the flat start, where the Jacobian does not depend on the instance:
+  // the handle factors it once (gs_create) and keeps the blocks here -- [lu_n_slots] off-diagonal blocks as the factorisation
+  // leaves them (column blocks scaled by D_k^-1), then [n] diagonal blocks D_i, then one flag (a pivot was singular); read as
+  // wave-uniform scalars.  Iteration 0 then only carries the right-hand side through: lu_r = phase B's right-hand-side records
+  // alone, same format, per wave and level.  NULL: every solve factors for itself.
+  const double* lu_flat;
+  const int32_t* lu_r_ptr;       // [W * (lu_n_levels + 1)]
+  const int32_t* lu_r;
   // dense partial-pivoting LU (reference-faithful linear solve, power_flow.py:187): unknown
   // order [theta(non-slack, ascending) ; Vm(pq, ascending)] exactly as power_flow.py:232-240
   int32_t dn_N, pad2;

@@ -92,9 +92,9 @@ __device__ __forceinline__ void gd_gemm64(double* C, int ldc, const double* A, i
 // the owner of the pivot tile P inverts it in registers and publishes P^-1; the owners of P's block row publish their tiles
 // R_j, the owners of its block column their tiles C_i.  With T_j = P^-1 R_j, in-place Gauss-Jordan is
 //     M_ij -= C_i T_j  (i, j != kb),   row block kb <- T_j,   column block kb <- -C_i P^-1,   pivot tile <- P^-1,
-// and ONE uniform update M -= C' T' does all of it when C'_kb = P - I and T'_kb = I + P^-1 (the block form of the scalar
-// identities m_kk - 1 and 1 + 1/m_kk); the row block takes T_j and the pivot tile P^-1 directly, the column block keeps the
-// uniform form (it loses log10 |P| digits there, three of sixteen for these matrices).
+// the row block's owners form T_j and publish it (second barrier), their tiles and the pivot tile are then final; every other
+// tile takes M -= C_i T'_j with T'_kb = I + P^-1 for the pivot's tile column, which yields -C_i P^-1 there (the block form of
+// the scalar identity 1 + 1/m_kk; it loses log10 |P| digits in that column block, three of sixteen for these matrices).
 // buf: [2 parities][rowb 4 x 64 | colb 64 x 4 | pinv 16] doubles.  Returns 1 if a pivot was zero or not finite.
 #define GD_GJ_DOUBLES (2 * 528)
 __device__ __forceinline__ double gd_rcp(double x) {
@@ -114,13 +114,7 @@ __device__ __forceinline__ int gd_invert64(double* D, int ld, double* buf) {
   for (int kb = 0; kb < 16; ++kb) {
     double* rowb = buf + (kb & 1) * 528, *colb = rowb + 256, *pinv = colb + 256;
     const bool rown = tr == kb, cown = tc == kb;
-    if (rown) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *(double2*)(rowb + 64 * i + 4 * tc) = make_double2(m[i][0], m[i][1]);
-        *(double2*)(rowb + 64 * i + 4 * tc + 2) = make_double2(m[i][2], m[i][3]);
-      }
-    }
+    // (1) the pivot tile's owner inverts it in registers and publishes P^-1; the column block's owners publish their tiles C_i
     if (cown) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -128,7 +122,7 @@ __device__ __forceinline__ int gd_invert64(double* D, int ld, double* buf) {
         *(double2*)(colb + 16 * tr + 4 * i + 2) = make_double2(m[i][2], m[i][3]);
       }
     }
-    if (rown && cown) {      // the pivot tile: in-place Gauss-Jordan on 4 x 4, static indices
+    if (rown && cown) {      // in-place Gauss-Jordan on 4 x 4, static indices
       double a[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -158,39 +152,57 @@ __device__ __forceinline__ int gd_invert64(double* D, int ld, double* buf) {
       }
     }
     __syncthreads();
-    double pi[4][4], r[4][4], c[4][4];
+    // (2) the row block's owners form T_j = P^-1 R_j once (every thread of a tile column formed it for itself before: half
+    // of a step's arithmetic and LDS reads) and publish it; their own tiles take it as they stand
+    if (rown) {
+      double pi[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const double2 p0 = *(const double2*)(pinv + 4 * i), p1 = *(const double2*)(pinv + 4 * i + 2);
-      const double2 r0 = *(const double2*)(rowb + 64 * i + 4 * tc), r1 = *(const double2*)(rowb + 64 * i + 4 * tc + 2);
-      const double2 c0 = *(const double2*)(colb + 16 * tr + 4 * i), c1 = *(const double2*)(colb + 16 * tr + 4 * i + 2);
-      pi[i][0] = p0.x; pi[i][1] = p0.y; pi[i][2] = p1.x; pi[i][3] = p1.y;
-      r[i][0] = r0.x; r[i][1] = r0.y; r[i][2] = r1.x; r[i][3] = r1.y;
-      c[i][0] = c0.x; c[i][1] = c0.y; c[i][2] = c1.x; c[i][3] = c1.y;
+      for (int i = 0; i < 4; ++i) {
+        const double2 p0 = *(const double2*)(pinv + 4 * i), p1 = *(const double2*)(pinv + 4 * i + 2);
+        pi[i][0] = p0.x; pi[i][1] = p0.y; pi[i][2] = p1.x; pi[i][3] = p1.y;
+      }
+      double t[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double v = pi[i][0] * m[0][j];
+          v = __builtin_fma(pi[i][1], m[1][j], v); v = __builtin_fma(pi[i][2], m[2][j], v); v = __builtin_fma(pi[i][3], m[3][j], v);
+          t[i][j] = v;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // the tile column of the pivot publishes T' = I + P^-1 (what makes the uniform update below right for the column block)
+        const double d0 = (i == 0 ? 1.0 : 0.0), d1 = (i == 1 ? 1.0 : 0.0), d2 = (i == 2 ? 1.0 : 0.0), d3 = (i == 3 ? 1.0 : 0.0);
+        const double2 lo = cown ? make_double2(pi[i][0] + d0, pi[i][1] + d1) : make_double2(t[i][0], t[i][1]);
+        const double2 hi = cown ? make_double2(pi[i][2] + d2, pi[i][3] + d3) : make_double2(t[i][2], t[i][3]);
+        *(double2*)(rowb + 64 * i + 4 * tc) = lo;
+        *(double2*)(rowb + 64 * i + 4 * tc + 2) = hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = cown ? pi[i][j] : t[i][j];
+      }
     }
-    // T = P^-1 R (column block kb: I + P^-1), C' = C (row block kb: P - I)
-    double t[4][4];
+    __syncthreads();
+    // (3) everybody else: M -= C_i T_j
+    if (!rown) {
+      double t[4][4], c[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double v = pi[i][0] * r[0][j];
-        v = __builtin_fma(pi[i][1], r[1][j], v); v = __builtin_fma(pi[i][2], r[2][j], v); v = __builtin_fma(pi[i][3], r[3][j], v);
-        double alt = pi[i][j] + (i == j ? 1.0 : 0.0);
-        asm volatile("" : "+v"(v), "+v"(alt));       // both sides computed by every lane: a select, not sixteen divergent branches
-        t[i][j] = cown ? alt : v;
+      for (int i = 0; i < 4; ++i) {
+        const double2 r0 = *(const double2*)(rowb + 64 * i + 4 * tc), r1 = *(const double2*)(rowb + 64 * i + 4 * tc + 2);
+        const double2 c0 = *(const double2*)(colb + 16 * tr + 4 * i), c1 = *(const double2*)(colb + 16 * tr + 4 * i + 2);
+        t[i][0] = r0.x; t[i][1] = r0.y; t[i][2] = r1.x; t[i][3] = r1.y;
+        c[i][0] = c0.x; c[i][1] = c0.y; c[i][2] = c1.x; c[i][3] = c1.y;
       }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c[i][i] = rown ? c[i][i] - 1.0 : c[i][i];
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double v = m[i][j];
-        v = __builtin_fma(-c[i][0], t[0][j], v); v = __builtin_fma(-c[i][1], t[1][j], v);
-        v = __builtin_fma(-c[i][2], t[2][j], v); v = __builtin_fma(-c[i][3], t[3][j], v);
-        m[i][j] = rown ? (cown ? pi[i][j] : t[i][j]) : v;
-      }
+        for (int j = 0; j < 4; ++j) {
+          double v = m[i][j];
+          v = __builtin_fma(-c[i][0], t[0][j], v); v = __builtin_fma(-c[i][1], t[1][j], v);
+          v = __builtin_fma(-c[i][2], t[2][j], v); v = __builtin_fma(-c[i][3], t[3][j], v);
+          m[i][j] = v;
+        }
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

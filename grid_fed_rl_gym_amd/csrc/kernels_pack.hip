@@ -97,3 +97,11 @@ gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long 
   if (expand) dst[r * D + c] = src[idx];
   else dst[idx] = src[r * D + c];
 }
+
+// out[q] = row (row0 + q) of lane `lane` of group 0, q < count (gs_create: the handle's flat-start LU blocks, read off the
+// rows one ordinary factorisation left there)
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_gather_lane(int row0, int count, int lane, const double* __restrict__ slab, double* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < count) out[q] = slab[GS_ELEM(row0 + q, lane)];
+}

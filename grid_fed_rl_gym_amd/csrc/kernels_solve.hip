@@ -668,6 +668,61 @@ __device__ __forceinline__ void linsolve_lu(Ctx& c, const GsSolveCfg& C, NrState
   stamp(c, ST_TOP_DOWN);
 }
 
+// Iteration 0 with the handle's flat-start factors (GsTables::lu_flat): the blocks are wave-uniform scalars, only the
+// right-hand side and the solution go through the rows.
+__device__ __forceinline__ Blk flat_blk(const GsTables& T, int idx) {
+  Blk b; b.a00 = cld(T.lu_flat, 4 * idx); b.a01 = cld(T.lu_flat, 4 * idx + 1); b.a10 = cld(T.lu_flat, 4 * idx + 2); b.a11 = cld(T.lu_flat, 4 * idx + 3);
+  return b;
+}
+__device__ __forceinline__ void linsolve_lu_flat(Ctx& c, const GsSolveCfg& C, NrState& st, int par) {
+  const GsTables& T = c.T; const GsRows& R = c.R; GsLaneRows S = c.S;
+  const int NL = T.lu_n_levels, pw = c.wave * (NL + 1);
+  for (int L = 0; L < NL; ++L) {          // forward: r_i -= (A_ik D_k^-1) r_k, level by level
+    int p = cld(T.lu_r_ptr, pw + L);
+    const int p1 = cld(T.lu_r_ptr, pw + L + 1);
+    while (p < p1) {
+      const int i = -cld(T.lu_r, p) - 1 - T.n, cnt = cld(T.lu_r, p + 1);
+      p += 2;
+      double r0 = ROW(R.R0 + i), r1 = ROW(R.R1 + i);
+      for (int u = 0; u < cnt; ++u, p += 2) {
+        const Blk l = flat_blk(T, cld(T.lu_r, p));
+        const int k = cld(T.lu_r, p + 1);
+        const double rk0 = ROW(R.R0 + k), rk1 = ROW(R.R1 + k);
+        r0 -= l.a00 * rk0 + l.a01 * rk1;
+        r1 -= l.a10 * rk0 + l.a11 * rk1;
+      }
+      ROW(R.R0 + i) = r0; ROW(R.R1 + i) = r1;
+    }
+    __syncthreads();
+  }
+  stamp(c, ST_BOTTOM_UP);
+  const bool sing_all = cld(T.lu_flat, 4 * (T.lu_n_slots + T.n)) != 0.0;
+  if (!st.done && sing_all) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+  const bool upd = !st.done;
+  for (int L = NL - 1; L >= 0; --L) {
+    const int q1 = cld(T.lu_c_ptr, pw + L + 1);
+    for (int q = cld(T.lu_c_ptr, pw + L); q < q1; ++q) {
+      const int t = cld(T.lu_c, q), k = cld(T.lu_piv_bus, t);
+      int dummy = 0;
+      const Blk inv = inv2(flat_blk(T, T.lu_n_slots + k), &dummy);
+      double r0 = ROW(R.R0 + k), r1 = ROW(R.R1 + k);
+      const int n1 = cld(T.lu_nb_ptr, t + 1);
+      for (int u = cld(T.lu_nb_ptr, t); u < n1; ++u) {
+        const int j = cld(T.lu_nb_bus, u);
+        const Blk akj = flat_blk(T, cld(T.lu_nb_kj, u));
+        const double xj0 = ROW(R.X0 + j), xj1 = ROW(R.X1 + j);
+        r0 -= akj.a00 * xj0 + akj.a01 * xj1;
+        r1 -= akj.a10 * xj0 + akj.a11 * xj1;
+      }
+      ROW(R.X0 + k) = inv.a00 * r0 + inv.a01 * r1;
+      ROW(R.X1 + k) = inv.a10 * r0 + inv.a11 * r1;
+      apply_step(c, k, C.alpha, upd);
+    }
+    __syncthreads();
+  }
+  stamp(c, ST_TOP_DOWN);
+}
+
 // ---- dense, partially pivoted LU per instance: the reference-faithful linear solve -------------
 // (np.linalg.solve = LAPACK dgesv, power_flow.py:187): same unknown order, same pivot rule
 // (largest |a_ik| in the column), exact-zero pivot = singular.  Row exchanges are per instance,
@@ -774,7 +829,7 @@ __device__ __forceinline__ void newton_loop(Ctx& c, const GsSolveCfg& C, NrState
     if (__all(st.done)) break;
     if (KIND == KIND_TREE) linsolve_tree(c, C, st, it & 1);
     else if (KIND == KIND_TREE_LDS) linsolve_tree_lds(c, C, st, it & 1);
-    else if (KIND == KIND_LU) linsolve_lu(c, C, st, it & 1);
+    else if (KIND == KIND_LU) { if (it == 0 && c.T.lu_flat != nullptr) linsolve_lu_flat(c, C, st, it & 1); else linsolve_lu(c, C, st, it & 1); }
     else linsolve_dense(c, C, st, it & 1);
     stale = true;
   }

@@ -199,6 +199,32 @@ def test_linear_solver_paths_agree(name):
         assert sol.converged.all()
 
 
+@pytest.mark.parametrize("name", ["solve_meshed30", "solve_scal20", "solve_tree123"])
+def test_sparse_lu_flat_start_factors_shared_by_the_handle_change_nothing(name, monkeypatch):
+    """The sparse block LU keeps the factors of the flat-start Jacobian (the same for every instance) as a table of scalars and
+    iteration 0 only carries its right-hand side through them: bit for bit what every solve factoring for itself gives
+    (GS_LU_NO_FLAT=1) -- the same blocks, the same operations in the same order."""
+    d = golden(name)
+    spec = spec_of(d)
+    rng = np.random.default_rng(6)
+    Pb = d["P_spec"][None, :] * rng.uniform(0.3, 1.5, (70, 1)) * (1.0 + 0.1 * rng.standard_normal((70, spec.n)))
+    Pb[3] = 0.0
+    outs = []
+    for flag in (None, "1"):
+        if flag:
+            monkeypatch.setenv("GS_LU_NO_FLAT", flag)
+        for cap in (1, 30):
+            s = P.BatchedNewtonRaphsonSolver(tolerance=1e-10, max_iterations=cap, linear_solver="sparse_lu")
+            outs.append(s.solve_batch(spec, Pb))
+            s.close()
+    monkeypatch.delenv("GS_LU_NO_FLAT")
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert np.array_equal(a.iterations, b.iterations) and np.array_equal(a.status, b.status)
+        for f in ("bus_voltages", "bus_angles", "line_flows", "losses", "max_mismatch"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert outs[1].converged.all()
+
+
 def test_dense_mfma_flat_start_factors_shared_by_the_handle_change_nothing(monkeypatch):
     """Iteration 0 of every solve starts from the flat start, where the Jacobian does not depend on the instance: its block
     factors are computed once per handle (by the solver kernel itself) and only substituted with.  The same iterates as every
