@@ -105,3 +105,38 @@ def test_device_array_interface_and_device_address_validation():
     FakeTensor.dtype = "torch.float32"
     with pytest.raises(PowerFlowError):
         _device_address(FakeTensor(), (4, 3))
+
+
+def test_scalable_like_generator_is_seeded_meshed_and_in_the_reference_recipes_range():
+    """feeders.scalable_like: the recipe of the reference's ScalableFeeder (feeders/synthetic.py:233-251) from a private seeded
+    generator -- a connected graph of ~1000 lines on 123 buses (the reference's own instance has 1035, tests/golden/solve_scal123),
+    the spanning tree alone with connectivity 0, hash-pinned like the other synthetic feeders."""
+    s = P.scalable_like(123, seed=1)
+    assert (s.n, s.m, s.n_loads, s.n_gens, s.n_bats) == (123, 1038, 111, 26, 17) and not s.is_radial()
+    assert s.sha256() == P.scalable_like(123, seed=1).sha256() != P.scalable_like(123, seed=2).sha256()
+    assert s.sha256().startswith("1e19c85ae909a99c")
+    pairs = {(min(a, b), max(a, b)) for a, b in zip(s.frm, s.to)}
+    assert len(pairs) == s.m and all(a != b for a, b in pairs)                       # no parallel lines, no self loops
+    assert 0.0 < s.r.min() and s.r.max() < 0.05 and 0.0 < s.x.min() and s.x.max() < 0.07     # 0.2-0.5 / 0.3-0.7 ohm/km over 0.05-1.5 km on 15.55 ohm
+    assert 2e6 <= s.rating.min() and s.rating.max() <= 10e6 and 20e3 <= s.load_base.min() and s.load_base.max() <= 300e3
+    t = P.scalable_like(40, seed=3, connectivity=0.0)
+    assert t.m == 39 and t.is_radial()
+
+
+def test_bench_reports_counter_traffic_only_for_the_kernel_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic is a constant from profiles/hbm_traffic.json, not something a bench run measures: bench.py hands it out only
+    while the kernel sources hash to what the entry recorded, and says where it came from either way."""
+    import importlib, json, sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    cur = bench.csrc_hash()
+    assert len(cur) == 16 and cur == bench.csrc_hash()
+    prof = tmp_path / "profiles"; prof.mkdir()
+    json.dump({"a:fbs": {"solve_bytes_per_launch": 123, "csrc_sha": cur, "profile": "rXX"},
+               "b:nr": {"solve_bytes_per_launch": 456, "csrc_sha": "0" * 16, "profile": "old"}}, open(prof / "hbm_traffic.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_hash", lambda: cur)
+    assert bench.traffic_of("a:fbs") == 123 and bench.traffic_of("b:nr") is None and bench.traffic_of("missing") is None
+    src = bench.traffic_source("b:nr")
+    assert src["stale"] and src["bytes_when_measured"] == 456 and src["profile"] == "old"
+    assert not bench.traffic_source("a:fbs")["stale"]
