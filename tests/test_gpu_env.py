@@ -610,3 +610,49 @@ def test_result_rows_restored_on_demand_equal_rows_written_by_every_step(solver,
             for q in a:
                 assert np.array_equal(np.asarray(a[q]), np.asarray(b[q])), (k, q)
     lean.close(); eager.close()
+
+
+def test_environment_on_a_meshed_feeder_through_the_dense_mfma_solver_equals_the_sparse_lu_path():
+    """A step of a handle whose Newton-Raphson is the dense block LU on the matrix cores is three launches (prologue | one workgroup
+    per instance | epilogue + observation pack).  Against the same environment on the sparse block LU (one fused launch): steps with
+    stochastic loads and weather, the fused post-step checks, a masked reset, a checkpoint round trip and a device rollout with
+    in-place resets -- observations within 1e-10 (two linear solvers), discrete outputs equal."""
+    from grid_fed_rl_gym_amd.safety import PostStepChecks
+    spec = P.scalable_like(40, seed=3)
+    B = 150
+    kw = dict(num_envs=B, solver="nr", stochastic_loads=True, weather_variation=True, episode_length=6, tolerance=1e-9)
+    envs = {ls: P.BatchedGridEnvironment(spec, linear_solver=ls, **kw) for ls in ("dense_mfma", "sparse_lu")}
+    assert envs["dense_mfma"].handle.describe()["solve_kernel"] == "nr_dense_mfma"
+    rng = np.random.default_rng(17)
+    acts = rng.uniform(-1, 1, (5, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 40
+    mask = (rng.random(B) < 0.3).astype(np.uint8)
+    outs = {}
+    for ls, env in envs.items():
+        got = []
+        h = env.handle
+        env.reset(seed=seeds); h.upload_actions(acts)
+        for k in range(2):
+            h.step_device(k)
+        got.append(h.download_step()); got.append(env.last_solution())
+        ck = PostStepChecks(env, fused=True)
+        h.step_device(2)
+        got.append(ck.download()); got.append(h.download_step())
+        ck.close()
+        h.reset(seeds + np.uint64(1), mask, want_obs=False)
+        env.set_state(env.get_state())
+        h.step_device(3)
+        got.append(h.download_step())
+        h.rollout(9, "random", seed=5)
+        got.append(h.rollout_download())
+        outs[ls] = got
+    for k, (a, b) in enumerate(zip(outs["dense_mfma"], outs["sparse_lu"])):
+        for q in a:
+            x, y = np.asarray(a[q]), np.asarray(b[q])
+            if x.dtype.kind == "f":
+                assert np.max(np.abs(x - y) / np.maximum(1.0, np.abs(y)), initial=0.0) < 1e-10, (k, q)
+            else:
+                assert np.array_equal(x, y), (k, q)
+    assert outs["dense_mfma"][-1]["n_terminal"] > 0
+    for env in envs.values():
+        env.close()
