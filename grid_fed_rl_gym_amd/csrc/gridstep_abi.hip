@@ -86,7 +86,7 @@ struct gs_handle {
   // the env step of a handle whose solver is the dataflow sweep runs the second-generation kernel (kernels_flow2.hip:
   // 32 instances per workgroup, half-waves on different buses) when the feeder fits its tables; gs_solve keeps kernel 6
   bool flow2 = false; GsF2Tables F2{}; std::string flow2_why;
-  bool f2_small = false, f2_half = false, f2_wide = false; int f2_iw = 32, f2_nw = 16;
+  bool f2_small = false, f2_half = false, f2_wide = false; int f2_iw = 32, f2_nw = 16, f2_npos = 0;
   // A step of the 16-instance sweep kernel goes out as TWO launches, each half of the workgroups, on two streams: consecutive
   // steps of one half need nothing from the other half, so the second stream's kernels slide into the launch gaps and the
   // uneven tails of the first's (two handles of 4096 instances on two streams: 205 M env-steps/s against 186 M for one of
@@ -826,6 +826,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const int NW = small ? GS_F2NS_WAVES : GS_F2N_WAVES, NI = small ? GS_F2NS_ITEMS : GS_F2N_ITEMS, IW = small ? GS_F2S_IW : 32, HV = 64 / IW;
     const int max_items = deal(NW, HV, mine, mine_lv);
     const int NPOS = NW * HV * NI, maxw = ht.max_level_width;
+    h->f2_npos = NPOS;
     GsF2Tables& F = h->F2;
     const size_t ring_bytes = (size_t)2 * maxw * 3 * IW * 16;
     const int pos_off = (2 * ht.n * GS_F2_CHILDREN + nsl + 3) & ~3;
@@ -1130,6 +1131,25 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         hipMemset(h->slab, 0, (size_t)R.total * GS_LANES * sizeof(double)) != hipSuccess)      // group 0 as gs_create leaves every group
       return bail(fail(nullptr, GS_E_HIP, "sparse LU: flat-start table"));
     h->T.lu_flat = tab;
+  }
+  // Newton-Raphson on the second-generation frame: the constants of the flat-start elimination (GsF2Tables::nrflat), written by
+  // ONE workgroup of the step kernel itself on the zeroed state of group 0, then group 0 is cleared again.  GS_NR_NO_FLAT=1: off.
+  if (h->nr2 && h->f2_npos > 0 && !getenv("GS_NR_NO_FLAT")) {
+    double* tab = nullptr;
+    if ((rc = dev_alloc(h, &tab, (size_t)h->f2_npos * 16))) return bail(rc);
+    if (hipMemset(tab, 0, (size_t)h->f2_npos * 16 * sizeof(double)) != hipSuccess ||
+        hipMemset(h->d_in, 0, h->in_doubles * sizeof(double)) != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipMemset failed"));      // (d_in: zero actions for the capture step)
+    GsF2Tables cap = h->F2; cap.nrflat = tab; cap.nrflat_mode = 1; cap.wg_offset = 0;
+    GsPackArgs pa{}; GsFusedChecks fc{}; GsRolloutStep rsv{};
+    GsSolveCfg sc = h->SC; sc.stamps = nullptr;
+    const dim3 b2(64 * h->f2_nw);
+    const int Bc = std::min(h->B, h->f2_iw);
+    if (h->f2_small) hipLaunchKernelGGL(gs_k_step_nr_flow2s, dim3(1), b2, h->F2.lds_bytes, h->stream, h->T, cap, h->R, sc, h->EC, h->slab, Bc, h->d_in, h->total_load, pa, fc, rsv);
+    else hipLaunchKernelGGL(gs_k_step_nr_flow2, dim3(1), b2, h->F2.lds_bytes, h->stream, h->T, cap, h->R, sc, h->EC, h->slab, Bc, h->d_in, h->total_load, pa, fc, rsv);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemset(h->slab, 0, (size_t)R.total * GS_LANES * sizeof(double)) != hipSuccess)
+      return bail(fail(nullptr, GS_E_HIP, "Newton-Raphson: flat-start table"));
+    h->F2.nrflat = tab; h->F2.nrflat_mode = 2;
   }
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipDeviceSynchronize failed"));
   *out = h;

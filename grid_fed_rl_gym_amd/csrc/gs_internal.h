@@ -383,6 +383,12 @@ struct GsF2Tables {
   int32_t n_fixed, fixed_slot0;
   double fixed_val0;
   const int32_t* fixed_slot; const double* fixed_val;
+  // Newton-Raphson: iteration 0 starts from the flat start, where the Jacobian -- and with it every D_i^-1, T_i and the
+  // branch's lower block L_i of the elimination -- does not depend on the instance.  nrflat: [positions][16] doubles per item
+  // position (P calc, Q calc, its share of the losses sum, -, D^-1 (4), T (4), L (4)), written ONCE per handle by the kernel
+  // itself (nrflat_mode 1: one workgroup, gs_create) and read by iteration 0 of every later step (mode 2), which then only
+  // carries its right-hand side up and down the tree.  Mode 0 / NULL: every iteration eliminates for itself.
+  double* nrflat; int32_t nrflat_mode, pad_nrflat;
 };
 
 // gs_k_rollout_post (kernels_env.hip): bookkeeping after step t of gs_rollout

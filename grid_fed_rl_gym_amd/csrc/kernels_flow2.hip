@@ -466,6 +466,24 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // not kept: |V| = sqrt(e^2 + f^2) where it is needed, corrections rotate (e, f) by the angle increment
   double pcj[NI], qcj[NI];
   // S = V conj(Y V) through the branch currents: (Y V)_i = K_i - sum over children K_c; returns this lane's max |mismatch|
+  const bool flat_use = F.nrflat != nullptr && F.nrflat_mode == 2, flat_cap = F.nrflat != nullptr && F.nrflat_mode == 1;
+  double* const flat_tab = F.nrflat + (size_t)pos0 * 16;      // this lane's items: [j][16]
+  // iteration 0 with the handle's flat-start table: P / Q calculated and the losses share are constants of the position
+  auto mismatch_flat = [&]() -> double {
+    double lmax = 0.0, bad = 0.0, ps = 0.0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const double2 c0 = *(const double2*)(flat_tab + 16 * j), c1 = *(const double2*)(flat_tab + 16 * j + 2);
+      const double pc = c0.x, qc = c0.y;
+      pcj[j] = pc; qcj[j] = qc;
+      const double dP = Pj[j] - pc, dQ = 0.0 - qc;
+      if (ibus[j] < n) { lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ))); bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad)); }
+      ps += c1.x;
+    }
+    if (bad != bad) lmax = INFINITY;
+    psum = ps;
+    return lmax;
+  };
   auto mismatch = [&](bool want_max) -> double {
     double kr[NI], ki[NI], ee[NI], ff[NI], sl[NI];
 #pragma unroll
@@ -504,21 +522,24 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double dP = Pj[j] - pc, dQ = 0.0 - qc;
       if (bus < n) { lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ))); bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad)); }
       ps += pc; ps -= sl[j];
+      if (flat_cap && want_max && l == 0) {      // (capture: the first mismatch of the capture launch is the flat-start one)
+        flat_tab[16 * j] = pc; flat_tab[16 * j + 1] = qc; flat_tab[16 * j + 2] = pc - sl[j]; flat_tab[16 * j + 3] = 0.0;
+      }
     }
     if (bad != bad) lmax = INFINITY;
     psum = ps;
-    (void)want_max;
     return lmax;
   };
   bool stale = true;
   for (int it = 0; it < C.max_iterations; ++it) {
-    const double lm = mismatch(true);
+    const bool flat_it = flat_use && it == 0;
+    const double lm = flat_it ? mismatch_flat() : mismatch(it == 0);
     stp.hit(F2_ST_MISMATCH);
     const double mm = wg_max(lm);                     // (its barrier also protects the K slots before the ring reuses the region)
     stp.hit(F2_ST_FLAG);
     f2_check(st, mm, mm, it, C.tolerance);
     stale = false;
-    if (__all(st.done)) break;
+    if (__all(st.done) && !(flat_cap && it == 0)) break;      // (the capture launch always runs its first elimination)
     // ---------------- bottom-up: D_i = J_ii - sum C_c, r_i = rhs_i - sum q_c, T_i = D_i^-1 J_ip, s_i = D_i^-1 r_i ----------------
     double T00[NI], T01[NI], T10[NI], T11[NI], s0[NI], s1[NI];
     int sing = 0;
@@ -530,6 +551,36 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const int lev = ilev[j];
         const bool live = lev >= 0;                   // an item of this wave (both halves share the level)
         T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; s0[j] = 0.0; s1[j] = 0.0;
+        if (live && flat_it) {
+          // iteration 0 with the handle's flat-start table: D^-1, T and L of the position are constants; only the right-hand
+          // side travels: s = D^-1 (r - sum of the children's q), q to the parent = L s
+          int bus = ibus[j]; F2_OPAQUE(bus);
+          int pj = pos0 + j; F2_OPAQUE(pj);
+          const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);
+          const double* tb = flat_tab + 16 * j;
+          const double2 iv0 = *(const double2*)(tb + 4), iv1 = *(const double2*)(tb + 6), tt0 = *(const double2*)(tb + 8), tt1 = *(const double2*)(tb + 10),
+                        ll0 = *(const double2*)(tb + 12), ll1 = *(const double2*)(tb + 14);
+          double r0 = Pj[j] - pcj[j], r1 = 0.0 - qcj[j];
+          const int nch = bus < n ? nch_tab[bus] : 0;
+          const int cbr = bus < n ? bus : 0;
+          const f2_i4 r_lo = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr + 16u);
+          while (lv < lev) { f2_lds_sync(); ++lv; }
+#pragma unroll
+          for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
+            if (u0 < imax[j]) {
+              const int ca = u0 < 4 ? r_lo[u0 & 3] : r_hi[u0 & 3], cb2 = u0 + 1 < 4 ? r_lo[(u0 + 1) & 3] : r_hi[(u0 + 1) & 3];
+              const int sa = u0 < nch ? ca : 0, sb = u0 + 1 < nch ? cb2 : 0;
+              const double2 aq = f2_ld2(ring3(sa, 2)), bq = f2_ld2(ring3(sb, 2));
+              if (u0 < nch) { r0 -= aq.x; r1 -= aq.y; }
+              if (u0 + 1 < nch) { r0 -= bq.x; r1 -= bq.y; }
+            }
+          }
+          s0[j] = iv0.x * r0 + iv0.y * r1; s1[j] = iv1.x * r0 + iv1.y * r1;
+          if (bus < n && !((roots >> j) & 1u)) {
+            T00[j] = tt0.x; T01[j] = tt0.y; T10[j] = tt1.x; T11[j] = tt1.y;
+            f2_st2(ring3(px[2], 2), make_double2(ll0.x * s0[j] + ll0.y * s1[j], ll1.x * s0[j] + ll1.y * s1[j]));
+          }
+        } else
         if (live) {
         // everything that does not depend on the children's messages comes BEFORE the wait for the item's level (it
         // overlaps the levels below): own and parent voltage, 1 / |V| of both, the branch's two off-diagonal blocks, the
@@ -579,6 +630,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           f2_st2(ring3(px[2], 0), make_double2(l00 * t00 + l01 * t10, l00 * t01 + l01 * t11));
           f2_st2(ring3(px[2], 1), make_double2(l10 * t00 + l11 * t10, l10 * t01 + l11 * t11));
           f2_st2(ring3(px[2], 2), make_double2(l00 * s0[j] + l01 * s1[j], l10 * s0[j] + l11 * s1[j]));
+        }
+        if (flat_cap && it == 0 && l == 0) {       // capture launch: this position's constants of the flat-start elimination
+          double* tb = flat_tab + 16 * j;
+          tb[4] = i00; tb[5] = i01; tb[6] = i10; tb[7] = i11;
+          tb[8] = T00[j]; tb[9] = T01[j]; tb[10] = T10[j]; tb[11] = T11[j];
+          tb[12] = l00; tb[13] = l01; tb[14] = l10; tb[15] = l11;
         }
               }
       }
