@@ -64,14 +64,27 @@ def make_feeder(name):
     return P.ieee123_like() if name == "ieee123_like" else P.ieee13_like("epsilon")
 
 
-def csrc_hash():
-    """SHA-256 over the kernel sources: what a counter measurement under profiles/ was taken on."""
+# which kernel sources a workload's step kernel is built from (a counter measurement is tied to these, see traffic_of)
+_COMMON_SOURCES = ["gs_internal.h", "env_device.h", "fastmath.h", "kernels.h", "gridstep_abi.hip", "topology.cpp", "topology.h"]
+KERNEL_SOURCES = {
+    "ieee123_b8192:fbs": ["kernels_flow2.hip"], "ieee123_b8192:nr": ["kernels_flow2.hip"], "ieee13_b4096:nr": ["kernels_flow2.hip"],
+    "ieee8500_3ph_b1024:fbs3": ["gridstep3.hip"],
+    "meshed_loops26_b8192:nr": ["kernels_solve.hip"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
+}
+
+
+def csrc_hash(key=None):
+    """SHA-256 over the kernel sources a counter measurement under profiles/ was taken on: the files of `key`'s step kernel plus the
+    shared headers and the launch code (every source when the key is unknown)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "grid_fed_rl_gym_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    names = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h", ".cpp")))
+    if key in KERNEL_SOURCES:
+        want = set(KERNEL_SOURCES[key]) | (set() if key.startswith("ieee8500") else set(_COMMON_SOURCES))
+        names = [f for f in names if f in want]
+    for f in names:
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -105,7 +118,7 @@ def traffic_of(key):
     ones it was measured on (`csrc_sha` recorded with the entry); otherwise null."""
     try:
         e = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key, {})
-        return e.get("solve_bytes_per_launch") if e.get("csrc_sha") == csrc_hash() else None
+        return e.get("solve_bytes_per_launch") if e.get("csrc_sha") == csrc_hash(key) else None
     except Exception:
         return None
 
@@ -113,7 +126,7 @@ def traffic_of(key):
 def traffic_source(key):
     try:
         e = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key, {})
-        cur = csrc_hash()
+        cur = csrc_hash(key)
         return {"profile": e.get("profile"), "measured_on_csrc_sha": e.get("csrc_sha"), "this_build_csrc_sha": cur,
                 "stale": e.get("csrc_sha") != cur, "bytes_when_measured": e.get("solve_bytes_per_launch")}
     except Exception:

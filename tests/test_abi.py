@@ -131,11 +131,12 @@ def test_bench_reports_counter_traffic_only_for_the_kernel_sources_it_was_measur
     bench = importlib.import_module("bench")
     cur = bench.csrc_hash()
     assert len(cur) == 16 and cur == bench.csrc_hash()
+    assert bench.csrc_hash("ieee8500_3ph_b1024:fbs3") != bench.csrc_hash("ieee123_b8192:fbs")      # tied to the kernel's own sources
     prof = tmp_path / "profiles"; prof.mkdir()
     json.dump({"a:fbs": {"solve_bytes_per_launch": 123, "csrc_sha": cur, "profile": "rXX"},
                "b:nr": {"solve_bytes_per_launch": 456, "csrc_sha": "0" * 16, "profile": "old"}}, open(prof / "hbm_traffic.json", "w"))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    monkeypatch.setattr(bench, "csrc_hash", lambda: cur)
+    monkeypatch.setattr(bench, "csrc_hash", lambda key=None: cur)
     assert bench.traffic_of("a:fbs") == 123 and bench.traffic_of("b:nr") is None and bench.traffic_of("missing") is None
     src = bench.traffic_source("b:nr")
     assert src["stale"] and src["bytes_when_measured"] == 456 and src["profile"] == "old"

@@ -76,7 +76,7 @@ def main():
         d = json.load(open(tfile)) if os.path.exists(tfile) else {}
         sys.path.insert(0, ROOT)
         import bench as _bench
-        d[a.traffic_key] = {"kernel": a.kernel, "profile": a.out_prefix, "csrc_sha": _bench.csrc_hash(), "fetch_size_kb_raw": fe_kb, "write_size_kb": wr_kb,
+        d[a.traffic_key] = {"kernel": a.kernel, "profile": a.out_prefix, "csrc_sha": _bench.csrc_hash(a.traffic_key), "fetch_size_kb_raw": fe_kb, "write_size_kb": wr_kb,
                             "solve_bytes_per_launch": int((2 * fe_kb + wr_kb) * 1024),
                             "note": "fabric-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per the gfx950 correction "
                                     "(MI355X_MICROARCH.md, HBM) | " + (a.note or a.out_prefix + " counters") +
