@@ -387,13 +387,22 @@ gs3_k_solve(Topo3 T, double2* __restrict__ state, int B, double tol, int max_it,
   }
 }
 
-// P/Q [B][n][3] in caller node order -> the P, Q rows of the slots
+#include "gridstep3_resident.h"
+
+typedef void (*res_fn)(Res3, double2*, int, double, int, double*, double*, int32_t*, uint8_t*);
+res_fn resident_kernel(int K, int MK) {
+  if (K == 2) return gs3_k_resident<2, 2>;
+  if (K == 6) return MK == 2 ? gs3_k_resident<6, 2> : gs3_k_resident<6, 6>;
+  return MK == 2 ? gs3_k_resident<10, 2> : gs3_k_resident<10, 10>;
+}
+
+// P/Q [B][n][3] in caller node order -> the P, Q rows of the slots (src_of < 0: a padding entry of the resident layout)
 extern "C" __global__ void __launch_bounds__(256)
 gs3_k_scatter_in(int n, int ns, int rows, const int32_t* __restrict__ src_of, const double* __restrict__ P,
                  const double* __restrict__ Q, double2* __restrict__ state) {
   const int b = blockIdx.y;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ns) return;
+  if (s >= ns || src_of[s] < 0) return;
   double2* S = state + (size_t)b * rows * ns;
   const size_t src = (size_t)b * n * 3 + src_of[s];
   ST(C_S, s) = make_double2(P[src], Q ? Q[src] : 0.0);
@@ -419,9 +428,13 @@ thread_local std::string g3_error;
 
 struct gs3_handle {
   int device = 0, n = 0, ns = 0, B = 0, n_levels = 0, max_width = 0, max_it = 50, threads = 256, lds_bytes = 0, rows = C_COUNT, prefetch = GS3_PREFETCH_LEVELS;
+  int ns_store = 0;          // entries per state row: ns, or K x threads in the resident layout
+  int resident_k = 0;        // > 0: gs3_k_resident<resident_k, resident_mk> with `threads` threads solves the instance inside one CU
+  int resident_mk = 0;
   double tol = 1e-6;
   hipStream_t stream = nullptr;
   Topo3 T{};
+  Res3 R{};
   std::vector<void*> allocs;
   int32_t *d_src_of = nullptr, *d_slot_of = nullptr;
   double2* d_state = nullptr;
@@ -586,16 +599,94 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   h->lds_bytes = 2 * 2 * h->max_width * (int)sizeof(double);
   if (h->lds_bytes > 38 * 1024 || getenv("GS3_NO_LDS")) h->lds_bytes = 0;
   h->rows = h->lds_bytes ? C_COUNT : C_COUNT_NOLDS;
+  h->ns_store = ns;
+  // Resident layout (gridstep3_resident.h) when the conductors fit in one CU: ns + 1 LDS entries beside 1 KB of scratch,
+  // at most 10 positions per thread.  K = 2 mod 4 keeps a thread's 16-byte LDS accesses (stride K x 16 bytes across lanes)
+  // free of bank conflicts.
+  {
+    int lds_max = 0;
+    (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+    lds_max = std::max(lds_max, 64 * 1024);
+    if (const char* e = getenv("GS3_RESIDENT_LDS")) lds_max = atoi(e);
+    const int need = (((ns + 4) & ~3) + 64) * (int)sizeof(double2);
+    int K = 0;
+    for (int k : {2, 6, 10}) if (!K && (ns + k - 1) / k <= 1024) K = k;
+    if (K && ns <= GS3_RESIDENT_MAX_CONDUCTORS && need <= lds_max && !getenv("GS3_NO_RESIDENT")) {
+      h->resident_k = K;
+      h->threads = std::max(64, ((ns + K - 1) / K + 63) / 64 * 64);
+      h->lds_bytes = need;
+      h->rows = 2;
+      h->ns_store = K * h->threads;
+    }
+  }
+  if (h->resident_k) {
+    const int K = h->resident_k, nt = h->threads, npad = h->ns_store;
+    // depth-first pre- and postorder of each phase's tree, the three blocks one after the other
+    std::vector<int32_t> pre((size_t)3 * n, -1), post((size_t)3 * n, -1), size((size_t)3 * n, 0);
+    std::vector<int32_t> pos_node, pos_ph;
+    int off = 0;
+    for (int ph = 0; ph < 3; ++ph) {
+      int cpre = off, cpost = off;
+      std::vector<std::pair<int, size_t>> stack{{t->source, 0}};
+      pre[(size_t)t->source * 3 + ph] = cpre++; pos_node.push_back(t->source); pos_ph.push_back(ph);
+      while (!stack.empty()) {
+        auto& top = stack.back();
+        const int node = top.first;
+        bool went = false;
+        while (top.second < kids[node].size()) {
+          const int c = kids[node][top.second++];
+          if (!((t->phases[c] >> ph) & 1)) continue;
+          pre[(size_t)c * 3 + ph] = cpre++; pos_node.push_back(c); pos_ph.push_back(ph);
+          stack.push_back({c, 0});
+          went = true;
+          break;
+        }
+        if (went) continue;
+        post[(size_t)node * 3 + ph] = cpost++;
+        size[(size_t)node * 3 + ph] = cpre - pre[(size_t)node * 3 + ph];
+        stack.pop_back();
+      }
+      off = cpre;
+    }
+    if (off != ns) return bail(fail3(nullptr, GS_E_TOPOLOGY, "internal: %d conductors in depth-first order, %d expected", off, ns));
+    auto mem = [&](int p) { return (p % K) * nt + p / K; };
+    std::vector<int32_t> rpk(npad, 0), rsrc(npad, -1), rslot((size_t)3 * n, -1);
+    std::vector<double2> rzd(npad, make_double2(0.0, 0.0)), rmz_a, rmz_b;
+    std::vector<int4> rmut;
+    for (int p = 0; p < ns; ++p) {
+      const int node = pos_node[p], ph = pos_ph[p], e = (int)((size_t)node * 3 + ph);
+      const int oa = ph == 0 ? 1 : 0, ob = ph == 2 ? 1 : 2;
+      rpk[mem(p)] = (int32_t)((unsigned)size[e] | (unsigned)post[e] << 14 | (node == t->source ? 1u << 28 : 0u) | (unsigned)ph << 29);
+      rsrc[mem(p)] = e; rslot[e] = mem(p);
+      if (node == t->source) continue;
+      const int sl = slot_of[e];                                 // the level layout's row of Z for the same conductor
+      rzd[mem(p)] = z[(size_t)Z_D * ns + sl];
+      const int pa = pre[(size_t)node * 3 + oa], pb = pre[(size_t)node * 3 + ob];
+      if (pa < 0 && pb < 0) continue;
+      rmut.push_back(make_int4(std::max(pa, 0), std::max(pb, 0), post[e], 0));
+      rmz_a.push_back(pa >= 0 ? z[(size_t)Z_A * ns + sl] : make_double2(0.0, 0.0));
+      rmz_b.push_back(pb >= 0 ? z[(size_t)Z_B * ns + sl] : make_double2(0.0, 0.0));
+    }
+    Res3& R = h->R;
+    R.ns = ns; R.npad = npad; R.K = K; R.M = (int)rmut.size();
+    h->resident_mk = R.M <= 2 * nt ? 2 : K;
+    rmz_a.insert(rmz_a.end(), rmz_b.begin(), rmz_b.end());
+    for (int ph = 0; ph < 3; ++ph) { R.vsr[ph] = T.vsr[ph]; R.vsi[ph] = T.vsi[ph]; }
+    if ((rc = upload3(h, &R.pk, rpk)) || (rc = upload3(h, &R.zd, rzd)) || (rc = upload3(h, &R.mut, rmut)) || (rc = upload3(h, &R.mz, rmz_a))) return bail(rc);
+    src_of = rsrc; slot_of = rslot;
+    if (hipFuncSetAttribute((const void*)resident_kernel(K, h->resident_mk), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes) != hipSuccess)
+      return bail(fail3(nullptr, GS_E_HIP, "cannot reserve %d bytes of LDS for the resident kernel", h->lds_bytes));
+  }
   { const int32_t* q = nullptr; if ((rc = upload3(h, &q, src_of))) return bail(rc); h->d_src_of = const_cast<int32_t*>(q); }
   { const int32_t* q = nullptr; if ((rc = upload3(h, &q, slot_of))) return bail(rc); h->d_slot_of = const_cast<int32_t*>(q); }
   if (const char* e = getenv("GS3_PREFETCH")) h->prefetch = std::max(1, std::min(3, atoi(e)));
-  if (const char* e = getenv("GS3_THREADS")) h->threads = std::max(64, std::min(256, atoi(e) / 64 * 64));
+  if (const char* e = getenv("GS3_THREADS")) if (!h->resident_k) h->threads = std::max(64, std::min(256, atoi(e) / 64 * 64));
   const size_t bn3 = (size_t)batch * n * 3;
-  if ((rc = alloc3(h, &h->d_state, (size_t)batch * h->rows * ns)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
+  if ((rc = alloc3(h, &h->d_state, (size_t)batch * h->rows * h->ns_store)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
       (rc = alloc3(h, &h->d_vre, bn3)) || (rc = alloc3(h, &h->d_vim, bn3)) || (rc = alloc3(h, &h->d_loss, batch)) ||
       (rc = alloc3(h, &h->d_mm, batch)) || (rc = alloc3(h, &h->d_it, batch)) || (rc = alloc3(h, &h->d_conv, batch)))
     return bail(rc);
-  if (hipMemset(h->d_state, 0, (size_t)batch * h->rows * ns * sizeof(double2)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
+  if (hipMemset(h->d_state, 0, (size_t)batch * h->rows * h->ns_store * sizeof(double2)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
   *out = h;
   return GS_OK;
 }
@@ -616,8 +707,8 @@ int gs3_upload_injections(gs3_handle* h, const double* P, const double* Q) {
   const size_t bytes = (size_t)h->B * h->n * 3 * sizeof(double);
   HIP3(h, hipMemcpyAsync(h->d_p, P, bytes, hipMemcpyHostToDevice, h->stream));
   if (Q) HIP3(h, hipMemcpyAsync(h->d_q, Q, bytes, hipMemcpyHostToDevice, h->stream));
-  dim3 grid((h->ns + 255) / 256, h->B);
-  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->ns, h->rows, h->d_src_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
+  dim3 grid((h->ns_store + 255) / 256, h->B);
+  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->ns_store, h->rows, h->d_src_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
   HIP3(h, hipGetLastError());
   HIP3(h, hipStreamSynchronize(h->stream));
   return GS_OK;
@@ -635,8 +726,13 @@ int gs3_solve_device(gs3_handle* h) {
   HIP3(h, hipEventRecord(e.first, h->stream));
   typedef void (*solve_fn)(Topo3, double2*, int, double, int, double*, double*, int32_t*, uint8_t*);
   static const solve_fn with_lds[3] = {gs3_k_solve<true, 1>, gs3_k_solve<true, 2>, gs3_k_solve<true, 3>};
-  const solve_fn fn = h->lds_bytes ? with_lds[h->prefetch - 1] : gs3_k_solve<false, 1>;
-  hipLaunchKernelGGL(fn, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
+  if (h->resident_k) {
+    const res_fn rf = resident_kernel(h->resident_k, h->resident_mk);
+    hipLaunchKernelGGL(rf, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->R, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
+  } else {
+    const solve_fn fn = h->lds_bytes ? with_lds[h->prefetch - 1] : gs3_k_solve<false, 1>;
+    hipLaunchKernelGGL(fn, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
+  }
   HIP3(h, hipGetLastError());
   HIP3(h, hipEventRecord(e.second, h->stream));
   return GS_OK;
@@ -648,7 +744,7 @@ int gs3_download_solution(gs3_handle* h, const gs3_solution_view* out) {
   const size_t bn3 = (size_t)h->B * h->n * 3;
   if (out->v_re || out->v_im) {
     dim3 grid((3 * h->n + 255) / 256, h->B);
-    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->ns, h->rows, h->d_slot_of, h->d_state, h->d_vre, h->d_vim);
+    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->ns_store, h->rows, h->d_slot_of, h->d_state, h->d_vre, h->d_vim);
     HIP3(h, hipGetLastError());
     if (out->v_re) HIP3(h, hipMemcpyAsync(out->v_re, h->d_vre, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (out->v_im) HIP3(h, hipMemcpyAsync(out->v_im, h->d_vim, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -690,8 +786,10 @@ int gs3_timing_read(gs3_handle* h, double* total_ms, int64_t* launches) {
 
 int gs3_describe(const gs3_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail3(nullptr, GS_E_INVALID, "bad arguments");
-  snprintf(buf, buflen, "{\"kernel\": \"fbs3\", \"n\": %d, \"conductors\": %d, \"levels\": %d, \"max_level_width\": %d, \"batch\": %d, \"lds_messages\": %d, \"state_bytes\": %zu}",
-           h->n, h->ns, h->n_levels, h->max_width, h->B, h->lds_bytes, (size_t)h->B * h->rows * h->ns * sizeof(double2));
+  snprintf(buf, buflen, "{\"kernel\": \"%s\", \"n\": %d, \"conductors\": %d, \"levels\": %d, \"max_level_width\": %d, \"batch\": %d, \"lds_messages\": %d, \"state_bytes\": %zu, "
+           "\"threads\": %d, \"positions_per_thread\": %d, \"lds_bytes\": %d}",
+           h->resident_k ? "fbs3_resident" : "fbs3", h->n, h->ns, h->n_levels, h->max_width, h->B, h->resident_k ? 0 : h->lds_bytes,
+           (size_t)h->B * h->rows * h->ns_store * sizeof(double2), h->threads, h->resident_k, h->lds_bytes);
   return GS_OK;
 }
 

@@ -1,0 +1,304 @@
+// gridstep3_resident.h -- three-phase forward/backward sweep with the whole instance resident in one CU (included by
+// gridstep3.hip; same gs3_* ABI, same answer as gs3_k_solve to rounding).
+//
+// gs3_k_solve walks the 60 levels of the 8500-node feeder one barrier at a time and streams three state rows per sweep: a
+// solve is a chain of ~400 dependent level steps, each paying an HBM round trip that four resident workgroups hide only
+// partly (0.6 ms per 1024 solves, 43 % of HBM peak on the bytes of SURVEY.md 8(d)).  This kernel removes both the chain
+// and the stream.  The sweeps are tree reductions, and a tree reduction over a depth-first numbering is a prefix sum:
+//
+//   positions   the conductors of phase a in depth-first PREORDER of the phase-a tree, then phase b, then phase c.  The
+//               subtree of a conductor is a contiguous range [p, e(p)) of its phase block, and so is its set of descendants
+//               in POSTORDER, [g(p), post(p)).
+//   backward    line current J_p = sum of the injection currents I over the subtree = X[e(p)] - X[p], X = exclusive prefix
+//               sum of I over positions.  (The prefix runs across the phase blocks; the blocks before p cancel in the
+//               difference.)  D_p = Z_p . (J_p, J_sibling A, J_sibling B).
+//   forward     V_p = V_source - sum of D over the ancestors-or-self of p.  a is an ancestor-or-self of p exactly when it
+//               comes no later than p in preorder and no earlier in postorder; the conductors that come before p in BOTH
+//               orders are those before p's first descendant in postorder, so
+//               sum over ancestors-or-self = Xi[p] - Y[g(p)],   Xi = inclusive preorder prefix of D, Y = exclusive
+//               postorder prefix of D: one sample at the thread's own position and one gather at a static index.
+//
+// So an iteration is three workgroup-wide prefix sums and three gathers, with no dependence on the depth of the feeder.  One
+// workgroup of up to 1024 threads solves one instance; a thread owns K consecutive positions.  What persists between
+// iterations is the injection current of each conductor, in registers (2 K doubles per thread; the mismatch of the new
+// voltages needs exactly that current, see gs3_k_solve); the array being gathered from (X, then J, then D / Y) is the one
+// thing that has to be visible to other threads and lives in LDS: (conductors + 1) x 16 bytes, 150 KB of the CU's 160 KB for
+// the 8500-node case.  D is stored at the conductor's POSTORDER index, so the postorder prefix runs over a thread's own
+// contiguous entries, in place.  All a position needs to know of the tree fits in one 32-bit word -- subtree size, postorder
+// index, phase, "is the source" -- kept in registers: e = p + size, g = post - size + 1.  The mutual terms of D exist on the
+// ~14 % of conductors that share a node with another phase; they are a separate compact list (conductor, its two
+// siblings, the two impedances) dealt over the threads, added to D through LDS.  Per iteration HBM sees S (150 KB per
+// workgroup; the working set of the 256 resident workgroups fits the MALL) and, per solve, V once; the self impedances
+// (16 bytes per conductor) come from L2.  Feeders whose conductors do not fit (more than ~10 100, or more than 10 per
+// thread) take gs3_k_solve.
+//
+// Rounding: prefix differences carry an absolute error of a few ulp of the LARGEST prefix (the feeder's total current, the
+// summed drops of a phase) instead of the subtree's own sum: ~1e-15 in V on the 8500-node case, far inside the 1e-10 the
+// tests hold the two kernels and the oracles to.  The convergence test, the iteration count and the loss accounting follow
+// gs3_k_solve line by line.
+#pragma once
+
+struct Res3 {
+  int32_t ns, npad, K, M;      // conductors; K x threads; positions per thread; entries of the mutual list
+  const int32_t* pk;           // [npad], storage order: subtree size | postorder index << 14 | is-source << 28 | phase << 29
+  const double2* zd;           // [npad], storage order: self impedance of the upstream line (zero for the source's conductors)
+  const int4* mut;             // [M]: {position of sibling A, of sibling B, postorder index of the conductor, 0}; an absent
+                               //      sibling points at position 0 with a zero impedance
+  const double2* mz;           // [2][M]: mutual impedances to A and to B
+  double vsr[3], vsi[3];
+};
+// storage order: element k of thread t at k * threads + t (one coalesced access per k)
+#define R3_SIZE(w) ((w) & 0x3fff)
+#define R3_POST(w) (((w) >> 14) & 0x3fff)
+#define R3_ROOT(w) (((w) >> 28) & 1)
+#define R3_PH(w) ((unsigned)(w) >> 29)
+#define GS3_RESIDENT_MAX_CONDUCTORS 16383
+
+template <int CTRL, int ROWS> __device__ __forceinline__ double r3_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 16 lanes of a row
+__device__ __forceinline__ double r3_row_scan(double v) {
+  v += r3_dpp<0x111, 0xf>(v);      // row_shr:1
+  v += r3_dpp<0x112, 0xf>(v);      // row_shr:2
+  v += r3_dpp<0x114, 0xf>(v);      // row_shr:4
+  v += r3_dpp<0x118, 0xf>(v);      // row_shr:8
+  return v;
+}
+// ... over the 64 lanes of a wavefront
+__device__ __forceinline__ double r3_wave_scan(double v) {
+  v = r3_row_scan(v);
+  v += r3_dpp<0x142, 0xa>(v);      // row_bcast:15 -> rows 1 and 3 take lane 15 of the row before
+  v += r3_dpp<0x143, 0xc>(v);      // row_bcast:31 -> rows 2 and 3 take lane 31
+  return v;
+}
+__device__ __forceinline__ double r3_readlane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ void r3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct R3Wg {
+  double2* scr;        // [2][16] wave totals of the prefix sums, [2][16] of the reductions; zeroed at start
+  int par, rpar, wave, lane;
+
+  // in: the thread's total; out: the sum over the threads before it (exclusive), and the workgroup's total
+  __device__ __forceinline__ void scan(double& re, double& im, double& tr, double& ti) {
+    const double sr = r3_wave_scan(re), si = r3_wave_scan(im);
+    if (lane == 63) scr[par * 16 + wave] = make_double2(sr, si);
+    r3_barrier();
+    const double2 t = scr[par * 16 + (lane & 15)];
+    const double wr = r3_row_scan(t.x), wi = r3_row_scan(t.y);
+    tr = r3_readlane(wr, 15); ti = r3_readlane(wi, 15);
+    double or_ = 0.0, oi = 0.0;
+    if (wave > 0) { or_ = r3_readlane(wr, wave - 1); oi = r3_readlane(wi, wave - 1); }
+    re = or_ + sr - re; im = oi + si - im;
+    par ^= 1;
+  }
+  // max of m and sum of s over the workgroup
+  __device__ __forceinline__ void max_sum(double& m, double& s) {
+    for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); s += __shfl_xor(s, o); }
+    if (lane == 0) scr[32 + rpar * 16 + wave] = make_double2(m, s);
+    r3_barrier();
+    const double2 t = scr[32 + rpar * 16 + (lane & 15)];     // entries of absent waves: (0, 0); m >= 0 always
+    m = t.x; s = t.y;
+    for (int o = 8; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); s += __shfl_xor(s, o); }
+    rpar ^= 1;
+  }
+};
+
+extern __shared__ double2 r3_lds[];
+
+// K positions per thread; MK entries of the mutual list per thread (2: the usual feeder, mostly single-phase laterals; K:
+// up to every conductor has siblings)
+template <int K, int MK>
+__global__ void __launch_bounds__(1024)
+gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_it, double* __restrict__ out_loss,
+               double* __restrict__ out_mm, int32_t* __restrict__ out_it, uint8_t* __restrict__ out_conv) {
+  constexpr int G = 2;                                               // global loads kept in flight ahead of their use
+  const int ns = T.ns, npad = T.npad, M = T.M, tid = threadIdx.x, nt = blockDim.x;
+  double2* __restrict__ A = r3_lds;                                  // [ns + 1]: X, then J, then D / Y
+  R3Wg wg = {r3_lds + ((ns + 4) & ~3), 0, 0, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+  if (tid < 64) wg.scr[tid] = make_double2(0.0, 0.0);
+  double2* __restrict__ Vrow = state + (size_t)blockIdx.x * 2 * npad;
+  const double2* __restrict__ Srow = Vrow + npad;
+  const int p0 = tid * K;
+  const double vsr0 = T.vsr[0], vsr1 = T.vsr[1], vsr2 = T.vsr[2], vsi0 = T.vsi[0], vsi1 = T.vsi[1], vsi2 = T.vsi[2];
+#define R3_SRC_R(ph) ((ph) == 0 ? vsr0 : ((ph) == 1 ? vsr1 : vsr2))
+#define R3_SRC_I(ph) ((ph) == 0 ? vsi0 : ((ph) == 1 ? vsi1 : vsi2))
+#define R3_M(k) ((k) * nt + tid)
+  // Global rows through buffer descriptors: the descriptor and the row offset k * threads sit in SGPRs, the thread's
+  // offset is one VGPR for all rows (a 64-bit address per thread and row would cost 2 K registers per table).
+  const unsigned t16 = (unsigned)tid << 4, t4 = (unsigned)tid << 2;
+  const __amdgpu_buffer_rsrc_t rs_pk = __builtin_amdgcn_make_buffer_rsrc((void*)T.pk, 0, npad * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_zd = __builtin_amdgcn_make_buffer_rsrc((void*)T.zd, 0, npad * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)Srow, 0, npad * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vrow, 0, npad * 16, 0x00020000);
+#define R3_LD16(rs, k) __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, t16, (k) * nt * 16, 0))
+#define R3_LD4(rs, k) ((int)__builtin_amdgcn_raw_buffer_load_b32(rs, t4, (k) * nt * 4, 0))
+
+  int pk[K];                // the tree as this thread's positions see it
+  double ar[K], ai[K];      // injection currents of the thread's conductors: what persists between iterations
+  double br[K], bi[K];      // X -> J -> D, then Xi -> V
+  double lmax = 0.0;
+  r3_barrier();             // scratch zeroed
+  // ---- flat start: V = V_source everywhere, first mismatch = |S_spec|
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    pk[k] = R3_LD4(rs_pk, k);
+    const int ph = R3_PH(pk[k]);
+    double2 s = R3_LD16(rs_s, k);
+    if (R3_ROOT(pk[k])) s = make_double2(0.0, 0.0);               // nothing is drawn at the source itself
+    const double dP = fabs(s.x), dQ = fabs(s.y);
+    lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
+    const double vr = R3_SRC_R(ph), vi = R3_SRC_I(ph), rd = 1.0 / (vr * vr + vi * vi);
+    ar[k] = -(s.x * vr + s.y * vi) * rd; ai[k] = -(s.x * vi - s.y * vr) * rd;
+    br[k] = vr; bi[k] = vi;
+  }
+  double mm, losses = 0.0, zero = 0.0;
+  mm = lmax; wg.max_sum(mm, zero);
+  int iters = max_it, conv = 0;
+  if (!(mm < INFINITY) || mm < tol) {       // no sweep will follow: the answer is the flat start itself
+    iters = 1; conv = mm < tol;
+  } else {
+    for (int it = 0; it < max_it; ++it) {
+      // (what follows from pk -- indices, the source voltage of the phase -- is recomputed where it is used: hoisted out of
+      // the loop it would take ten more registers per position than there are)
+#define R3_OPAQUE_PK() _Pragma("unroll") for (int k = 0; k < K; ++k) asm volatile("" : "+v"(pk[k]))
+      R3_OPAQUE_PK();
+      // ---- backward: X = exclusive prefix of I over positions
+      double rr = 0.0, ri = 0.0, tr, ti;
+      double2 zq[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) zq[k] = R3_LD16(rs_zd, k);       // the self impedances of the first positions, needed after three barriers
+#pragma unroll
+      for (int k = 0; k < K; ++k) { br[k] = rr; bi[k] = ri; rr += ar[k]; ri += ai[k]; }
+      wg.scan(rr, ri, tr, ti);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        br[k] += rr; bi[k] += ri;
+        if (p0 + k < ns) A[p0 + k] = make_double2(br[k], bi[k]);
+      }
+      if (tid == 0) A[ns] = make_double2(tr, ti);
+      r3_barrier();
+      // J = X[e] - X[own]; the source's share of sum P_calc is V_source . J of the phase's root
+      double psrc = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const double2 xe = A[min(p0 + k + R3_SIZE(pk[k]), ns)];
+        br[k] = xe.x - br[k]; bi[k] = xe.y - bi[k];
+        if (R3_ROOT(pk[k])) { const int ph = R3_PH(pk[k]); psrc += R3_SRC_R(ph) * br[k] + R3_SRC_I(ph) * bi[k]; }
+      }
+      r3_barrier();                          // every X has been read
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (p0 + k < ns) A[p0 + k] = make_double2(br[k], bi[k]);
+      r3_barrier();
+      // D = Z-row . (J, J of the node's other conductors): the mutual part from the compact list
+      double mr[MK], mi[MK]; int ml[MK];
+#pragma unroll
+      for (int j = 0; j < MK; ++j) {
+        const int i = tid + j * nt;
+        mr[j] = 0.0; mi[j] = 0.0; ml[j] = 0;
+        if (i < M) {
+          const int4 ix = T.mut[i];
+          const double2 za = T.mz[i], zb = T.mz[M + i], ja = A[ix.x], jb = A[ix.y];
+          mr[j] = za.x * ja.x - za.y * ja.y + zb.x * jb.x - zb.y * jb.y;
+          mi[j] = za.x * ja.y + za.y * ja.x + zb.x * jb.y + zb.y * jb.x;
+          ml[j] = ix.z;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const double2 zd = zq[k % G];
+        if (k + G < K) zq[k % G] = R3_LD16(rs_zd, k + G);
+        const double dr = zd.x * br[k] - zd.y * bi[k], di = zd.x * bi[k] + zd.y * br[k];
+        br[k] = dr; bi[k] = di;
+      }
+      r3_barrier();                          // every J has been read
+      // ---- forward: D at the conductor's postorder index
+      R3_OPAQUE_PK();
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (p0 + k < ns) A[R3_POST(pk[k])] = make_double2(br[k], bi[k]);
+      if (M > 0) {
+        r3_barrier();
+#pragma unroll
+        for (int j = 0; j < MK; ++j)
+          if (tid + j * nt < M) { double2 d = A[ml[j]]; d.x += mr[j]; d.y += mi[j]; A[ml[j]] = d; }
+        r3_barrier();
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (p0 + k < ns) { const double2 d = A[R3_POST(pk[k])]; br[k] = d.x; bi[k] = d.y; }
+      }
+      // Xi = inclusive preorder prefix of D (registers)
+      double2 sq[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) sq[k] = R3_LD16(rs_s, k);        // S of the first positions, needed after three barriers
+      rr = 0.0; ri = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { rr += br[k]; ri += bi[k]; br[k] = rr; bi[k] = ri; }
+      wg.scan(rr, ri, tr, ti);               // its barrier also publishes D
+#pragma unroll
+      for (int k = 0; k < K; ++k) { br[k] += rr; bi[k] += ri; }
+      // Y = exclusive postorder prefix of D, in place: postorder index q is entry q
+      double yr = 0.0, yi = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (p0 + k < ns) { const double2 d = A[p0 + k]; yr += d.x; yi += d.y; }
+      wg.scan(yr, yi, tr, ti);
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (p0 + k < ns) { const double2 d = A[p0 + k]; A[p0 + k] = make_double2(yr, yi); yr += d.x; yi += d.y; }
+      r3_barrier();
+      // V = V_source - (Xi[own] - Y[g]); then the mismatch at the new voltages and the next injection currents
+      R3_OPAQUE_PK();
+      const bool check = it + 1 < max_it;
+      lmax = 0.0;
+      double psum = psrc;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int ph = R3_PH(pk[k]);
+        const double2 y = A[R3_POST(pk[k]) - R3_SIZE(pk[k]) + 1];
+        const bool real = p0 + k < ns;
+        const double wr = real ? R3_SRC_R(ph) - (br[k] - y.x) : 1.0, wi = real ? R3_SRC_I(ph) - (bi[k] - y.y) : 0.0;
+        br[k] = wr; bi[k] = wi;
+        double2 s = sq[k % G];
+        if (k + G < K) sq[k % G] = R3_LD16(rs_s, k + G);
+        if (check) {
+          if (R3_ROOT(pk[k])) s = make_double2(0.0, 0.0);
+          const double pc = -(wr * ar[k] + wi * ai[k]), qc = -(wi * ar[k] - wr * ai[k]);
+          const double dP = fabs(s.x - pc), dQ = fabs(s.y - qc);
+          lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
+          psum += pc;
+          const double rd = 1.0 / (wr * wr + wi * wi);
+          ar[k] = -(s.x * wr + s.y * wi) * rd; ai[k] = -(s.x * wi - s.y * wr) * rd;
+        }
+      }
+      if (check) {                           // what the backward sweep of iteration it + 1 would find
+        mm = lmax; losses = psum;
+        wg.max_sum(mm, losses);
+        if (!(mm < INFINITY)) { iters = it + 2; break; }
+        if (mm < tol) { iters = it + 2; conv = 1; break; }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {   // 16-byte store: row offset in the vector offset (see GsPairRef::put, gs_internal.h)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(br[k], bi[k])), rs_v, t16 + (unsigned)(k * nt * 16), 0, 0);
+  }
+  if (tid == 0) {
+    out_loss[blockIdx.x] = losses;
+    out_mm[blockIdx.x] = mm;
+    out_it[blockIdx.x] = iters;
+    out_conv[blockIdx.x] = (uint8_t)conv;
+  }
+#undef R3_SRC_R
+#undef R3_SRC_I
+#undef R3_M
+#undef R3_OPAQUE_PK
+#undef R3_LD16
+#undef R3_LD4
+}
