@@ -68,7 +68,7 @@ def make_feeder(name):
 _COMMON_SOURCES = ["gs_internal.h", "env_device.h", "fastmath.h", "kernels.h", "gridstep_abi.hip", "topology.cpp", "topology.h"]
 KERNEL_SOURCES = {
     "ieee123_b8192:fbs": ["kernels_flow2.hip"], "ieee123_b8192:nr": ["kernels_flow2.hip"], "ieee13_b4096:nr": ["kernels_flow2.hip"],
-    "ieee8500_3ph_b1024:fbs3": ["gridstep3.hip"],
+    "ieee8500_3ph_b1024:fbs3": ["gridstep3.hip", "gridstep3_resident.h"],
     "meshed_loops26_b8192:nr": ["kernels_solve.hip"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
 }
 
@@ -202,6 +202,21 @@ def measure_unbalanced(args, device, with_cpu):
     survey_bytes = 4 * 48 * spec.n * mean_it * B
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = traffic_of("ieee8500_3ph_b1024:fbs3") if B == WORKLOADS["ieee8500_3ph_b1024"]["batch"] else None
+    kernel = "gs3_k_resident" if desc["kernel"] == "fbs3_resident" else "gs3_k_solve"
+    # The resident kernel keeps V, I and the sweep's intermediates of an instance in the registers and LDS of one CU: what it
+    # has to move through HBM is S once per iteration (+ once for the flat start) and V once per solve, 16 B each per
+    # conductor.  The section-8(d) figure above models a kernel that streams the state every sweep, so against it this
+    # kernel reads > 1 of the HBM roofline; what bounds it is FP64 vector issue and LDS gathers (the "valu" entry: flops
+    # per conductor and iteration counted from gridstep3_resident.h -- 3 prefix sums 12, J and D 14, V 4, mismatch and
+    # next current 44 -- against the 78.6 TFLOP/s FP64 vector peak).
+    extra = {}
+    if kernel == "gs3_k_resident":
+        flops = 74.0 * desc["conductors"] * mean_it * B
+        extra = {"bytes_per_launch_resident_design": 16.0 * desc["conductors"] * B * (mean_it + 2.0),
+                 "valu": {"bound": "fp64 vector", "achieved": flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0, "peak": 78.6, "unit": "TFLOP/s",
+                          "frac": flops / (avg_ms * 1e-3) / 1e12 / 78.6 if avg_ms > 0 else 0.0, "flops_per_conductor_iteration": 74},
+                 "note": "frac > 1: the state of an instance never leaves its CU (registers + 156 KB of LDS); the algorithmic bytes are SURVEY 8(d)'s "
+                         "streaming model, the design figure beside it is what this kernel must move"}
     med, p10, p90 = quantiles(regions)
     result = {"metric": "three-phase load-flow solves/sec (batched feeders)", "value": B * args.steps / med, "unit": "solves/s",
               "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats, "ms_per_step": 1e3 * med / args.steps,
@@ -210,11 +225,12 @@ def measure_unbalanced(args, device, with_cpu):
               "config": {"workload": f"{spec.name}, 3-phase unbalanced FBS, batch={B}, per-instance loading U(0.5,1.5), tolerance {args.tolerance:g}",
                          "n_nodes": spec.n, "phase_conductors": desc["conductors"], "tree_levels": desc["levels"],
                          "max_level_width": desc["max_level_width"],
-                         "batch_per_gpu": B, "kernel": "gs3_k_solve",
+                         "batch_per_gpu": B, "kernel": kernel, "threads_per_instance": desc.get("threads"),
+                         "positions_per_thread": desc.get("positions_per_thread"), "lds_bytes": desc.get("lds_bytes"),
                          "parity": "unpinned: the reference has no three-phase solver (README prose only)"},
               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": "gs3_k_solve", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                           "bytes_per_launch_at_3_conductors_per_node": survey_bytes, "mean_iterations": mean_it},
+                           "traffic": traffic, "kernel": kernel, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                           "bytes_per_launch_at_3_conductors_per_node": survey_bytes, "mean_iterations": mean_it, **extra},
               "converged_fraction": float(sol.converged.mean()),
               "min_voltage_pu": float(np.abs(sol.voltages)[np.abs(sol.voltages) > 0].min())}
     if with_cpu:

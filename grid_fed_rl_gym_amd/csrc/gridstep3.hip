@@ -391,31 +391,31 @@ gs3_k_solve(Topo3 T, double2* __restrict__ state, int B, double tol, int max_it,
 
 typedef void (*res_fn)(Res3, double2*, int, double, int, double*, double*, int32_t*, uint8_t*);
 res_fn resident_kernel(int K, int MK) {
-  if (K == 2) return gs3_k_resident<2, 2>;
-  if (K == 6) return MK == 2 ? gs3_k_resident<6, 2> : gs3_k_resident<6, 6>;
-  return MK == 2 ? gs3_k_resident<10, 2> : gs3_k_resident<10, 10>;
+  if (K == 3) return gs3_k_resident<3, 3>;
+  if (K == 9) return MK == 4 ? gs3_k_resident<9, 4> : gs3_k_resident<9, 9>;
+  return MK == 4 ? gs3_k_resident<19, 4> : gs3_k_resident<19, 19>;
 }
 
 // P/Q [B][n][3] in caller node order -> the P, Q rows of the slots (src_of < 0: a padding entry of the resident layout)
 extern "C" __global__ void __launch_bounds__(256)
-gs3_k_scatter_in(int n, int ns, int rows, const int32_t* __restrict__ src_of, const double* __restrict__ P,
+gs3_k_scatter_in(int n, int ns, size_t stride, const int32_t* __restrict__ src_of, const double* __restrict__ P,
                  const double* __restrict__ Q, double2* __restrict__ state) {
   const int b = blockIdx.y;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns || src_of[s] < 0) return;
-  double2* S = state + (size_t)b * rows * ns;
+  double2* S = state + (size_t)b * stride;
   const size_t src = (size_t)b * n * 3 + src_of[s];
   ST(C_S, s) = make_double2(P[src], Q ? Q[src] : 0.0);
 }
 
 // V rows of the slots -> [B][n][3] in caller node order (absent phases 0)
 extern "C" __global__ void __launch_bounds__(256)
-gs3_k_gather_out(int n, int ns, int rows, const int32_t* __restrict__ slot_of, const double2* __restrict__ state,
+gs3_k_gather_out(int n, int ns, size_t stride, const int32_t* __restrict__ slot_of, const double2* __restrict__ state,
                  double* __restrict__ vre, double* __restrict__ vim) {
   const int b = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 3 * n) return;
-  double2* S = const_cast<double2*>(state) + (size_t)b * rows * ns;
+  double2* S = const_cast<double2*>(state) + (size_t)b * stride;
   const int s = slot_of[e];
   const size_t dst = (size_t)b * n * 3 + e;
   const double2 v = s >= 0 ? ST(C_V, s) : make_double2(0.0, 0.0);
@@ -429,6 +429,7 @@ thread_local std::string g3_error;
 struct gs3_handle {
   int device = 0, n = 0, ns = 0, B = 0, n_levels = 0, max_width = 0, max_it = 50, threads = 256, lds_bytes = 0, rows = C_COUNT, prefetch = GS3_PREFETCH_LEVELS;
   int ns_store = 0;          // entries per state row: ns, or K x threads in the resident layout
+  size_t inst_stride = 0;    // double2 entries from one instance's rows to the next's
   int resident_k = 0;        // > 0: gs3_k_resident<resident_k, resident_mk> with `threads` threads solves the instance inside one CU
   int resident_mk = 0;
   double tol = 1e-6;
@@ -601,22 +602,22 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   h->rows = h->lds_bytes ? C_COUNT : C_COUNT_NOLDS;
   h->ns_store = ns;
   // Resident layout (gridstep3_resident.h) when the conductors fit in one CU: ns + 1 LDS entries beside 1 KB of scratch,
-  // at most 10 positions per thread.  K = 2 mod 4 keeps a thread's 16-byte LDS accesses (stride K x 16 bytes across lanes)
-  // free of bank conflicts.
+  // at most 19 positions per thread of at most 512.
   {
     int lds_max = 0;
     (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     lds_max = std::max(lds_max, 64 * 1024);
     if (const char* e = getenv("GS3_RESIDENT_LDS")) lds_max = atoi(e);
-    const int need = (((ns + 4) & ~3) + 64) * (int)sizeof(double2);
     int K = 0;
-    for (int k : {2, 6, 10}) if (!K && (ns + k - 1) / k <= 1024) K = k;
+    for (int k : {3, 9, 19}) if (!K && (ns + k - 1) / k <= 512) K = k;
+    const int nthr = K ? std::max(64, ((ns + K - 1) / K + 63) / 64 * 64) : 0;
+    const int need = (((K * nthr + 4) & ~3) + 64) * (int)sizeof(double2);
     if (K && ns <= GS3_RESIDENT_MAX_CONDUCTORS && need <= lds_max && !getenv("GS3_NO_RESIDENT")) {
       h->resident_k = K;
-      h->threads = std::max(64, ((ns + K - 1) / K + 63) / 64 * 64);
+      h->threads = nthr;
       h->lds_bytes = need;
       h->rows = 2;
-      h->ns_store = K * h->threads;
+      h->ns_store = K * nthr;
     }
   }
   if (h->resident_k) {
@@ -651,6 +652,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     if (off != ns) return bail(fail3(nullptr, GS_E_TOPOLOGY, "internal: %d conductors in depth-first order, %d expected", off, ns));
     auto mem = [&](int p) { return (p % K) * nt + p / K; };
     std::vector<int32_t> rpk(npad, 0), rsrc(npad, -1), rslot((size_t)3 * n, -1);
+    for (int p = ns; p < npad; ++p) rpk[mem(p)] = (int32_t)((unsigned)p << 14);        // padding: size 0, postorder index = position
     std::vector<double2> rzd(npad, make_double2(0.0, 0.0)), rmz_a, rmz_b;
     std::vector<int4> rmut;
     for (int p = 0; p < ns; ++p) {
@@ -663,15 +665,17 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
       rzd[mem(p)] = z[(size_t)Z_D * ns + sl];
       const int pa = pre[(size_t)node * 3 + oa], pb = pre[(size_t)node * 3 + ob];
       if (pa < 0 && pb < 0) continue;
-      rmut.push_back(make_int4(std::max(pa, 0), std::max(pb, 0), post[e], 0));
+      const int ea = pa >= 0 ? pa + size[(size_t)node * 3 + oa] : 0, eb = pb >= 0 ? pb + size[(size_t)node * 3 + ob] : 0;
+      rmut.push_back(make_int4(std::max(pa, 0) | ea << 14, std::max(pb, 0) | eb << 14, post[e], 0));
       rmz_a.push_back(pa >= 0 ? z[(size_t)Z_A * ns + sl] : make_double2(0.0, 0.0));
       rmz_b.push_back(pb >= 0 ? z[(size_t)Z_B * ns + sl] : make_double2(0.0, 0.0));
     }
     Res3& R = h->R;
     R.ns = ns; R.npad = npad; R.K = K; R.M = (int)rmut.size();
-    h->resident_mk = R.M <= 2 * nt ? 2 : K;
+    h->resident_mk = K > 4 && R.M <= 4 * nt ? 4 : K;      // (19, 19) spills: a large feeder with every node multi-phase runs, slowly
     rmz_a.insert(rmz_a.end(), rmz_b.begin(), rmz_b.end());
     for (int ph = 0; ph < 3; ++ph) { R.vsr[ph] = T.vsr[ph]; R.vsi[ph] = T.vsi[ph]; }
+    if (getenv("GS3_STAMPS")) { if ((rc = alloc3(h, &R.stamps, 16))) return bail(rc); (void)hipMemset(R.stamps, 0, 16 * sizeof(long long)); }
     if ((rc = upload3(h, &R.pk, rpk)) || (rc = upload3(h, &R.zd, rzd)) || (rc = upload3(h, &R.mut, rmut)) || (rc = upload3(h, &R.mz, rmz_a))) return bail(rc);
     src_of = rsrc; slot_of = rslot;
     if (hipFuncSetAttribute((const void*)resident_kernel(K, h->resident_mk), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes) != hipSuccess)
@@ -682,11 +686,20 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   if (const char* e = getenv("GS3_PREFETCH")) h->prefetch = std::max(1, std::min(3, atoi(e)));
   if (const char* e = getenv("GS3_THREADS")) if (!h->resident_k) h->threads = std::max(64, std::min(256, atoi(e) / 64 * 64));
   const size_t bn3 = (size_t)batch * n * 3;
-  if ((rc = alloc3(h, &h->d_state, (size_t)batch * h->rows * h->ns_store)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
+  // Instances of the resident layout start 256 x (37 mod 128) bytes apart: with a stride that is a multiple of 16 KB all
+  // workgroups, which run in step, would ask the same few memory channels for the same row at the same time.
+  h->inst_stride = (size_t)h->rows * h->ns_store;
+  if (h->resident_k && !getenv("GS3_NO_STRIDE_PAD")) {
+    size_t units = (h->inst_stride * sizeof(double2) + 255) / 256;
+    while (units % 128 != 37) ++units;
+    h->inst_stride = units * 256 / sizeof(double2);
+  }
+  h->R.stride = h->inst_stride;
+  if ((rc = alloc3(h, &h->d_state, (size_t)batch * h->inst_stride)) || (rc = alloc3(h, &h->d_p, bn3)) || (rc = alloc3(h, &h->d_q, bn3)) ||
       (rc = alloc3(h, &h->d_vre, bn3)) || (rc = alloc3(h, &h->d_vim, bn3)) || (rc = alloc3(h, &h->d_loss, batch)) ||
       (rc = alloc3(h, &h->d_mm, batch)) || (rc = alloc3(h, &h->d_it, batch)) || (rc = alloc3(h, &h->d_conv, batch)))
     return bail(rc);
-  if (hipMemset(h->d_state, 0, (size_t)batch * h->rows * h->ns_store * sizeof(double2)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
+  if (hipMemset(h->d_state, 0, (size_t)batch * h->inst_stride * sizeof(double2)) != hipSuccess) return bail(fail3(nullptr, GS_E_HIP, "hipMemset failed"));
   *out = h;
   return GS_OK;
 }
@@ -708,7 +721,7 @@ int gs3_upload_injections(gs3_handle* h, const double* P, const double* Q) {
   HIP3(h, hipMemcpyAsync(h->d_p, P, bytes, hipMemcpyHostToDevice, h->stream));
   if (Q) HIP3(h, hipMemcpyAsync(h->d_q, Q, bytes, hipMemcpyHostToDevice, h->stream));
   dim3 grid((h->ns_store + 255) / 256, h->B);
-  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->ns_store, h->rows, h->d_src_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
+  hipLaunchKernelGGL(gs3_k_scatter_in, grid, dim3(256), 0, h->stream, h->n, h->ns_store, h->inst_stride, h->d_src_of, h->d_p, Q ? h->d_q : (const double*)nullptr, h->d_state);
   HIP3(h, hipGetLastError());
   HIP3(h, hipStreamSynchronize(h->stream));
   return GS_OK;
@@ -729,6 +742,14 @@ int gs3_solve_device(gs3_handle* h) {
   if (h->resident_k) {
     const res_fn rf = resident_kernel(h->resident_k, h->resident_mk);
     hipLaunchKernelGGL(rf, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->R, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
+    if (h->R.stamps) {       // development aid: where the cycles of an iteration go (100 MHz clock of workgroup 0)
+      long long st[16];
+      HIP3(h, hipStreamSynchronize(h->stream));
+      HIP3(h, hipMemcpy(st, h->R.stamps, sizeof st, hipMemcpyDeviceToHost));
+      fprintf(stderr, "gs3 resident stamps (cycles since the top of iteration 1):");
+      for (int i = 1; i <= 9; ++i) fprintf(stderr, " %lld", st[i] - st[0]);
+      fprintf(stderr, "\n");
+    }
   } else {
     const solve_fn fn = h->lds_bytes ? with_lds[h->prefetch - 1] : gs3_k_solve<false, 1>;
     hipLaunchKernelGGL(fn, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->T, h->d_state, h->B, h->tol, h->max_it, h->d_loss, h->d_mm, h->d_it, h->d_conv);
@@ -744,7 +765,7 @@ int gs3_download_solution(gs3_handle* h, const gs3_solution_view* out) {
   const size_t bn3 = (size_t)h->B * h->n * 3;
   if (out->v_re || out->v_im) {
     dim3 grid((3 * h->n + 255) / 256, h->B);
-    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->ns_store, h->rows, h->d_slot_of, h->d_state, h->d_vre, h->d_vim);
+    hipLaunchKernelGGL(gs3_k_gather_out, grid, dim3(256), 0, h->stream, h->n, h->ns_store, h->inst_stride, h->d_slot_of, h->d_state, h->d_vre, h->d_vim);
     HIP3(h, hipGetLastError());
     if (out->v_re) HIP3(h, hipMemcpyAsync(out->v_re, h->d_vre, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (out->v_im) HIP3(h, hipMemcpyAsync(out->v_im, h->d_vim, bn3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -787,9 +808,9 @@ int gs3_timing_read(gs3_handle* h, double* total_ms, int64_t* launches) {
 int gs3_describe(const gs3_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail3(nullptr, GS_E_INVALID, "bad arguments");
   snprintf(buf, buflen, "{\"kernel\": \"%s\", \"n\": %d, \"conductors\": %d, \"levels\": %d, \"max_level_width\": %d, \"batch\": %d, \"lds_messages\": %d, \"state_bytes\": %zu, "
-           "\"threads\": %d, \"positions_per_thread\": %d, \"lds_bytes\": %d}",
+           "\"threads\": %d, \"positions_per_thread\": %d, \"mutual_entries\": %d, \"mutual_per_thread\": %d, \"lds_bytes\": %d}",
            h->resident_k ? "fbs3_resident" : "fbs3", h->n, h->ns, h->n_levels, h->max_width, h->B, h->resident_k ? 0 : h->lds_bytes,
-           (size_t)h->B * h->rows * h->ns_store * sizeof(double2), h->threads, h->resident_k, h->lds_bytes);
+           (size_t)h->B * h->inst_stride * sizeof(double2), h->threads, h->resident_k, h->R.M, h->resident_mk, h->lds_bytes);
   return GS_OK;
 }
 

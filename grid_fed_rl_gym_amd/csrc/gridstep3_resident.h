@@ -19,7 +19,9 @@
 //               postorder prefix of D: one sample at the thread's own position and one gather at a static index.
 //
 // So an iteration is three workgroup-wide prefix sums and three gathers, with no dependence on the depth of the feeder.  One
-// workgroup of up to 1024 threads solves one instance; a thread owns K consecutive positions.  What persists between
+// workgroup of up to 512 threads solves one instance; a thread owns K consecutive positions (K up to 19: the arrays of a
+// thread take 9 K registers, what is left of the 256 a wave may have at two waves per SIMD are the temporaries -- with 1024
+// threads and 128 registers the compiler spilled the currents to scratch and the kernel waited for them one by one).  What persists between
 // iterations is the injection current of each conductor, in registers (2 K doubles per thread; the mismatch of the new
 // voltages needs exactly that current, see gs3_k_solve); the array being gathered from (X, then J, then D / Y) is the one
 // thing that has to be visible to other threads and lives in LDS: (conductors + 1) x 16 bytes, 150 KB of the CU's 160 KB for
@@ -29,8 +31,8 @@
 // ~14 % of conductors that share a node with another phase; they are a separate compact list (conductor, its two
 // siblings, the two impedances) dealt over the threads, added to D through LDS.  Per iteration HBM sees S (150 KB per
 // workgroup; the working set of the 256 resident workgroups fits the MALL) and, per solve, V once; the self impedances
-// (16 bytes per conductor) come from L2.  Feeders whose conductors do not fit (more than ~10 100, or more than 10 per
-// thread) take gs3_k_solve.
+// (16 bytes per conductor) come from L2.  Feeders whose conductors do not fit (more than ~9 700: 19 x 512) take
+// gs3_k_solve.
 //
 // Rounding: prefix differences carry an absolute error of a few ulp of the LARGEST prefix (the feeder's total current, the
 // summed drops of a phase) instead of the subtree's own sum: ~1e-15 in V on the 8500-node case, far inside the 1e-10 the
@@ -42,10 +44,15 @@ struct Res3 {
   int32_t ns, npad, K, M;      // conductors; K x threads; positions per thread; entries of the mutual list
   const int32_t* pk;           // [npad], storage order: subtree size | postorder index << 14 | is-source << 28 | phase << 29
   const double2* zd;           // [npad], storage order: self impedance of the upstream line (zero for the source's conductors)
-  const int4* mut;             // [M]: {position of sibling A, of sibling B, postorder index of the conductor, 0}; an absent
-                               //      sibling points at position 0 with a zero impedance
+  const int4* mut;             // [M]: {a | e(a) << 14, b | e(b) << 14, postorder index of the conductor, 0}, a / b = positions of the
+                               //      node's other two conductors; an absent one is (0, 0) with a zero impedance
   const double2* mz;           // [2][M]: mutual impedances to A and to B
+  // Positions ns .. npad - 1 are padding and behave like conductors that draw nothing and hang nowhere: S = 0, Z = 0,
+  // subtree size 0, postorder index = position.  Then no access needs a guard: X of a padding position is the total, its
+  // J and D are 0, and its V comes out as the source voltage.
   double vsr[3], vsi[3];
+  size_t stride;               // double2 entries between the rows (V, S) of consecutive instances
+  long long* stamps;           // development: clock of workgroup 0 at the phase boundaries of its second iteration (GS3_STAMPS=1), or NULL
 };
 // storage order: element k of thread t at k * threads + t (one coalesced access per k)
 #define R3_SIZE(w) ((w) & 0x3fff)
@@ -76,6 +83,14 @@ __device__ __forceinline__ double r3_wave_scan(double v) {
 }
 __device__ __forceinline__ double r3_readlane(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// 1 / d for a normal d (|V|^2 here): the hardware estimate and two Newton steps, ~1 ulp.  (A true division is twelve
+// instructions and a dozen temporaries per position, times the positions the scheduler interleaves.)
+__device__ __forceinline__ double r3_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
+  x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
+  return x;
 }
 __device__ __forceinline__ void r3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -110,33 +125,49 @@ struct R3Wg {
 
 extern __shared__ double2 r3_lds[];
 
-// K positions per thread; MK entries of the mutual list per thread (2: the usual feeder, mostly single-phase laterals; K:
-// up to every conductor has siblings)
+// K positions per thread (odd: a thread's 16-byte LDS accesses, K x 16 bytes apart across lanes, then fall on distinct banks);
+// MK entries of the mutual list per thread (3: the usual feeder, mostly single-phase laterals; K: up to every conductor
+// has siblings)
 template <int K, int MK>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(512)
 gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_it, double* __restrict__ out_loss,
                double* __restrict__ out_mm, int32_t* __restrict__ out_it, uint8_t* __restrict__ out_conv) {
-  constexpr int G = 2;                                               // global loads kept in flight ahead of their use
-  const int ns = T.ns, npad = T.npad, M = T.M, tid = threadIdx.x, nt = blockDim.x;
-  double2* __restrict__ A = r3_lds;                                  // [ns + 1]: X, then J, then D / Y
-  R3Wg wg = {r3_lds + ((ns + 4) & ~3), 0, 0, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+  // what is kept in flight ahead of its use: self impedances, injections (16-byte global loads); gathers from LDS per
+  // scheduling fence; positions of the mismatch loop interleaved.  (With 256 threads, K = 37 and one wave per SIMD the
+  // arrays spill over into AGPRs and there is room for rings of 8 -- measured 3.4 M solves/s against 4.3 M for this form.)
+  constexpr int GZ = 2, GS = 2, FA = 4, FB = 2;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int npad = T.npad, M = T.M, nt = blockDim.x;
+  int tid = threadIdx.x;
+  double2* __restrict__ A = r3_lds;                                  // [npad + 1]: X, then J, then D / Y
+  R3Wg wg = {r3_lds + ((npad + 4) & ~3), 0, 0, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
   if (tid < 64) wg.scr[tid] = make_double2(0.0, 0.0);
-  double2* __restrict__ Vrow = state + (size_t)blockIdx.x * 2 * npad;
-  const double2* __restrict__ Srow = Vrow + npad;
-  const int p0 = tid * K;
+  double2* __restrict__ Vrow = state + (size_t)blockIdx.x * T.stride;
   const double vsr0 = T.vsr[0], vsr1 = T.vsr[1], vsr2 = T.vsr[2], vsi0 = T.vsi[0], vsi1 = T.vsi[1], vsi2 = T.vsi[2];
 #define R3_SRC_R(ph) ((ph) == 0 ? vsr0 : ((ph) == 1 ? vsr1 : vsr2))
 #define R3_SRC_I(ph) ((ph) == 0 ? vsi0 : ((ph) == 1 ? vsi1 : vsi2))
-#define R3_M(k) ((k) * nt + tid)
   // Global rows through buffer descriptors: the descriptor and the row offset k * threads sit in SGPRs, the thread's
-  // offset is one VGPR for all rows (a 64-bit address per thread and row would cost 2 K registers per table).
-  const unsigned t16 = (unsigned)tid << 4, t4 = (unsigned)tid << 2;
+  // offset is one VGPR for all rows (a 64-bit address per thread and row would cost 2 K registers per table).  An entry
+  // beyond the end of a table reads as zero.
   const __amdgpu_buffer_rsrc_t rs_pk = __builtin_amdgcn_make_buffer_rsrc((void*)T.pk, 0, npad * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_zd = __builtin_amdgcn_make_buffer_rsrc((void*)T.zd, 0, npad * 16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)Srow, 0, npad * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(Vrow + npad), 0, npad * 16, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vrow, 0, npad * 16, 0x00020000);
-#define R3_LD16(rs, k) __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, t16, (k) * nt * 16, 0))
-#define R3_LD4(rs, k) ((int)__builtin_amdgcn_raw_buffer_load_b32(rs, t4, (k) * nt * 4, 0))
+  const __amdgpu_buffer_rsrc_t rs_mut = __builtin_amdgcn_make_buffer_rsrc((void*)T.mut, 0, M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mz = __builtin_amdgcn_make_buffer_rsrc((void*)T.mz, 0, 2 * M * 16, 0x00020000);
+#define R3_LD16(rs, k) __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)tid << 4, (k) * nt * 16, 0))
+#define R3_LD4(rs, k) ((int)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)tid << 2, (k) * nt * 4, 0))
+  // What follows from the thread index and from pk -- addresses, indices, the source voltage of a position's phase -- is
+  // recomputed where it is used: the compiler would otherwise hoist all of it out of the iteration loop, a dozen registers
+  // per position, and spill.
+#define R3_OPAQUE() do { asm volatile("" : "+v"(tid)); _Pragma("unroll") for (int k = 0; k < K; ++k) asm volatile("" : "+v"(pk[k])); } while (0)
+// The scheduler would issue all K gathers of a loop at once (four result registers each) and the allocator then spills the
+// arrays: a fence after every n positions bounds what is in flight.
+#define R3_EVERY(k, n) do { if ((k) % (n) == (n) - 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+// ... and the arithmetic on what was gathered has to stay in front of the fence too (pure register work otherwise sinks
+// below the next barrier, and the K gathered operands wait for it in registers)
+#define R3_PIN(x, y) asm volatile("" : "+v"(x), "+v"(y))
+#define R3_OWN (A + tid * K)                  /* the thread's K entries: one address register, the rest immediate offsets */
 
   int pk[K];                // the tree as this thread's positions see it
   double ar[K], ai[K];      // injection currents of the thread's conductors: what persists between iterations
@@ -144,6 +175,7 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
   double lmax = 0.0;
   r3_barrier();             // scratch zeroed
   // ---- flat start: V = V_source everywhere, first mismatch = |S_spec|
+  const double rd0 = r3_rcp(vsr0 * vsr0 + vsi0 * vsi0), rd1 = r3_rcp(vsr1 * vsr1 + vsi1 * vsi1), rd2 = r3_rcp(vsr2 * vsr2 + vsi2 * vsi2);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     pk[k] = R3_LD4(rs_pk, k);
@@ -152,9 +184,11 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
     if (R3_ROOT(pk[k])) s = make_double2(0.0, 0.0);               // nothing is drawn at the source itself
     const double dP = fabs(s.x), dQ = fabs(s.y);
     lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
-    const double vr = R3_SRC_R(ph), vi = R3_SRC_I(ph), rd = 1.0 / (vr * vr + vi * vi);
+    const double vr = R3_SRC_R(ph), vi = R3_SRC_I(ph), rd = ph == 0 ? rd0 : (ph == 1 ? rd1 : rd2);
     ar[k] = -(s.x * vr + s.y * vi) * rd; ai[k] = -(s.x * vi - s.y * vr) * rd;
     br[k] = vr; bi[k] = vi;
+    R3_PIN(ar[k], ai[k]);
+    R3_EVERY(k, 4);
   }
   double mm, losses = 0.0, zero = 0.0;
   mm = lmax; wg.max_sum(mm, zero);
@@ -163,132 +197,138 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
     iters = 1; conv = mm < tol;
   } else {
     for (int it = 0; it < max_it; ++it) {
-      // (what follows from pk -- indices, the source voltage of the phase -- is recomputed where it is used: hoisted out of
-      // the loop it would take ten more registers per position than there are)
-#define R3_OPAQUE_PK() _Pragma("unroll") for (int k = 0; k < K; ++k) asm volatile("" : "+v"(pk[k]))
-      R3_OPAQUE_PK();
+      R3_OPAQUE();
+#define R3_STAMP(i) do { if (T.stamps && it == 1 && blockIdx.x == 0 && tid == 0) T.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+      R3_STAMP(0);
       // ---- backward: X = exclusive prefix of I over positions
       double rr = 0.0, ri = 0.0, tr, ti;
-      double2 zq[G];
-#pragma unroll
-      for (int k = 0; k < G; ++k) zq[k] = R3_LD16(rs_zd, k);       // the self impedances of the first positions, needed after three barriers
 #pragma unroll
       for (int k = 0; k < K; ++k) { br[k] = rr; bi[k] = ri; rr += ar[k]; ri += ai[k]; }
       wg.scan(rr, ri, tr, ti);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         br[k] += rr; bi[k] += ri;
-        if (p0 + k < ns) A[p0 + k] = make_double2(br[k], bi[k]);
+        R3_OWN[k] = make_double2(br[k], bi[k]);
       }
-      if (tid == 0) A[ns] = make_double2(tr, ti);
+      if (tid == 0) A[npad] = make_double2(tr, ti);
+      // (requested before the barrier, used after it) the mutual list's entries of this thread, the first self impedances
+      int4 mx[MK]; double2 mza[MK], mzb[MK];
+#pragma unroll
+      for (int j = 0; j < MK; ++j) {
+        mx[j] = __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(rs_mut, (unsigned)tid << 4, j * nt * 16, 0));
+        mza[j] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs_mz, (unsigned)tid << 4, j * nt * 16, 0));
+        mzb[j] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs_mz, (unsigned)tid << 4, (M + j * nt) * 16, 0));
+      }
+      double2 zq[GZ];
+#pragma unroll
+      for (int k = 0; k < GZ; ++k) zq[k] = R3_LD16(rs_zd, k);
       r3_barrier();
-      // J = X[e] - X[own]; the source's share of sum P_calc is V_source . J of the phase's root
+      R3_STAMP(1);
+      // J = X[e] - X[own], and at once D = Z-row . (J, J of the node's other conductors): the own part here, ...
       double psrc = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const double2 xe = A[min(p0 + k + R3_SIZE(pk[k]), ns)];
-        br[k] = xe.x - br[k]; bi[k] = xe.y - bi[k];
-        if (R3_ROOT(pk[k])) { const int ph = R3_PH(pk[k]); psrc += R3_SRC_R(ph) * br[k] + R3_SRC_I(ph) * bi[k]; }
+        const double2 xe = R3_OWN[k + R3_SIZE(pk[k])];
+        const double2 zd = zq[k % GZ];
+        if (k + GZ < K) zq[k % GZ] = R3_LD16(rs_zd, k + GZ);
+        const double jr = xe.x - br[k], ji = xe.y - bi[k];
+        if (R3_ROOT(pk[k])) { const int ph = R3_PH(pk[k]); psrc += R3_SRC_R(ph) * jr + R3_SRC_I(ph) * ji; }    // the source's share of sum P_calc
+        br[k] = zd.x * jr - zd.y * ji; bi[k] = zd.x * ji + zd.y * jr;
+        R3_PIN(br[k], bi[k]);
+        asm volatile("" : "+v"(psrc));
+        R3_EVERY(k, FA);
       }
-      r3_barrier();                          // every X has been read
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (p0 + k < ns) A[p0 + k] = make_double2(br[k], bi[k]);
-      r3_barrier();
-      // D = Z-row . (J, J of the node's other conductors): the mutual part from the compact list
-      double mr[MK], mi[MK]; int ml[MK];
+      // ... the mutual part from the compact list, the siblings' J again as differences of X
+      double mr[MK], mi[MK];
 #pragma unroll
       for (int j = 0; j < MK; ++j) {
-        const int i = tid + j * nt;
-        mr[j] = 0.0; mi[j] = 0.0; ml[j] = 0;
-        if (i < M) {
-          const int4 ix = T.mut[i];
-          const double2 za = T.mz[i], zb = T.mz[M + i], ja = A[ix.x], jb = A[ix.y];
-          mr[j] = za.x * ja.x - za.y * ja.y + zb.x * jb.x - zb.y * jb.y;
-          mi[j] = za.x * ja.y + za.y * ja.x + zb.x * jb.y + zb.y * jb.x;
-          ml[j] = ix.z;
-        }
+        const double2 a1 = A[(unsigned)mx[j].x >> 14], a0 = A[mx[j].x & 0x3fff], b1 = A[(unsigned)mx[j].y >> 14], b0 = A[mx[j].y & 0x3fff];
+        const double jar = a1.x - a0.x, jai = a1.y - a0.y, jbr = b1.x - b0.x, jbi = b1.y - b0.y;
+        mr[j] = mza[j].x * jar - mza[j].y * jai + mzb[j].x * jbr - mzb[j].y * jbi;
+        mi[j] = mza[j].x * jai + mza[j].y * jar + mzb[j].x * jbi + mzb[j].y * jbr;
+        R3_PIN(mr[j], mi[j]);
+        R3_EVERY(j, 2);
       }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const double2 zd = zq[k % G];
-        if (k + G < K) zq[k % G] = R3_LD16(rs_zd, k + G);
-        const double dr = zd.x * br[k] - zd.y * bi[k], di = zd.x * bi[k] + zd.y * br[k];
-        br[k] = dr; bi[k] = di;
-      }
-      r3_barrier();                          // every J has been read
+      r3_barrier();                          // every X has been read
+      R3_STAMP(2);
       // ---- forward: D at the conductor's postorder index
-      R3_OPAQUE_PK();
+      R3_OPAQUE();
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (p0 + k < ns) A[R3_POST(pk[k])] = make_double2(br[k], bi[k]);
+      for (int k = 0; k < K; ++k) A[R3_POST(pk[k])] = make_double2(br[k], bi[k]);
       if (M > 0) {
         r3_barrier();
 #pragma unroll
         for (int j = 0; j < MK; ++j)
-          if (tid + j * nt < M) { double2 d = A[ml[j]]; d.x += mr[j]; d.y += mi[j]; A[ml[j]] = d; }
+          if (tid + j * nt < M) { double2 d = A[mx[j].z]; d.x += mr[j]; d.y += mi[j]; A[mx[j].z] = d; }
         r3_barrier();
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-          if (p0 + k < ns) { const double2 d = A[R3_POST(pk[k])]; br[k] = d.x; bi[k] = d.y; }
+        for (int k = 0; k < K; ++k) { const double2 d = A[R3_POST(pk[k])]; br[k] = d.x; bi[k] = d.y; }
       }
+      R3_STAMP(3);
       // Xi = inclusive preorder prefix of D (registers)
-      double2 sq[G];
-#pragma unroll
-      for (int k = 0; k < G; ++k) sq[k] = R3_LD16(rs_s, k);        // S of the first positions, needed after three barriers
       rr = 0.0; ri = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) { rr += br[k]; ri += bi[k]; br[k] = rr; bi[k] = ri; }
       wg.scan(rr, ri, tr, ti);               // its barrier also publishes D
+      R3_STAMP(4);
 #pragma unroll
       for (int k = 0; k < K; ++k) { br[k] += rr; bi[k] += ri; }
       // Y = exclusive postorder prefix of D, in place: postorder index q is entry q
       double yr = 0.0, yi = 0.0;
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (p0 + k < ns) { const double2 d = A[p0 + k]; yr += d.x; yi += d.y; }
+      for (int k = 0; k < K; ++k) { const double2 d = R3_OWN[k]; yr += d.x; yi += d.y; if (k % FA == FA - 1) R3_PIN(yr, yi); R3_EVERY(k, FA); }
       wg.scan(yr, yi, tr, ti);
+      R3_STAMP(5);
+      double2 sq[GS];
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (p0 + k < ns) { const double2 d = A[p0 + k]; A[p0 + k] = make_double2(yr, yi); yr += d.x; yi += d.y; }
+      for (int k = 0; k < GS; ++k) sq[k] = R3_LD16(rs_s, k);    // S of the first positions, needed after the gathers
+#pragma unroll
+      for (int k = 0; k < K; ++k) { const double2 d = R3_OWN[k]; R3_OWN[k] = make_double2(yr, yi); yr += d.x; yi += d.y; if (k % FA == FA - 1) R3_PIN(yr, yi); R3_EVERY(k, FA); }
+      if (tid == 0) A[npad] = make_double2(tr, ti);
       r3_barrier();
-      // V = V_source - (Xi[own] - Y[g]); then the mismatch at the new voltages and the next injection currents
-      R3_OPAQUE_PK();
-      const bool check = it + 1 < max_it;
-      lmax = 0.0;
-      double psum = psrc;
+      R3_STAMP(6);
+      // V = V_source - (Xi[own] - Y[g])
+      R3_OPAQUE();
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int ph = R3_PH(pk[k]);
         const double2 y = A[R3_POST(pk[k]) - R3_SIZE(pk[k]) + 1];
-        const bool real = p0 + k < ns;
-        const double wr = real ? R3_SRC_R(ph) - (br[k] - y.x) : 1.0, wi = real ? R3_SRC_I(ph) - (bi[k] - y.y) : 0.0;
-        br[k] = wr; bi[k] = wi;
-        double2 s = sq[k % G];
-        if (k + G < K) sq[k % G] = R3_LD16(rs_s, k + G);
-        if (check) {
-          if (R3_ROOT(pk[k])) s = make_double2(0.0, 0.0);
-          const double pc = -(wr * ar[k] + wi * ai[k]), qc = -(wi * ar[k] - wr * ai[k]);
-          const double dP = fabs(s.x - pc), dQ = fabs(s.y - qc);
-          lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
-          psum += pc;
-          const double rd = 1.0 / (wr * wr + wi * wi);
-          ar[k] = -(s.x * wr + s.y * wi) * rd; ai[k] = -(s.x * wi - s.y * wr) * rd;
-        }
+        br[k] = R3_SRC_R(ph) - (br[k] - y.x); bi[k] = R3_SRC_I(ph) - (bi[k] - y.y);
+        R3_PIN(br[k], bi[k]);
+        R3_EVERY(k, FA);
       }
-      if (check) {                           // what the backward sweep of iteration it + 1 would find
-        mm = lmax; losses = psum;
-        wg.max_sum(mm, losses);
-        if (!(mm < INFINITY)) { iters = it + 2; break; }
-        if (mm < tol) { iters = it + 2; conv = 1; break; }
+      R3_STAMP(7);
+      if (it + 1 >= max_it) break;           // the last sweep allowed: its voltages are the answer, nobody asks how good they are
+      // the mismatch at the new voltages = what the backward sweep of iteration it + 1 would find, and the next injection currents
+      lmax = 0.0;
+      double psum = psrc;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double2 s = sq[k % GS];
+        if (k + GS < K) sq[k % GS] = R3_LD16(rs_s, k + GS);
+        if (R3_ROOT(pk[k])) s = make_double2(0.0, 0.0);
+        const double wr = br[k], wi = bi[k];
+        const double pc = -(wr * ar[k] + wi * ai[k]), qc = -(wi * ar[k] - wr * ai[k]);
+        const double dP = fabs(s.x - pc), dQ = fabs(s.y - qc);
+        lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
+        psum += pc;
+        const double rd = r3_rcp(wr * wr + wi * wi);
+        ar[k] = -(s.x * wr + s.y * wi) * rd; ai[k] = -(s.x * wi - s.y * wr) * rd;
+        R3_PIN(ar[k], ai[k]);
+        R3_PIN(lmax, psum);
+        R3_EVERY(k, FB);
       }
+      R3_STAMP(8);
+      mm = lmax; losses = psum;
+      wg.max_sum(mm, losses);
+      R3_STAMP(9);
+      if (!(mm < INFINITY)) { iters = it + 2; break; }
+      if (mm < tol) { iters = it + 2; conv = 1; break; }
     }
   }
 #pragma unroll
-  for (int k = 0; k < K; ++k) {   // 16-byte store: row offset in the vector offset (see GsPairRef::put, gs_internal.h)
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(br[k], bi[k])), rs_v, t16 + (unsigned)(k * nt * 16), 0, 0);
-  }
+  for (int k = 0; k < K; ++k)                // 16-byte store: row offset in the vector offset (see GsPairRef::put, gs_internal.h)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(br[k], bi[k])), rs_v, ((unsigned)tid << 4) + (unsigned)(k * nt * 16), 0, 0);
   if (tid == 0) {
     out_loss[blockIdx.x] = losses;
     out_mm[blockIdx.x] = mm;
@@ -297,8 +337,11 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
   }
 #undef R3_SRC_R
 #undef R3_SRC_I
-#undef R3_M
-#undef R3_OPAQUE_PK
 #undef R3_LD16
 #undef R3_LD4
+#undef R3_OPAQUE
+#undef R3_OWN
+#undef R3_EVERY
+#undef R3_PIN
+#undef R3_STAMP
 }

@@ -15,18 +15,33 @@ def _fs_of(d):
     return P.FeederSpec(name="g", bus_ids=list(range(n)), bus_type=bt.astype(np.uint8), v_set=vs, frm=frm, to=to, r=r, x=x, rating=rating)
 
 
-def _random_case(n, seed, lateral=0.35):
+def _random_case(n, seed, lateral=0.35, local=0):
+    """Random radial feeder; `local` > 0 attaches a node to one of the `local` nodes before it (a deep tree), and the
+    impedances shrink with n so that large cases stay solvable."""
     rng = np.random.default_rng(seed)
     parent = np.full(n, -1, dtype=np.int32); phases = np.full(n, 7, dtype=np.uint8); z = np.zeros((n, 3, 3), dtype=complex)
     for b in range(1, n):
-        p = int(rng.integers(0, b)); parent[b] = p
+        p = int(rng.integers(max(0, b - local) if local else 0, b)); parent[b] = p
         m = int(phases[p])
         if m == 7 and rng.random() < lateral:
             m = [1, 2, 4, 3, 5, 6][int(rng.integers(0, 6))]
         phases[b] = m
-        zs = complex(rng.uniform(0.004, 0.01), rng.uniform(0.008, 0.02))
+        zs = complex(rng.uniform(0.004, 0.01), rng.uniform(0.008, 0.02)) * (30.0 / n if n > 300 else 1.0)
         z[b] = zs * np.eye(3) + rng.uniform(0.2, 0.4) * zs * (1 - np.eye(3))
     return UnbalancedFeederSpec("rnd", parent, phases, z)
+
+
+# The two kernels behind gs3_solve: "resident" (gridstep3_resident.h: the instance stays in one CU, sweeps as prefix sums;
+# taken whenever the conductors fit) and "levels" (gs3_k_solve: level by level through HBM; GS3_NO_RESIDENT=1 forces it).
+KERNELS = ["resident", "levels"]
+
+
+def _solver(monkeypatch, kernel, **kw):
+    if kernel == "levels":
+        monkeypatch.setenv("GS3_NO_RESIDENT", "1")
+    else:
+        monkeypatch.delenv("GS3_NO_RESIDENT", raising=False)
+    return UnbalancedPowerFlow(**kw)
 
 
 @pytest.mark.parametrize("name", ["solve_radial13", "solve_tree123"])
@@ -47,13 +62,15 @@ def test_oracle_balanced_limit_equals_reference_anchor(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", ["solve_radial13", "solve_tree123"])
-def test_gpu_balanced_limit_equals_reference_anchor(name):
+def test_gpu_balanced_limit_equals_reference_anchor(name, kernel, monkeypatch):
     d = golden(name)
     spec = unbalanced_from_single_phase(_fs_of(d), coupling=0.0)
     Pb = np.stack([np.repeat((d["P_spec"] * lam)[:, None], 3, axis=1) for lam in d["exact_scales"]])
-    s = UnbalancedPowerFlow(tolerance=1e-11, max_iterations=300)
+    s = _solver(monkeypatch, kernel, tolerance=1e-11, max_iterations=300)
     sol = s.solve_batch(spec, Pb)
+    assert s.describe()["kernel"] == ("fbs3_resident" if kernel == "resident" else "fbs3")
     for q in range(len(d["exact_scales"])):
         V1 = d[f"C{q}_Vm"] * np.exp(1j * d[f"C{q}_Va"])
         assert sol.converged[q]
@@ -63,15 +80,19 @@ def test_gpu_balanced_limit_equals_reference_anchor(name):
     s.close()
 
 
+# (n, batch, seed, lateral probability, local attachment): the last four are sized for the resident kernel's variants --
+# 9 and 19 positions per thread, the mutual list dealt 4 per thread or one per position (every node three-phase)
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,B,seed", [(40, 5, 1), (150, 70, 2), (333, 9, 3)])
-def test_gpu_unbalanced_against_oracle(n, B, seed):
-    spec = _random_case(n, seed)
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("n,B,seed,lateral,local", [(40, 5, 1, 0.35, 0), (150, 70, 2, 0.35, 0), (333, 9, 3, 0.35, 0),
+                                                    (900, 3, 4, 0.0, 60), (2500, 3, 5, 0.3, 60), (2300, 2, 6, 0.0, 60), (4000, 2, 7, 0.5, 60)])
+def test_gpu_unbalanced_against_oracle(n, B, seed, lateral, local, kernel, monkeypatch):
+    spec = _random_case(n, seed, lateral, local)
     rng = np.random.default_rng(seed + 100)
     pres = ((spec.phases[:, None] >> np.arange(3)[None, :]) & 1).astype(bool)
-    Pb = np.where(pres[None], -rng.uniform(0.0002, 0.003, (B, n, 3)), 0.0); Pb[:, 0] = 0
+    Pb = np.where(pres[None], -rng.uniform(0.0002, 0.003, (B, n, 3)) * min(1.0, 100.0 / n), 0.0); Pb[:, 0] = 0
     Qb = Pb * rng.uniform(0.2, 0.5, (B, n, 3))
-    s = UnbalancedPowerFlow(tolerance=1e-9, max_iterations=200)
+    s = _solver(monkeypatch, kernel, tolerance=1e-9, max_iterations=200)
     sol = s.solve_batch(spec, Pb, Qb)
     assert sol.converged.all()
     for b in range(0, B, max(1, B // 4)):
@@ -86,18 +107,53 @@ def test_gpu_unbalanced_against_oracle(n, B, seed):
 
 
 @pytest.mark.gpu
-def test_gpu_8500_node_property():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_gpu_8500_node_property(kernel, monkeypatch):
     """Full-size feeder: the converged voltages satisfy S = V conj(Y3 V) (independent assembly)."""
     spec, Pn, Qn = ieee8500_like()
     B = 3
     lam = np.array([0.6, 1.0, 1.3])
-    s = UnbalancedPowerFlow(tolerance=1e-8, max_iterations=200)
+    s = _solver(monkeypatch, kernel, tolerance=1e-8, max_iterations=200)
     sol = s.solve_batch(spec, lam[:, None, None] * Pn[None], lam[:, None, None] * Qn[None])
+    d = s.describe()
+    assert d["kernel"] == ("fbs3_resident" if kernel == "resident" else "fbs3")
+    if kernel == "resident":          # the benchmark's variant: 19 positions per thread, the mutual list 4 per thread
+        assert (d["threads"], d["positions_per_thread"], d["mutual_per_thread"]) == (512, 19, 4)
     assert sol.converged.all() and sol.iterations.max() < 60
     assert 0.85 < np.abs(sol.voltages[1][np.abs(sol.voltages[1]) > 0]).min() < 1.0
     res, _ = O3.residual(spec.parent, spec.phases, spec.z, 0, sol.voltages[1], Pn, Qn)
     assert res < 1e-7
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,lateral", [(60, 0.35), (700, 0.3)])
+def test_gpu_resident_and_level_kernels_agree_on_the_edge_cases(n, lateral, monkeypatch):
+    """No load (the flat start is the answer, one iteration), a sweep budget that runs out (the last sweep's voltages, not
+    converged, mismatch of the sweep before), a non-finite injection (reported, not propagated into other instances): the two
+    kernels return the same record, field by field."""
+    spec = _random_case(n, 11, lateral, 30)
+    rng = np.random.default_rng(12)
+    pres = ((spec.phases[:, None] >> np.arange(3)[None, :]) & 1).astype(bool)
+    Pn = np.where(pres, -rng.uniform(0.0002, 0.003, (n, 3)) * min(1.0, 100.0 / n), 0.0); Pn[0] = 0
+    Pb = np.stack([0.0 * Pn, Pn, 1.4 * Pn, Pn, Pn]); Qb = 0.3 * Pb
+    Pb[3, n // 2, int(np.argmax(pres[n // 2]))] = np.nan
+    out = {}
+    for kernel in KERNELS:
+        for max_it in (2, 50):
+            s = _solver(monkeypatch, kernel, tolerance=1e-9, max_iterations=max_it)
+            out[kernel, max_it] = s.solve_batch(spec, Pb, Qb)
+            s.close()
+    for max_it in (2, 50):
+        a, b = out["resident", max_it], out["levels", max_it]
+        assert (a.converged == b.converged).all() and (a.iterations == b.iterations).all()
+        ok = [0, 1, 2, 4]
+        assert np.max(np.abs(a.voltages[ok] - b.voltages[ok])) < 1e-12 and np.max(np.abs(a.losses[ok] - b.losses[ok])) < 1e-12
+        assert np.max(np.abs(a.max_mismatch[ok] - b.max_mismatch[ok])) < 1e-13
+        assert a.converged[0] and a.iterations[0] == 1 and a.max_mismatch[0] == 0.0
+        assert not a.converged[3] and not np.isfinite(a.max_mismatch[3]) and not np.isfinite(b.max_mismatch[3])
+    assert not out["resident", 2].converged[1:].any() and (out["resident", 2].iterations[[1, 2, 4]] == 2).all()
+    assert out["resident", 50].converged[[0, 1, 2, 4]].all()
 
 
 def test_topology_validation_cpu():

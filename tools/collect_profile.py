@@ -42,7 +42,7 @@ def main():
             w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
             w.writerow(rows[0])
             for r in rows[1:]:
-                if r and (r[0].startswith("gs_") or r[0].startswith("gs3_") or "gs3_k_solve" in r[0]):
+                if r and (r[0].startswith("gs_") or r[0].startswith("gs3_") or "gs3_k_" in r[0]):
                     w.writerow(r)
         print("kernel stats:", [(r[0], float(r[3]) / 1e3) for r in rows[1:] if r and r[0].startswith("gs_k_step")])
     per_kernel = {}
@@ -53,8 +53,9 @@ def main():
             continue
         for r in csv.DictReader(open(path)):
             k = r["Kernel_Name"]
-            if "gs3_k_solve" in k:
-                k = "gs3_k_solve"                      # (a mangled template name)
+            for t in ("gs3_k_solve", "gs3_k_resident"):
+                if t in k:
+                    k = t                              # (a mangled template name)
             if not k.startswith("gs"):
                 continue
             out_rows.append((k, r["Counter_Name"], "%.6f" % float(r["Counter_Value"])))
