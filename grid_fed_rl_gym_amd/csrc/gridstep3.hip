@@ -611,7 +611,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     int K = 0;
     for (int k : {3, 9, 19}) if (!K && (ns + k - 1) / k <= 512) K = k;
     const int nthr = K ? std::max(64, ((ns + K - 1) / K + 63) / 64 * 64) : 0;
-    const int need = (((K * nthr + 4) & ~3) + 64) * (int)sizeof(double2);
+    const int need = (((K * nthr + 4) & ~3) + 72) * (int)sizeof(double2);
     if (K && ns <= GS3_RESIDENT_MAX_CONDUCTORS && need <= lds_max && !getenv("GS3_NO_RESIDENT")) {
       h->resident_k = K;
       h->threads = nthr;
@@ -659,8 +659,9 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
       const int node = pos_node[p], ph = pos_ph[p], e = (int)((size_t)node * 3 + ph);
       const int oa = ph == 0 ? 1 : 0, ob = ph == 2 ? 1 : 2;
       rpk[mem(p)] = (int32_t)((unsigned)size[e] | (unsigned)post[e] << 14 | (node == t->source ? 1u << 28 : 0u) | (unsigned)ph << 29);
-      rsrc[mem(p)] = e; rslot[e] = mem(p);
-      if (node == t->source) continue;
+      rslot[e] = mem(p);
+      if (node == t->source) continue;                           // nothing is drawn at the source: its S entries stay zero
+      rsrc[mem(p)] = e;
       const int sl = slot_of[e];                                 // the level layout's row of Z for the same conductor
       rzd[mem(p)] = z[(size_t)Z_D * ns + sl];
       const int pa = pre[(size_t)node * 3 + oa], pb = pre[(size_t)node * 3 + ob];
@@ -674,7 +675,8 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     R.ns = ns; R.npad = npad; R.K = K; R.M = (int)rmut.size();
     h->resident_mk = K > 4 && R.M <= 4 * nt ? 4 : K;      // (19, 19) spills: a large feeder with every node multi-phase runs, slowly
     rmz_a.insert(rmz_a.end(), rmz_b.begin(), rmz_b.end());
-    for (int ph = 0; ph < 3; ++ph) { R.vsr[ph] = T.vsr[ph]; R.vsi[ph] = T.vsi[ph]; }
+    for (int ph = 0; ph < 3; ++ph) { R.vsr[ph] = T.vsr[ph]; R.vsi[ph] = T.vsi[ph]; R.off[ph] = pre[(size_t)t->source * 3 + ph]; }
+    R.off[3] = ns;
     if (getenv("GS3_STAMPS")) { if ((rc = alloc3(h, &R.stamps, 16))) return bail(rc); (void)hipMemset(R.stamps, 0, 16 * sizeof(long long)); }
     if ((rc = upload3(h, &R.pk, rpk)) || (rc = upload3(h, &R.zd, rzd)) || (rc = upload3(h, &R.mut, rmut)) || (rc = upload3(h, &R.mz, rmz_a))) return bail(rc);
     src_of = rsrc; slot_of = rslot;

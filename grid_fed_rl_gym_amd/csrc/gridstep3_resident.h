@@ -51,6 +51,7 @@ struct Res3 {
   // subtree size 0, postorder index = position.  Then no access needs a guard: X of a padding position is the total, its
   // J and D are 0, and its V comes out as the source voltage.
   double vsr[3], vsi[3];
+  int32_t off[4];              // first position of each phase block, ns: the source's conductor of phase ph is position off[ph]
   size_t stride;               // double2 entries between the rows (V, S) of consecutive instances
   long long* stamps;           // development: clock of workgroup 0 at the phase boundaries of its second iteration (GS3_STAMPS=1), or NULL
 };
@@ -142,6 +143,8 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
   double2* __restrict__ A = r3_lds;                                  // [npad + 1]: X, then J, then D / Y
   R3Wg wg = {r3_lds + ((npad + 4) & ~3), 0, 0, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
   if (tid < 64) wg.scr[tid] = make_double2(0.0, 0.0);
+  double2* __restrict__ srcv = wg.scr + 64;                          // [3] source voltage by phase: one LDS read where a position needs it
+  if (tid < 3) srcv[tid] = make_double2(T.vsr[tid], T.vsi[tid]);
   double2* __restrict__ Vrow = state + (size_t)blockIdx.x * T.stride;
   const double vsr0 = T.vsr[0], vsr1 = T.vsr[1], vsr2 = T.vsr[2], vsi0 = T.vsi[0], vsi1 = T.vsi[1], vsi2 = T.vsi[2];
 #define R3_SRC_R(ph) ((ph) == 0 ? vsr0 : ((ph) == 1 ? vsr1 : vsr2))
@@ -180,8 +183,7 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
   for (int k = 0; k < K; ++k) {
     pk[k] = R3_LD4(rs_pk, k);
     const int ph = R3_PH(pk[k]);
-    double2 s = R3_LD16(rs_s, k);
-    if (R3_ROOT(pk[k])) s = make_double2(0.0, 0.0);               // nothing is drawn at the source itself
+    const double2 s = R3_LD16(rs_s, k);                           // (zero at the source's own conductors: gs3_k_scatter_in skips them)
     const double dP = fabs(s.x), dQ = fabs(s.y);
     lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
     const double vr = R3_SRC_R(ph), vi = R3_SRC_I(ph), rd = ph == 0 ? rd0 : (ph == 1 ? rd1 : rd2);
@@ -224,18 +226,24 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
       for (int k = 0; k < GZ; ++k) zq[k] = R3_LD16(rs_zd, k);
       r3_barrier();
       R3_STAMP(1);
-      // J = X[e] - X[own], and at once D = Z-row . (J, J of the node's other conductors): the own part here, ...
+      // the source's share of sum P_calc: V_source . (J of the phase's root = the phase's total current), by one thread
       double psrc = 0.0;
+      if (tid == 0) {
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+          const double2 x1 = A[T.off[ph + 1]], x0 = A[T.off[ph]];
+          psrc += R3_SRC_R(ph) * (x1.x - x0.x) + R3_SRC_I(ph) * (x1.y - x0.y);
+        }
+      }
+      // J = X[e] - X[own], and at once D = Z-row . (J, J of the node's other conductors): the own part here, ...
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const double2 xe = R3_OWN[k + R3_SIZE(pk[k])];
         const double2 zd = zq[k % GZ];
         if (k + GZ < K) zq[k % GZ] = R3_LD16(rs_zd, k + GZ);
         const double jr = xe.x - br[k], ji = xe.y - bi[k];
-        if (R3_ROOT(pk[k])) { const int ph = R3_PH(pk[k]); psrc += R3_SRC_R(ph) * jr + R3_SRC_I(ph) * ji; }    // the source's share of sum P_calc
         br[k] = zd.x * jr - zd.y * ji; bi[k] = zd.x * ji + zd.y * jr;
         R3_PIN(br[k], bi[k]);
-        asm volatile("" : "+v"(psrc));
         R3_EVERY(k, FA);
       }
       // ... the mutual part from the compact list, the siblings' J again as differences of X
@@ -291,9 +299,8 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
       R3_OPAQUE();
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int ph = R3_PH(pk[k]);
-        const double2 y = A[R3_POST(pk[k]) - R3_SIZE(pk[k]) + 1];
-        br[k] = R3_SRC_R(ph) - (br[k] - y.x); bi[k] = R3_SRC_I(ph) - (bi[k] - y.y);
+        const double2 y = A[R3_POST(pk[k]) - R3_SIZE(pk[k]) + 1], sv = srcv[R3_PH(pk[k])];
+        br[k] = sv.x - (br[k] - y.x); bi[k] = sv.y - (bi[k] - y.y);
         R3_PIN(br[k], bi[k]);
         R3_EVERY(k, FA);
       }
@@ -304,9 +311,8 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
       double psum = psrc;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        double2 s = sq[k % GS];
+        const double2 s = sq[k % GS];
         if (k + GS < K) sq[k % GS] = R3_LD16(rs_s, k + GS);
-        if (R3_ROOT(pk[k])) s = make_double2(0.0, 0.0);
         const double wr = br[k], wi = bi[k];
         const double pc = -(wr * ar[k] + wi * ai[k]), qc = -(wi * ar[k] - wr * ai[k]);
         const double dP = fabs(s.x - pc), dQ = fabs(s.y - qc);
