@@ -204,7 +204,7 @@ def measure_unbalanced(args, device, with_cpu):
     traffic = traffic_of("ieee8500_3ph_b1024:fbs3") if B == WORKLOADS["ieee8500_3ph_b1024"]["batch"] else None
     kernel = "gs3_k_resident" if desc["kernel"] == "fbs3_resident" else "gs3_k_solve"
     # The resident kernel keeps V, I and the sweep's intermediates of an instance in the registers and LDS of one CU: what it
-    # has to move through HBM is S once per iteration (+ once for the flat start) and V once per solve, 16 B each per
+    # has to move through HBM is S once per sweep (one sweep fewer than the iteration count) and for the flat start, and V once per solve, 16 B each per
     # conductor.  The section-8(d) figure above models a kernel that streams the state every sweep, so against it this
     # kernel reads > 1 of the HBM roofline; what bounds it is FP64 vector issue and LDS gathers (the "valu" entry: flops
     # per conductor and iteration counted from gridstep3_resident.h -- 3 prefix sums 12, J and D 14, V 4, mismatch and
@@ -212,7 +212,7 @@ def measure_unbalanced(args, device, with_cpu):
     extra = {}
     if kernel == "gs3_k_resident":
         flops = 74.0 * desc["conductors"] * mean_it * B
-        extra = {"bytes_per_launch_resident_design": 16.0 * desc["conductors"] * B * (mean_it + 2.0),
+        extra = {"bytes_per_launch_resident_design": 16.0 * desc["conductors"] * B * (mean_it + 1.0),
                  "valu": {"bound": "fp64 vector", "achieved": flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0, "peak": 78.6, "unit": "TFLOP/s",
                           "frac": flops / (avg_ms * 1e-3) / 1e12 / 78.6 if avg_ms > 0 else 0.0, "flops_per_conductor_iteration": 74},
                  "note": "frac > 1: the state of an instance never leaves its CU (registers + 156 KB of LDS); the algorithmic bytes are SURVEY 8(d)'s "
