@@ -7,7 +7,11 @@
 // 150-171) applied per phase, and in the balanced, uncoupled limit the answer reduces to the
 // single-phase solution that IS pinned by the reference (tests/test_unbalanced.py).
 //
-// Mapping (differs from the single-phase kernels, which put one instance on each lane): one
+// Two kernels.  gs3_k_resident (gridstep3_resident.h, the one a feeder of up to ~9 700 conductors gets): one workgroup
+// keeps the whole instance in its CU's registers and LDS, the sweeps are prefix sums over depth-first orders of the tree.
+// gs3_k_solve (below; larger feeders, GS3_NO_RESIDENT=1): level by level, the state streamed through HBM.
+//
+// Mapping of gs3_k_solve (differs from the single-phase kernels, which put one instance on each lane): one
 // workgroup per instance, lanes over the PHASE CONDUCTORS ("slots") of a tree level.  A distribution
 // feeder is mostly single-phase laterals (1.1 conductors per node on the 8500-node case), so storing
 // three phases per node would move 2.7x the bytes that carry information.  Nodes are numbered
