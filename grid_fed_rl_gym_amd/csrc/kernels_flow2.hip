@@ -642,15 +642,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       while (lv < NL) { f2_lds_sync(); ++lv; }
     }
     stp.hit(F2_ST_BOTTOM_UP);
-    {  // exact singularity anywhere in the instance: stop it where it is (status 2), as the reference's LinAlgError break does
+    {  // exact singularity anywhere in the instance: stop it where it is (status 2), as the reference's LinAlgError break does.
+       // The flag is raised here and read behind the top-down pass, whose level barriers publish it (the pass only forms the
+       // step; whether it is applied is decided afterwards): a barrier of its own cost ~800 cycles per iteration.
 #pragma unroll
       for (int o = IW; o < 64; o <<= 1) sing |= __shfl_xor(sing, o);
       if (sing && hv == 0) atomicOr(icell + 15 * IW + l, 1u);
-      f2_lds_sync();
-      const unsigned sa = icell[15 * IW + l];
-      if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
     }
-    const bool upd = !st.done;
     stp.hit(F2_ST_INIT);
     // ---------------- top-down: x_i = s_i - T_i x_p; corrections (power_flow.py:315-327); new (e, f) into the slots ----------------
     {
@@ -675,6 +673,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       }
       while (lv >= 0) { f2_lds_sync(); --lv; }
     }
+    {
+      const unsigned sa = icell[15 * IW + l];
+      if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+    }
+    const bool upd = !st.done;
     stp.hit(F2_ST_TOP_DOWN);
     // corrections (power_flow.py:315-327): theta += alpha dtheta, |V| += alpha d|V|, as a rotation and scaling of (e, f)
     if (__any(upd)) {
