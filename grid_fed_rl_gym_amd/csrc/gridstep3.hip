@@ -395,9 +395,9 @@ gs3_k_solve(Topo3 T, double2* __restrict__ state, int B, double tol, int max_it,
 
 typedef void (*res_fn)(Res3, double2*, int, double, int, double*, double*, int32_t*, uint8_t*);
 res_fn resident_kernel(int K, int MK) {
-  if (K == 3) return gs3_k_resident<3, 3>;
-  if (K == 9) return MK == 4 ? gs3_k_resident<9, 4> : gs3_k_resident<9, 9>;
-  return MK == 4 ? gs3_k_resident<19, 4> : gs3_k_resident<19, 19>;
+  if (K == 3) return MK ? gs3_k_resident<3, 3> : gs3_k_resident<3, 0>;
+  if (K == 9) return MK ? gs3_k_resident<9, 4> : gs3_k_resident<9, 0>;
+  return MK ? gs3_k_resident<19, 4> : gs3_k_resident<19, 0>;
 }
 
 // P/Q [B][n][3] in caller node order -> the P, Q rows of the slots (src_of < 0: a padding entry of the resident layout)
@@ -657,8 +657,9 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     auto mem = [&](int p) { return (p % K) * nt + p / K; };
     std::vector<int32_t> rpk(npad, 0), rsrc(npad, -1), rslot((size_t)3 * n, -1);
     for (int p = ns; p < npad; ++p) rpk[mem(p)] = (int32_t)((unsigned)p << 14);        // padding: size 0, postorder index = position
-    std::vector<double2> rzd(npad, make_double2(0.0, 0.0)), rmz_a, rmz_b;
+    std::vector<double2> rzd(npad, make_double2(0.0, 0.0)), rmz_a, rmz_b, rmzp((size_t)2 * npad, make_double2(0.0, 0.0));
     std::vector<int4> rmut;
+    std::vector<int2> rmutp(npad, make_int2(0, 0));
     for (int p = 0; p < ns; ++p) {
       const int node = pos_node[p], ph = pos_ph[p], e = (int)((size_t)node * 3 + ph);
       const int oa = ph == 0 ? 1 : 0, ob = ph == 2 ? 1 : 2;
@@ -674,10 +675,14 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
       rmut.push_back(make_int4(std::max(pa, 0) | ea << 14, std::max(pb, 0) | eb << 14, post[e], 0));
       rmz_a.push_back(pa >= 0 ? z[(size_t)Z_A * ns + sl] : make_double2(0.0, 0.0));
       rmz_b.push_back(pb >= 0 ? z[(size_t)Z_B * ns + sl] : make_double2(0.0, 0.0));
+      rmutp[mem(p)] = make_int2(rmut.back().x, rmut.back().y);
+      rmzp[mem(p)] = rmz_a.back(); rmzp[(size_t)npad + mem(p)] = rmz_b.back();
     }
     Res3& R = h->R;
     R.ns = ns; R.npad = npad; R.K = K; R.M = (int)rmut.size();
-    h->resident_mk = K > 4 && R.M <= 4 * nt ? 4 : K;      // (19, 19) spills: a large feeder with every node multi-phase runs, slowly
+    // the list dealt over the threads (3 or 4 entries each) where it is short; else every position computes its own mutual term
+    h->resident_mk = R.M <= (K == 3 ? 3 : 4) * nt && !getenv("GS3_DENSE_MUTUAL") ? (K == 3 ? 3 : 4) : 0;
+    if (!h->resident_mk && ((rc = upload3(h, &R.mutp, rmutp)) || (rc = upload3(h, &R.mzp, rmzp)))) return bail(rc);
     rmz_a.insert(rmz_a.end(), rmz_b.begin(), rmz_b.end());
     for (int ph = 0; ph < 3; ++ph) { R.vsr[ph] = T.vsr[ph]; R.vsi[ph] = T.vsi[ph]; R.off[ph] = pre[(size_t)t->source * 3 + ph]; }
     R.off[3] = ns;

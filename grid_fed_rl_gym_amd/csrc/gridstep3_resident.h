@@ -28,8 +28,9 @@
 // the 8500-node case.  D is stored at the conductor's POSTORDER index, so the postorder prefix runs over a thread's own
 // contiguous entries, in place.  All a position needs to know of the tree fits in one 32-bit word -- subtree size, postorder
 // index, phase, "is the source" -- kept in registers: e = p + size, g = post - size + 1.  The mutual terms of D exist on the
-// ~14 % of conductors that share a node with another phase; they are a separate compact list (conductor, its two
-// siblings, the two impedances) dealt over the threads, added to D through LDS.  Per iteration HBM sees S (150 KB per
+// ~17 % of conductors that share a node with another phase; they are a separate compact list (conductor, its two
+// siblings, the two impedances) dealt over the threads, added to D through LDS -- or, where most conductors have
+// siblings, computed by every position for itself (template parameter MK = 0).  Per iteration HBM sees S (150 KB per
 // workgroup; the working set of the 256 resident workgroups fits the MALL) and, per solve, V once; the self impedances
 // (16 bytes per conductor) come from L2.  Feeders whose conductors do not fit (more than ~9 700: 19 x 512) take
 // gs3_k_solve.
@@ -47,6 +48,9 @@ struct Res3 {
   const int4* mut;             // [M]: {a | e(a) << 14, b | e(b) << 14, postorder index of the conductor, 0}, a / b = positions of the
                                //      node's other two conductors; an absent one is (0, 0) with a zero impedance
   const double2* mz;           // [2][M]: mutual impedances to A and to B
+  // the same per POSITION, for feeders where most conductors have siblings (the list would be one entry per position):
+  const int2* mutp;            // [npad], storage order: {a | e(a) << 14, b | e(b) << 14}
+  const double2* mzp;          // [2][npad], storage order
   // Positions ns .. npad - 1 are padding and behave like conductors that draw nothing and hang nowhere: S = 0, Z = 0,
   // subtree size 0, postorder index = position.  Then no access needs a guard: X of a padding position is the total, its
   // J and D are 0, and its V comes out as the source voltage.
@@ -127,8 +131,8 @@ struct R3Wg {
 extern __shared__ double2 r3_lds[];
 
 // K positions per thread (odd: a thread's 16-byte LDS accesses, K x 16 bytes apart across lanes, then fall on distinct banks);
-// MK entries of the mutual list per thread (3: the usual feeder, mostly single-phase laterals; K: up to every conductor
-// has siblings)
+// MK entries of the mutual list per thread (4: the usual feeder, mostly single-phase laterals); MK = 0: no list, every
+// position computes its own mutual term from the per-position tables (feeders where most nodes are multi-phase)
 template <int K, int MK>
 __global__ void __launch_bounds__(512)
 gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_it, double* __restrict__ out_loss,
@@ -158,6 +162,8 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vrow, 0, npad * 16, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_mut = __builtin_amdgcn_make_buffer_rsrc((void*)T.mut, 0, M * 16, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_mz = __builtin_amdgcn_make_buffer_rsrc((void*)T.mz, 0, 2 * M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mutp = __builtin_amdgcn_make_buffer_rsrc((void*)T.mutp, 0, MK == 0 ? npad * 8 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mzp = __builtin_amdgcn_make_buffer_rsrc((void*)T.mzp, 0, MK == 0 ? 2 * npad * 16 : 0, 0x00020000);
 #define R3_LD16(rs, k) __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)tid << 4, (k) * nt * 16, 0))
 #define R3_LD4(rs, k) ((int)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)tid << 2, (k) * nt * 4, 0))
   // What follows from the thread index and from pk -- addresses, indices, the source voltage of a position's phase -- is
@@ -214,7 +220,17 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
       }
       if (tid == 0) A[npad] = make_double2(tr, ti);
       // (requested before the barrier, used after it) the mutual list's entries of this thread, the first self impedances
-      int4 mx[MK]; double2 mza[MK], mzb[MK];
+      constexpr int MKA = MK > 0 ? MK : 1;
+      int4 mx[MKA]; double2 mza[MKA], mzb[MKA];
+      int2 pq[GZ]; double2 paq[GZ], pbq[GZ];                    // (MK = 0) ring of per-position sibling words and mutual impedances
+      if (MK == 0) {
+#pragma unroll
+        for (int k = 0; k < GZ; ++k) {
+          pq[k] = __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(rs_mutp, (unsigned)tid << 3, k * nt * 8, 0));
+          paq[k] = R3_LD16(rs_mzp, k);
+          pbq[k] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs_mzp, (unsigned)tid << 4, (npad + k * nt) * 16, 0));
+        }
+      }
 #pragma unroll
       for (int j = 0; j < MK; ++j) {
         mx[j] = __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(rs_mut, (unsigned)tid << 4, j * nt * 16, 0));
@@ -243,11 +259,23 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
         if (k + GZ < K) zq[k % GZ] = R3_LD16(rs_zd, k + GZ);
         const double jr = xe.x - br[k], ji = xe.y - bi[k];
         br[k] = zd.x * jr - zd.y * ji; bi[k] = zd.x * ji + zd.y * jr;
+        if (MK == 0) {                       // the siblings' J as differences of X, like the own
+          const int2 w = pq[k % GZ]; const double2 za = paq[k % GZ], zb = pbq[k % GZ];
+          if (k + GZ < K) {
+            pq[k % GZ] = __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(rs_mutp, (unsigned)tid << 3, (k + GZ) * nt * 8, 0));
+            paq[k % GZ] = R3_LD16(rs_mzp, k + GZ);
+            pbq[k % GZ] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs_mzp, (unsigned)tid << 4, (npad + (k + GZ) * nt) * 16, 0));
+          }
+          const double2 a1 = A[(unsigned)w.x >> 14], a0 = A[w.x & 0x3fff], b1 = A[(unsigned)w.y >> 14], b0 = A[w.y & 0x3fff];
+          const double jar = a1.x - a0.x, jai = a1.y - a0.y, jbr = b1.x - b0.x, jbi = b1.y - b0.y;
+          br[k] += za.x * jar - za.y * jai + zb.x * jbr - zb.y * jbi;
+          bi[k] += za.x * jai + za.y * jar + zb.x * jbi + zb.y * jbr;
+        }
         R3_PIN(br[k], bi[k]);
-        R3_EVERY(k, FA);
+        R3_EVERY(k, MK == 0 ? 2 : FA);
       }
       // ... the mutual part from the compact list, the siblings' J again as differences of X
-      double mr[MK], mi[MK];
+      double mr[MKA], mi[MKA];
 #pragma unroll
       for (int j = 0; j < MK; ++j) {
         const double2 a1 = A[(unsigned)mx[j].x >> 14], a0 = A[mx[j].x & 0x3fff], b1 = A[(unsigned)mx[j].y >> 14], b0 = A[mx[j].y & 0x3fff];
@@ -263,7 +291,7 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
       R3_OPAQUE();
 #pragma unroll
       for (int k = 0; k < K; ++k) A[R3_POST(pk[k])] = make_double2(br[k], bi[k]);
-      if (M > 0) {
+      if (MK > 0 && M > 0) {
         r3_barrier();
 #pragma unroll
         for (int j = 0; j < MK; ++j)

@@ -33,14 +33,18 @@ def _random_case(n, seed, lateral=0.35, local=0):
 
 # The two kernels behind gs3_solve: "resident" (gridstep3_resident.h: the instance stays in one CU, sweeps as prefix sums;
 # taken whenever the conductors fit) and "levels" (gs3_k_solve: level by level through HBM; GS3_NO_RESIDENT=1 forces it).
-KERNELS = ["resident", "levels"]
+# "resident-dense": the resident kernel's form for feeders where most nodes are multi-phase (every position computes its own
+# mutual term instead of a compact list dealt over the threads), forced here on every case (GS3_DENSE_MUTUAL=1).
+KERNELS = ["resident", "resident-dense", "levels"]
 
 
 def _solver(monkeypatch, kernel, **kw):
+    monkeypatch.delenv("GS3_NO_RESIDENT", raising=False)
+    monkeypatch.delenv("GS3_DENSE_MUTUAL", raising=False)
     if kernel == "levels":
         monkeypatch.setenv("GS3_NO_RESIDENT", "1")
-    else:
-        monkeypatch.delenv("GS3_NO_RESIDENT", raising=False)
+    elif kernel == "resident-dense":
+        monkeypatch.setenv("GS3_DENSE_MUTUAL", "1")
     return UnbalancedPowerFlow(**kw)
 
 
@@ -70,7 +74,7 @@ def test_gpu_balanced_limit_equals_reference_anchor(name, kernel, monkeypatch):
     Pb = np.stack([np.repeat((d["P_spec"] * lam)[:, None], 3, axis=1) for lam in d["exact_scales"]])
     s = _solver(monkeypatch, kernel, tolerance=1e-11, max_iterations=300)
     sol = s.solve_batch(spec, Pb)
-    assert s.describe()["kernel"] == ("fbs3_resident" if kernel == "resident" else "fbs3")
+    assert s.describe()["kernel"] == ("fbs3" if kernel == "levels" else "fbs3_resident")
     for q in range(len(d["exact_scales"])):
         V1 = d[f"C{q}_Vm"] * np.exp(1j * d[f"C{q}_Va"])
         assert sol.converged[q]
@@ -116,9 +120,9 @@ def test_gpu_8500_node_property(kernel, monkeypatch):
     s = _solver(monkeypatch, kernel, tolerance=1e-8, max_iterations=200)
     sol = s.solve_batch(spec, lam[:, None, None] * Pn[None], lam[:, None, None] * Qn[None])
     d = s.describe()
-    assert d["kernel"] == ("fbs3_resident" if kernel == "resident" else "fbs3")
-    if kernel == "resident":          # the benchmark's variant: 19 positions per thread, the mutual list 4 per thread
-        assert (d["threads"], d["positions_per_thread"], d["mutual_per_thread"]) == (512, 19, 4)
+    assert d["kernel"] == ("fbs3" if kernel == "levels" else "fbs3_resident")
+    if kernel != "levels":            # the benchmark's variant: 19 positions per thread, the mutual list 4 per thread
+        assert (d["threads"], d["positions_per_thread"], d["mutual_per_thread"]) == (512, 19, 4 if kernel == "resident" else 0)
     assert sol.converged.all() and sol.iterations.max() < 60
     assert 0.85 < np.abs(sol.voltages[1][np.abs(sol.voltages[1]) > 0]).min() < 1.0
     res, _ = O3.residual(spec.parent, spec.phases, spec.z, 0, sol.voltages[1], Pn, Qn)
@@ -139,7 +143,7 @@ def test_gpu_resident_and_level_kernels_agree_on_the_edge_cases(n, lateral, monk
     Pb = np.stack([0.0 * Pn, Pn, 1.4 * Pn, Pn, Pn]); Qb = 0.3 * Pb
     Pb[3, n // 2, int(np.argmax(pres[n // 2]))] = np.nan
     out = {}
-    for kernel in KERNELS:
+    for kernel in ("resident", "levels"):
         for max_it in (2, 50):
             s = _solver(monkeypatch, kernel, tolerance=1e-9, max_iterations=max_it)
             out[kernel, max_it] = s.solve_batch(spec, Pb, Qb)
