@@ -88,7 +88,7 @@ def test_gpu_balanced_limit_equals_reference_anchor(name, kernel, monkeypatch):
 # 9 and 19 positions per thread, the mutual list dealt 4 per thread or one per position (every node three-phase)
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("n,B,seed,lateral,local", [(40, 5, 1, 0.35, 0), (150, 70, 2, 0.35, 0), (333, 9, 3, 0.35, 0),
+@pytest.mark.parametrize("n,B,seed,lateral,local", [(2, 3, 8, 0.0, 0), (3, 2, 9, 1.0, 0), (40, 5, 1, 0.35, 0), (150, 70, 2, 0.35, 0), (333, 9, 3, 0.35, 0),
                                                     (900, 3, 4, 0.0, 60), (2500, 3, 5, 0.3, 60), (2300, 2, 6, 0.0, 60), (4000, 2, 7, 0.5, 60)])
 def test_gpu_unbalanced_against_oracle(n, B, seed, lateral, local, kernel, monkeypatch):
     spec = _random_case(n, seed, lateral, local)
