@@ -261,10 +261,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=500,
                     help="untimed steps before the first timed region (default 500 = 20 ms: the GPU's clocks take that long to settle "
                          "under this load -- with 5 warm-up steps the median over the regions reads 5 %% low and the p10 10 %% low)")
-    ap.add_argument("--repeats", type=int, default=40,
+    ap.add_argument("--repeats", type=int, default=120,
                     help="timed regions of exactly --steps steps each, every one bracketed by barrier + device synchronisation; median / p10 / p90 "
-                         "are reported.  40 regions (round 3; 10 before): with the driver's `--steps 20 --warmup 5` ten regions of 0.9 ms all fall "
-                         "into the ~20 ms the GPU's clocks take to settle under this load, and the median read 10 %% below the sustained rate")
+                         "are reported, and the median of the FIRST 40 regions beside them (`value_first_40_regions`: rounds 2-3's statistic).  "
+                         "120 regions = 0.1 s of GPU time at the driver's `--steps 20 --warmup 5`: the GPU's clocks take ~20 ms to settle under "
+                         "this load, so ten regions of 0.9 ms (round 2) all fell into the ramp and read 10 %% below the sustained rate, forty "
+                         "(round 3) had their median at its end (5 %% below); with 120 the median is the sustained rate and the p10 shows the ramp")
     ap.add_argument("--workload", default="ieee123_b8192", choices=sorted(WORKLOADS))
     ap.add_argument("--solver", default="", choices=["", "nr", "fbs"],
                     help="fbs = BASELINE.json config 3 (DistributionPowerFlow); nr = the reference's Newton-Raphson; default: the workload's")
@@ -605,7 +607,7 @@ def main():
         K = m.get("steps", args.steps)
         sps = [n_ranks * m["B"] * K / t for t in m["regions"]]
         s_med, s_p10, s_p90 = quantiles(sps)
-        return dict(value=s_med, value_p10_p90=[s_p10, s_p90], ms_per_step=1e3 * med / K,
+        return dict(value=s_med, value_p10_p90=[s_p10, s_p90], value_first_40_regions=quantiles(sps[:40])[0], value_first_region=sps[0], ms_per_step=1e3 * med / K,
                     ms_per_step_p10_p90=[1e3 * p10 / K, 1e3 * p90 / K],
                     avg_launch_ms=m["kernel_ms"] / max(m["kernel_launches"], 1))
 
@@ -664,7 +666,9 @@ def main():
             "metric": "env steps/sec (batched feeders)", "value": head["value"], "unit": "env_steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
             "ms_per_step": head["ms_per_step"], "value_p10_p90": head["value_p10_p90"], "ms_per_step_p10_p90": head["ms_per_step_p10_p90"],
-            "statistic": "median over the timed regions of --steps steps each (max over ranks per region)",
+            "value_first_40_regions": head["value_first_40_regions"], "value_first_region": head["value_first_region"],
+            "statistic": "median over the timed regions of --steps steps each (max over ranks per region); value_first_40_regions: the median of the "
+                         "first 40 of them (the GPU's clocks are still ramping there), value_first_region: the first region alone",
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{fs.name}, batch={B} per GPU, {solver_text[solver0]}, "
@@ -700,7 +704,7 @@ def main():
             o = summarize(other, 1)
             result["also"] = {"solver": other["solver"], "kernel": "gs_k_step_" + KERNEL_NAMES.get(other["desc"]["kernel"], other["desc"]["kernel"]),
                               "value": o["value"], "unit": "env_steps/s", "ms_per_step": o["ms_per_step"], "value_p10_p90": o["value_p10_p90"],
-                              "avg_launch_ms": o["avg_launch_ms"], "mean_iterations": other["mean_iterations"],
+                              "value_first_40_regions": o["value_first_40_regions"], "avg_launch_ms": o["avg_launch_ms"], "mean_iterations": other["mean_iterations"],
                               "converged_fraction": other["converged_fraction"], "roofline": roofline_of(other, o, args.workload)}
         if world == 1 and not args.no_also and args.workload == "ieee123_b8192":
             # BASELINE configs 2 and 5 in the same line, each with its own roofline
@@ -711,7 +715,7 @@ def main():
                 s2 = summarize(m2, 1)
                 result["also_config2"] = {"workload": f"{fs2.name}, batch={w2['batch']}, Newton-Raphson (BASELINE config 2)", "value": s2["value"],
                                           "unit": "env_steps/s", "ms_per_step": s2["ms_per_step"], "value_p10_p90": s2["value_p10_p90"],
-                                          "kernel": m2["desc"]["kernel"], "waves_per_group": m2["desc"]["waves_per_group"],
+                                          "value_first_40_regions": s2["value_first_40_regions"], "kernel": m2["desc"]["kernel"], "waves_per_group": m2["desc"]["waves_per_group"],
                                           "workgroups": m2["desc"].get("workgroups", m2["desc"]["groups"]), "mean_iterations": m2["mean_iterations"],
                                           "converged_fraction": m2["converged_fraction"], "roofline": roofline_of(m2, s2, "ieee13_b4096")}
             except Exception as e:
