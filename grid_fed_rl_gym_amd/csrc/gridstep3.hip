@@ -759,7 +759,8 @@ int gs3_solve_device(gs3_handle* h) {
       HIP3(h, hipMemcpy(st, h->R.stamps, sizeof st, hipMemcpyDeviceToHost));
       fprintf(stderr, "gs3 resident stamps (cycles since the top of iteration 1):");
       for (int i = 1; i <= 9; ++i) fprintf(stderr, " %lld", st[i] - st[0]);
-      fprintf(stderr, "\n");
+      fprintf(stderr, "; from the kernel's first instruction: loads landed %lld, first mismatch %lld, iteration 1 starts %lld, loop left %lld, end %lld\n",
+              st[11] - st[10], st[12] - st[10], st[0] - st[10], st[13] - st[10], st[14] - st[10]);
     }
   } else {
     const solve_fn fn = h->lds_bytes ? with_lds[h->prefetch - 1] : gs3_k_solve<false, 1>;

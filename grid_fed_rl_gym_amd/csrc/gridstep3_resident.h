@@ -178,6 +178,8 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
 #define R3_PIN(x, y) asm volatile("" : "+v"(x), "+v"(y))
 #define R3_OWN (A + tid * K)                  /* the thread's K entries: one address register, the rest immediate offsets */
 
+#define R3_STAMP0(i) do { if (T.stamps && blockIdx.x == 0 && tid == 0) T.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+  R3_STAMP0(10);
   int pk[K];                // the tree as this thread's positions see it
   double ar[K], ai[K];      // injection currents of the thread's conductors: what persists between iterations
   double br[K], bi[K];      // X -> J -> D, then Xi -> V
@@ -185,21 +187,31 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
   r3_barrier();             // scratch zeroed
   // ---- flat start: V = V_source everywhere, first mismatch = |S_spec|
   const double rd0 = r3_rcp(vsr0 * vsr0 + vsi0 * vsi0), rd1 = r3_rcp(vsr1 * vsr1 + vsi1 * vsi1), rd2 = r3_rcp(vsr2 * vsr2 + vsi2 * vsi2);
+  // (all 2 K loads of the thread in flight at once -- S lands in the registers that take the voltages afterwards; four at a
+  // time behind fences, as everywhere else, this start-up was five HBM round trips = 10 of a workgroup's 54 us)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     pk[k] = R3_LD4(rs_pk, k);
-    const int ph = R3_PH(pk[k]);
     const double2 s = R3_LD16(rs_s, k);                           // (zero at the source's own conductors: gs3_k_scatter_in skips them)
-    const double dP = fabs(s.x), dQ = fabs(s.y);
+    br[k] = s.x; bi[k] = s.y;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int ph = R3_PH(pk[k]);
+    const double sx = br[k], sy = bi[k];
+    const double dP = fabs(sx), dQ = fabs(sy);
     lmax = fmax(lmax, fmax(dP < INFINITY ? dP : INFINITY, dQ < INFINITY ? dQ : INFINITY));
     const double vr = R3_SRC_R(ph), vi = R3_SRC_I(ph), rd = ph == 0 ? rd0 : (ph == 1 ? rd1 : rd2);
-    ar[k] = -(s.x * vr + s.y * vi) * rd; ai[k] = -(s.x * vi - s.y * vr) * rd;
+    ar[k] = -(sx * vr + sy * vi) * rd; ai[k] = -(sx * vi - sy * vr) * rd;
     br[k] = vr; bi[k] = vi;
     R3_PIN(ar[k], ai[k]);
+    R3_PIN(br[k], bi[k]);
     R3_EVERY(k, 4);
   }
   double mm, losses = 0.0, zero = 0.0;
+  R3_STAMP0(11);
   mm = lmax; wg.max_sum(mm, zero);
+  R3_STAMP0(12);
   int iters = max_it, conv = 0;
   if (!(mm < INFINITY) || mm < tol) {       // no sweep will follow: the answer is the flat start itself
     iters = 1; conv = mm < tol;
@@ -360,6 +372,7 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
       if (mm < tol) { iters = it + 2; conv = 1; break; }
     }
   }
+  R3_STAMP0(13);
 #pragma unroll
   for (int k = 0; k < K; ++k)                // 16-byte store: row offset in the vector offset (see GsPairRef::put, gs_internal.h)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(br[k], bi[k])), rs_v, ((unsigned)tid << 4) + (unsigned)(k * nt * 16), 0, 0);
@@ -369,6 +382,8 @@ gs3_k_resident(Res3 T, double2* __restrict__ state, int B, double tol, int max_i
     out_it[blockIdx.x] = iters;
     out_conv[blockIdx.x] = (uint8_t)conv;
   }
+  R3_STAMP0(14);
+#undef R3_STAMP0
 #undef R3_SRC_R
 #undef R3_SRC_I
 #undef R3_LD16
