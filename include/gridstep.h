@@ -402,8 +402,10 @@ int gs_checks_set_fused(gs_checks* c, int32_t on, int32_t want_masks);
  * reference names UnbalancedPowerFlow (README.md:187-197, API_REFERENCE.md:420) but contains no
  * implementation, so there is no reference interface to cite beyond the solver plug point
  * (environments/power_flow.py:38-46) whose record layout the outputs follow, with a phase axis.
- * Mapping differs from the single-phase path: one workgroup per instance, lanes over the nodes
- * of a tree level (networks of thousands of nodes, batches of ~1000).
+ * Mapping differs from the single-phase path: one workgroup per instance (networks of thousands
+ * of nodes, batches of ~1000).  Feeders of up to ~9 700 phase conductors stay in that workgroup's
+ * registers and LDS for the whole solve, the sweeps evaluated as prefix sums over depth-first
+ * orders of the tree (csrc/gridstep3_resident.h); larger ones are swept level by level through HBM.
  * ====================================================================================== */
 typedef struct gs3_topology {
   int32_t struct_size;            /* = sizeof(gs3_topology) */
