@@ -51,7 +51,7 @@ WORKLOADS = {
     "meshed_loops26_b8192": dict(feeder="meshed_loops26", batch=8192, solver="nr"),
     "meshed_scalable_b8192": dict(feeder="meshed_scalable", batch=8192, solver="nr"),
 }
-KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "nr_dense_mfma": "nr_dense_mfma", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
+KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "nr_dense_mfma": "nr_dense_mfma", "nr_sparse_lds": "nr_sparse_lds", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
                 "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow", "fbs_flow2": "fbs_flow2", "fbs_flow2h": "fbs_flow2h", "fbs_flow2s": "fbs_flow2s", "nr_flow2s": "nr_flow2s",
                 "nr_flow2": "nr_flow2"}
 
@@ -69,7 +69,7 @@ _COMMON_SOURCES = ["gs_internal.h", "env_device.h", "fastmath.h", "kernels.h", "
 KERNEL_SOURCES = {
     "ieee123_b8192:fbs": ["kernels_flow2.hip"], "ieee123_b8192:nr": ["kernels_flow2.hip"], "ieee13_b4096:nr": ["kernels_flow2.hip"],
     "ieee8500_3ph_b1024:fbs3": ["gridstep3.hip", "gridstep3_resident.h"],
-    "meshed_loops26_b8192:nr": ["kernels_solve.hip"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
+    "meshed_loops26_b8192:nr": ["kernels_sparse.hip", "kernels_solve.hip"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
 }
 
 
@@ -761,6 +761,9 @@ def main():
                               "how": f"(2/3) N^3 + 2 N^2 = {fl_solve:.3g} flops per Newton solve at N = {N_}, {solves:.2f} solves per step (iterations - 1); the peak is the dense FP64 "
                                      "MFMA rate (= the FP64 vector rate on this part); the first solve of a step reuses the handle's flat-start factors, so the executed flops are about half",
                               "hbm_view": {"achieved_GB_per_s": rl["achieved"], "frac": rl["frac"], "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"]}}
+                    if mm["desc"]["kernel"] == "nr_sparse_lds":
+                        rl["kernel"] = "gs_k_nr_sparse_lds (between gs_k_pre_nr_dmfma and gs_k_post_nr_dmfma)"
+                        rl["avg_launch_method"] = rl.get("avg_launch_method", "") + "; a step here is three launches (prologue, Newton-Raphson with the sparse LU in LDS, epilogue): the span covers all three"
                     rl["traffic"] = traffic_of(f"meshed_{key}_b8192:nr") if Bm == 8192 else None
                     rl["traffic_source"] = traffic_source(f"meshed_{key}_b8192:nr")
                     entry = {"workload": f"{fsm.name}, batch={Bm}, Newton-Raphson (exact Jacobian), stochastic loads + weather",

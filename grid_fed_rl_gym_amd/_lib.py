@@ -25,7 +25,7 @@ GS_OK, GS_E_INVALID, GS_E_NO_DEVICE, GS_E_HIP, GS_E_TOPOLOGY, GS_E_STATE, GS_E_C
 JACOBIAN = {"as_coded": 0, "exact": 1}
 ZERO_Z = {"open": 0, "epsilon": 1}
 SOLVER = {"nr": 0, "newton_raphson": 0, "fbs": 1}
-LINSOLVE = {"auto": 0, "tree": 1, "sparse_lu": 2, "dense_pivot": 3, "dense_mfma": 4}
+LINSOLVE = {"auto": 0, "tree": 1, "sparse_lu": 2, "dense_pivot": 3, "dense_mfma": 4, "sparse_lds": 5}
 KERNEL_NAMES = ["unpack", "env_pre", "solve", "env_post", "pack"]
 
 _dp = C.POINTER(C.c_double)

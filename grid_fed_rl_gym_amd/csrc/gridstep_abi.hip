@@ -101,6 +101,9 @@ struct gs_handle {
   // solve_kernel 7: Newton-Raphson with the dense block LU on the matrix cores (kernels_dense.hip), a launch of its own between
   // the two halves of the step / solve
   GsDenseArgs DA{}; int dense_grid = 0; size_t dense_lds = 0;
+  // solve_kernel 8: Newton-Raphson with the sparse block LU of an instance in the LDS of a one-wave workgroup (kernels_sparse.hip),
+  // launched the same way
+  GsSparseArgs SA{}; int sparse_grid = 0; size_t sparse_lds = 0;
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
@@ -298,6 +301,10 @@ int launch_solve(gs_handle* h) {
     hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
     hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   }
+  else if (h->solve_kernel == 8) {
+    hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
+    hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
+  }
   else if (h->solve_kernel == 5) GS_SOLVE(gs_k_fbs_lds);
   else if (h->solve_kernel == 6) GS_SOLVE(gs_k_fbs_flow);
   else GS_SOLVE(gs_k_fbs);
@@ -365,6 +372,11 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     if (h->solve_kernel == 7) {      // prologue | dense Newton-Raphson, one workgroup per instance | epilogue + observation pack
       GS_STEP(gs_k_pre_nr_dmfma);
       hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
+      if (fc.enabled) GS_STEP(gs_k_postc_nr_dmfma); else GS_STEP(gs_k_post_nr_dmfma);
+    } else
+    if (h->solve_kernel == 8) {      // prologue | sparse LU in LDS, one wavefront per instance | epilogue + observation pack
+      GS_STEP(gs_k_pre_nr_dmfma);
+      hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
       if (fc.enabled) GS_STEP(gs_k_postc_nr_dmfma); else GS_STEP(gs_k_post_nr_dmfma);
     } else
     if (fc.enabled) {
@@ -487,7 +499,14 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       int rc = fail(nullptr, GS_E_TOPOLOGY, "dense_mfma needs the exact Jacobian and at most 128 non-slack buses (have %d)", na_); delete h; return rc; }
     if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && mfma_fits && (long long)ht.lu_n_slots * 4 > (long long)na_ * na_)
       ls = GS_LINSOLVE_DENSE_MFMA;
-    h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : (ls == GS_LINSOLVE_DENSE_MFMA) ? 7 : 3;
+    // meshed network with few loops: the sparse block LU of an instance in LDS, when its blocks fit beside a second workgroup's
+    const size_t sparse_need = ((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)6 * ht.n + (size_t)6 * ((ht.n + 1) & ~1)) * sizeof(double);
+    const bool sparse_fits = ht.has_lu && !ht.is_forest && ht.lu_n_piv > 0 && sparse_need <= 64 * 1024;
+    if (ls == GS_LINSOLVE_SPARSE_LDS && !sparse_fits) {
+      int rc = fail(nullptr, GS_E_TOPOLOGY, "sparse_lds needs a meshed network whose block LU fits 64 KB of LDS (%zu bytes here)", sparse_need); delete h; return rc; }
+    if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && sparse_fits && !getenv("GS_NO_SPARSE_LDS"))
+      ls = GS_LINSOLVE_SPARSE_LDS;
+    h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : (ls == GS_LINSOLVE_DENSE_MFMA) ? 7 : (ls == GS_LINSOLVE_SPARSE_LDS) ? 8 : 3;
     // forest sweeps through LDS messages when two adjacent levels fit next to the 24 KB static block
     const size_t msg_bytes = (size_t)2 * ht.max_level_width * 6 * GS_LANES * sizeof(double);
     if (h->solve_kernel == 0 && msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) h->solve_kernel = 4;
@@ -1107,6 +1126,70 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       (rc = dev_alloc(h, &h->d_mask, (size_t)h->B)))
     return bail(rc);
   h->h_f.resize((size_t)SF_COUNT * h->Bp); h->h_i.resize((size_t)SI_COUNT * h->Bp); h->h_u.resize((size_t)SU_COUNT * h->Bp);
+  // ---- sparse block LU in LDS (kernels_sparse.hip): the level schedule without the split over waves, the flat-start factors ----
+  if (h->solve_kernel == 8) {
+    GsSparseArgs& Sp = h->SA;
+    const int NL = ht.lu_n_levels;
+    std::vector<int32_t> a_ptr{0}, a, b_ptr{0}, b_rec, b_pair, r_ptr{0}, r_rec, r_pair, c_ptr{0}, cc;
+    for (int L = 0; L < NL; ++L) {
+      std::map<int32_t, std::vector<std::pair<int32_t, int32_t>>> tgt;        // target code -> updates, as for linsolve_lu
+      for (int t = 0; t < ht.lu_n_piv; ++t) {
+        if (ht.lu_piv_level[t] != L) continue;
+        const int k = ht.lu_piv_bus[t];
+        a.push_back(k); a.push_back(-1);
+        for (int q = ht.lu_nb_ptr[t]; q < ht.lu_nb_ptr[t + 1]; ++q) {
+          a.push_back(k); a.push_back(ht.lu_nb_jk[q]);
+          tgt[-(1 + ht.n + ht.lu_nb_bus[q])].push_back({ht.lu_nb_jk[q], k});
+        }
+        for (int q = ht.lu_pair_ptr[t]; q < ht.lu_pair_ptr[t + 1]; ++q) tgt[ht.lu_pair_ij[q]].push_back({ht.lu_pair_ik[q], ht.lu_pair_kj[q]});
+        cc.push_back(t);
+      }
+      // longest records first: the lanes of one pass then carry records of similar length
+      std::vector<std::pair<int32_t, std::vector<std::pair<int32_t, int32_t>>>> order(tgt.begin(), tgt.end());
+      std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.second.size() > y.second.size(); });
+      for (auto& e : order) {
+        b_rec.push_back(e.first); b_rec.push_back((int32_t)e.second.size()); b_rec.push_back((int32_t)b_pair.size() / 2);
+        for (auto& u : e.second) { b_pair.push_back(u.first); b_pair.push_back(u.second); }
+        if (e.first < -ht.n) {
+          r_rec.push_back(e.first); r_rec.push_back((int32_t)e.second.size()); r_rec.push_back((int32_t)r_pair.size() / 2);
+          for (auto& u : e.second) { r_pair.push_back(u.first); r_pair.push_back(u.second); }
+        }
+      }
+      a_ptr.push_back((int32_t)a.size() / 2); b_ptr.push_back((int32_t)b_rec.size() / 3); r_ptr.push_back((int32_t)r_rec.size() / 3);
+      c_ptr.push_back((int32_t)cc.size());
+    }
+    Sp.n = ht.n; Sp.n_slots = ht.lu_n_slots; Sp.n_orig = ht.lu_n_orig; Sp.n_piv = ht.lu_n_piv; Sp.n_levels = NL;
+    Sp.max_it = cfg->max_iterations; Sp.jacobian_exact = cfg->jacobian_mode == GS_JACOBIAN_EXACT ? 1 : 0; Sp.rows_total = h->R.total;
+    Sp.tol = cfg->tolerance; Sp.alpha = cfg->acceleration_factor;
+    Sp.row_ptr = T.row_ptr; Sp.col = T.col; Sp.G = T.G; Sp.Bv = T.Bv; Sp.Gd = T.Gd; Sp.Bd = T.Bd;
+    Sp.th_free = T.th_free; Sp.vm_free = T.vm_free; Sp.fixed_v = T.fixed_v; Sp.v_set = T.v_set;
+    Sp.piv_bus = T.lu_piv_bus; Sp.nb_ptr = T.lu_nb_ptr; Sp.nb_bus = T.lu_nb_bus; Sp.nb_kj = T.lu_nb_kj;
+    Sp.orig_slot = T.lu_orig_slot; Sp.orig_i = T.lu_orig_i; Sp.orig_j = T.lu_orig_j; Sp.orig_pos = T.lu_orig_pos;
+    if ((rc = dev_upload(h, &Sp.a_ptr, a_ptr)) || (rc = dev_upload(h, &Sp.a, a)) || (rc = dev_upload(h, &Sp.b_ptr, b_ptr)) ||
+        (rc = dev_upload(h, &Sp.b_rec, b_rec)) || (rc = dev_upload(h, &Sp.b_pair, b_pair)) || (rc = dev_upload(h, &Sp.r_ptr, r_ptr)) ||
+        (rc = dev_upload(h, &Sp.r_rec, r_rec)) || (rc = dev_upload(h, &Sp.r_pair, r_pair)) || (rc = dev_upload(h, &Sp.c_ptr, c_ptr)) ||
+        (rc = dev_upload(h, &Sp.c, cc))) return bail(rc);
+    Sp.R = h->R;
+    h->sparse_lds = ((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)6 * ht.n + (size_t)6 * ((ht.n + 1) & ~1)) * sizeof(double);
+    if (hipFuncSetAttribute((const void*)gs_k_nr_sparse_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+      return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(gs_k_nr_sparse_lds) failed"));
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const int per_cu = std::max(1, std::min(16, (int)((160 * 1024) / std::max<size_t>(h->sparse_lds, 1))));
+    if (const char* e = getenv("GS_SPARSE_LDS_PER_CU")) h->sparse_grid = std::max(1, atoi(e)) * cus; else h->sparse_grid = per_cu * cus;
+    h->sparse_grid = std::max(1, std::min(h->B, h->sparse_grid));   // persistent: as many one-wave workgroups as fit, instances strided over them
+    // the flat-start Jacobian is the same for every instance: factor it once, here, with the solver kernel itself (GS_LU_NO_FLAT=1: off)
+    if (!getenv("GS_LU_NO_FLAT")) {
+      double* flat = nullptr;
+      if ((rc = dev_alloc(h, &flat, (size_t)4 * (ht.lu_n_slots + ht.n) + 4))) return bail(rc);
+      GsSparseArgs once = Sp;
+      once.flat_out = flat; once.mode = 1; once.max_it = 1;
+      hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(1), dim3(64), h->sparse_lds, h->stream, once, h->slab, 1);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return bail(fail(nullptr, GS_E_HIP, "sparse_lds: factorisation of the flat-start Jacobian failed"));
+      Sp.flat = flat;
+    }
+  }
   // Sparse block LU: iteration 0 of every solve factors the flat-start Jacobian, which is the same for every instance.  One
   // ordinary solve of group 0, capped at one iteration, leaves those factors in the rows of lane 0; they are kept as a table
   // of wave-uniform scalars (GsTables::lu_flat) and iteration 0 then only carries its right-hand side through
@@ -1194,7 +1277,7 @@ int gs_dims(const gs_handle* h, int32_t* n, int32_t* m, int32_t* obs_dim, int32_
 
 int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
   if (!h || !buf || buflen <= 0) return fail(nullptr, GS_E_INVALID, "bad arguments");
-  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds", "fbs_lds", "fbs_flow", "nr_dense_mfma"};
+  static const char* kn[] = {"nr_tree", "nr_sparse_lu", "fbs", "nr_dense_pivot", "nr_tree_lds", "fbs_lds", "fbs_flow", "nr_dense_mfma", "nr_sparse_lds"};
   snprintf(buf, buflen,
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
@@ -1816,6 +1899,7 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
     HIPCHK(h, hipMemset(h->d_stamps, 0, (16 + 2 * GS_STAMP_BLOCKS) * sizeof(unsigned long long)));
     h->SC.stamps = h->d_stamps;
     h->DA.stamps = h->d_stamps;
+    h->SA.stamps = h->d_stamps;
     h->SC.stamp_wave = getenv("GS_STAMP_WAVE") ? atoi(getenv("GS_STAMP_WAVE")) : 0;
     h->SC.block_times = getenv("GS_STAMP_BLOCK_TIMES") ? 1 : 0;
     for (int k = 0; k < n; ++k) cycles_out[k] = 0;

@@ -50,7 +50,10 @@ enum { GS_SOLVER_NR = 0, GS_SOLVER_FBS = 1 };
 enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2, GS_LINSOLVE_DENSE_PIVOT = 3,
        /* dense block LU on the matrix cores, one workgroup per instance (exact Jacobian, at most 128 non-slack buses);
         * what AUTO takes for a meshed network whose sparse LU would fill in (more than a quarter of all blocks) */
-       GS_LINSOLVE_DENSE_MFMA = 4 };
+       GS_LINSOLVE_DENSE_MFMA = 4,
+       /* sparse 2x2-block LU with all blocks of an instance in LDS, one wavefront per instance; what AUTO takes for a meshed
+        * network with few loops (its blocks, right-hand side and voltages within 64 KB) */
+       GS_LINSOLVE_SPARSE_LDS = 5 };
 enum { GS_GEN_SOLAR = 0, GS_GEN_WIND = 1 };
 enum { GS_STATUS_OK = 0, GS_STATUS_MAX_ITER = 1, GS_STATUS_SINGULAR = 2, GS_STATUS_NAN = 3,
        GS_STATUS_FALLBACK_LINEAR = 4 /* answer replaced by gs_fallback_linear; converged = 1 as the reference's linear solver reports */ };

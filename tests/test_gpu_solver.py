@@ -173,21 +173,26 @@ def test_reference_plug_point_signature_and_batch_helper():
 
 @pytest.mark.parametrize("name", ["solve_env3", "solve_radial13", "solve_tree123", "solve_meshed30", "solve_pv12", "solve_scal20", "solve_scal123"])
 def test_linear_solver_paths_agree(name):
-    """tree elimination, sparse block LU, dense partial-pivot LU and the dense block LU on the matrix cores (one workgroup per
-    instance, kernels_dense.hip) are four routes to the same Newton step: identical iteration counts, solutions within 1e-10."""
+    """tree elimination, sparse block LU (blocks in slab rows, and blocks in the LDS of a one-wave workgroup per instance,
+    kernels_sparse.hip), dense partial-pivot LU and the dense block LU on the matrix cores (one workgroup per instance,
+    kernels_dense.hip) are five routes to the same Newton step: identical iteration counts, solutions within 1e-10."""
     d = golden(name)
     spec = spec_of(d, name)
     Pb = np.stack([d["P_spec"] * lam for lam in d["exact_scales"]])
     sols = {}
-    for ls in ("tree", "sparse_lu", "dense_pivot", "dense_mfma"):
+    for ls in ("tree", "sparse_lu", "sparse_lds", "dense_pivot", "dense_mfma"):
         if ls == "tree" and not spec.is_radial():
             continue
+        if ls == "sparse_lds" and (spec.is_radial() or name == "solve_scal123"):
+            continue                                     # (meshed networks only; the 123-bus dense graph's 8600 blocks do not fit LDS)
         if ls == "dense_pivot" and spec.n > 100 and not spec.is_radial():
             continue                                     # (the lane-per-instance pivoted LU on a 244 x 244 matrix: minutes)
         s = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, jacobian="exact", linear_solver=ls)
         sols[ls] = s.solve_batch(spec, Pb)
         if ls == "dense_mfma":
             assert s.handle_for(spec, len(Pb)).describe()["solve_kernel"] == "nr_dense_mfma"
+        if ls == "sparse_lds":
+            assert s.handle_for(spec, len(Pb)).describe()["solve_kernel"] == "nr_sparse_lds"
         s.close()
     base = sols.get("dense_pivot", sols["sparse_lu"])
     for ls, sol in sols.items():
@@ -260,7 +265,7 @@ def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_t
     a = s.solve_batch(dense, Pd)
     assert s.handle_for(dense, B).describe()["solve_kernel"] == "nr_dense_mfma"
     s.solve_batch(sparse, np.zeros((2, sparse.n)))
-    assert s.handle_for(sparse, 2).describe()["solve_kernel"] == "nr_sparse_lu"
+    assert s.handle_for(sparse, 2).describe()["solve_kernel"] == "nr_sparse_lds"
     s.close()
     ref = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, linear_solver="sparse_lu")
     b = ref.solve_batch(dense, Pd)
@@ -285,6 +290,54 @@ def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_t
     d = golden("solve_pv12")
     spec = spec_of(d)
     q = P.BatchedNewtonRaphsonSolver(tolerance=1e-6, max_iterations=50, linear_solver="dense_mfma")
+    sol = q.solve_batch(spec, np.stack([d["P_spec"] * lam for lam in d["exact_scales"]]))
+    q.close()
+    for k in range(len(d["exact_scales"])):
+        check(sol, k, d, f"B{k}_", 1e-9)
+
+
+def test_sparse_lds_is_what_auto_takes_for_a_few_loops_and_handles_the_edge_cases(monkeypatch):
+    """AUTO on a meshed feeder with few loops: the sparse block LU with the instance's blocks in LDS (kernels_sparse.hip).  Against
+    the slab-row sparse LU: a ragged batch larger than the persistent grid's stride pattern, a zero-load instance (one iteration),
+    iteration caps (status 1, same iterates), a non-finite injection (status 3), PV buses, and the handle's shared flat-start
+    factors against every solve factoring for itself (GS_LU_NO_FLAT=1)."""
+    fs = P.random_meshed(123, 26, seed=1)
+    rng = np.random.default_rng(3)
+    B = 333
+    Pb = -rng.uniform(0.0, 0.004, (B, fs.n)); Pb[:, 0] = 0.0; Pb[7] = 0.0
+    outs = {}
+    for ls in ("auto", "sparse_lu"):
+        s = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, linear_solver=ls)
+        outs[ls] = s.solve_batch(fs, Pb)
+        assert s.handle_for(fs, B).describe()["solve_kernel"] == ("nr_sparse_lds" if ls == "auto" else "nr_sparse_lu")
+        s.close()
+    a, b = outs["auto"], outs["sparse_lu"]
+    assert a.converged.all() and np.array_equal(a.iterations, b.iterations) and a.iterations[7] == 1
+    assert np.all(a.bus_voltages[7] == 1.0) and np.max(np.abs(a.bus_voltages - b.bus_voltages)) < 1e-11
+    assert np.max(np.abs(a.bus_angles - b.bus_angles)) < 1e-11 and np.max(np.abs(a.line_flows - b.line_flows)) < 1e-10
+    assert np.max(np.abs(a.losses - b.losses)) < 1e-11 and np.max(np.abs(a.max_mismatch - b.max_mismatch)) < 1e-11
+    for cap in (1, 2):
+        o = []
+        for ls in ("sparse_lds", "sparse_lu"):
+            q = P.BatchedNewtonRaphsonSolver(tolerance=1e-12, max_iterations=cap, linear_solver=ls)
+            o.append(q.solve_batch(fs, Pb[:9]))
+            q.close()
+        assert np.array_equal(o[0].status, o[1].status) and np.array_equal(o[0].iterations, o[1].iterations)
+        assert np.max(np.abs(o[0].bus_voltages - o[1].bus_voltages)) < 1e-11 and np.max(np.abs(o[0].max_mismatch - o[1].max_mismatch)) < 1e-11
+    bad = Pb[:4].copy(); bad[2, 9] = np.nan
+    q = P.BatchedNewtonRaphsonSolver(linear_solver="sparse_lds")
+    o = q.solve_batch(fs, bad)
+    q.close()
+    assert o.status[2] == 3 and not o.converged[2] and o.converged[[0, 1, 3]].all()
+    monkeypatch.setenv("GS_LU_NO_FLAT", "1")
+    q = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, linear_solver="sparse_lds")
+    c = q.solve_batch(fs, Pb[:40])
+    q.close()
+    monkeypatch.delenv("GS_LU_NO_FLAT")
+    assert np.array_equal(c.iterations, a.iterations[:40]) and np.max(np.abs(c.bus_voltages - a.bus_voltages[:40])) < 1e-13
+    d = golden("solve_meshed30")
+    spec = spec_of(d, "solve_meshed30")
+    q = P.BatchedNewtonRaphsonSolver(tolerance=1e-6, max_iterations=50, linear_solver="sparse_lds")
     sol = q.solve_batch(spec, np.stack([d["P_spec"] * lam for lam in d["exact_scales"]]))
     q.close()
     for k in range(len(d["exact_scales"])):
