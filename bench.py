@@ -69,7 +69,7 @@ _COMMON_SOURCES = ["gs_internal.h", "env_device.h", "fastmath.h", "kernels.h", "
 KERNEL_SOURCES = {
     "ieee123_b8192:fbs": ["kernels_flow2.hip"], "ieee123_b8192:nr": ["kernels_flow2.hip"], "ieee13_b4096:nr": ["kernels_flow2.hip"],
     "ieee8500_3ph_b1024:fbs3": ["gridstep3.hip", "gridstep3_resident.h"],
-    "meshed_loops26_b8192:nr": ["kernels_sparse.hip", "kernels_solve.hip"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
+    "meshed_loops26_b8192:nr": ["kernels_solve.hip"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
 }
 
 

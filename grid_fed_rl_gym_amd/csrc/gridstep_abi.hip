@@ -302,7 +302,7 @@ int launch_solve(gs_handle* h) {
     hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   }
   else if (h->solve_kernel == 8) {
-    hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
+    hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64 * h->SA.waves), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
     hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   }
   else if (h->solve_kernel == 5) GS_SOLVE(gs_k_fbs_lds);
@@ -376,7 +376,7 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     } else
     if (h->solve_kernel == 8) {      // prologue | sparse LU in LDS, one wavefront per instance | epilogue + observation pack
       GS_STEP(gs_k_pre_nr_dmfma);
-      hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
+      hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64 * h->SA.waves), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
       if (fc.enabled) GS_STEP(gs_k_postc_nr_dmfma); else GS_STEP(gs_k_post_nr_dmfma);
     } else
     if (fc.enabled) {
@@ -500,11 +500,15 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && mfma_fits && (long long)ht.lu_n_slots * 4 > (long long)na_ * na_)
       ls = GS_LINSOLVE_DENSE_MFMA;
     // meshed network with few loops: the sparse block LU of an instance in LDS, when its blocks fit beside a second workgroup's
-    const size_t sparse_need = ((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)6 * ht.n + (size_t)6 * ((ht.n + 1) & ~1)) * sizeof(double);
-    const bool sparse_fits = ht.has_lu && !ht.is_forest && ht.lu_n_piv > 0 && sparse_need <= 64 * 1024;
+    // (one instance: its blocks + 7 doubles per bus; the shared schedule is about 2.5 x the blocks in bytes: two instances at least)
+    const size_t sparse_need = ((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)7 * ht.n) * sizeof(double);
+    const bool sparse_fits = ht.has_lu && !ht.is_forest && ht.lu_n_piv > 0 && ht.n <= 256 && sparse_need <= 32 * 1024;
     if (ls == GS_LINSOLVE_SPARSE_LDS && !sparse_fits) {
-      int rc = fail(nullptr, GS_E_TOPOLOGY, "sparse_lds needs a meshed network whose block LU fits 64 KB of LDS (%zu bytes here)", sparse_need); delete h; return rc; }
-    if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && sparse_fits && !getenv("GS_NO_SPARSE_LDS"))
+      int rc = fail(nullptr, GS_E_TOPOLOGY, "sparse_lds needs a meshed network of at most 256 buses whose block LU fits 32 KB of LDS (%zu bytes here)", sparse_need); delete h; return rc; }
+    // (AUTO does not take it: measured on the 123-bus feeder with 26 loops it reaches 12.9 M env-steps/s against the slab-row
+    // kernel's 17.7 M -- four instances per CU, each a chain of 7-to-40-lane steps, lose to 64 instances per workgroup on full
+    // lanes, bytes or not; DESIGN.md section 7.  GS_SPARSE_LDS_AUTO=1 makes AUTO take it, for measurements.)
+    if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && sparse_fits && getenv("GS_SPARSE_LDS_AUTO"))
       ls = GS_LINSOLVE_SPARSE_LDS;
     h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : (ls == GS_LINSOLVE_DENSE_MFMA) ? 7 : (ls == GS_LINSOLVE_SPARSE_LDS) ? 8 : 3;
     // forest sweeps through LDS messages when two adjacent levels fit next to the 24 KB static block
@@ -1161,30 +1165,40 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     Sp.n = ht.n; Sp.n_slots = ht.lu_n_slots; Sp.n_orig = ht.lu_n_orig; Sp.n_piv = ht.lu_n_piv; Sp.n_levels = NL;
     Sp.max_it = cfg->max_iterations; Sp.jacobian_exact = cfg->jacobian_mode == GS_JACOBIAN_EXACT ? 1 : 0; Sp.rows_total = h->R.total;
     Sp.tol = cfg->tolerance; Sp.alpha = cfg->acceleration_factor;
-    Sp.row_ptr = T.row_ptr; Sp.col = T.col; Sp.G = T.G; Sp.Bv = T.Bv; Sp.Gd = T.Gd; Sp.Bd = T.Bd;
-    Sp.th_free = T.th_free; Sp.vm_free = T.vm_free; Sp.fixed_v = T.fixed_v; Sp.v_set = T.v_set;
-    Sp.piv_bus = T.lu_piv_bus; Sp.nb_ptr = T.lu_nb_ptr; Sp.nb_bus = T.lu_nb_bus; Sp.nb_kj = T.lu_nb_kj;
+    // one packed copy of everything the elimination chases pointers through: staged into LDS once per workgroup
+    std::vector<int32_t> ipack; std::vector<double> dpack;
+    auto addi = [&](const std::vector<int32_t>& v) { const int32_t o = (int32_t)ipack.size(); ipack.insert(ipack.end(), v.begin(), v.end()); return o; };
+    auto addd = [&](const std::vector<double>& v) { const int32_t o = (int32_t)dpack.size(); dpack.insert(dpack.end(), v.begin(), v.end()); return o; };
+    Sp.o_row_ptr = addi(ht.row_ptr); Sp.o_col = addi(ht.col); Sp.o_th_free = addi(ht.th_free); Sp.o_vm_free = addi(ht.vm_free); Sp.o_fixed_v = addi(ht.fixed_v);
+    Sp.o_piv_bus = addi(ht.lu_piv_bus); Sp.o_nb_ptr = addi(ht.lu_nb_ptr); Sp.o_nb_bus = addi(ht.lu_nb_bus); Sp.o_nb_kj = addi(ht.lu_nb_kj);
+    Sp.o_a_ptr = addi(a_ptr); Sp.o_a = addi(a); Sp.o_b_ptr = addi(b_ptr); Sp.o_b_rec = addi(b_rec); Sp.o_b_pair = addi(b_pair);
+    Sp.o_r_ptr = addi(r_ptr); Sp.o_r_rec = addi(r_rec); Sp.o_r_pair = addi(r_pair); Sp.o_c_ptr = addi(c_ptr); Sp.o_c = addi(cc);
+    Sp.od_G = addd(ht.G); Sp.od_B = addd(ht.B); Sp.od_Gd = addd(ht.Gd); Sp.od_Bd = addd(ht.Bd); Sp.od_vset = addd(ht.v_set);
+    Sp.ipack_n = (int32_t)ipack.size(); Sp.dpack_n = (int32_t)dpack.size();
+    if ((rc = dev_upload(h, &Sp.ipack, ipack)) || (rc = dev_upload(h, &Sp.dpack, dpack))) return bail(rc);
     Sp.orig_slot = T.lu_orig_slot; Sp.orig_i = T.lu_orig_i; Sp.orig_j = T.lu_orig_j; Sp.orig_pos = T.lu_orig_pos;
-    if ((rc = dev_upload(h, &Sp.a_ptr, a_ptr)) || (rc = dev_upload(h, &Sp.a, a)) || (rc = dev_upload(h, &Sp.b_ptr, b_ptr)) ||
-        (rc = dev_upload(h, &Sp.b_rec, b_rec)) || (rc = dev_upload(h, &Sp.b_pair, b_pair)) || (rc = dev_upload(h, &Sp.r_ptr, r_ptr)) ||
-        (rc = dev_upload(h, &Sp.r_rec, r_rec)) || (rc = dev_upload(h, &Sp.r_pair, r_pair)) || (rc = dev_upload(h, &Sp.c_ptr, c_ptr)) ||
-        (rc = dev_upload(h, &Sp.c, cc))) return bail(rc);
     Sp.R = h->R;
-    h->sparse_lds = ((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)6 * ht.n + (size_t)6 * ((ht.n + 1) & ~1)) * sizeof(double);
-    if (hipFuncSetAttribute((const void*)gs_k_nr_sparse_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+    const size_t shared_bytes = ((((size_t)Sp.dpack_n + 1) & ~(size_t)1) * 8 + (size_t)Sp.ipack_n * 4 + 15) & ~(size_t)15;
+    Sp.wave_bytes = (int32_t)((((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)7 * ht.n) * sizeof(double) + 15) & ~(size_t)15);
+    int waves = (int)((160 * 1024 - 512 - (long long)shared_bytes) / Sp.wave_bytes);
+    if (const char* e = getenv("GS_SPARSE_LDS_WAVES")) waves = std::min(waves, atoi(e));
+    waves = std::max(0, std::min(4, waves));
+    if (waves < 1 || ht.n > 256)
+      return bail(fail(nullptr, GS_E_TOPOLOGY, "sparse_lds: the schedule (%zu bytes) and one instance (%d bytes) do not fit the LDS, or more than 256 buses", shared_bytes, Sp.wave_bytes));
+    Sp.waves = waves;
+    h->sparse_lds = shared_bytes + (size_t)waves * Sp.wave_bytes;
+    if (hipFuncSetAttribute((const void*)gs_k_nr_sparse_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(gs_k_nr_sparse_lds) failed"));
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    const int per_cu = std::max(1, std::min(16, (int)((160 * 1024) / std::max<size_t>(h->sparse_lds, 1))));
-    if (const char* e = getenv("GS_SPARSE_LDS_PER_CU")) h->sparse_grid = std::max(1, atoi(e)) * cus; else h->sparse_grid = per_cu * cus;
-    h->sparse_grid = std::max(1, std::min(h->B, h->sparse_grid));   // persistent: as many one-wave workgroups as fit, instances strided over them
+    h->sparse_grid = std::max(1, std::min((h->B + waves - 1) / waves, cus));      // persistent: one workgroup per CU, instances strided over the wavefronts
     // the flat-start Jacobian is the same for every instance: factor it once, here, with the solver kernel itself (GS_LU_NO_FLAT=1: off)
     if (!getenv("GS_LU_NO_FLAT")) {
       double* flat = nullptr;
       if ((rc = dev_alloc(h, &flat, (size_t)4 * (ht.lu_n_slots + ht.n) + 4))) return bail(rc);
       GsSparseArgs once = Sp;
       once.flat_out = flat; once.mode = 1; once.max_it = 1;
-      hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(1), dim3(64), h->sparse_lds, h->stream, once, h->slab, 1);
+      hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(1), dim3(64 * Sp.waves), h->sparse_lds, h->stream, once, h->slab, 1);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "sparse_lds: factorisation of the flat-start Jacobian failed"));
       Sp.flat = flat;

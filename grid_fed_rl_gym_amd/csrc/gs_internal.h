@@ -322,24 +322,29 @@ struct GsDenseArgs {
 };
 
 
-// gs_k_nr_sparse_lds (kernels_sparse.hip): Newton-Raphson with the sparse 2x2-block LU of ONE instance in the LDS of a one-wave
-// workgroup.  The schedule is the level schedule of linsolve_lu (kernels_solve.hip) without its split over waves: per level a
-// list of phase-A items and a list of phase-B records, each taken by a lane.
+// gs_k_nr_sparse_lds (kernels_sparse.hip): Newton-Raphson with the sparse 2x2-block LU of an instance in LDS, one wavefront per
+// instance, several wavefronts (instances) per workgroup sharing ONE copy of the schedule and of the Ybus rows in LDS.  The
+// schedule is the level schedule of linsolve_lu (kernels_solve.hip) without its split over waves: per level a list of phase-A
+// items and a list of phase-B records, each taken by a lane.
 struct GsSparseArgs {
   int32_t n, n_slots, n_orig, n_piv, n_levels, max_it, jacobian_exact, rows_total;
   double tol, alpha;
-  const int32_t* row_ptr; const int32_t* col; const double* G; const double* Bv; const double* Gd; const double* Bd;   // Ybus rows (GsTables)
-  const int32_t* th_free; const int32_t* vm_free; const int32_t* fixed_v; const double* v_set;
-  const int32_t* piv_bus;                              // [n_piv] bus of pivot t (GsTables::lu_piv_bus)
-  const int32_t* nb_ptr; const int32_t* nb_bus; const int32_t* nb_kj;      // per pivot: the neighbours left when it is eliminated, slot of A_kj
-  const int32_t* orig_slot; const int32_t* orig_i; const int32_t* orig_j; const int32_t* orig_pos;   // [n_orig] the network's own off-diagonal blocks
-  const int32_t* a_ptr; const int32_t* a;              // [n_levels + 1]; (pivot bus k, slot of A_ik or -1: the pivot's singularity test alone)
-  const int32_t* b_ptr; const int32_t* b_rec; const int32_t* b_pair;       // [n_levels + 1] record ranges; (target, count, first pair); (slot of L_ik, slot of A_kj | bus k)
-                                                       // target: >= 0 an off-diagonal slot, -1 - i the diagonal block of bus i, -1 - n - i the right-hand side of bus i
-  const int32_t* r_ptr; const int32_t* r_rec; const int32_t* r_pair;       // the right-hand-side records alone (iteration 0 with the flat-start factors)
-  const int32_t* c_ptr; const int32_t* c;              // [n_levels + 1]; pivots (index t) of a level, for the back substitution
+  // staged into LDS once per workgroup: `ipack` (int32) and `dpack` (double), the arrays below at these offsets
+  const int32_t* ipack; const double* dpack;
+  int32_t ipack_n, dpack_n;
+  int32_t o_row_ptr, o_col, o_th_free, o_vm_free, o_fixed_v;        // Ybus rows (CSR), unknown masks
+  int32_t o_piv_bus;                                                // [n_piv] bus of pivot t
+  int32_t o_nb_ptr, o_nb_bus, o_nb_kj;                              // per pivot: the neighbours left when it is eliminated, slot of A_kj
+  int32_t o_a_ptr, o_a;                                             // [n_levels + 1]; (pivot bus k, slot of A_ik or -1: the pivot's singularity test alone)
+  int32_t o_b_ptr, o_b_rec, o_b_pair;                               // [n_levels + 1] record ranges; (target, count, first pair); (slot of L_ik, slot of A_kj | bus k)
+                                                                    // target: >= 0 an off-diagonal slot, -1 - i the diagonal block of bus i, -1 - n - i the right-hand side of bus i
+  int32_t o_r_ptr, o_r_rec, o_r_pair;                               // the right-hand-side records alone (iteration 0 with the flat-start factors)
+  int32_t o_c_ptr, o_c;                                             // [n_levels + 1]; pivots (index t) of a level, for the back substitution
+  int32_t od_G, od_B, od_Gd, od_Bd, od_vset;                        // offsets into dpack
+  int32_t waves, wave_bytes;                                        // wavefronts (instances) per workgroup; LDS bytes of one wavefront's instance
+  const int32_t* orig_slot; const int32_t* orig_i; const int32_t* orig_j; const int32_t* orig_pos;   // [n_orig] the network's own off-diagonal blocks (global: read once per assembly, no chains)
   const double* flat;                                  // [4 (n_slots + n) + 1] factors of the flat-start Jacobian + singular flag, or NULL
-  double* flat_out;                                    // mode 1: where one workgroup leaves them
+  double* flat_out;                                    // mode 1: where one wavefront leaves them
   int32_t mode, pad0;
   unsigned long long* stamps;
   GsRows R;

@@ -51,8 +51,9 @@ enum { GS_LINSOLVE_AUTO = 0, GS_LINSOLVE_TREE = 1, GS_LINSOLVE_SPARSE_LU = 2, GS
        /* dense block LU on the matrix cores, one workgroup per instance (exact Jacobian, at most 128 non-slack buses);
         * what AUTO takes for a meshed network whose sparse LU would fill in (more than a quarter of all blocks) */
        GS_LINSOLVE_DENSE_MFMA = 4,
-       /* sparse 2x2-block LU with all blocks of an instance in LDS, one wavefront per instance; what AUTO takes for a meshed
-        * network with few loops (its blocks, right-hand side and voltages within 64 KB) */
+       /* sparse 2x2-block LU with all blocks of an instance in LDS, one wavefront per instance (meshed networks of at most 256
+        * buses whose blocks fit 32 KB).  An alternative to SPARSE_LU that moves 1/20 of its bytes and is slower on the feeders
+        * measured: never AUTO's choice */
        GS_LINSOLVE_SPARSE_LDS = 5 };
 enum { GS_GEN_SOLAR = 0, GS_GEN_WIND = 1 };
 enum { GS_STATUS_OK = 0, GS_STATUS_MAX_ITER = 1, GS_STATUS_SINGULAR = 2, GS_STATUS_NAN = 3,

@@ -265,7 +265,7 @@ def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_t
     a = s.solve_batch(dense, Pd)
     assert s.handle_for(dense, B).describe()["solve_kernel"] == "nr_dense_mfma"
     s.solve_batch(sparse, np.zeros((2, sparse.n)))
-    assert s.handle_for(sparse, 2).describe()["solve_kernel"] == "nr_sparse_lds"
+    assert s.handle_for(sparse, 2).describe()["solve_kernel"] == "nr_sparse_lu"
     s.close()
     ref = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, linear_solver="sparse_lu")
     b = ref.solve_batch(dense, Pd)
@@ -296,9 +296,9 @@ def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_t
         check(sol, k, d, f"B{k}_", 1e-9)
 
 
-def test_sparse_lds_is_what_auto_takes_for_a_few_loops_and_handles_the_edge_cases(monkeypatch):
-    """AUTO on a meshed feeder with few loops: the sparse block LU with the instance's blocks in LDS (kernels_sparse.hip).  Against
-    the slab-row sparse LU: a ragged batch larger than the persistent grid's stride pattern, a zero-load instance (one iteration),
+def test_sparse_lu_in_lds_handles_the_edge_cases(monkeypatch):
+    """linear_solver="sparse_lds": the sparse block LU with an instance's blocks in LDS, one wavefront per instance
+    (kernels_sparse.hip; an alternative AUTO does not take).  Against the slab-row sparse LU: a ragged batch larger than the persistent grid's stride pattern, a zero-load instance (one iteration),
     iteration caps (status 1, same iterates), a non-finite injection (status 3), PV buses, and the handle's shared flat-start
     factors against every solve factoring for itself (GS_LU_NO_FLAT=1)."""
     fs = P.random_meshed(123, 26, seed=1)
@@ -306,12 +306,12 @@ def test_sparse_lds_is_what_auto_takes_for_a_few_loops_and_handles_the_edge_case
     B = 333
     Pb = -rng.uniform(0.0, 0.004, (B, fs.n)); Pb[:, 0] = 0.0; Pb[7] = 0.0
     outs = {}
-    for ls in ("auto", "sparse_lu"):
+    for ls in ("sparse_lds", "auto"):
         s = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, linear_solver=ls)
         outs[ls] = s.solve_batch(fs, Pb)
-        assert s.handle_for(fs, B).describe()["solve_kernel"] == ("nr_sparse_lds" if ls == "auto" else "nr_sparse_lu")
+        assert s.handle_for(fs, B).describe()["solve_kernel"] == ("nr_sparse_lds" if ls == "sparse_lds" else "nr_sparse_lu")
         s.close()
-    a, b = outs["auto"], outs["sparse_lu"]
+    a, b = outs["sparse_lds"], outs["auto"]
     assert a.converged.all() and np.array_equal(a.iterations, b.iterations) and a.iterations[7] == 1
     assert np.all(a.bus_voltages[7] == 1.0) and np.max(np.abs(a.bus_voltages - b.bus_voltages)) < 1e-11
     assert np.max(np.abs(a.bus_angles - b.bus_angles)) < 1e-11 and np.max(np.abs(a.line_flows - b.line_flows)) < 1e-10
