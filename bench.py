@@ -518,21 +518,27 @@ def main():
         except Exception as e:
             m["rollout"] = {"error": str(e)}
         # what a caller of BatchedGridEnvironment.step() gets: actions from host memory in, the whole observation block and
-        # the info arrays out, every step (PCIe-bound; never `value`)
-        try:
-            env.step(actions[0]); env.step(actions[1])
-            ts = []
-            for k in range(10):
-                t1 = time.perf_counter()
-                env.step(actions[k % n_act])
-                ts.append(time.perf_counter() - t1)
-            med, p10, p90 = quantiles(ts)
-            m["with_host_io"] = {"env_steps_per_s": B / med, "ms_per_step": 1e3 * med, "ms_per_step_p10_p90": [1e3 * p10, 1e3 * p90],
-                                 "what_is_copied": f"per step: actions [B][{fs.action_dim}] f64 host->device ({B * fs.action_dim * 8} B), observations "
-                                                   f"[B][{fs.obs_dim}] f64 device->host ({B * fs.obs_dim * 8} B), reward / flags / info arrays (~{B * 70} B), "
-                                                   "pageable NumPy memory on the host side"}
-        except Exception as e:
-            m["with_host_io"] = {"error": str(e)}
+        # the info arrays out, every step (PCIe-bound; never `value`).  The environment's default: views of page-locked buffer
+        # sets that are reused once the caller has dropped what it got from them (Handle.use_recycled_outputs)
+        def host_io(label, what):
+            try:
+                env.step(actions[0]); env.step(actions[1])
+                ts = []
+                for k in range(10):
+                    t1 = time.perf_counter()
+                    env.step(actions[k % n_act])
+                    ts.append(time.perf_counter() - t1)
+                med, p10, p90 = quantiles(ts)
+                m[label] = {"env_steps_per_s": B / med, "ms_per_step": 1e3 * med, "ms_per_step_p10_p90": [1e3 * p10, 1e3 * p90],
+                            "GB_per_s_of_observations": B * fs.obs_dim * 8 / med / 1e9, "what": what}
+            except Exception as e:
+                m[label] = {"error": str(e)}
+        host_io("with_host_io", f"BatchedGridEnvironment.step() as it is by default; per step: actions [B][{fs.action_dim}] f64 host->device ({B * fs.action_dim * 8} B), "
+                                f"observations [B][{fs.obs_dim}] f64 device->host ({B * fs.obs_dim * 8} B), reward / flags / info arrays (~{B * 70} B); the arrays returned "
+                                "are views of page-locked buffer sets, a set reused only when the caller holds nothing of it any more")
+        saved, h._recycle = getattr(h, "_recycle", None), None
+        host_io("with_host_io_fresh_arrays", "recycle_host_buffers=False: a freshly allocated pageable NumPy array per output and step (rounds 1-3's default)")
+        h._recycle = saved
         # the same call with the output arrays in page-locked memory (BatchedGridEnvironment(pinned_host_buffers=True):
         # step() returns views of two rotating pinned buffer sets instead of fresh arrays)
         try:
@@ -683,7 +689,7 @@ def main():
             "converged_fraction": head_m["converged_fraction"],
             "host": host_description(),
         }
-        for k in ("post_step_checks", "rollout", "with_host_io", "with_host_io_pinned"):
+        for k in ("post_step_checks", "rollout", "with_host_io", "with_host_io_fresh_arrays", "with_host_io_pinned"):
             if k in main_m:
                 result[k] = main_m[k]
         if world > 1:

@@ -66,7 +66,7 @@ class BatchedGridEnvironment:
                  tolerance: float = 1e-6, max_iterations: int = 50, acceleration_factor: float = 1.0,
                  linear_solver: str = "auto", power_base: Optional[float] = None, device: int = 0,
                  first_instance: int = 0, waves_per_group: int = 0, warm_start: bool = False,
-                 pinned_host_buffers: bool = False, **kwargs: Any) -> None:
+                 pinned_host_buffers: bool = False, recycle_host_buffers: bool = True, **kwargs: Any) -> None:
         spec = feeder if isinstance(feeder, FeederSpec) else flatten_feeder(feeder)
         if renewable_sources is not None:
             keep = [g for g in range(spec.n_gens)
@@ -109,6 +109,10 @@ class BatchedGridEnvironment:
             # step() then returns views of two rotating page-locked buffer sets instead of fresh arrays (valid until the
             # next-but-one step): the 45 MB observation copy of a B = 8192 batch runs at the link's rate
             self._h.use_pinned_outputs()
+        elif recycle_host_buffers:
+            # the default: step() returns views of page-locked buffer sets that are reused only once the caller has let go of
+            # everything it got from them -- fresh-array semantics without a fresh 45 MB allocation and a pageable copy per step
+            self._h.use_recycled_outputs()
         self.obs_dim, self.action_dim, self.state_dim = self._h.obs_dim, self._h.action_dim, self._h.state_dim
         big = np.finfo(np.float64).max
         self.single_observation_space = Box(-big, big, shape=(self.obs_dim,), dtype=np.float64)

@@ -687,3 +687,40 @@ def test_newton_raphson_flat_start_table_changes_nothing_beyond_rounding(maker, 
         assert np.max(np.abs(a["obs"] - b["obs"]) / np.maximum(1.0, np.abs(b["obs"]))) < 1e-12, k
         assert np.max(np.abs(a["reward"] - b["reward"]) / np.maximum(1.0, np.abs(b["reward"]))) < 1e-12
     tab.close(); own.close()
+
+
+def test_step_outputs_are_recycled_only_when_the_caller_has_let_go():
+    """BatchedGridEnvironment.step() by default returns views of buffer sets the handle owns (page-locked when it can get them)
+    and takes a set again only when nothing the caller got from it is alive: an observation that is kept -- or a slice of it --
+    is never overwritten by later steps, and a loop that drops what it got runs on two or three sets for ever."""
+    fs = P.ieee13_like("epsilon")
+    B = 64
+    env = P.BatchedGridEnvironment(fs, num_envs=B, solver="nr")
+    env.reset(seed=5)
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (12, B, fs.action_dim))
+    kept, copies = [], []
+    for k in range(6):                       # keep everything: more sets than the pool's cap, then fresh arrays
+        obs, rew, *_ = env.step(acts[k])
+        kept.append((obs[3:7], rew)); copies.append((obs[3:7].copy(), rew.copy()))
+    for (o, r), (oc, rc) in zip(kept, copies):
+        assert np.array_equal(o, oc) and np.array_equal(r, rc)
+    addrs = {o.__array_interface__["data"][0] for o, _ in kept}
+    assert len(addrs) == 6                    # six different buffers while all six are alive
+    del kept, obs, rew, o, r
+    seen = []
+    for k in range(6, 12):                   # drop everything every step: the same few buffers come round again
+        obs, *_ = env.step(acts[k])
+        seen.append(obs.__array_interface__["data"][0])
+        del obs
+    assert len(set(seen)) <= 2
+    # the same trajectory with fresh arrays every step
+    ref = P.BatchedGridEnvironment(fs, num_envs=B, solver="nr", recycle_host_buffers=False)
+    ref.reset(seed=5)
+    for k in range(12):
+        o2, r2, *_ = ref.step(acts[k])
+    o1, r1, *_ = env.step(acts[0]); o2, r2, *_ = ref.step(acts[0])
+    assert np.array_equal(o1, o2) and np.array_equal(r1, r2)
+    held = o1[:2]
+    env.close(); ref.close()
+    assert np.array_equal(held, o2[:2])       # an array held across close() stays readable
