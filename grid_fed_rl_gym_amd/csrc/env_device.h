@@ -237,12 +237,15 @@ __device__ __forceinline__ void env_actions_clock(const GsTables& T, const GsRow
 __device__ __forceinline__ double load_power_z(const GsTables& T, int l, double z, double prof) {
   return fmax(0.0, cld(T.load_base, l) * (prof * (1.0 + 0.1 * z)) * 1.0);
 }
-__device__ __forceinline__ double daily_profile(double time_s) {
+// (the table through any pointer: the second-generation step kernels keep a copy in LDS, kernels_flow2.hip)
+template <typename TablePtr>
+__device__ __forceinline__ double daily_profile_from(TablePtr table, double time_s) {
   const double hour = hour_of_day(time_s);
   const int hi = (int)hour;
   const double frac = hour - (double)hi;
-  return kDailyProfile[hi] * (1.0 - frac) + kDailyProfile[(hi + 1) % 24] * frac;
+  return table[hi] * (1.0 - frac) + table[(hi + 1) % 24] * frac;
 }
+__device__ __forceinline__ double daily_profile(double time_s) { return daily_profile_from(kDailyProfile, time_s); }
 
 // per-bus injection in the reference's accumulation order (grid_env.py:689-718), then
 // P_spec = (0 - loads) + generation (power_flow.py:112-121); Q_spec = 0 (power_flow.py:107)

@@ -108,6 +108,7 @@ struct gs_handle {
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
   std::vector<void*> allocs;
+  char* arena = nullptr; size_t arena_left = 0;      // dev_alloc: the current chunk of small tables
   double* slab = nullptr;
   double* d_in = nullptr; size_t in_doubles = 0;
   double* d_out = nullptr; size_t out_doubles = 0;
@@ -181,10 +182,25 @@ static int join_streams(gs_handle* h) {
   do { HIPCHK((h), hipSetDevice((h)->device));                                                    \
        if ((h)->forked) { int rc_ = join_streams(h); if (rc_) return rc_; } } while (0)
 
+constexpr size_t GS_ARENA_SMALL = 64 * 1024, GS_ARENA_CHUNK = 2 * 1024 * 1024;
 template <typename X>
 int dev_alloc(gs_handle* h, X** p, size_t count) {
   void* q = nullptr;
   const size_t bytes = std::max<size_t>(count, 1) * sizeof(X);
+  // Tables (a few hundred bytes to a few KB each, forty of them) share 2 MB chunks: as allocations of their own each sat on a
+  // page of its own, and a workgroup's first touch of every one of them was an address-translation miss at kernel start.
+  if (bytes <= GS_ARENA_SMALL && !getenv("GS_NO_TABLE_ARENA")) {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (h->arena_left < need) {
+      hipError_t e = hipMalloc(&q, GS_ARENA_CHUNK);
+      if (e != hipSuccess) return fail(h, GS_E_NOMEM, "hipMalloc(%zu) failed: %s", (size_t)GS_ARENA_CHUNK, hipGetErrorString(e));
+      h->allocs.push_back(q);
+      h->arena = (char*)q; h->arena_left = GS_ARENA_CHUNK;
+    }
+    *p = (X*)h->arena;
+    h->arena += need; h->arena_left -= need;
+    return GS_OK;
+  }
   hipError_t e = hipMalloc(&q, bytes);
   if (e != hipSuccess) return fail(h, GS_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
   h->allocs.push_back(q);
@@ -714,6 +730,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     off += up16(std::max<size_t>({(size_t)nsl * SB, second_region_min, (size_t)ht.m * SB, (size_t)(topo->n_loads + 4) * IW * sizeof(double)}));
     F.off_anc = (int32_t)off; off += up16(n_table_ints * 4);
     F.off_z = (int32_t)off; off += up16((size_t)nsl * zcols * 8);
+    F.off_prof = (int32_t)off; off += up16(24 * sizeof(double));
     F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
     F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * IW * sizeof(double));
     F.off_red = (int32_t)off; off += 2 * (size_t)NW * IW * sizeof(double);
@@ -780,20 +797,22 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
               IW = small ? GS_F2S_IW : (wide || half) ? GS_F2H_IW : 32;
     const int NPOS = NW * (64 / IW) * NI;
     GsF2Tables& F = h->F2;
-    const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl * 4, 2);
+    const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl, 2);
     F.n_jump = n_jump;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
     else if (N > NPOS) why = "more than " + std::to_string(NPOS) + " buses below the slack";
     else if (N != ht.lvl_ptr[ht.n_levels]) why = "part of the forest does not hang off the slack bus";
     else if (max_dev > 2) why = "more than two devices of a kind at one bus";
     else if (off > 160 * 1024) why = "LDS tables do not fit";
+    else if (nsl > 1023) why = "slot numbers beyond the 10 bits of an ancestor word";
     else if (ht.n < 2 || ht.m < 1 || N < 1) why = "trivial network";
     if (why.empty()) {
       h->flow2 = true; h->f2_small = small; h->f2_half = half; h->f2_wide = wide; h->f2_iw = IW; h->f2_nw = NW;
       GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY;
       f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 2, 0.0);
-      f2anc.assign((size_t)n_jump * nsl * 4, SL_ZERO);            // [round][slot][4]: the slot's ancestors 1, 2, 3 steps of 4^round up (no ancestor: ZERO)
+      // [round][slot]: the slot's ancestors 1, 2, 3 steps of 4^round up (no ancestor: ZERO), 10 bits each in one word
+      f2anc.assign((size_t)n_jump * nsl, SL_ZERO | (SL_ZERO << 10) | (SL_ZERO << 20));
       std::vector<int> up1((size_t)nsl, SL_ZERO);                    // parent slot of every slot (the slack's children: ZERO)
       for (int p = 0; p < N; ++p) {
         GsF2Rec& r = f2recs[p];
@@ -811,7 +830,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         for (int r = 0; r < n_jump; ++r) {
           for (int sidx = 0; sidx < nsl; ++sidx) {
             int a = sidx;
-            for (int k = 0; k < 3; ++k) { a = step[a]; f2anc[((size_t)r * nsl + sidx) * 4 + k] = a; }
+            int32_t word = 0;
+            for (int k = 0; k < 3; ++k) { a = step[a]; word |= a << (10 * k); }
+            f2anc[(size_t)r * nsl + sidx] = word;
           }
           std::vector<int> nxt((size_t)nsl);
           for (int sidx = 0; sidx < nsl; ++sidx) nxt[sidx] = step[step[step[step[sidx]]]];

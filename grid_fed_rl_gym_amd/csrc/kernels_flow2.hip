@@ -55,11 +55,19 @@ typedef int f2_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double2 f2_ld2(unsigned off) { const f2_v2 v = *F2_P(const f2_v2, off); return make_double2(v.x, v.y); }
 __device__ __forceinline__ void f2_st2(unsigned off, double2 v) { f2_v2 w; w.x = v.x; w.y = v.y; *F2_P(f2_v2, off) = w; }
 __device__ __forceinline__ double f2_ld(unsigned off) { return *F2_P(const double, off); }
+// 16-byte store of data nobody on the GPU reads again (the observation block): non-temporal, so that 58 MB per step do not
+// push the topology tables every workgroup reads at its start out of the L2
+__device__ __forceinline__ void f2_stream2(double* p, double2 v) {
+  f2_v2 w; w.x = v.x; w.y = v.y;
+  __builtin_nontemporal_store(w, (f2_v2*)p);
+}
 __device__ __forceinline__ void f2_st(unsigned off, double v) { *F2_P(double, off) = v; }
 
 // Keeps the compiler from hoisting everything derived from a per-item index (slot, table and ring addresses of 8 items x
 // three phases: ~100 registers) out of the Newton loop: the addresses are a shift and an add away wherever they are used.
 #define F2_OPAQUE(x) asm volatile("" : "+v"(x))
+// a wave-uniform value the compiler must hold on to rather than read again from the kernel arguments
+#define F2_KEEP(x) asm volatile("" : "+s"(x))
 // LDS integer atomics (exact and order-independent; workgroup scope is all LDS needs)
 #define atomicMax(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define atomicMin(p, v) __hip_atomic_fetch_min((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -139,6 +147,28 @@ __device__ __forceinline__ double f2_rsq(double x) {
   return __builtin_fma(0.5 * y, __builtin_fma(-(x * y), y, 1.0), y);
 }
 
+// The kernels take their tables by value: 1.6 KB of kernel arguments, which the compiler reads in a dozen batches at the top
+// of the kernel, waiting for each.  A fresh launch finds none of the block's 64-byte lines in the scalar cache, so each batch
+// that reaches a new line is a miss of its own, one after the other (measured: 7 k cycles from the wave's first instruction
+// to the end of the LDS initialisation).  One scalar load per line, all in flight together, first: the batches then hit.
+// (The results are not used.  F2ArgBlock mirrors the parameter list of the step kernels; every touched line lies inside it.)
+struct F2ArgBlock { GsTables T; GsF2Tables F; GsRows R; GsSolveCfg C; GsEnvCfg E; double* slab; int B; const double* actions; double total_load;
+                    GsPackArgs PA; GsFusedChecks FC; GsRolloutStep RS; };
+__device__ __forceinline__ void f2_touch_arguments() {
+  const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned sink;
+  static_assert(sizeof(F2ArgBlock) >= 0x644 && sizeof(F2ArgBlock) <= 0x680, "argument block size changed: adjust the touched lines");
+  asm volatile(
+      "s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\t"
+      "s_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\ts_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0\n\t"
+      "s_load_dword %0, %1, 0x200\n\ts_load_dword %0, %1, 0x240\n\ts_load_dword %0, %1, 0x280\n\ts_load_dword %0, %1, 0x2c0\n\t"
+      "s_load_dword %0, %1, 0x300\n\ts_load_dword %0, %1, 0x340\n\ts_load_dword %0, %1, 0x380\n\ts_load_dword %0, %1, 0x3c0\n\t"
+      "s_load_dword %0, %1, 0x400\n\ts_load_dword %0, %1, 0x440\n\ts_load_dword %0, %1, 0x480\n\ts_load_dword %0, %1, 0x4c0\n\t"
+      "s_load_dword %0, %1, 0x500\n\ts_load_dword %0, %1, 0x540\n\ts_load_dword %0, %1, 0x580\n\ts_load_dword %0, %1, 0x5c0\n\t"
+      "s_load_dword %0, %1, 0x600\n\ts_load_dword %0, %1, 0x640\n\ts_waitcnt lgkmcnt(0)"
+      : "=&s"(sink) : "s"(ka) : "memory");
+}
+
 struct F2State { double mm; int iters, conv, status; bool done; };
 // mm: the maximum mismatch (what PowerFlowSolution.max_mismatch reports); crit: what is held against the tolerance -- the
 // same maximum for Newton-Raphson (power_flow.py:168-171), the mismatch summed over the buses for the sweeps (below)
@@ -193,6 +223,7 @@ template <int SOLVER, int CHK, int NW, int NI, int IW>
 __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                         double* __restrict__ slab, int B, const double* __restrict__ actions, double total_load,
                                         const GsPackArgs& PA, const GsFusedChecks& FC, const GsRolloutStep& RS) {
+  f2_touch_arguments();
   // IW instances per workgroup (32; 16 or 8 for small feeders, where more of a wavefront's lanes go to different buses):
   // lane = hv * IW + l, sub-group hv of the wave works on its own bus for instance l
   constexpr int HV = 64 / IW;                          // sub-groups (buses) per wavefront
@@ -207,20 +238,30 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const int b = g * GS_LANES + L;
   const bool valid = b < B;
   const GsLaneRows S = gs_lane_rows(slab, g, R.total, L);
-  const int n = T.n, m = T.m, nsl = F.n_slots;
+  // Scalars of the start-up, read from the kernel arguments ONCE: the compiler treats an argument as free to read again
+  // wherever it is short of scalar registers, and the start-up was 47 scalar loads, most of them waited for one by one
+  // (~150 cycles each, 4 k cycles before the first barrier); a value that went through F2_KEEP is kept (or parked in a
+  // vector lane) instead.
+  int n = T.n, m = T.m, nsl = F.n_slots;
+  int o_env = F.off_env, o_tile = F.off_tile, o_red = F.off_red, o_atom = F.off_atom, o_anc = F.off_anc, o_z = F.off_z, o_prof = F.off_prof;
+  int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl : F.n_anc_ints;      // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
+  const int32_t* anc_g = F.anc; const double* zbus_g = F.zbus;
+  F2_KEEP(n); F2_KEEP(m); F2_KEEP(nsl); F2_KEEP(o_env); F2_KEEP(o_tile); F2_KEEP(o_red); F2_KEEP(o_atom); F2_KEEP(o_anc); F2_KEEP(o_z);
+  F2_KEEP(o_prof); F2_KEEP(n_tab); F2_KEEP(anc_g); F2_KEEP(zbus_g);
   const int SL_ZERO = n;                 // slots n, n + 1, n + 2: ZERO (0, 0), ONE (1, 0), DUMMY (idle positions)
-  double F2_AS3* const env_lds = F2_P(double, F.off_env);                 // [row][32 lanes]
-  double F2_AS3* const loadp_lds = F2_P(double, F.off_tile);               // [load][32 lanes], dead before the line tile is written
-  double F2_AS3* const red_lsum = F2_P(double, F.off_red);                 // [16 waves][32 lanes]
+  double F2_AS3* const env_lds = F2_P(double, o_env);                 // [row][32 lanes]
+  double F2_AS3* const loadp_lds = F2_P(double, o_tile);               // [load][32 lanes], dead before the line tile is written
+  double F2_AS3* const red_lsum = F2_P(double, o_red);                 // [16 waves][32 lanes]
   double F2_AS3* const red_dev = red_lsum + NW * IW;
-  unsigned long long F2_AS3* const cell = F2_P(unsigned long long, F.off_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits, [5..7] convergence sums
+  unsigned long long F2_AS3* const cell = F2_P(unsigned long long, o_atom);   // [3][32] convergence maxima, then [3] vmax, [4] vmin bits, [5..7] convergence sums
   unsigned F2_AS3* const icell = (unsigned F2_AS3*)(cell + 8 * IW);                // [16][32] integer counts
   // (Two workgroups share a CU in the 16-instance members and the instruction arbiter serves the oldest wave first: the
   // workgroup that arrived first finishes in 32 us, the other in 42 (tools/block_times.py).  Flipping s_setprio at every phase
   // boundary, the two in opposite states, evens them out -- 38 to 42 us each -- and leaves the launch at 42: the CU's
   // throughput, not the sharing, sets the time.  Not kept.)
+  const unsigned long long t_entry = __builtin_readcyclecounter();
   F2Stamp stp{C.stamps, 0ull, bid == 0 && wave == C.stamp_wave && lane == 0};
-  if (C.stamps) stp.t = __builtin_readcyclecounter();
+  if (C.stamps) stp.t = t_entry;
   if (C.stamps && C.block_times && threadIdx.x == 0 && bid < GS_STAMP_BLOCKS) C.stamps[16 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
 
   // ---- start-up: every global load the prologue's first barrier waits for is asked for FIRST -- the clock and seed rows, the
@@ -229,21 +270,25 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // round trips in a row, 9 k cycles = 13 % of the launch before the first useful instruction)
   double told = ROW(R.TIME), kold = ROW(R.STEP);
   uint64_t seed = lane_seed(S, R);
-  const int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl * 4 : F.n_anc_ints;  // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
   const int n_z = (SOLVER == F2_FBS ? 2 : 4) * nsl;                        // z per bus; Newton-Raphson (G_ip, B_ip, G_ii, B_ii) per bus
-  const int tab0 = (int)threadIdx.x < n_tab ? F.anc[threadIdx.x] : 0;
-  const double z0 = (int)threadIdx.x < n_z ? F.zbus[threadIdx.x] : 0.0;
+  const int tab0 = (int)threadIdx.x < n_tab ? anc_g[threadIdx.x] : 0;
+  const double z0 = (int)threadIdx.x < n_z ? zbus_g[threadIdx.x] : 0.0;
+  // (the load profile's 24 factors too: read from the module's table where it is used, every draw wave waited a round trip
+  // of its own for two of them -- 3 to 5 k cycles behind the clock)
+  const double prof0 = threadIdx.x < 24 ? kDailyProfile[threadIdx.x] : 0.0;
   // flat start in every slot: 1 + 0j, the ZERO slot 0, buses with a voltage set point (the slack; F.fixed_*) their set point
-  for (int k = threadIdx.x; k < nsl * IW; k += blockDim.x) {
+  constexpr int NT = 64 * NW;         // the workgroup's size (NT is a scalar load of its own wherever it is used)
+  for (int k = threadIdx.x; k < nsl * IW; k += NT) {
     const int s = k / IW, ll = k & (IW - 1);
     f2_st2(f2_slot(s, ll), make_double2(s == SL_ZERO ? 0.0 : 1.0, 0.0));
   }
-  for (int k = threadIdx.x; k < 8 * IW; k += blockDim.x) cell[k] = (k >= 4 * IW && k < 5 * IW) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
-  for (int k = threadIdx.x; k < 16 * IW; k += blockDim.x) icell[k] = 0u;
-  if ((int)threadIdx.x < n_tab) F2_P(int, F.off_anc)[threadIdx.x] = tab0;
-  for (int k = threadIdx.x + blockDim.x; k < n_tab; k += blockDim.x) F2_P(int, F.off_anc)[k] = F.anc[k];
-  if ((int)threadIdx.x < n_z) F2_P(double, F.off_z)[threadIdx.x] = z0;
-  for (int k = threadIdx.x + blockDim.x; k < n_z; k += blockDim.x) F2_P(double, F.off_z)[k] = F.zbus[k];
+  for (int k = threadIdx.x; k < 8 * IW; k += NT) cell[k] = (k >= 4 * IW && k < 5 * IW) ? 0x7ff0000000000000ull : 0ull;   // [4] = vmin starts at +inf
+  for (int k = threadIdx.x; k < 16 * IW; k += NT) icell[k] = 0u;
+  if ((int)threadIdx.x < n_tab) F2_P(int, o_anc)[threadIdx.x] = tab0;
+  for (int k = threadIdx.x + NT; k < n_tab; k += NT) F2_P(int, o_anc)[k] = anc_g[k];
+  if ((int)threadIdx.x < n_z) F2_P(double, o_z)[threadIdx.x] = z0;
+  if (threadIdx.x < 24) F2_P(double, o_prof)[threadIdx.x] = prof0;
+  for (int k = threadIdx.x + NT; k < n_z; k += NT) F2_P(double, o_z)[k] = zbus_g[k];
   f2_lds_sync();                      // (the set points below overwrite slots other threads have just initialised)
   for (int q = 0; q < F.n_fixed; ++q) {
     const int s = q == 0 ? F.fixed_slot0 : F.fixed_slot[q];
@@ -258,7 +303,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const uint64_t inst = (uint64_t)(E.first_instance + b);
   // (the clock and seed rows were asked for at the top, in the same round trip as the rollout's flags; re-read after a reset)
   if (RS.active && RS.t > 0) {
-    int F2_AS3* const fin = F2_P(int, F.off_red);        // [IW] entry of the side list (>= 0), -1 list full, -2 not finished
+    int F2_AS3* const fin = F2_P(int, o_red);        // [IW] entry of the side list (>= 0), -1 list full, -2 not finished
     if (wave == 0 && hv == 0) {
       int kx = -2;
       const double te = ROW(R.TERM), tr = ROW(R.TRUNC);
@@ -278,7 +323,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       if (kx >= 0) {
         const double* row = RS.obs_prev + (size_t)(b - l + k) * RS.obs_dim;
         double* dst = RS.term_obs + (size_t)kx * RS.obs_dim;
-        for (int c = threadIdx.x; c < RS.obs_dim; c += blockDim.x) dst[c] = row[c];
+        for (int c = threadIdx.x; c < RS.obs_dim; c += NT) dst[c] = row[c];
       }
     }
     any = __builtin_amdgcn_readfirstlane(any);
@@ -287,14 +332,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       for (int k = 0; k < IW; ++k) {           // the per-bus / per-line rows of the finished instances: every thread takes a share
         if (fin[k] == -2) continue;
         const GsLaneRows Sk = gs_lane_rows(slab, g, R.total, hs * IW + k);
-        for (int j = threadIdx.x; j < n + m; j += blockDim.x) env_reset_element(T, R, Sk, j);
+        for (int j = threadIdx.x; j < n + m; j += NT) env_reset_element(T, R, Sk, j);
       }
       f2_sync();                     // the reset rows are in memory (vmcnt covers stores) before the other waves gather them
       for (int k = 0; k < IW; ++k) {
         if (fin[k] == -2) continue;
         const GsLaneRows Sk = gs_lane_rows(slab, g, R.total, hs * IW + k);
         double* row = RS.obs_prev + (size_t)(b - l + k) * RS.obs_dim;
-        for (int c = threadIdx.x; c < RS.obs_dim; c += blockDim.x) {
+        for (int c = threadIdx.x; c < RS.obs_dim; c += NT) {
           const int sidx = RS.map[c];
           row[c] = (sidx >= 0) ? Sk.lane_row((size_t)sidx * GS_LANES).get() : RS.cst[-sidx - 1];
         }
@@ -307,6 +352,19 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const uint32_t snew = (uint32_t)(kold + 1.0);
   f2_sync();                         // every wave has read the clock and seed rows before wave 0 moves them on
   stp.hit(15);                       // (kernel start, LDS tables, clock round trip)
+  // ---- the records of this lane's items: position p = ((wave * HV + sub-group) * NI + j) of the forest's preorder.  Asked for
+  // HERE, before the chains: vector loads and stores return in order, and behind the chains' row stores the injection pass
+  // waited ~3 k cycles for its records
+  const GsF2Rec* const rec0 = F.recs + ((size_t)(wave * HV + hv) * NI);
+  int ibus[NI], ilast[NI];
+  unsigned roots = 0u;                   // bit j: item j hangs off the slack bus
+  f2_i4 rdev[NI][2]; int rdev_b1[NI];    // devices at the bus (GsF2Rec: nl, l0, l1, ng | g0, g1, nb, b0 | b1)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const f2_i4 a = *(const f2_i4*)&rec0[j].bus;
+    ibus[j] = a.x; ilast[j] = a.w; roots |= (a.z & 2) ? (1u << j) : 0u;
+    rdev[j][0] = *(const f2_i4*)&rec0[j].nl; rdev[j][1] = *(const f2_i4*)&rec0[j].g0; rdev_b1[j] = rec0[j].b1;
+  }
   const int nb = T.n_bats, ng = T.n_gens, nl_ = T.n_loads;
   if (wave == 0) {
     // _apply_actions (grid_env.py:621-651, dynamics.py:189-220): the halves take alternate batteries / generators
@@ -362,16 +420,18 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   if (NW < 3 || wave >= 2) {
     // realised load powers (dynamics.py:54-75): loads 4 p .. 4 p + 3 share one Philox call; one quad per sub-group of a wave
     // (workgroups of one or two waves: every wave draws, the first after its two scalar chains)
-    const double prof = E.stochastic_loads ? daily_profile(tnew) : 1.0;
+    const double prof = E.stochastic_loads ? daily_profile_from(F2_P(const double, o_prof), tnew) : 1.0;
     for (int p = (NW < 3 ? wave : wave - 2) * HV + hv; 4 * p < nl_; p += (NW < 3 ? NW : NW - 2) * HV) {
+      const int l0 = 4 * p;
+      double base4[4];                 // asked for before the draw, whose ~350 instructions cover the round trip
+#pragma unroll
+      for (int k = 0; k < 4; ++k) base4[k] = T.load_base[min(l0 + k, nl_ - 1)];
       double z[4] = {0.0, 0.0, 0.0, 0.0};
       if (E.stochastic_loads) rng_normal_quad(seed, inst, snew, DRAW_LOAD0 + p, z);
-      const int l0 = 4 * p;
       double lp[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int li = min(l0 + k, nl_ - 1);
-        const double base = T.load_base[li];
+        const double base = base4[k];
         lp[k] = E.stochastic_loads ? fmax(0.0, base * (prof * (1.0 + 0.1 * z[k])) * 1.0) : base;
         if (l0 + k < nl_) loadp_lds[(l0 + k) * IW + l] = lp[k];
       }
@@ -384,19 +444,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   f2_lds_sync();                                  // what the injection pass reads is in LDS
   stp.hit(F2_ST_PRO_SCALAR);
 
-  // ---- the records of this lane's items: position p = ((wave * 2 + half) * NI + j) of the forest's preorder ----
-  const GsF2Rec* const rec0 = F.recs + ((size_t)(wave * HV + hv) * NI);
-  int ibus[NI], ilast[NI];
-  unsigned roots = 0u;                   // bit j: item j hangs off the slack bus
-#pragma unroll
-  for (int j = 0; j < NI; ++j) { ibus[j] = rec0[j].bus; ilast[j] = rec0[j].last; roots |= (rec0[j].flags & 2) ? (1u << j) : 0u; }
-
   // ---- injections of this lane's buses, reference accumulation order (grid_env.py:683-720, power_flow.py:112-121) ----
   double Pj[NI], IR[NI], II[NI], JR[NI], JI[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const GsF2Rec* q = rec0 + j;
-    const int nl = q->nl, l0 = q->l0, l1 = q->l1, ngj = q->ng, g0 = q->g0, g1 = q->g1, nbj = q->nb, b0 = q->b0, b1 = q->b1;
+    const int nl = rdev[j][0].x, l0 = rdev[j][0].y, l1 = rdev[j][0].z, ngj = rdev[j][0].w, g0 = rdev[j][1].x, g1 = rdev[j][1].y,
+              nbj = rdev[j][1].z, b0 = rdev[j][1].w, b1 = rdev_b1[j];
     double ls = 0.0, gs = 0.0;
     if (nl > 0) ls += loadp_lds[l0 * IW + l];
     if (nl > 1) ls += loadp_lds[l1 * IW + l];
@@ -409,7 +462,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   }
   stp.hit(F2_ST_PROLOGUE);
   f2_lds_sync();                     // the load powers (tile region) have been read: the region becomes the solver's second buffer
-  if (wave == 0) f2_st2((unsigned)F.off_tile + f2_slot(SL_ZERO, l), make_double2(0.0, 0.0));      // "no ancestor" reads as 0 in both buffers
+  if (wave == 0) f2_st2((unsigned)o_tile + f2_slot(SL_ZERO, l), make_double2(0.0, 0.0));      // "no ancestor" reads as 0 in both buffers
 
   F2State st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
@@ -426,16 +479,24 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     return f2_dbl(cell[c0 * IW + l]);
   };
   // the same with the mismatch summed over the buses beside its maximum (the sweeps' stopping criterion)
-  auto wg_max_sum = [&](double lmax, double lsum, double& sum_out) -> double {
+  // (in two parts, so that the barrier between them can be one the caller needs anyway)
+  auto post_max_sum = [&](double lmax, double lsum) -> int {
     const int c0 = check % 3, c1 = (check + 1) % 3;
     ++check;
     lmax = f2_xmax<IW>(lmax);
     lsum = f2_xsum<IW>(lsum, l);
     if (wave == 0 && hv == 0) { cell[c1 * IW + l] = 0ull; cell[(5 + c1) * IW + l] = 0ull; }
     if (hv == 0) { atomicMax(cell + c0 * IW + l, f2_bits(lmax)); atomicAdd(cell + (5 + c0) * IW + l, f2_fix(lsum)); }
-    f2_lds_sync();
+    return c0;
+  };
+  auto read_max_sum = [&](int c0, double& sum_out) -> double {
     sum_out = (double)cell[(5 + c0) * IW + l] * (2.0 / F2_SUM_SCALE);      // twice the sum: what is held against the tolerance
     return f2_dbl(cell[c0 * IW + l]);
+  };
+  auto wg_max_sum = [&](double lmax, double lsum, double& sum_out) -> double {
+    const int c0 = post_max_sum(lmax, lsum);
+    f2_lds_sync();
+    return read_max_sum(c0, sum_out);
   };
 
   if constexpr (SOLVER == F2_NR) {
@@ -448,8 +509,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // child -> parent / parent -> child messages share the second LDS region.  The two sweeps are level-synchronous
   // (2x2 inverses do not compose into prefix sums): a wave's items are pairs of buses of one level, walked in level order
   // with an LDS barrier per level.
-  const unsigned bufA = 0u, bufB = (unsigned)F.off_tile;
-  const int F2_AS3* const tab = F2_P(const int, F.off_anc);
+  const unsigned bufA = 0u, bufB = (unsigned)o_tile;
+  const int F2_AS3* const tab = F2_P(const int, o_anc);
   // tab: child buses [n][8], ring slots of the children's messages [n][8], then:
   const int F2_AS3* const nch_tab = tab + 2 * n * 8;                // [n_slots]
   const int F2_AS3* const pos_tab = tab + F.pos_off;                // [positions][4]: bus, parent, ring, parent's ring
@@ -490,7 +551,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     for (int j = 0; j < NI; ++j) {
       int bus = ibus[j]; F2_OPAQUE(bus);
       const int par = pos_tab[(pos0 + j) * 4 + 1];
-      const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(par, l)), y = f2_ld2(F.off_z + 32u * bus);
+      const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(par, l)), y = f2_ld2(o_z + 32u * bus);
       const double dr = v.x - vp.x, di = v.y - vp.y;
       // branch admittance = -Y_ip
       kr[j] = __builtin_fma(-y.x, dr, y.y * di); ki[j] = -__builtin_fma(y.x, di, y.y * dr);
@@ -507,7 +568,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const int nch = nch_tab[bus];
       {   // the children's currents: the row of child indices first, then every current in one batch (no wait in between)
         const int cb = bus < n ? bus : 0;
-        const f2_i4 c_lo = *F2_P(const f2_i4, F.off_anc + 32u * cb), c_hi = *F2_P(const f2_i4, F.off_anc + 32u * cb + 16u);
+        const f2_i4 c_lo = *F2_P(const f2_i4, o_anc + 32u * cb), c_hi = *F2_P(const f2_i4, o_anc + 32u * cb + 16u);
 #pragma unroll
         for (int u = 0; u < GS_F2_CHILDREN; ++u) {
           if (u < imax[j]) {
@@ -556,14 +617,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           // side travels: s = D^-1 (r - sum of the children's q), q to the parent = L s
           int bus = ibus[j]; F2_OPAQUE(bus);
           int pj = pos0 + j; F2_OPAQUE(pj);
-          const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);
+          const f2_i4 px = *F2_P(const f2_i4, o_anc + 4u * F.pos_off + 16u * pj);
           const double* tb = flat_tab + 16 * j;
           const double2 iv0 = *(const double2*)(tb + 4), iv1 = *(const double2*)(tb + 6), tt0 = *(const double2*)(tb + 8), tt1 = *(const double2*)(tb + 10),
                         ll0 = *(const double2*)(tb + 12), ll1 = *(const double2*)(tb + 14);
           double r0 = Pj[j] - pcj[j], r1 = 0.0 - qcj[j];
           const int nch = bus < n ? nch_tab[bus] : 0;
           const int cbr = bus < n ? bus : 0;
-          const f2_i4 r_lo = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr + 16u);
+          const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr + 16u);
           while (lv < lev) { f2_lds_sync(); ++lv; }
 #pragma unroll
           for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
@@ -587,8 +648,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         // diagonal block and right-hand side without the children's contributions
         int bus = ibus[j]; F2_OPAQUE(bus);
         int pj = pos0 + j; F2_OPAQUE(pj);
-        const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);      // bus, parent, ring, parent's ring
-        const double2 yo = f2_ld2(F.off_z + 32u * bus), yd = f2_ld2(F.off_z + 32u * bus + 16u);       // (G_ip, B_ip), (G_ii, B_ii)
+        const f2_i4 px = *F2_P(const f2_i4, o_anc + 4u * F.pos_off + 16u * pj);      // bus, parent, ring, parent's ring
+        const double2 yo = f2_ld2(o_z + 32u * bus), yd = f2_ld2(o_z + 32u * bus + 16u);       // (G_ip, B_ip), (G_ii, B_ii)
         const double2 v = f2_ld2(bufA + f2_slot(bus, l)), vp = f2_ld2(bufA + f2_slot(px[1], l));
         const double v2 = __builtin_fma(v.x, v.x, v.y * v.y), rvm = f2_rsq(v2), vmi = v2 * rvm;
         const double rvmp = f2_rsq(__builtin_fma(vp.x, vp.x, vp.y * vp.y));
@@ -605,7 +666,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const double l00 = gsp, l01 = gcp * rvm, l10 = -gcp, l11 = gsp * rvm;
         const int nch = live && bus < n ? nch_tab[bus] : 0;
         const int cbr = bus < n ? bus : 0;
-        const f2_i4 r_lo = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, F.off_anc + 4u * (n * 8) + 32u * cbr + 16u);
+        const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr + 16u);
         while (lv < lev) { f2_lds_sync(); ++lv; }
         // the children's messages, two children (six 16-byte reads) per round trip
 #pragma unroll
@@ -661,7 +722,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         if (live) { while (lv > lev) { f2_lds_sync(); --lv; } }
         int bus = ibus[j]; F2_OPAQUE(bus);
         int pj = pos0 + j; F2_OPAQUE(pj);
-        const f2_i4 px = *F2_P(const f2_i4, F.off_anc + 4u * F.pos_off + 16u * pj);
+        const f2_i4 px = *F2_P(const f2_i4, o_anc + 4u * F.pos_off + 16u * pj);
         double x0 = s0[j], x1 = s1[j];
         if (live && bus < n && !((roots >> j) & 1u)) {
           const double2 xp = f2_ld2(ring3(px[3], 0));
@@ -753,10 +814,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   //             four rounds for the IEEE-123 tree = three more LDS stores and two more barriers per bus and sweep.)
   // The sums associate differently from the sequential recurrences: results agree with them to a few ulp of |V|
   // (absolute ~1e-16 in J, ~1e-15 in V; the tests compare at 1e-12).
-  const unsigned bufA = 0u, bufB = (unsigned)F.off_tile;
-  f2_v2 F2_AS3* const tot_lds = F2_P(f2_v2, F.off_red);            // [16 waves][32 lanes] wave totals of the scan
-  // backward sweep: J of this lane's buses from the injection currents of all buses
-  auto backward = [&]() {
+  const unsigned bufA = 0u, bufB = (unsigned)o_tile;
+  f2_v2 F2_AS3* const tot_lds = F2_P(f2_v2, o_red);            // [16 waves][32 lanes] wave totals of the scan
+  // backward sweep: J of this lane's buses from the injection currents of all buses.  at_barrier() runs behind the sweep's
+  // first barrier and ends the sweep there if it returns true (the flat-start convergence check rides on that barrier)
+  auto backward = [&](auto&& at_barrier) {
     double qr[NI], qi[NI];
     double ar = 0.0, ai = 0.0;
 #pragma unroll
@@ -767,8 +829,19 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_xscan<IW>(ai, l, hv, pre_i, wt_i);
     if (hv == 0) { f2_v2 t; t.x = wt_r; t.y = wt_i; tot_lds[wave * IW + l] = t; }
     f2_lds_sync();
-    double br = 0.0, bi = 0.0;                                    // sum of the totals of the waves before this one, in wave order
-    {
+    if (at_barrier()) return;
+    double br = 0.0, bi = 0.0;                                    // sum of the totals of the waves before this one
+    if constexpr (NW % HV == 0 && HV > 1) {
+      // every sub-group reads the totals of NW / HV waves (its share, in wave order) and the shares are added across the
+      // sub-groups without the LDS pipe: two 16-byte reads per lane instead of eight for the 8-wave member
+      constexpr int TPS = NW / HV;
+      f2_v2 tw[TPS];
+#pragma unroll
+      for (int w = 0; w < TPS; ++w) tw[w] = tot_lds[(hv * TPS + w) * IW + l];
+#pragma unroll
+      for (int w = 0; w < TPS; ++w) { const bool before = hv * TPS + w < wave; br += before ? tw[w].x : 0.0; bi += before ? tw[w].y : 0.0; }
+      br = f2_xsum<IW>(br, l); bi = f2_xsum<IW>(bi, l);
+    } else {
       constexpr int TB = NW < 8 ? NW : 8;
 #pragma unroll
       for (int w0 = 0; w0 < NW; w0 += TB) {                       // eight totals per LDS round trip
@@ -813,11 +886,15 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       IR[j] = p; II[j] = -0.0;                                // I = conj(S_spec / V) at V = 1
     }
     if (bad != bad) lmax = INFINITY;
-    double sum;
-    const double mm = wg_max_sum(lmax, lsum, sum);
-    stp.hit(F2_ST_FLAG);
-    f2_check(st, mm, sum, 0, C.tolerance);
-    if (!__all(st.done)) backward();
+    // the flat-start check shares the first backward sweep's barrier: the currents of that sweep are the same whether an
+    // instance stops here or not (a lane that stops here reports the flat start, epilogue)
+    const int c0 = post_max_sum(lmax, lsum);
+    backward([&]() -> bool {
+      double sum;
+      const double mm = read_max_sum(c0, sum);
+      f2_check(st, mm, sum, 0, C.tolerance);
+      return __all(st.done);
+    });
     stp.hit(F2_ST_BOTTOM_UP);
   }
   const double vs_r = f2_ld(f2_slot(F.slack, l));               // the slack's set point (real)
@@ -829,7 +906,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     double sr[NI], si[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const double2 z = f2_ld2(F.off_z + 16u * ibus[j]);
+      const double2 z = f2_ld2(o_z + 16u * ibus[j]);
       sr[j] = __builtin_fma(JR[j], z.x, -(JI[j] * z.y)); si[j] = __builtin_fma(JR[j], z.y, JI[j] * z.x);      // D = z J
       f2_st2(bufA + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
       if ((roots >> j) & 1u) pnew += vs_r * JR[j];              // the slack's share of the losses sum: Re(V_s conj(J_root)), V_s real
@@ -837,16 +914,17 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_lds_sync();
     for (int r = 0; r < R2; ++r) {
       const unsigned rd = (r & 1) ? bufB : bufA, wr = (r & 1) ? bufA : bufB;
-      // radix 4: the partial sums of the ancestors 4^r, 2 * 4^r and 3 * 4^r steps up (one 16-byte table entry per bus and
-      // round), added in that order -- depth 16 in two rounds, one LDS store per bus between them
-      f2_i4 aq[NI];
+      // radix 4: the partial sums of the ancestors 4^r, 2 * 4^r and 3 * 4^r steps up (one table word per bus and round:
+      // three 10-bit slot numbers, a 4-byte LDS read), added in that order -- depth 16 in two rounds, one LDS store per bus
+      // between them
+      unsigned aq[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) aq[j] = *F2_P(const f2_i4, (unsigned)F.off_anc + 16u * (unsigned)(r * nsl + ibus[j]));
+      for (int j = 0; j < NI; ++j) aq[j] = *F2_P(const unsigned, (unsigned)o_anc + 4u * (unsigned)(r * nsl + ibus[j]));
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         double2 sa[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) sa[j] = f2_ld2(rd + f2_slot(aq[j][k], l));
+        for (int j = 0; j < NI; ++j) sa[j] = f2_ld2(rd + f2_slot((int)((aq[j] >> (10 * k)) & 1023u), l));
 #pragma unroll
         for (int j = 0; j < NI; ++j) { sr[j] += sa[j].x; si[j] += sa[j].y; }
       }
@@ -865,7 +943,6 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     for (int j = 0; j < NI; ++j) {
       const double en = vs_r - sr[j], fn = 0.0 - si[j];
       sr[j] = en; si[j] = fn;
-      f2_st2(bufA + f2_slot(ibus[j], l), make_double2(en, fn));
       const double pc = __builtin_fma(en, IR[j], fn * II[j]), qc = __builtin_fma(fn, IR[j], -(en * II[j]));     // S_calc = V_new conj(I_old)
       const double dP = Pj[j] - pc, dQ = 0.0 - qc;
       lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
@@ -875,13 +952,19 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     }
     if (bad != bad) lmax = INFINITY;
     stp.hit(F2_ST_MISMATCH);
-    if (upd) psum = pnew;                                     // losses at the voltages just stored
-    if (it + 1 >= C.max_iterations) break;                    // iteration cap: mismatch / count stay the last check's
-    double sum;
-    const double mm = wg_max_sum(lmax, lsum, sum);
-    stp.hit(F2_ST_FLAG);
-    f2_check(st, mm, sum, it + 1, C.tolerance);
-    if (__all(st.done)) break;
+    if (upd) psum = pnew;                                     // losses at the voltages of this sweep
+    auto publish = [&]() {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) f2_st2(bufA + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
+    };
+    const bool cap = it + 1 >= C.max_iterations;              // iteration cap: mismatch / count stay the last check's
+    if (!cap) {
+      double sum;
+      const double mm = wg_max_sum(lmax, lsum, sum);
+      stp.hit(F2_ST_FLAG);
+      f2_check(st, mm, sum, it + 1, C.tolerance);
+    }
+    if (cap || __all(st.done)) { publish(); break; }
     // I_new = conj(S_spec / V_new) for the lanes that go on; a lane that has converged keeps the current that produced
     // its voltages: its J and V repeat bit for bit while the rest of the group iterates
 #pragma unroll
@@ -889,7 +972,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double rd = f2_rcp(__builtin_fma(sr[j], sr[j], si[j] * si[j]));
       if (!st.done && ibus[j] < n) { IR[j] = (Pj[j] * sr[j]) * rd; II[j] = (Pj[j] * si[j]) * rd; }      // (idle positions keep a zero current)
     }
-    backward();
+    backward([]() -> bool { return false; });
     stp.hit(F2_ST_BOTTOM_UP);
   }
   }
@@ -929,7 +1012,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     if (on) {
       f2_row(S, R.LOAD + k) = ql;
       if (!PA.lean) f2_pair(S, R.FLOW + k) = make_double2(sr, ld);
-      f2_st2(F.off_tile + (unsigned)k * SB + ((unsigned)l << 4), make_double2(sr, ld));
+      f2_st2(o_tile + (unsigned)k * SB + ((unsigned)l << 4), make_double2(sr, ld));
       over += (ld > 0.8) ? 1 : 0;
       if (chk) {
         const double cld_ = K.stride_cload == 2 ? ld : ql;             // which loading the limits apply to
@@ -1010,12 +1093,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         if (br >= B) continue;
         double* o = PA.out + (size_t)br * PA.obs_dim;
         if (!(PA.obs_dim & 1)) {            // every row of the block starts on a 16-byte boundary: one store per column pair
-          for (int cp = lane; cp < n; cp += 64) *(double2*)(o + 2 * cp) = f2_ld2(f2_slot(cp, r));
-          for (int cp = lane; cp < m; cp += 64) *(double2*)(o + 2 * n + 2 * cp) = f2_ld2(F.off_tile + (unsigned)cp * SB + ((unsigned)r << 4));
+          for (int cp = lane; cp < n; cp += 64) f2_stream2(o + 2 * cp, f2_ld2(f2_slot(cp, r)));
+          for (int cp = lane; cp < m; cp += 64) f2_stream2(o + 2 * n + 2 * cp, f2_ld2(o_tile + (unsigned)cp * SB + ((unsigned)r << 4)));
         } else {
           for (int cp = lane; cp < n; cp += 64) { const double2 v = f2_ld2(f2_slot(cp, r)); o[2 * cp] = v.x; o[2 * cp + 1] = v.y; }
           for (int cp = lane; cp < m; cp += 64) {
-            const double2 v = f2_ld2(F.off_tile + (unsigned)cp * SB + ((unsigned)r << 4)); o[2 * n + 2 * cp] = v.x; o[2 * n + 2 * cp + 1] = v.y; }
+            const double2 v = f2_ld2(o_tile + (unsigned)cp * SB + ((unsigned)r << 4)); o[2 * n + 2 * cp] = v.x; o[2 * n + 2 * cp + 1] = v.y; }
         }
       }
     }
@@ -1132,16 +1215,26 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     atomicMax(&C.stamps[17 + 2 * bid], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// The step kernels read their arguments where they use them, through a pointer to the argument block the compiler cannot see
+// through.  Taken from the formal parameters, all ~400 scalar words are loaded at the top of the kernel and, for lack of
+// scalar registers, parked in vector lanes: a quarter of the vector instructions of a step were v_writelane / v_readlane,
+// in kernels bound by vector instruction issue (rocprofv3 SQ_ACTIVE_INST_VALU: 75 % of the launch).
+#define F2_ARGS_IN_PLACE                                                                                                   \
+  const __attribute__((address_space(4))) char* ka_ = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr(); \
+  asm volatile("" : "+s"(ka_));                                                                                            \
+  const F2ArgBlock* A = (const F2ArgBlock*)ka_
 #define F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, OCC)                                                                      \
   extern "C" __global__ void __launch_bounds__(64 * NW) OCC                                                                \
   gs_k_step_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,         \
                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
-    f2_step<SOLVER, 0, NW, NI, IW>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                               \
+    F2_ARGS_IN_PLACE;                                                                                                      \
+    f2_step<SOLVER, 0, NW, NI, IW>(A->T, A->F, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC, A->RS); \
   }                                                                                                                        \
   extern "C" __global__ void __launch_bounds__(64 * NW) OCC /* the step with the post-step checks in its epilogue */       \
   gs_k_stepc_##name(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,        \
                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS) { \
-    f2_step<SOLVER, 1, NW, NI, IW>(T, F, R, C, E, slab, B, actions, total_load, PA, FC, RS);                               \
+    F2_ARGS_IN_PLACE;                                                                                                      \
+    f2_step<SOLVER, 1, NW, NI, IW>(A->T, A->F, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC, A->RS); \
   }
 #define F2_KERNELS(name, SOLVER, NW, NI, IW) F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, )
 F2_KERNELS(fbs_flow2, F2_FBS, 16, 4, 32)       // up to 128 buses below the slack
