@@ -273,7 +273,14 @@ struct GdStamp {
 };
 
 extern "C" __global__ void __launch_bounds__(256)
-gs_k_nr_dense_mfma(GsDenseArgs A, double* __restrict__ slab, int B) {
+gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) {
+  // (arguments read in place through an opaque pointer, kernels_flow2.hip F2_ARGS_IN_PLACE: no scalar words parked in vector lanes)
+  struct ArgBlock { GsDenseArgs A; double* slab; int B; };
+  const __attribute__((address_space(4))) char* ka_ = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka_));
+  const GsDenseArgs& A = ((const ArgBlock*)ka_)->A;
+  double* __restrict__ const slab = ((const ArgBlock*)ka_)->slab;
+  const int B = ((const ArgBlock*)ka_)->B;
   const int tid = threadIdx.x, n = A.n, na = A.na, NB = A.NB, NP = DB * NB;
   // LDS carve-up
   double* panel = gd_lds;                                  // [NP][DLD]

@@ -1869,45 +1869,62 @@ __device__ __forceinline__ void main_body(const GsTables& T, const GsRows& R, co
   stamp(c, ST_EPILOGUE);
 }
 
+// The kernels read their arguments where they use them, through a pointer to the argument block the compiler cannot see
+// through (kernels_flow2.hip F2_ARGS_IN_PLACE says why: taken from the formal parameters every scalar word is loaded at the
+// top and parked in vector lanes -- 250 to 340 spilled scalar registers in the step kernels of this file).
+struct GsStepArgBlock { GsTables T; GsRows R; GsSolveCfg C; GsEnvCfg E; double* slab; int B; const double* actions; double total_load;
+                        GsPackArgs PA; GsFusedChecks FC; };
+struct GsSolveArgBlock { GsTables T; GsRows R; GsSolveCfg C; double* slab; int B; };
+#define GS_ARGS_IN_PLACE(Block)                                                                               \
+  const __attribute__((address_space(4))) char* ka_ = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr(); \
+  asm volatile("" : "+s"(ka_));                                                                               \
+  const Block* A = (const Block*)ka_
 #define GS_DEFINE_KERNELS(name, KIND)                                                                         \
   extern "C" __global__ void __launch_bounds__(1024)                                                          \
   gs_k_##name(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {                         \
     GsEnvCfg E{};                                                                                             \
     GsPackArgs PA{};                                                                                          \
     GsFusedChecks FC{};                                                                                       \
-    main_body<KIND, 0, 0>(T, R, C, E, slab, B, nullptr, 0.0, PA, FC);                                         \
+    GS_ARGS_IN_PLACE(GsSolveArgBlock);                                                                        \
+    main_body<KIND, 0, 0>(A->T, A->R, A->C, E, A->slab, A->B, nullptr, 0.0, PA, FC);                          \
   }                                                                                                           \
   extern "C" __global__ void __launch_bounds__(1024)                                                          \
   gs_k_step_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,          \
                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {  \
-    main_body<KIND, 1, 0>(T, R, C, E, slab, B, actions, total_load, PA, FC);                                  \
+    GS_ARGS_IN_PLACE(GsStepArgBlock);                                                                         \
+    main_body<KIND, 1, 0>(A->T, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC);    \
   }                                                                                                           \
   extern "C" __global__ void __launch_bounds__(1024)   /* the step with the post-step checks in its epilogue */ \
   gs_k_stepc_##name(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,         \
                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) { \
-    main_body<KIND, 1, 1>(T, R, C, E, slab, B, actions, total_load, PA, FC);                                  \
+    GS_ARGS_IN_PLACE(GsStepArgBlock);                                                                         \
+    main_body<KIND, 1, 1>(A->T, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC);    \
   }
 
 // the two halves of a step / solve around the dense MFMA Newton-Raphson kernel (kernels_dense.hip)
 extern "C" __global__ void __launch_bounds__(1024)
 gs_k_pre_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
-  main_body<KIND_LU, 1, 0, 1>(T, R, C, E, slab, B, actions, total_load, PA, FC);
+  GS_ARGS_IN_PLACE(GsStepArgBlock);
+  main_body<KIND_LU, 1, 0, 1>(A->T, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC);
 }
 extern "C" __global__ void __launch_bounds__(1024)
 gs_k_post_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
-  main_body<KIND_LU, 1, 0, 2>(T, R, C, E, slab, B, actions, total_load, PA, FC);
+  GS_ARGS_IN_PLACE(GsStepArgBlock);
+  main_body<KIND_LU, 1, 0, 2>(A->T, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC);
 }
 extern "C" __global__ void __launch_bounds__(1024)
 gs_k_postc_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC) {
-  main_body<KIND_LU, 1, 1, 2>(T, R, C, E, slab, B, actions, total_load, PA, FC);
+  GS_ARGS_IN_PLACE(GsStepArgBlock);
+  main_body<KIND_LU, 1, 1, 2>(A->T, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC);
 }
 extern "C" __global__ void __launch_bounds__(1024)       // solver-only API (gs_solve): line flows, losses, wrapped angles
 gs_k_posts_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B) {
   GsEnvCfg E{}; GsPackArgs PA{}; GsFusedChecks FC{};
-  main_body<KIND_LU, 0, 0, 2>(T, R, C, E, slab, B, nullptr, 0.0, PA, FC);
+  GS_ARGS_IN_PLACE(GsSolveArgBlock);
+  main_body<KIND_LU, 0, 0, 2>(A->T, A->R, A->C, E, A->slab, A->B, nullptr, 0.0, PA, FC);
 }
 
 GS_DEFINE_KERNELS(nr_tree, KIND_TREE)
