@@ -797,22 +797,20 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
               IW = small ? GS_F2S_IW : (wide || half) ? GS_F2H_IW : 32;
     const int NPOS = NW * (64 / IW) * NI;
     GsF2Tables& F = h->F2;
-    const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl, 2);
+    const size_t off = f2_layout(F, NW, IW, 0, (size_t)n_jump * nsl * 4, 2);
     F.n_jump = n_jump;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
     else if (N > NPOS) why = "more than " + std::to_string(NPOS) + " buses below the slack";
     else if (N != ht.lvl_ptr[ht.n_levels]) why = "part of the forest does not hang off the slack bus";
     else if (max_dev > 2) why = "more than two devices of a kind at one bus";
     else if (off > 160 * 1024) why = "LDS tables do not fit";
-    else if (nsl > 1023) why = "slot numbers beyond the 10 bits of an ancestor word";
     else if (ht.n < 2 || ht.m < 1 || N < 1) why = "trivial network";
     if (why.empty()) {
       h->flow2 = true; h->f2_small = small; h->f2_half = half; h->f2_wide = wide; h->f2_iw = IW; h->f2_nw = NW;
       GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY;
       f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 2, 0.0);
-      // [round][slot]: the slot's ancestors 1, 2, 3 steps of 4^round up (no ancestor: ZERO), 10 bits each in one word
-      f2anc.assign((size_t)n_jump * nsl, SL_ZERO | (SL_ZERO << 10) | (SL_ZERO << 20));
+      f2anc.assign((size_t)n_jump * nsl * 4, SL_ZERO);            // [round][slot][4]: the slot's ancestors 1, 2, 3 steps of 4^round up (no ancestor: ZERO)
       std::vector<int> up1((size_t)nsl, SL_ZERO);                    // parent slot of every slot (the slack's children: ZERO)
       for (int p = 0; p < N; ++p) {
         GsF2Rec& r = f2recs[p];
@@ -830,9 +828,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         for (int r = 0; r < n_jump; ++r) {
           for (int sidx = 0; sidx < nsl; ++sidx) {
             int a = sidx;
-            int32_t word = 0;
-            for (int k = 0; k < 3; ++k) { a = step[a]; word |= a << (10 * k); }
-            f2anc[(size_t)r * nsl + sidx] = word;
+            for (int k = 0; k < 3; ++k) { a = step[a]; f2anc[((size_t)r * nsl + sidx) * 4 + k] = a; }
           }
           std::vector<int> nxt((size_t)nsl);
           for (int sidx = 0; sidx < nsl; ++sidx) nxt[sidx] = step[step[step[step[sidx]]]];

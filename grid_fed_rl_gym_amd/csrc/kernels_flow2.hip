@@ -229,7 +229,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   constexpr int HV = 64 / IW;                          // sub-groups (buses) per wavefront
   constexpr unsigned SB = (unsigned)(IW + 1) * 16u;    // bytes of an LDS slot: IW lanes x 16 B + one entry of padding
   const int lane = threadIdx.x & 63, l = lane & (IW - 1), hv = lane / IW;
-  auto f2_slot = [](int slot, int ll) -> unsigned { return (unsigned)slot * SB + ((unsigned)ll << 4); };
+  // (a 24-bit multiply-add: full rate; the compiler's choice for a 32-bit product it cannot bound is the quarter-rate v_mad_u64_u32)
+  auto f2_slot = [](int slot, int ll) -> unsigned { return __umul24((unsigned)slot, SB) + ((unsigned)ll << 4); };
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // (a step may be launched as two halves of the grid on two streams, gs_internal.h GsF2Tables::wg_offset: bid is the
   // workgroup's index in the whole grid)
@@ -244,7 +245,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // vector lane) instead.
   int n = T.n, m = T.m, nsl = F.n_slots;
   int o_env = F.off_env, o_tile = F.off_tile, o_red = F.off_red, o_atom = F.off_atom, o_anc = F.off_anc, o_z = F.off_z, o_prof = F.off_prof;
-  int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl : F.n_anc_ints;      // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
+  int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl * 4 : F.n_anc_ints;  // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
   const int32_t* anc_g = F.anc; const double* zbus_g = F.zbus;
   F2_KEEP(n); F2_KEEP(m); F2_KEEP(nsl); F2_KEEP(o_env); F2_KEEP(o_tile); F2_KEEP(o_red); F2_KEEP(o_atom); F2_KEEP(o_anc); F2_KEEP(o_z);
   F2_KEEP(o_prof); F2_KEEP(n_tab); F2_KEEP(anc_g); F2_KEEP(zbus_g);
@@ -483,10 +484,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   auto post_max_sum = [&](double lmax, double lsum) -> int {
     const int c0 = check % 3, c1 = (check + 1) % 3;
     ++check;
-    lmax = f2_xmax<IW>(lmax);
-    lsum = f2_xsum<IW>(lsum, l);
+    // every sub-group posts its own share (the LDS atomics do the cross-sub-group reduction: the kernel is bound by vector
+    // instruction issue, and the two exchanges through v_permlane swaps were 25 vector instructions per check)
     if (wave == 0 && hv == 0) { cell[c1 * IW + l] = 0ull; cell[(5 + c1) * IW + l] = 0ull; }
-    if (hv == 0) { atomicMax(cell + c0 * IW + l, f2_bits(lmax)); atomicAdd(cell + (5 + c0) * IW + l, f2_fix(lsum)); }
+    atomicMax(cell + c0 * IW + l, f2_bits(lmax)); atomicAdd(cell + (5 + c0) * IW + l, f2_fix(lsum));
     return c0;
   };
   auto read_max_sum = [&](int c0, double& sum_out) -> double {
@@ -569,9 +570,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       {   // the children's currents: the row of child indices first, then every current in one batch (no wait in between)
         const int cb = bus < n ? bus : 0;
         const f2_i4 c_lo = *F2_P(const f2_i4, o_anc + 32u * cb), c_hi = *F2_P(const f2_i4, o_anc + 32u * cb + 16u);
+        int im = imax[j]; F2_KEEP(im);      // (compared here: hoisted out of the Newton loop the 64 wave masks u < imax[j] live in vector lanes)
 #pragma unroll
         for (int u = 0; u < GS_F2_CHILDREN; ++u) {
-          if (u < imax[j]) {
+          if (u < im) {
             const int c = u < 4 ? c_lo[u & 3] : c_hi[u & 3];
             const double2 kc = f2_ld2(bufB + f2_slot(u < nch ? c : bus, l));
             if (u < nch) { icr -= kc.x; ici -= kc.y; }
@@ -626,9 +628,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           const int cbr = bus < n ? bus : 0;
           const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr + 16u);
           while (lv < lev) { f2_lds_sync(); ++lv; }
+          int im = imax[j]; F2_KEEP(im);
 #pragma unroll
           for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
-            if (u0 < imax[j]) {
+            if (u0 < im) {
               const int ca = u0 < 4 ? r_lo[u0 & 3] : r_hi[u0 & 3], cb2 = u0 + 1 < 4 ? r_lo[(u0 + 1) & 3] : r_hi[(u0 + 1) & 3];
               const int sa = u0 < nch ? ca : 0, sb = u0 + 1 < nch ? cb2 : 0;
               const double2 aq = f2_ld2(ring3(sa, 2)), bq = f2_ld2(ring3(sb, 2));
@@ -669,9 +672,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr + 16u);
         while (lv < lev) { f2_lds_sync(); ++lv; }
         // the children's messages, two children (six 16-byte reads) per round trip
+        int im = imax[j]; F2_KEEP(im);
 #pragma unroll
         for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
-          if (u0 < imax[j]) {
+          if (u0 < im) {
             const int ca = u0 < 4 ? r_lo[u0 & 3] : r_hi[u0 & 3], cb2 = u0 + 1 < 4 ? r_lo[(u0 + 1) & 3] : r_hi[(u0 + 1) & 3];
             const int sa = u0 < nch ? ca : 0, sb = u0 + 1 < nch ? cb2 : 0;
             const double2 a0 = f2_ld2(ring3(sa, 0)), a1 = f2_ld2(ring3(sa, 1)), aq = f2_ld2(ring3(sa, 2));
@@ -862,12 +866,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     for (int j = 0; j < NI; ++j) {
       const double2 ql = f2_ld2(bufB + f2_slot(ilast[j], l));       // Q at the last position of the bus's subtree
       const double er = j ? br + qr[j ? j - 1 : 0] : br, ei = j ? bi + qi[j ? j - 1 : 0] : bi;             // Q[p - 1]
-      JR[j] = ibus[j] < n ? ql.x - er : 0.0; JI[j] = ibus[j] < n ? ql.y - ei : 0.0;
+      // (an idle position gets some finite difference of prefix sums: its impedance is 0, so is its drop, and nothing else reads its J)
+      JR[j] = ql.x - er; JI[j] = ql.y - ei;
     }
   };
   stp.hit(F2_ST_INIT);
   {  // at the flat start: every voltage but the slack's is 1, S_calc = conj(K) with K = y (1 - V_slack) at the roots
-    double lmax = 0.0, bad = 0.0, lsum = 0.0;
+    double lmax = 0.0, lsum = 0.0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const GsF2Rec* q = rec0 + j;
@@ -880,12 +885,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double dP = p - pc, dQ = 0.0 - qc;
       lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
       lsum += fabs(dP) + fabs(dQ);
-      bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
       psum += pc;
       if (root) psum -= ep * kr;                              // the slack's share: Re(V_s conj(-K_root))
       IR[j] = p; II[j] = -0.0;                                // I = conj(S_spec / V) at V = 1
     }
-    if (bad != bad) lmax = INFINITY;
+    if (!(lsum < INFINITY)) lmax = INFINITY;     // a NaN or infinite mismatch anywhere shows in the sum (fmax would drop a NaN)
     // the flat-start check shares the first backward sweep's barrier: the currents of that sweep are the same whether an
     // instance stops here or not (a lane that stops here reports the flat start, epilogue)
     const int c0 = post_max_sum(lmax, lsum);
@@ -901,7 +905,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const int R2 = F.n_jump;                                      // even
   for (int it = 0; it < C.max_iterations && !__all(st.done); ++it) {
     const bool upd = !st.done;
-    double lmax = 0.0, pnew = 0.0, bad = 0.0, lsum = 0.0;
+    double lmax = 0.0, pnew = 0.0, lsum = 0.0;
     // forward sweep by pointer jumping; buffers alternate so that the last round reads B (then A may take the voltages)
     double sr[NI], si[NI];
 #pragma unroll
@@ -914,17 +918,18 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_lds_sync();
     for (int r = 0; r < R2; ++r) {
       const unsigned rd = (r & 1) ? bufB : bufA, wr = (r & 1) ? bufA : bufB;
-      // radix 4: the partial sums of the ancestors 4^r, 2 * 4^r and 3 * 4^r steps up (one table word per bus and round:
-      // three 10-bit slot numbers, a 4-byte LDS read), added in that order -- depth 16 in two rounds, one LDS store per bus
-      // between them
-      unsigned aq[NI];
+      // radix 4: the partial sums of the ancestors 4^r, 2 * 4^r and 3 * 4^r steps up (one 16-byte table entry per bus and
+      // round), added in that order -- depth 16 in two rounds, one LDS store per bus between them.  (Three 10-bit slot
+      // numbers in one word were tried: a quarter of the table's LDS bytes, but a bit-field extract more per gather, and the
+      // kernel is bound by vector instruction issue.)
+      f2_i4 aq[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) aq[j] = *F2_P(const unsigned, (unsigned)o_anc + 4u * (unsigned)(r * nsl + ibus[j]));
+      for (int j = 0; j < NI; ++j) aq[j] = *F2_P(const f2_i4, (unsigned)o_anc + 16u * (unsigned)(r * nsl + ibus[j]));
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         double2 sa[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) sa[j] = f2_ld2(rd + f2_slot((int)((aq[j] >> (10 * k)) & 1023u), l));
+        for (int j = 0; j < NI; ++j) sa[j] = f2_ld2(rd + f2_slot(aq[j][k], l));
 #pragma unroll
         for (int j = 0; j < NI; ++j) { sr[j] += sa[j].x; si[j] += sa[j].y; }
       }
@@ -947,10 +952,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double dP = Pj[j] - pc, dQ = 0.0 - qc;
       lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
       lsum += fabs(dP) + fabs(dQ);
-      bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad));
       pnew += pc;
     }
-    if (bad != bad) lmax = INFINITY;
+    if (!(lsum < INFINITY)) lmax = INFINITY;
     stp.hit(F2_ST_MISMATCH);
     if (upd) psum = pnew;                                     // losses at the voltages of this sweep
     auto publish = [&]() {
@@ -967,10 +971,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     if (cap || __all(st.done)) { publish(); break; }
     // I_new = conj(S_spec / V_new) for the lanes that go on; a lane that has converged keeps the current that produced
     // its voltages: its J and V repeat bit for bit while the rest of the group iterates
+    // (one branch around the block instead of a select per component; an idle position has P = 0 and so a zero current)
+    if (!st.done) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const double rd = f2_rcp(__builtin_fma(sr[j], sr[j], si[j] * si[j]));
-      if (!st.done && ibus[j] < n) { IR[j] = (Pj[j] * sr[j]) * rd; II[j] = (Pj[j] * si[j]) * rd; }      // (idle positions keep a zero current)
+      for (int j = 0; j < NI; ++j) {
+        const double rd = f2_rcp(__builtin_fma(sr[j], sr[j], si[j] * si[j]));
+        IR[j] = (Pj[j] * sr[j]) * rd; II[j] = (Pj[j] * si[j]) * rd;
+      }
     }
     backward([]() -> bool { return false; });
     stp.hit(F2_ST_BOTTOM_UP);
