@@ -868,11 +868,14 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const int NPOS = NW * HV * NI, maxw = ht.max_level_width;
     h->f2_npos = NPOS;
     GsF2Tables& F = h->F2;
-    const size_t ring_bytes = (size_t)2 * maxw * 3 * IW * 16;
-    const int pos_off = (2 * ht.n * GS_F2_CHILDREN + nsl + 3) & ~3;
+    // the ring's zero entry: behind the ring's two parities and behind the K slots that share the region
+    const size_t ring_entry = (size_t)3 * IW * 16;
+    const int ring_zero = (int)std::max<size_t>((size_t)2 * maxw, ((size_t)nsl * (IW + 1) * 16 + ring_entry - 1) / ring_entry);
+    const size_t ring_bytes = (size_t)(ring_zero + 1) * ring_entry;
+    const int pos_off = (2 * (ht.n + 1) * GS_F2_CHILDREN + nsl + 3) & ~3;
     const int n_ints = pos_off + NPOS * 4;
     const size_t off = f2_layout(F, NW, IW, ring_bytes, (size_t)n_ints, 4);
-    F.n_jump = 0; F.n_levels = ht.n_levels; F.pos_off = pos_off; F.n_anc_ints = n_ints;
+    F.n_jump = 0; F.n_levels = ht.n_levels; F.pos_off = pos_off; F.n_anc_ints = n_ints; F.ring_zero = ring_zero;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
     else if (!h->SC.jacobian_exact && cfg->jacobian_mode != GS_JACOBIAN_EXACT) why = "as-coded Jacobian";
     else if (!all_pq) why = "a bus below the slack is not a PQ bus";
@@ -888,7 +891,10 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       f2recs.assign((size_t)NPOS, idle);
       f2z.assign((size_t)nsl * 4, 0.0);
       f2anc.assign((size_t)n_ints, 0);
-      int32_t* child_bus = f2anc.data(); int32_t* child_ring = child_bus + ht.n * GS_F2_CHILDREN; int32_t* nch = child_ring + ht.n * GS_F2_CHILDREN;
+      // rows of n + 1 buses (row n: idle positions); entries beyond a bus's children name the ZERO slot / the ring's zero entry
+      int32_t* child_bus = f2anc.data(); int32_t* child_ring = child_bus + (ht.n + 1) * GS_F2_CHILDREN; int32_t* nch = child_ring + (ht.n + 1) * GS_F2_CHILDREN;
+      std::fill(child_bus, child_bus + (ht.n + 1) * GS_F2_CHILDREN, SL_ZERO);
+      std::fill(child_ring, child_ring + (ht.n + 1) * GS_F2_CHILDREN, ring_zero);
       int32_t* pos_tab = f2anc.data() + pos_off;
       std::vector<int> level_of(ht.n, 0);
       for (int lv = 0; lv < ht.n_levels; ++lv) for (int t = ht.lvl_ptr[lv]; t < ht.lvl_ptr[lv + 1]; ++t) level_of[ht.lvl_bus[t]] = lv;

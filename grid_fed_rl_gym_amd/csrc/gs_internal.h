@@ -406,7 +406,7 @@ struct GsF2Tables {
   int32_t n_jump;                 // rounds of the forward sweep's pointer jumping: ceil(log2(depth)), rounded up to even
   int32_t n_levels, pos_off, n_anc_ints, wg_offset;   // Newton-Raphson: levels of the tree below the slack; layout of `anc`
   int32_t off_tile, off_anc, off_z, off_env, off_red, off_atom, lds_bytes;     // LDS byte offsets (slots at 0)
-  int32_t off_prof, pad_prof;     // the 24 hourly factors of the load profile (dynamics.py:37-44), copied from kDailyProfile at kernel start
+  int32_t off_prof, ring_zero;    // ring_zero (Newton-Raphson): index of the ring entry that stays zero;     // the 24 hourly factors of the load profile (dynamics.py:37-44), copied from kDailyProfile at kernel start
   int32_t env_genp, env_curt, env_batp, env_soc;      // row indices inside the env area ([row][32 lanes] doubles)
   // buses with a voltage set point (normally the slack alone): slot and |V|; the first inline, the rest through the arrays
   int32_t n_fixed, fixed_slot0;

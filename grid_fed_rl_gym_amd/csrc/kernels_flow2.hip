@@ -512,8 +512,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // with an LDS barrier per level.
   const unsigned bufA = 0u, bufB = (unsigned)o_tile;
   const int F2_AS3* const tab = F2_P(const int, o_anc);
-  // tab: child buses [n][8], ring slots of the children's messages [n][8], then:
-  const int F2_AS3* const nch_tab = tab + 2 * n * 8;                // [n_slots]
+  // tab: child buses [n + 1][8], ring slots of the children's messages [n + 1][8] (row n: an idle position), child counts
+  // [n_slots] (the kernel does not read them: an entry beyond a bus's children names the ZERO slot / the ring's zero entry,
+  // so that a lane subtracts every entry up to its group's largest child count -- no per-lane predicate, no selects)
   const int F2_AS3* const pos_tab = tab + F.pos_off;                // [positions][4]: bus, parent, ring, parent's ring
   int ilev[NI];                                                     // level of the wave's j-th pair (-1: none), wave-uniform
 #pragma unroll
@@ -524,6 +525,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const int pos0 = (wave * HV + hv) * NI;
   const int NL = F.n_levels;
   auto ring3 = [&](int slot, int part) -> unsigned { return bufB + ((unsigned)(slot * 3 + part) * (unsigned)IW + (unsigned)l) * 16u; };
+  // the ring's zero entry (what the ring table names beyond a bus's children) lies behind everything the solver writes in
+  // the region: written once; the first reader is a barrier or more away
+  if (wave == 0 && hv == 0) {
+#pragma unroll
+    for (int part = 0; part < 3; ++part) f2_st2(ring3(F.ring_zero, part), make_double2(0.0, 0.0));
+  }
   // flat start: the slots hold it already (every bus below the slack is a PQ bus, the host checks).  |V| and the angle are
   // not kept: |V| = sqrt(e^2 + f^2) where it is needed, corrections rotate (e, f) by the angle increment
   double pcj[NI], qcj[NI];
@@ -560,23 +567,23 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       sl[j] = ((roots >> j) & 1u) ? __builtin_fma(vp.x, kr[j], vp.y * ki[j]) : 0.0;      // Re(V_s conj(K_root)): the slack's share of the losses sum, negated below
       f2_st2(bufB + f2_slot(bus, l), make_double2(kr[j], ki[j]));
     }
+    if (wave == 0) f2_st2(bufB + f2_slot(SL_ZERO, l), make_double2(0.0, 0.0));      // "no child" reads as 0 (the ring shares the region and may have written here)
     f2_lds_sync();
     double lmax = 0.0, bad = 0.0, ps = 0.0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       int bus = ibus[j]; F2_OPAQUE(bus);
       double icr = kr[j], ici = ki[j];
-      const int nch = nch_tab[bus];
       {   // the children's currents: the row of child indices first, then every current in one batch (no wait in between)
-        const int cb = bus < n ? bus : 0;
+        const int cb = bus < n ? bus : n;
         const f2_i4 c_lo = *F2_P(const f2_i4, o_anc + 32u * cb), c_hi = *F2_P(const f2_i4, o_anc + 32u * cb + 16u);
         int im = imax[j]; F2_KEEP(im);      // (compared here: hoisted out of the Newton loop the 64 wave masks u < imax[j] live in vector lanes)
 #pragma unroll
         for (int u = 0; u < GS_F2_CHILDREN; ++u) {
           if (u < im) {
             const int c = u < 4 ? c_lo[u & 3] : c_hi[u & 3];
-            const double2 kc = f2_ld2(bufB + f2_slot(u < nch ? c : bus, l));
-            if (u < nch) { icr -= kc.x; ici -= kc.y; }
+            const double2 kc = f2_ld2(bufB + f2_slot(c, l));
+            icr -= kc.x; ici -= kc.y;
           }
         }
       }
@@ -624,19 +631,17 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           const double2 iv0 = *(const double2*)(tb + 4), iv1 = *(const double2*)(tb + 6), tt0 = *(const double2*)(tb + 8), tt1 = *(const double2*)(tb + 10),
                         ll0 = *(const double2*)(tb + 12), ll1 = *(const double2*)(tb + 14);
           double r0 = Pj[j] - pcj[j], r1 = 0.0 - qcj[j];
-          const int nch = bus < n ? nch_tab[bus] : 0;
-          const int cbr = bus < n ? bus : 0;
-          const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr + 16u);
+          const int cbr = bus < n ? bus : n;
+          const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * ((n + 1) * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * ((n + 1) * 8) + 32u * cbr + 16u);
           while (lv < lev) { f2_lds_sync(); ++lv; }
           int im = imax[j]; F2_KEEP(im);
 #pragma unroll
           for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
             if (u0 < im) {
               const int ca = u0 < 4 ? r_lo[u0 & 3] : r_hi[u0 & 3], cb2 = u0 + 1 < 4 ? r_lo[(u0 + 1) & 3] : r_hi[(u0 + 1) & 3];
-              const int sa = u0 < nch ? ca : 0, sb = u0 + 1 < nch ? cb2 : 0;
-              const double2 aq = f2_ld2(ring3(sa, 2)), bq = f2_ld2(ring3(sb, 2));
-              if (u0 < nch) { r0 -= aq.x; r1 -= aq.y; }
-              if (u0 + 1 < nch) { r0 -= bq.x; r1 -= bq.y; }
+              const double2 aq = f2_ld2(ring3(ca, 2)), bq = f2_ld2(ring3(cb2, 2));
+              r0 -= aq.x; r1 -= aq.y;
+              r0 -= bq.x; r1 -= bq.y;
             }
           }
           s0[j] = iv0.x * r0 + iv0.y * r1; s1[j] = iv1.x * r0 + iv1.y * r1;
@@ -667,9 +672,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const double gsp = yo.x * bbp - yo.y * a, gcp = yo.x * a + yo.y * bbp;             // row p, column i
         const double u00 = gsi, u01 = gci * rvmp, u10 = -gci, u11 = gsi * rvmp;
         const double l00 = gsp, l01 = gcp * rvm, l10 = -gcp, l11 = gsp * rvm;
-        const int nch = live && bus < n ? nch_tab[bus] : 0;
-        const int cbr = bus < n ? bus : 0;
-        const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * (n * 8) + 32u * cbr + 16u);
+        const int cbr = bus < n ? bus : n;
+        const f2_i4 r_lo = *F2_P(const f2_i4, o_anc + 4u * ((n + 1) * 8) + 32u * cbr), r_hi = *F2_P(const f2_i4, o_anc + 4u * ((n + 1) * 8) + 32u * cbr + 16u);
         while (lv < lev) { f2_lds_sync(); ++lv; }
         // the children's messages, two children (six 16-byte reads) per round trip
         int im = imax[j]; F2_KEEP(im);
@@ -677,11 +681,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         for (int u0 = 0; u0 < GS_F2_CHILDREN; u0 += 2) {
           if (u0 < im) {
             const int ca = u0 < 4 ? r_lo[u0 & 3] : r_hi[u0 & 3], cb2 = u0 + 1 < 4 ? r_lo[(u0 + 1) & 3] : r_hi[(u0 + 1) & 3];
-            const int sa = u0 < nch ? ca : 0, sb = u0 + 1 < nch ? cb2 : 0;
-            const double2 a0 = f2_ld2(ring3(sa, 0)), a1 = f2_ld2(ring3(sa, 1)), aq = f2_ld2(ring3(sa, 2));
-            const double2 b0 = f2_ld2(ring3(sb, 0)), b1 = f2_ld2(ring3(sb, 1)), bq = f2_ld2(ring3(sb, 2));
-            if (u0 < nch) { d00 -= a0.x; d01 -= a0.y; d10 -= a1.x; d11 -= a1.y; r0 -= aq.x; r1 -= aq.y; }
-            if (u0 + 1 < nch) { d00 -= b0.x; d01 -= b0.y; d10 -= b1.x; d11 -= b1.y; r0 -= bq.x; r1 -= bq.y; }
+            const double2 a0 = f2_ld2(ring3(ca, 0)), a1 = f2_ld2(ring3(ca, 1)), aq = f2_ld2(ring3(ca, 2));
+            const double2 b0 = f2_ld2(ring3(cb2, 0)), b1 = f2_ld2(ring3(cb2, 1)), bq = f2_ld2(ring3(cb2, 2));
+            d00 -= a0.x; d01 -= a0.y; d10 -= a1.x; d11 -= a1.y; r0 -= aq.x; r1 -= aq.y;
+            d00 -= b0.x; d01 -= b0.y; d10 -= b1.x; d11 -= b1.y; r0 -= bq.x; r1 -= bq.y;
           }
         }
         const double det = d00 * d11 - d01 * d10;
