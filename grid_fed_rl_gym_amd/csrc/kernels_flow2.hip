@@ -180,12 +180,28 @@ __device__ __forceinline__ void f2_check(F2State& st, double mm, double crit, in
   }
 }
 // The sweeps stop on sum_i |dP_i| + |dQ_i| < tolerance / 2 (oracle_np.fbs_solve says why: on a radial feeder the sum bounds the
-// error of every line flow; the maximum alone left the head-of-feeder flows n_loads x tolerance off).  Across the waves of a
-// workgroup the sum is an LDS integer add of fixed-point values (2^-44 pu: exact and order-independent like the maxima);
-// inside a wave the additions are in item and sub-group order.  Anything that is not a small finite number saturates.
+// error of every line flow; the maximum alone left the head-of-feeder flows n_loads x tolerance off).  Across the sub-groups and
+// waves of a workgroup the sum is an LDS integer add of fixed-point values (2^-44 pu: exact and order-independent like the
+// maxima); inside a lane the additions are in item order.  The conversion is the add-2^52 trick (the integer is the low 52 bits
+// of the sum's mantissa: two vector instructions; the compiler's double -> u64 conversion is ten, in a kernel bound by vector
+// instruction issue), a lane's share beyond 255 pu saturates there (a NaN is caught through the maximum), and the criterion is
+// compared as an integer: sum 2^44 < tolerance 2^43.
 #define F2_SUM_SCALE 0x1p44
-#define F2_SUM_SAT (1ull << 58)
-__device__ __forceinline__ unsigned long long f2_fix(double s) { return (s < 8192.0) ? (unsigned long long)(s * F2_SUM_SCALE) : F2_SUM_SAT; }
+__device__ __forceinline__ unsigned long long f2_fix(double s) {
+  const double d = __builtin_fma(fmin(s, 255.0), F2_SUM_SCALE, 0x1p52);
+  return __builtin_bit_cast(unsigned long long, d) & 0x000fffffffffffffull;
+}
+__device__ __forceinline__ unsigned long long f2_fix_tolerance(double tol) {      // the integer the summed mismatch must stay below
+  const double t = fmin(fmax(tol, 0.0), 255.0) * (0.5 * F2_SUM_SCALE);
+  return (unsigned long long)t;
+}
+__device__ __forceinline__ void f2_check_sum(F2State& st, double mm, unsigned long long sum_fix, unsigned long long tol_fix, int it) {
+  if (!st.done) {
+    st.mm = mm; st.iters = it + 1;
+    if (!(mm < INFINITY)) { st.status = GS_STATUS_NAN; st.done = true; }
+    else if (sum_fix < tol_fix) { st.conv = 1; st.status = GS_STATUS_OK; st.done = true; }
+  }
+}
 
 // Bus voltage angle from (e, f) (see bus_angle in kernels_solve.hip): series for small angles, libm otherwise.
 __device__ __forceinline__ double f2_angle(double f, double e) {
@@ -490,11 +506,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     atomicMax(cell + c0 * IW + l, f2_bits(lmax)); atomicAdd(cell + (5 + c0) * IW + l, f2_fix(lsum));
     return c0;
   };
-  auto read_max_sum = [&](int c0, double& sum_out) -> double {
-    sum_out = (double)cell[(5 + c0) * IW + l] * (2.0 / F2_SUM_SCALE);      // twice the sum: what is held against the tolerance
+  auto read_max_sum = [&](int c0, unsigned long long& sum_out) -> double {
+    sum_out = cell[(5 + c0) * IW + l];                                     // the summed mismatch in units of 2^-44 pu
     return f2_dbl(cell[c0 * IW + l]);
   };
-  auto wg_max_sum = [&](double lmax, double lsum, double& sum_out) -> double {
+  auto wg_max_sum = [&](double lmax, double lsum, unsigned long long& sum_out) -> double {
     const int c0 = post_max_sum(lmax, lsum);
     f2_lds_sync();
     return read_max_sum(c0, sum_out);
@@ -874,6 +890,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     }
   };
   stp.hit(F2_ST_INIT);
+  const unsigned long long tol_fix = f2_fix_tolerance(C.tolerance);
+  const bool any_root = __any(roots != 0u);                   // (the slack's one to three children sit in one or two waves)
   {  // at the flat start: every voltage but the slack's is 1, S_calc = conj(K) with K = y (1 - V_slack) at the roots
     double lmax = 0.0, lsum = 0.0;
 #pragma unroll
@@ -897,9 +915,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // instance stops here or not (a lane that stops here reports the flat start, epilogue)
     const int c0 = post_max_sum(lmax, lsum);
     backward([&]() -> bool {
-      double sum;
+      unsigned long long sum;
       const double mm = read_max_sum(c0, sum);
-      f2_check(st, mm, sum, 0, C.tolerance);
+      f2_check_sum(st, mm, sum, tol_fix, 0);
       return __all(st.done);
     });
     stp.hit(F2_ST_BOTTOM_UP);
@@ -916,7 +934,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double2 z = f2_ld2(o_z + 16u * ibus[j]);
       sr[j] = __builtin_fma(JR[j], z.x, -(JI[j] * z.y)); si[j] = __builtin_fma(JR[j], z.y, JI[j] * z.x);      // D = z J
       f2_st2(bufA + f2_slot(ibus[j], l), make_double2(sr[j], si[j]));
-      if ((roots >> j) & 1u) pnew += vs_r * JR[j];              // the slack's share of the losses sum: Re(V_s conj(J_root)), V_s real
+    }
+    if (any_root) {                                             // the slack's share of the losses sum: Re(V_s conj(J_root)), V_s real
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { if ((roots >> j) & 1u) pnew += vs_r * JR[j]; }
     }
     f2_lds_sync();
     for (int r = 0; r < R2; ++r) {
@@ -943,18 +964,17 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       }
     }
     stp.hit(F2_ST_TOP_DOWN);
-    // V = V_slack - S; mismatch and sum of P_calc at the new voltages (power_flow.py:150-168); the voltages go to buffer A
-    // (its last reader was round R2 - 2, a barrier ago), where the epilogue finds those of the last sweep.  (Publishing them
-    // only when the loop ends -- an LDS store costs three times a load -- was tried: the extra live range or the extra exits
-    // cost 30-80 spilled registers at the 128-VGPR budget, -25 %.)
+    // V = V_slack - S; mismatch and sum of P_calc at the new voltages (power_flow.py:150-168).  The voltages go to buffer A
+    // (its last reader was round R2 - 2, a barrier ago) when the loop ends -- `publish` below, ONE exit: with a `break` at the
+    // cap and another behind the check the compiler duplicated the body and spilled 50 registers.
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const double en = vs_r - sr[j], fn = 0.0 - si[j];
+      const double en = vs_r - sr[j], fn = -si[j];            // (a negation rides on its consumers' operands; 0.0 - x is an instruction)
       sr[j] = en; si[j] = fn;
       const double pc = __builtin_fma(en, IR[j], fn * II[j]), qc = __builtin_fma(fn, IR[j], -(en * II[j]));     // S_calc = V_new conj(I_old)
-      const double dP = Pj[j] - pc, dQ = 0.0 - qc;
-      lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ)));
-      lsum += fabs(dP) + fabs(dQ);
+      const double dP = Pj[j] - pc;                           // dQ = 0 - Q_calc enters through its magnitude only
+      lmax = fmax(lmax, fmax(fabs(dP), fabs(qc)));
+      lsum += fabs(dP) + fabs(qc);
       pnew += pc;
     }
     if (!(lsum < INFINITY)) lmax = INFINITY;
@@ -966,10 +986,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     };
     const bool cap = it + 1 >= C.max_iterations;              // iteration cap: mismatch / count stay the last check's
     if (!cap) {
-      double sum;
+      unsigned long long sum;
       const double mm = wg_max_sum(lmax, lsum, sum);
       stp.hit(F2_ST_FLAG);
-      f2_check(st, mm, sum, it + 1, C.tolerance);
+      f2_check_sum(st, mm, sum, tol_fix, it + 1);
     }
     if (cap || __all(st.done)) { publish(); break; }
     // I_new = conj(S_spec / V_new) for the lanes that go on; a lane that has converged keeps the current that produced
