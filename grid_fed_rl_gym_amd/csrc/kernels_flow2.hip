@@ -828,8 +828,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // IEEE-123 feeder, ~900 cycles each with sixteen waves polling), and the six to eight sweeps of a solve were 60 % of
   // the step.  Both recurrences are sums, so they have log-depth forms with plain barriers in between:
   //   backward  J_i = -I_i + sum_children J_c = sum of -I over the SUBTREE of i.  The buses sit in preorder of the forest,
-  //             a subtree is the contiguous range [p_i, last_i], so J_i = Q[last_i] - Q[p_i - 1] with Q the inclusive
-  //             prefix sums of -I: a scan of <= 128 values per instance = local scan of a lane's items, the 16 wave
+  //             a subtree is the contiguous range [p_i, last_i], so J_i = Q[p_i - 1] - Q[last_i] with Q the inclusive
+  //             prefix sums of I: a scan of <= 128 values per instance = local scan of a lane's items, the 16 wave
   //             totals through LDS, one barrier, offsets, Q to LDS, one barrier, one read.
   //   forward   V_i = V_slack - sum of z_k J_k over the PATH root .. i.  Pointer jumping, radix 4: S_i starts as D_i = z_i J_i
   //             and in round r adds the S of the ancestors 4^r, 2 * 4^r, 3 * 4^r steps up (ancestor tables from the host);
@@ -843,9 +843,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // first barrier and ends the sweep there if it returns true (the flat-start convergence check rides on that barrier)
   auto backward = [&](auto&& at_barrier) {
     double qr[NI], qi[NI];
-    double ar = 0.0, ai = 0.0;
+    // local inclusive scan of +I (J = -(Q[last] - Q[p - 1]) is formed as Q[p - 1] - Q[last] below: no negations, no 0 + x)
+    double ar = IR[0], ai = II[0];
+    qr[0] = ar; qi[0] = ai;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) { ar += -IR[j]; ai += -II[j]; qr[j] = ar; qi[j] = ai; }      // local inclusive scan
+    for (int j = 1; j < NI; ++j) { ar += IR[j]; ai += II[j]; qr[j] = ar; qi[j] = ai; }
     // totals of the sub-groups before this one inside the wave (in sub-group order), and of the whole wave
     double pre_r, pre_i, wt_r, wt_i;
     f2_xscan<IW>(ar, l, hv, pre_r, wt_r);
@@ -886,7 +888,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double2 ql = f2_ld2(bufB + f2_slot(ilast[j], l));       // Q at the last position of the bus's subtree
       const double er = j ? br + qr[j ? j - 1 : 0] : br, ei = j ? bi + qi[j ? j - 1 : 0] : bi;             // Q[p - 1]
       // (an idle position gets some finite difference of prefix sums: its impedance is 0, so is its drop, and nothing else reads its J)
-      JR[j] = ql.x - er; JI[j] = ql.y - ei;
+      JR[j] = er - ql.x; JI[j] = ei - ql.y;
     }
   };
   stp.hit(F2_ST_INIT);
