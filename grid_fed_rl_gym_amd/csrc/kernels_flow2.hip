@@ -90,19 +90,29 @@ __device__ __forceinline__ F2Two f2_rows16(double x) {
   return F2Two{__builtin_bit_cast(double, make_uint2(lo[0], hi[0])), __builtin_bit_cast(double, make_uint2(lo[1], hi[1]))};
 }
 // the same instance's values in all HV sub-groups of the wave: maximum, and sum in a fixed order (the same on every lane:
-// sub-group order for IW = 32 and 8, (0 + 1) + (2 + 3) for the four sub-groups of IW = 16)
+// sub-group order for IW = 32, pairs first for IW = 16 and 8: (0 + 1) + (2 + 3) ...)
+// the value of the lane 8 further on in this lane's row of 16 (rotation by 8: DPP row_ror, no LDS)
+__device__ __forceinline__ double f2_ror8(double x) {
+  const uint2 u = __builtin_bit_cast(uint2, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u.x, 0x128, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u.y, 0x128, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, make_uint2(lo, hi));
+}
 template <int IW> __device__ __forceinline__ double f2_xmax(double v) {
   if constexpr (IW == 32) { const F2Two t = f2_halves32(v); return fmax(t.a, t.b); }
   else if constexpr (IW == 16) { const F2Two r = f2_rows16(v); const F2Two t = f2_halves32(fmax(r.a, r.b)); return fmax(t.a, t.b); }
+  else if constexpr (IW == 8) { return f2_xmax<16>(fmax(v, f2_ror8(v))); }
   else {
 #pragma unroll
     for (int o = IW; o < 64; o <<= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
   }
 }
+// (IW = 8: ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)), pairs first -- eight LDS shuffles until round 3)
 template <int IW> __device__ __forceinline__ double f2_xsum(double v, int l) {
   if constexpr (IW == 32) { const F2Two t = f2_halves32(v); return t.a + t.b; }
   else if constexpr (IW == 16) { const F2Two r = f2_rows16(v); const F2Two t = f2_halves32(r.a + r.b); return t.a + t.b; }
+  else if constexpr (IW == 8) { return f2_xsum<16>(v + f2_ror8(v), l); }
   else {
     double s = __shfl(v, l);
 #pragma unroll
@@ -489,9 +499,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   auto wg_max = [&](double lmax) -> double {
     const int c0 = check % 3, c1 = (check + 1) % 3;
     ++check;
-    lmax = f2_xmax<IW>(lmax);
+    // (every sub-group posts its own maximum: the LDS atomic reduces across sub-groups; an exchange first is three dependent
+    // LDS shuffles in the 8-instance member)
     if (wave == 0 && hv == 0) cell[c1 * IW + l] = 0ull;
-    if (hv == 0) atomicMax(cell + c0 * IW + l, f2_bits(lmax));
+    atomicMax(cell + c0 * IW + l, f2_bits(lmax));
     f2_lds_sync();
     return f2_dbl(cell[c0 * IW + l]);
   };
@@ -729,9 +740,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     {  // exact singularity anywhere in the instance: stop it where it is (status 2), as the reference's LinAlgError break does.
        // The flag is raised here and read behind the top-down pass, whose level barriers publish it (the pass only forms the
        // step; whether it is applied is decided afterwards): a barrier of its own cost ~800 cycles per iteration.
-#pragma unroll
-      for (int o = IW; o < 64; o <<= 1) sing |= __shfl_xor(sing, o);
-      if (sing && hv == 0) atomicOr(icell + 15 * IW + l, 1u);
+      if (sing) atomicOr(icell + 15 * IW + l, 1u);             // (any sub-group of the instance; no exchange first)
     }
     stp.hit(F2_ST_INIT);
     // ---------------- top-down: x_i = s_i - T_i x_p; corrections (power_flow.py:315-327); new (e, f) into the slots ----------------
