@@ -404,13 +404,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const double cmd = a * rating;
       if (valid && cmd > 0.0) {                               // discharge, dynamics.py:206-220
         const double p = fmin(cmd, rating);
-        const double e = fmin(p * dt / 3600.0, soc * cap * eff);
+        const double e = fmin(gs_div_by(p * dt, 3600.0, 1.0 / 3600.0), soc * cap * eff);      // (x / 3600 correctly rounded, without the division sequence)
         soc -= e / (cap * eff);
         bp = e * 3600.0 / dt;
       } else if (valid && cmd < 0.0) {                        // charge, dynamics.py:189-204
         const double p = fmin(-cmd, rating);
         const double max_e = (1.0 - soc) * cap;
-        const double e = fmin(p * dt / 3600.0, max_e / eff);
+        const double e = fmin(gs_div_by(p * dt, 3600.0, 1.0 / 3600.0), max_e / eff);
         soc += e * eff / cap;
         bp = -(e * 3600.0 / dt);
       }
@@ -1165,8 +1165,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     total_gen += p;
     total_curt += p * (1.0 - env_lds[(F.env_curt + gi) * IW + l]);
   }
-  const double totloss = totloss0 + losses * dt / 3600.0;              // grid_env.py:739
-  const double imbalance = (total_gen - total_load - losses * E.power_base) / 1e6;
+  const double totloss = totloss0 + gs_div_by(losses * dt, 3600.0, 1.0 / 3600.0);      // grid_env.py:739
+  const double imbalance = gs_div_by(total_gen - total_load - losses * E.power_base, 1e6, 1.0 / 1e6);
   double f = f_old;                                                    // dynamics.py:260-273
   f += ((imbalance - E.D * (f - E.f0)) / (2.0 * E.H * E.f0)) * dt;
   f = fmax(55.0, fmin(65.0, f));
