@@ -499,6 +499,41 @@ def test_dataflow_sweeps_agree_with_the_level_synchronous_kernel(maker, B, monke
         assert spread > 0        # at some tolerance the first group mixes instances that stop one iteration apart
 
 
+@pytest.mark.parametrize("battery_w, status, iterations", [(1e13, 1, 50), (1e300, 3, 2), (float("inf"), 3, 1)])
+def test_a_diverging_instance_is_flagged_and_leaves_its_workgroup_alone(battery_w, status, iterations, monkeypatch):
+    """One instance of a workgroup is driven out of the solvable range through its state (a battery delivering 1e13 W, 1e300 W,
+    inf): the sweeps of the second-generation kernel stop it where the level-synchronous kernel does (iteration cap / non-finite
+    mismatch, seen through the summed mismatch), and the 15 instances that share its workgroup -- and everybody else -- come out
+    bit for bit as without it."""
+    fs = P.ieee123_like()
+    B = 40
+
+    def run(perturb):
+        env = P.BatchedGridEnvironment(fs, num_envs=B, solver="fbs", stochastic_loads=False, weather_variation=False)
+        env.reset(seed=np.arange(B, dtype=np.uint64))
+        st = env.get_state()
+        if perturb:
+            st[3, env.state_layout()["battery_power"].start] = battery_w
+        env.set_state(st)
+        obs, rew, term, trunc, info = env.step(np.zeros((B, env.action_dim)))
+        kernel = env.handle.describe()["kernel"]
+        mm = env.last_solution()["max_mismatch"].copy()
+        env.close()
+        return kernel, obs.copy(), info["status"].copy(), info["iterations"].copy(), mm
+
+    k_bad, o_bad, s_bad, it_bad, mm_bad = run(True)
+    k_ok, o_ok, s_ok, it_ok, _ = run(False)
+    assert k_bad == k_ok == "fbs_flow2h"
+    others = [b for b in range(B) if b != 3]
+    assert s_bad[3] == status and it_bad[3] == iterations and (mm_bad[3] > 1e6 or not np.isfinite(mm_bad[3]))
+    assert np.all(s_bad[others] == 0) and np.array_equal(it_bad[others], it_ok[others])
+    assert np.array_equal(o_bad[others], o_ok[others])
+    monkeypatch.setenv("GS_NO_FLOW2", "1")
+    k_lvl, _, s_lvl, it_lvl, _ = run(True)
+    monkeypatch.delenv("GS_NO_FLOW2")
+    assert k_lvl != k_bad and np.array_equal(s_lvl, s_bad) and np.array_equal(it_lvl, it_bad)
+
+
 def test_dataflow_kernel_falls_back_when_a_wave_would_own_too_many_buses(monkeypatch):
     """The dataflow kernel keeps the state of at most 8 buses per wave in registers: with 4 waves per group the
     123-bus feeder takes the level-synchronous kernel, and the results do not depend on which one ran."""
