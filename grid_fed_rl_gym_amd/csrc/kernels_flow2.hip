@@ -1035,6 +1035,21 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   if (chk && wave == 0 && hv == 0) { cell[l] = 0ull; cell[IW + l] = 0ull; }      // the first two convergence cells take two maxima of the checks
   const GsChecksCfg& K = FC.C;
   double* Pv = chk ? FC.prev + (size_t)g * (n + 1) * GS_LANES + L : nullptr;
+  // The previous step's |V| of this lane's buses (and the previous frequency, and the three words of the monitor's state
+  // wave 0 updates at the very end), asked for NOW: read where they are used, each waited behind the stores issued before it
+  // (vector loads and stores return in order) -- 1.5 us of the fused step.
+  constexpr int BUS_PASSES = CHK ? NI + 1 : 1;               // passes of the bus loop: ceil(n / (HV * NW)) <= NI + 1
+  double pvp[BUS_PASSES];
+  double pv_f = 0.0;
+  int ck_has_prev = 0, ck_consec = 0, ck_emode = 0;
+  if constexpr (CHK) {
+    if (chk) {
+#pragma unroll
+      for (int q = 0; q < BUS_PASSES; ++q) { const int i0 = wave * HV + hv + q * HV * NW; pvp[q] = i0 < n ? Pv[(size_t)i0 * GS_LANES] : 0.0; }
+      if (wave == 0) pv_f = Pv[(size_t)n * GS_LANES];
+      if (wave == 0 && hv == 0 && b < (int)FC.Bp && valid) { ck_has_prev = FC.state[b]; ck_consec = FC.state[FC.Bp + b]; ck_emode = FC.state[2 * FC.Bp + b]; }
+    }
+  }
   int k_nlow = 0, k_nhigh = 0, k_mhigh = 0, k_mlow = 0, k_mem = 0, k_cover = 0, k_mover = 0, k_vbad = 0, k_fbad = 0;
   double k_dv = 0.0, k_ql = 0.0; int k_dvnan = 0, k_qlnan = 0;
 
@@ -1070,7 +1085,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // buses: (e, f) -> (|V|, angle) in place (the slots become the observation tile), state rows, reward / flag partials
   double dev = 0.0, vmax = -INFINITY, vmin = INFINITY;
   int vflags = 0;
-  for (int i0 = wave * HV + hv; i0 < ((n + HV * NW - 1) / (HV * NW)) * (HV * NW); i0 += HV * NW) {
+  auto bus_pass = [&](int i0, double pv) {
     const bool on = i0 < n; const int i = on ? i0 : n - 1;
     double2 ef = final_ef(i);
     if (!on) ef = make_double2(1.0, 0.0);                     // keep the wave on the series branch of the angle
@@ -1084,7 +1099,6 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       vflags |= (v > E.v_max) ? 1 : 0;
       vflags |= (v < E.v_min) ? 2 : 0;
       if (chk) {
-        const double pv = Pv[(size_t)i * GS_LANES];
         const bool cl = v < K.c_vlo, ch = !cl && v > K.c_vhi;                // safety.py:129-137 (elif)
         const bool mh = v > K.m_vhi, ml = v < K.m_vlo;                       // :333-337
         const bool em = v > K.m_evhi || v < K.m_evlo;                        // :340-341
@@ -1094,6 +1108,33 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         Pv[(size_t)i * GS_LANES] = v;                                        // :181-184
         if (!(fabs(v) < INFINITY)) k_vbad = 1;                               // robust_power_flow.py:643-647
         if (FC.bus_mask) FC.bus_mask[((size_t)g * n + i) * GS_LANES + L] = (uint8_t)(cl | (ch << 1) | (ml << 2) | (mh << 3) | (em << 4));
+      }
+    }
+  };
+  const int bus_passes = (n + HV * NW - 1) / (HV * NW);
+  if constexpr (CHK) {
+    if (chk) {
+#pragma unroll
+      for (int q = 0; q < BUS_PASSES; ++q) { if (q < bus_passes) bus_pass(wave * HV + hv + q * HV * NW, pvp[q]); }
+    } else {
+      for (int i0 = wave * HV + hv; i0 < bus_passes * (HV * NW); i0 += HV * NW) bus_pass(i0, 0.0);
+    }
+  } else {
+    // (the kernels without the checks keep the loop as it was written for them: the same statements, no lambda in between --
+    // the Newton-Raphson member came out 0.7 % slower through it)
+    for (int i0 = wave * HV + hv; i0 < bus_passes * (HV * NW); i0 += HV * NW) {
+      const bool on = i0 < n; const int i = on ? i0 : n - 1;
+      double2 ef = final_ef(i);
+      if (!on) ef = make_double2(1.0, 0.0);                     // keep the wave on the series branch of the angle
+      const double v = sqrt(__builtin_fma(ef.x, ef.x, ef.y * ef.y));
+      const double ang = f2_angle(ef.y, ef.x);
+      if (on) {
+        f2_st2(f2_slot(i, l), make_double2(v, ang));
+        if (!PA.lean) f2_pair(S, R.VM + i) = make_double2(v, ang);
+        dev += fabs(v - 1.0);                                   // reward / flags, grid_env.py:790-792, base.py:156-159
+        vmax = fmax(vmax, v); vmin = fmin(vmin, v);
+        vflags |= (v > E.v_max) ? 1 : 0;
+        vflags |= (v < E.v_min) ? 2 : 0;
       }
     }
   }
@@ -1221,8 +1262,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #define OF(k) FC.out_f[(size_t)(k) * FC.Bp + b]
     const int c_flow = f < K.c_flo, c_fhigh = !c_flow && f > K.c_fhi;        // safety.py:140-147
     const double vrate = k_dv / K.dt;                                        // NaN stays NaN
-    const double frate = fabs(f - Pv[(size_t)n * GS_LANES]) / K.dt;          // :174
-    const int hp = *has_prev;
+    const double frate = fabs(f - pv_f) / K.dt;                              // :174
+    const int hp = ck_has_prev;
     const int c_vr = hp && vrate > K.c_rocv, c_fr = hp && frate > K.c_rocf;
     Pv[(size_t)n * GS_LANES] = f; *has_prev = 1;
     const int c_total = c_nlow + c_nhigh + c_flow + c_fhigh + c_nover + c_vr + c_fr;
@@ -1232,9 +1273,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     OF(GS_CF_VRATE) = vrate; OF(GS_CF_FRATE) = frate;
     const int m_fhigh = f > K.m_fhi, m_flow = !m_fhigh && f < K.m_flo, m_fem = f > K.m_efhi || f < K.m_eflo;
     const int m_total = m_nhigh + m_nlow + m_nem + m_fhigh + m_flow + m_fem + m_nover;
-    const int cs = m_total > 0 ? *consec + 1 : 0;
+    const int cs = m_total > 0 ? ck_consec + 1 : 0;
     const int trigger = (m_nem > 0) || m_fem || cs > 5 || m_total > 10;
-    const int mode = *emode | trigger;
+    const int mode = ck_emode | trigger;
     *consec = cs; *emode = mode;
     OI(GS_CI_M_NHIGH) = m_nhigh; OI(GS_CI_M_NLOW) = m_nlow; OI(GS_CI_M_NEMERG) = m_nem; OI(GS_CI_M_FHIGH) = m_fhigh; OI(GS_CI_M_FLOW) = m_flow;
     OI(GS_CI_M_FEMERG) = m_fem; OI(GS_CI_M_NOVER) = m_nover; OI(GS_CI_M_TOTAL) = m_total; OI(GS_CI_M_ACTION) = trigger;
