@@ -390,6 +390,21 @@ def main():
             finally:
                 os.environ.pop("GS_STAMP_BLOCK_TIMES", None)
         if use_gather:
+            # the exchange checks itself, outside the timing: one more step and gather, every rank's own block against the
+            # slot it landed in on every rank, and what RCCL itself says about the communicator (ranks, devices)
+            try:
+                from grid_fed_rl_gym_amd.sharding import verify_gathered_block
+                h.step_device(0)
+                full = h.allgather_obs(to_host=True)
+                own = h.download_step()["obs"]
+                m["gather_check"] = verify_gathered_block(full, own, rank, world, rz.all_gather_bytes)
+                infos = [json.loads(b.decode()) for b in rz.all_gather_bytes(json.dumps(h.comm_info()).encode())]
+                m["rccl"] = {"nranks": infos[0]["nranks"], "version": infos[0]["rccl_version"], "ranks": infos,
+                             "every_rank_reports_the_same_nranks": len({i["nranks"] for i in infos}) == 1,
+                             "distinct_devices": len({i["device_uuid"] for i in infos}),
+                             "how": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion and hipDeviceGetUuid on every rank (gs_comm_info)"}
+            except Exception as e:
+                m["gather_check"] = {"gather_verified": False, "error": str(e)}
             h.comm_destroy()
         env.close()
         return m
@@ -431,11 +446,22 @@ def main():
         # the exchanged block against the members' own observations, once, outside the timing
         full = _lib.Handle.allgather_obs_shards(hs, to_host=True)
         same = all(np.array_equal(full[r * B:(r + 1) * B], hs[r].download_step()["obs"]) for r in range(W))
+        # the N-rank run's self-check (verify_gathered_block), rehearsed: every member's own gathered block, checksums "exchanged" in-process
+        from grid_fed_rl_gym_amd.sharding import block_checksum
+        owns = [h.download_step()["obs"] for h in hs]
+        sums = [block_checksum(o) for o in owns]
+        checks = []
+        for r, h in enumerate(hs):
+            mine = h.allgather_obs_download()
+            bad = [q for q in range(W) if block_checksum(mine[q * B:(q + 1) * B]) != sums[q]]
+            checks.append(not bad)
+        info0 = hs[0].comm_info()
         desc = hs[0].describe()
         for env in envs:
             env.close()
         return dict(plain=plain, gathered=gathered, desc=desc, converged_fraction=float(out["power_flow_converged"].mean()),
-                    gathered_block_equals_member_observations=bool(same))
+                    gathered_block_equals_member_observations=bool(same), gather_verified=bool(all(checks)) and len(set(sums)) == W,
+                    comm_info=info0)
 
     def loopback_summary(fs, B, W, m, steps):
         obs_bytes = B * (fs.obs_dim - 2 * fs.n_loads) * 8
@@ -449,6 +475,7 @@ def main():
                 "exchange_ms_per_step": d_ms, "bytes_sent_per_rank_per_step": obs_bytes,
                 "bytes_copied_on_the_device_per_step": W * W * obs_bytes,
                 "gathered_block_equals_member_observations": m["gathered_block_equals_member_observations"],
+                "gather_verified": m["gather_verified"], "comm_info_rank0": m["comm_info"],
                 "converged_fraction": m["converged_fraction"],
                 "note": f"all {W} ranks' shards are handles of ONE process on ONE GPU; the exchange is the RCCL transport's device code "
                         "(compaction, slot offsets, expansion, constant columns, double-buffer events) with device-to-device copies in "
@@ -606,6 +633,12 @@ def main():
                                                    reference_settings_vs_converged=fmt(worst["ref_vs_exact"])),
                    same_algorithm_same_tolerance=dict(fmt(worst["same"]), against=f"C oracle running the GPU's solver ({solver}) at the GPU's tolerance"),
                    sample=f"{b} instances x 3 steps of the workload", gpu_tolerance=kw["tolerance"])
+        # the bar, machine-readable: north_star words it against the reference solver's own output ("vs_reference_settings");
+        # for the sweep solver the line flows miss that by the reference iterate's own distance from convergence (the
+        # documented deviation, DESIGN.md section 2: tests/test_gpu_fullsize.py keeps the strict form as an expected failure)
+        inside = lambda w: {q: bool(w[q] < 1e-6) for q in ("Vm", "Va", "flow")}
+        out["within_bar"] = {"vs_reference_settings": inside(worst["ref"]), "vs_converged": inside(worst["exact"]),
+                             "reference_settings_vs_converged": inside(worst["ref_vs_exact"])}
         return out
 
     def summarize(m, n_ranks):
@@ -698,6 +731,9 @@ def main():
                                                "value_p10_p90": plain["value_p10_p90"],
                                                "note": "the same sharded steps with no exchange: the ranks are independent (a learner that consumes its own shard)"}
             if gather_m is not None:
+                result["gather_verified"] = bool(gather_m.get("gather_check", {}).get("gather_verified", False))
+                result["gather_check"] = gather_m.get("gather_check")
+                result["rccl"] = gather_m.get("rccl")
                 d_ms = head["ms_per_step"] - plain["ms_per_step"]
                 result["obs_allgather"] = {"allgather_ms_per_step": d_ms, "bytes_sent_per_rank_per_step": obs_bytes,
                                            "bytes_received_per_rank_per_step": (world - 1) * obs_bytes,
@@ -800,6 +836,10 @@ def main():
             result["cpu_baseline_1core"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=6.0, threads=1)
             # every CPU in this process's affinity mask (the 16-thread figure above is the share of the host one GPU gets)
             result["cpu_baseline_all_cores"] = cpu_baseline(fs, env_kwargs_of("nr"), budget_s=6.0, threads="all")
+            # the baseline the headline is set beside is the FASTER of the two (cores stated in it); the other stays in the line
+            a, b16 = result["cpu_baseline_all_cores"], result["cpu_baseline"]
+            if a and b16 and a.get("value", 0.0) > b16.get("value", 0.0):
+                result["cpu_baseline"], result["cpu_baseline_gpu_share_of_host"] = a, b16
             if solver0 != "nr":
                 result["cpu_baseline_same_solver"] = cpu_baseline(fs, env_kwargs_of(solver0), budget_s=6.0)
                 result["cpu_baseline_same_solver_1core"] = cpu_baseline(fs, env_kwargs_of(solver0), budget_s=4.0, threads=1)

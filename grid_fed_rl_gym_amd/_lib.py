@@ -108,6 +108,7 @@ SYMBOLS = [
     ("gs_comm_init", C.c_int, [_H, _up, C.c_int32, C.c_int32]),
     ("gs_allgather_obs", C.c_int, [_H, _dp]),
     ("gs_comm_destroy", C.c_int, [_H]),
+    ("gs_comm_info", C.c_int, [_H, C.c_void_p]),
     ("gs_comm_init_loopback", C.c_int, [C.POINTER(_H), C.c_int32]),
     ("gs_allgather_obs_shards", C.c_int, [C.POINTER(_H), C.c_int32, _dp]),
     ("gs_allgather_obs_view", C.c_int, [_H, C.c_void_p, C.c_void_p]),
@@ -178,6 +179,12 @@ def make_config(**kw) -> gs_config:
     for k, v in d.items():
         setattr(cfg, k, v)
     return cfg
+
+
+class gs_comm_info_t(C.Structure):
+    _fields_ = [("transport", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32), ("device", C.c_int32),
+                ("comm_device", C.c_int32), ("rccl_version", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+                ("device_uuid", C.c_uint8 * 16)]
 
 
 class gs_gathered_obs(C.Structure):
@@ -613,6 +620,15 @@ class Handle:
 
     def comm_destroy(self) -> None:
         self._check(self._lib.gs_comm_destroy(self._h))
+
+    def comm_info(self) -> dict:
+        """gs_comm_info: what the communicator itself reports about this member (RCCL's rank count, rank, device and version;
+        -1 where the library lacks the entry point) and the HIP device's UUID."""
+        v = gs_comm_info_t()
+        self._check(self._lib.gs_comm_info(self._h, C.byref(v)))
+        return {"transport": {1: "rccl", 2: "loopback"}.get(v.transport, "?"), "nranks": int(v.nranks), "rank": int(v.rank),
+                "device": int(v.device), "comm_device": int(v.comm_device), "rccl_version": int(v.rccl_version),
+                "device_uuid": bytes(v.device_uuid).hex()}
 
     @staticmethod
     def comm_init_loopback(handles) -> None:

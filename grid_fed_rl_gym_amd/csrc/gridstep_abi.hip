@@ -39,6 +39,10 @@ struct RcclApi {
   int (*CommDestroy)(gs_ncclComm_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*CommCount)(gs_ncclComm_t, int*) = nullptr;
+  int (*CommUserRank)(gs_ncclComm_t, int*) = nullptr;
+  int (*CommCuDevice)(gs_ncclComm_t, int*) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -56,6 +60,10 @@ bool load_rccl(std::string& why) {
   a.CommDestroy = (int (*)(gs_ncclComm_t))dlsym(lib, "ncclCommDestroy");
   a.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
   a.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+  a.CommCount = (int (*)(gs_ncclComm_t, int*))dlsym(lib, "ncclCommCount");
+  a.CommUserRank = (int (*)(gs_ncclComm_t, int*))dlsym(lib, "ncclCommUserRank");
+  a.CommCuDevice = (int (*)(gs_ncclComm_t, int*))dlsym(lib, "ncclCommCuDevice");
+  a.GetVersion = (int (*)(int*))dlsym(lib, "ncclGetVersion");
   a.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
   if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) { why = "librccl lacks a required symbol"; return false; }
   g_rccl = a;
@@ -801,6 +809,9 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     F.n_jump = n_jump;
     if (getenv("GS_NO_FLOW2")) why = "disabled by GS_NO_FLOW2";
     else if (N > NPOS) why = "more than " + std::to_string(NPOS) + " buses below the slack";
+    // (the second-generation sweeps hold their stopping criterion, the summed mismatch, in 2^-44 pu fixed point: below ~1e-10 the
+    // threshold is a handful of units and every lane's rounding shows; the first-generation kernels compare in double precision)
+    else if (!(cfg->tolerance >= 1e-10)) why = "tolerance below 1e-10";
     else if (N != ht.lvl_ptr[ht.n_levels]) why = "part of the forest does not hang off the slack bus";
     else if (max_dev > 2) why = "more than two devices of a kind at one bus";
     else if (off > 160 * 1024) why = "LDS tables do not fit";
@@ -1741,7 +1752,7 @@ struct GsLoopComm {
   std::vector<double*> host_out;
 };
 
-static int loop_complete(GsLoopComm* lc) {
+static int loop_complete_body(GsLoopComm* lc) {
   const gs_handle* h0 = lc->member[0];
   const int D = h0->obs_dim, nd = D - (h0->obs_skip1 - h0->obs_skip0);
   const size_t count = (size_t)h0->B * nd;
@@ -1762,12 +1773,21 @@ static int loop_complete(GsLoopComm* lc) {
     if (lc->host_out[r])
       HIPCHK(q, hipMemcpyAsync(lc->host_out[r], q->d_obs_full, (size_t)q->B * D * lc->world * sizeof(double), hipMemcpyDeviceToHost, q->comm_stream));
   }
-  for (int r = 0; r < lc->world; ++r) {
+  for (int r = 0; r < lc->world; ++r)
     if (lc->host_out[r]) HIPCHK(lc->member[r], hipStreamSynchronize(lc->member[r]->comm_stream));
-    lc->host_out[r] = nullptr; lc->arrived[r] = 0;
-  }
-  lc->n_arrived = 0;
   return GS_OK;
+}
+
+// The round ends here whether or not it succeeded: a failed round leaves no member "arrived" and keeps no pointer into
+// the callers' memory, so that the next call reports its own error (or works) instead of "called twice" / "gather half-way".
+static int loop_complete(GsLoopComm* lc) {
+  const int rc = loop_complete_body(lc);
+  if (rc)       // copies of the failed round may still be queued towards the callers' host arrays: drain before letting go of them
+    for (int r = 0; r < lc->world; ++r)
+      if (lc->host_out[r] && lc->member[r] && lc->member[r]->comm_stream) { (void)hipSetDevice(lc->member[r]->device); (void)hipStreamSynchronize(lc->member[r]->comm_stream); }
+  for (int r = 0; r < lc->world; ++r) { lc->host_out[r] = nullptr; lc->arrived[r] = 0; }
+  lc->n_arrived = 0;
+  return rc;
 }
 
 int gs_comm_init_loopback(gs_handle* const* shards, int32_t nshards) {
@@ -1807,13 +1827,15 @@ int gs_comm_init_loopback(gs_handle* const* shards, int32_t nshards) {
   return GS_OK;
 }
 
-int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
-  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
-  if (!h->comm && !h->loop) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init / gs_comm_init_loopback");
+// The exchange of one member in three parts, so that a process driving several members through RCCL can put ONLY the
+// collectives between ncclGroupStart and ncclGroupEnd: inside a group ncclAllGather merely records the call, the work is
+// enqueued on the exchange stream at ncclGroupEnd -- anything launched on that stream in between (the expansion, a
+// download) would run BEFORE the collective and see the previous round's block.
+//   gather_prepare     behind the step that produced the current observation buffer: compact its changing columns
+//   gather_collective  ncclAllGather of the compact blocks (RCCL transport only)
+//   gather_finish      expand into [world * B][obs_dim]; optional download
+static int gather_prepare(gs_handle* h) {
   GsLoopComm* lc = h->loop;
-  if (lc && lc->n_live != lc->world) return fail(h, GS_E_STATE, "a member of the loopback communicator has left");
-  if (lc && lc->arrived[h->rank]) return fail(h, GS_E_STATE, "rank %d called gs_allgather_obs twice before every member had called once", h->rank);
-  GS_ENTER(h);
   const int D = h->obs_dim, nd = D - (h->obs_skip1 - h->obs_skip0);
   const size_t count = (size_t)h->B * nd;
   // On its own stream, behind the step that produced the current observation buffer.  Only the columns that change
@@ -1831,15 +1853,19 @@ int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev_gather[cur], h->comm_stream));
   h->gather_pending[cur] = true;
-  if (lc) {
-    HIPCHK(h, hipEventRecord(lc->ev_sent[h->rank], h->comm_stream));
-    lc->arrived[h->rank] = 1; lc->host_out[h->rank] = obs_full_host;
-    if (++lc->n_arrived == lc->world) return loop_complete(lc);
-    return GS_OK;
-  }
-  int rc = g_rccl.AllGather(h->d_gather_send, h->d_gather_recv, count, /*ncclFloat64*/ 8, h->comm, h->comm_stream);
+  return GS_OK;
+}
+
+static int gather_collective(gs_handle* h) {
+  const size_t count = (size_t)h->B * (h->obs_dim - (h->obs_skip1 - h->obs_skip0));
+  const int rc = g_rccl.AllGather(h->d_gather_send, h->d_gather_recv, count, /*ncclFloat64*/ 8, h->comm, h->comm_stream);
   if (rc != 0) return fail(h, GS_E_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
-  const size_t total = count * h->world;
+  return GS_OK;
+}
+
+static int gather_finish(gs_handle* h, double* obs_full_host) {
+  const int D = h->obs_dim;
+  const size_t total = (size_t)h->B * (D - (h->obs_skip1 - h->obs_skip0)) * h->world;
   hipLaunchKernelGGL(gs_k_obs_compact, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->comm_stream, h->d_gather_recv, h->d_obs_full,
                      (long long)h->world * h->B, D, h->obs_skip0, h->obs_skip1, 1);
   HIPCHK(h, hipGetLastError());
@@ -1850,6 +1876,25 @@ int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
   return GS_OK;
 }
 
+int gs_allgather_obs(gs_handle* h, double* obs_full_host) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  if (!h->comm && !h->loop) return fail(h, GS_E_STATE, "gs_allgather_obs before gs_comm_init / gs_comm_init_loopback");
+  GsLoopComm* lc = h->loop;
+  if (lc && lc->n_live != lc->world) return fail(h, GS_E_STATE, "a member of the loopback communicator has left");
+  if (lc && lc->arrived[h->rank]) return fail(h, GS_E_STATE, "rank %d called gs_allgather_obs twice before every member had called once", h->rank);
+  GS_ENTER(h);
+  int rc = gather_prepare(h);
+  if (rc) return rc;
+  if (lc) {
+    HIPCHK(h, hipEventRecord(lc->ev_sent[h->rank], h->comm_stream));
+    lc->arrived[h->rank] = 1; lc->host_out[h->rank] = obs_full_host;
+    if (++lc->n_arrived == lc->world) return loop_complete(lc);
+    return GS_OK;
+  }
+  if ((rc = gather_collective(h))) return rc;
+  return gather_finish(h, obs_full_host);
+}
+
 int gs_allgather_obs_shards(gs_handle* const* shards, int32_t nshards, double* obs_full_host) {
   if (!shards || nshards < 1 || !shards[0]) return fail(nullptr, GS_E_INVALID, "bad arguments");
   GsLoopComm* lc = shards[0]->loop;
@@ -1858,15 +1903,27 @@ int gs_allgather_obs_shards(gs_handle* const* shards, int32_t nshards, double* o
     if (shards[r]->loop != lc || (!lc && !shards[r]->comm)) return fail(shards[r], GS_E_STATE, "shard %d is not in the communicator of shard 0", r);
   }
   if (lc && (nshards != lc->world || lc->n_arrived != 0)) return fail(shards[0], GS_E_STATE, "the call must name every member of the loopback communicator once, with no gather half-way");
-  if (!lc) {      // one process driving several GPUs through RCCL: the members' calls form one group
+  if (!lc) {      // one process driving several GPUs through RCCL: the members' collectives form one group (see gather_prepare)
     if (!g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(shards[0], GS_E_COMM, "librccl lacks ncclGroupStart / ncclGroupEnd");
-    g_rccl.GroupStart();
     int rc = GS_OK;
-    for (int r = 0; r < nshards && !rc; ++r) rc = gs_allgather_obs(shards[r], nullptr);
-    const int rg = g_rccl.GroupEnd();
+    for (int r = 0; r < nshards; ++r) {
+      gs_handle* h = shards[r];
+      GS_ENTER(h);
+      if ((rc = gather_prepare(h))) return rc;
+    }
+    g_rccl.GroupStart();
+    for (int r = 0; r < nshards && !rc; ++r) {
+      if (hipSetDevice(shards[r]->device) != hipSuccess) rc = fail(shards[r], GS_E_HIP, "hipSetDevice failed");
+      else rc = gather_collective(shards[r]);
+    }
+    const int rg = g_rccl.GroupEnd();          // (always closed, also after a failed call inside the group)
     if (rc) return rc;
     if (rg != 0) return fail(shards[0], GS_E_COMM, "ncclGroupEnd: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rg) : "error");
-    return obs_full_host ? gs_allgather_obs_download(shards[0], obs_full_host) : GS_OK;
+    for (int r = 0; r < nshards; ++r) {
+      HIPCHK(shards[r], hipSetDevice(shards[r]->device));
+      if ((rc = gather_finish(shards[r], r == 0 ? obs_full_host : nullptr))) return rc;
+    }
+    return GS_OK;
   }
   for (int r = 0; r < nshards; ++r) {
     int rc = gs_allgather_obs(shards[r], r == 0 ? obs_full_host : nullptr);
@@ -1897,6 +1954,27 @@ int gs_allgather_obs_download(gs_handle* h, double* obs_full_host) {
   int rc = gs_allgather_obs_view(h, &v, nullptr);
   if (rc) return rc;
   HIPCHK(h, hipMemcpy(obs_full_host, v.observations, (size_t)v.rows * v.obs_dim * sizeof(double), hipMemcpyDeviceToHost));
+  return GS_OK;
+}
+
+// What the communicator itself says about this member -- asked of RCCL (ncclCommCount / ncclCommUserRank /
+// ncclCommCuDevice / ncclGetVersion), not echoed from the arguments of gs_comm_init --, and the device's UUID, so that a
+// multi-rank run can show in its own output that N ranks on N different devices took part.
+int gs_comm_info(gs_handle* h, gs_comm_info_t* out) {
+  if (!h || !out) return fail(h, GS_E_INVALID, "handle / out is NULL");
+  if (!h->comm && !h->loop) return fail(h, GS_E_STATE, "no communicator on this handle");
+  memset(out, 0, sizeof *out);
+  out->transport = h->comm ? 1 : 2;
+  out->device = h->device;
+  hipUUID uu;
+  if (hipDeviceGetUuid(&uu, h->device) == hipSuccess) memcpy(out->device_uuid, uu.bytes, 16);
+  if (h->loop) { out->nranks = h->loop->world; out->rank = h->rank; out->comm_device = h->device; return GS_OK; }
+  int v = 0;
+  out->nranks = -1; out->rank = -1; out->comm_device = -1;
+  if (g_rccl.CommCount && g_rccl.CommCount(h->comm, &v) == 0) out->nranks = v;
+  if (g_rccl.CommUserRank && g_rccl.CommUserRank(h->comm, &v) == 0) out->rank = v;
+  if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(h->comm, &v) == 0) out->comm_device = v;
+  if (g_rccl.GetVersion && g_rccl.GetVersion(&v) == 0) out->rccl_version = v;
   return GS_OK;
 }
 

@@ -36,6 +36,32 @@ def instance_seeds(global_seed: int, start: int, stop: int) -> np.ndarray:
     return (np.uint64(global_seed) + np.arange(start, stop, dtype=np.uint64)).astype(np.uint64)
 
 
+def block_checksum(block: np.ndarray) -> bytes:
+    """SHA-256 of a block of observations as the bytes it holds (float64, row-major)."""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(block, dtype=np.float64).tobytes()).digest()
+
+
+def verify_gathered_block(full: np.ndarray, own: np.ndarray, rank: int, world: int, all_gather_bytes) -> dict:
+    """Does the block an all-gather left on THIS rank hold, in slot r, exactly what rank r computed?  Every rank checksums
+    its own observations, the checksums travel beside the data path (``all_gather_bytes``: a callable that all-gathers a
+    ``bytes`` object over the ranks in rank order, e.g. ``FileRendezvous.all_gather_bytes``), and every rank compares the
+    checksum of every slot of ITS gathered block with the owner's.  The per-rank verdicts are gathered the same way, so all
+    ranks return the same record: ``gather_verified`` is True only if every slot matched on every rank."""
+    rows = own.shape[0]
+    if full.shape[0] != world * rows:
+        raise ValueError(f"gathered block has {full.shape[0]} rows, expected {world} x {rows}")
+    sums = all_gather_bytes(block_checksum(own))
+    bad = [r for r in range(world) if block_checksum(full[r * rows:(r + 1) * rows]) != sums[r]]
+    verdicts = all_gather_bytes(bytes([0 if r in bad else 1 for r in range(world)]))
+    table = [list(v) for v in verdicts]                      # table[q][r]: rank q found slot r equal to rank r's block
+    return {"gather_verified": all(all(row) for row in table),
+            "slots_matching_per_rank": [int(sum(row)) for row in table],
+            "own_slot_is_own_block": bool(rank not in bad),
+            "distinct_shard_checksums": len(set(sums)),
+            "how": "SHA-256 of each rank's own [B][obs_dim] block, exchanged beside the data path; every rank compares every slot of its gathered block"}
+
+
 def host_all_gather(local: np.ndarray, total: int, rank: int, world: int, group: Any = None) -> np.ndarray:
     """All-gather of row blocks on host arrays; shards may be uneven.  Returns the [total, ...] array in global order.
     ``group``: a ``rendezvous.FileRendezvous`` (no framework at all), or a ``torch.distributed`` process group / None for

@@ -108,7 +108,9 @@ typedef struct gs_config {
   int32_t fbs_warm_start;         /* 0 (default): every step solves from the flat start, as the reference's solve() does
                                      (power_flow.py:125-134); 1: the sweep solver starts from the previous step's voltages --
                                      same tolerance, fewer sweeps; an option, never the measured headline */
-  double tolerance;               /* power_flow.py:81 (default 1e-6) */
+  double tolerance;               /* power_flow.py:81 (default 1e-6).  Sweep solver: the summed mismatch is held against
+                                     tolerance / 2; below 1e-10 a handle runs the first-generation sweep kernels (double-precision
+                                     comparison; the second generation keeps the sum in 2^-44 pu fixed point), gs_describe says so */
   double acceleration_factor;     /* power_flow.py:83 (default 1.0) */
   double timestep;                /* grid_env.py:164 */
   double v_min, v_max;            /* grid_env.py:170 */
@@ -289,6 +291,14 @@ int gs_comm_init(gs_handle* h, const uint8_t id[128], int32_t rank, int32_t worl
  * buffer [world*B][obs_dim]; obs_full_host may be NULL (stay on device) */
 int gs_allgather_obs(gs_handle* h, double* obs_full_host);
 int gs_comm_destroy(gs_handle* h);
+/* What the communicator reports about this member: asked of RCCL itself (ncclCommCount, ncclCommUserRank, ncclCommCuDevice,
+ * ncclGetVersion; -1 where the library lacks the entry point), plus the HIP device's UUID -- so that the output of an N-rank
+ * run shows N ranks on N distinct devices.  transport: 1 RCCL, 2 the in-process loopback (nranks / rank from the group). */
+typedef struct gs_comm_info_t {
+  int32_t transport, nranks, rank, device, comm_device, rccl_version, reserved0, reserved1;
+  uint8_t device_uuid[16];
+} gs_comm_info_t;
+int gs_comm_info(gs_handle* h, gs_comm_info_t* out);
 /* The in-process transport: `nshards` handles of ONE process (shard r built with first_instance = r * B; normally all on
  * one device) form the communicator, rank = position in `shards`.  A member's compact block reaches the others by
  * device-to-device copies on their exchange streams where RCCL would move it over xGMI; compaction, slot offsets,

@@ -324,6 +324,22 @@ static int fbs_one(const orc_net* t, const orc_prep* p, const orc_cfg* c, const 
 static size_t work_doubles(const orc_prep* p) { return (size_t)10 * p->n + 2 * (size_t)p->N + (size_t)p->N * p->N + 16; }
 static size_t work_ints(const orc_prep* p) { return (size_t)3 * p->n + p->N + 16; }
 
+/* Per-thread scratch that outlives a call.  The OpenMP runtime keeps its worker threads between parallel regions, so a
+ * buffer held in thread-local storage is allocated (and its pages first touched, on the thread's own NUMA node) once per
+ * thread and process.  Allocated inside every call it was half a megabyte per thread -- above malloc's mmap threshold, so
+ * every call of every thread mapped, faulted in and unmapped its pages under the process-wide address-space lock: with 256
+ * threads the batched step ran three times SLOWER than with 16. */
+static __thread double* tl_work = 0; static __thread size_t tl_work_cap = 0;
+static __thread int* tl_iwork = 0; static __thread size_t tl_iwork_cap = 0;
+static double* tl_doubles(size_t count) {
+  if (count > tl_work_cap) { free(tl_work); tl_work = (double*)malloc(sizeof(double) * count); tl_work_cap = tl_work ? count : 0; }
+  return tl_work;
+}
+static int* tl_ints(size_t count) {
+  if (count > tl_iwork_cap) { free(tl_iwork); tl_iwork = (int*)malloc(sizeof(int) * count); tl_iwork_cap = tl_iwork ? count : 0; }
+  return tl_iwork;
+}
+
 /* ---- batched solve: P[B][n], outputs [B][n] / [B][m] / [B] ------------------------------------ */
 int orc_solve_batch(const orc_net* t, const orc_cfg* c, int32_t B, const double* P, const double* Q, double* Vm, double* Va,
                     double* flow, double* loading, double* losses, double* max_mismatch, int32_t* iterations,
@@ -335,12 +351,20 @@ int orc_solve_batch(const orc_net* t, const orc_cfg* c, int32_t B, const double*
 #pragma omp parallel num_threads(nt)
 #endif
   {
-    double* work = (double*)malloc(sizeof(double) * work_doubles(&p));
-    int* iwork = (int*)malloc(sizeof(int) * work_ints(&p));
+    double* work = tl_doubles(work_doubles(&p));
+    int* iwork = tl_ints(work_ints(&p));
+    if (!work || !iwork) {
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 4)
+#pragma omp atomic write
+#endif
+      bad = 2;
+    }
+    /* static chunks of whole instances: every thread a contiguous block of the batch (its outputs in its own cache lines) */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
 #endif
     for (int b = 0; b < B; ++b) {
+      if (!work || !iwork) continue;
       orc_sol s; s.Vm = Vm + (size_t)b * t->n; s.Va = Va + (size_t)b * t->n;
       s.flow = flow + (size_t)b * t->m; s.loading = loading + (size_t)b * t->m;
       const double* Pb = P + (size_t)b * t->n; const double* Qb = Q ? Q + (size_t)b * t->n : 0;
@@ -349,10 +373,9 @@ int orc_solve_batch(const orc_net* t, const orc_cfg* c, int32_t B, const double*
       losses[b] = s.losses; max_mismatch[b] = s.max_mismatch; iterations[b] = s.iterations;
       converged[b] = (uint8_t)s.converged; status[b] = s.status;
     }
-    free(work); free(iwork);
   }
   prep_free(&p);
-  return bad ? -4 : 0;
+  return bad == 2 ? -2 : bad ? -4 : 0;
 }
 
 /* ---- Philox4x32-10, identical stream to oracle_np.py / kernels_env.hip ------------------------ */
@@ -470,14 +493,21 @@ int orc_env_step(const orc_net* t, const orc_cfg* c, int32_t B, const double* ac
 #pragma omp parallel num_threads(nt)
 #endif
   {
-    double* work = (double*)malloc(sizeof(double) * (work_doubles(&p) + 6 * (size_t)n + 2 * (size_t)m + t->n_loads));
-    int* iwork = (int*)malloc(sizeof(int) * work_ints(&p));
+    double* work = tl_doubles(work_doubles(&p) + 6 * (size_t)n + 2 * (size_t)m + t->n_loads);
+    int* iwork = tl_ints(work_ints(&p));
+    if (!work || !iwork) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+      bad = 2;
+    }
     double *Pspec = work + work_doubles(&p), *ls = Pspec + n, *gs = ls + n, *sVm = gs + n, *sVa = sVm + n;
     double *sflow = sVa + n + n, *sload = sflow + m, *loadp = sload + m;
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 4)
+#pragma omp for schedule(static)
 #endif
     for (int b = 0; b < B; ++b) {
+      if (!work || !iwork) continue;
       double* st = state + (size_t)b * sd;
       const double* act = actions + (size_t)b * A;
       double *soc = st + S_FIXED, *batp = soc + t->n_bats, *curt = batp + t->n_bats;
@@ -536,10 +566,9 @@ int orc_env_step(const orc_net* t, const orc_cfg* c, int32_t B, const double* ac
       if (viol4) { viol4[4 * b] = (uint8_t)vh; viol4[4 * b + 1] = (uint8_t)vl; viol4[4 * b + 2] = (uint8_t)fh; viol4[4 * b + 3] = (uint8_t)fl; }
       if (obs) observe(t, st, obs + (size_t)b * od);
     }
-    free(work); free(iwork);
   }
   prep_free(&p);
-  return bad ? -4 : 0;
+  return bad == 2 ? -2 : bad ? -4 : 0;
 }
 
 int orc_max_threads(void) {

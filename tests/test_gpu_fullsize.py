@@ -3,6 +3,8 @@ whole batch: the power-flow equations re-evaluated with the oracle's Ybus on the
 identity, the observation layout, independence of an instance's result from the batch it runs in (the property
 the multi-GPU sharding rests on), and monotonicity in the loading.  Complements the oracle-parity tests, which run
 at sizes the oracle finishes in seconds."""
+import functools
+
 import numpy as np
 import pytest
 
@@ -141,24 +143,12 @@ def test_full_size_three_phase_batch_properties():
     s.close()
 
 
-@pytest.mark.parametrize("maker,solver,bar", [(lambda: P.ieee123_like(), "fbs", 1e-6),            # BASELINE config 3 (headline)
-                                              (lambda: P.ieee123_like(), "nr", 1e-6),
-                                              (lambda: P.ieee13_like("epsilon"), "nr", 1e-6),      # BASELINE config 2
-                                              (lambda: P.ieee13_like("epsilon"), "fbs", 1e-6)])
-def test_north_star_accuracy_bar_against_the_reference_algorithm_at_its_own_settings(maker, solver, bar):
-    """north_star: "bus voltages and line flows within 1e-6 pu of the reference NumPy/CPU solver".  The reference's solver
-    is Newton-Raphson stopping at a 1e-6 mismatch (power_flow.py:81, 168-171); the oracle runs exactly that, the GPU runs
-    the benchmark's configuration (either solver, tolerance 1e-6) on the same instances, steps and draws.
-
-    Newton-Raphson (the reference's algorithm): the same iterates, 1e-13 -- held to the bar against the reference's own output.
-
-    The sweep solver is a different algorithm, and the reference's output at ITS tolerance is an unconverged iterate: in
-    this workload (midday peak) its line flows sit 1.3e-6 pu from the solution of the power-flow equations, so no other
-    algorithm can be promised to land within 1e-6 of it.  What the sweep solver is held to: (1) within the bar of the
-    CONVERGED solution (oracle Newton-Raphson at 1e-12) in |V|, angle and flows -- it stops on the summed mismatch, which
-    bounds every line flow's error (round 3; with the maximum alone it stopped up to 6.7e-6 away) --, and (2) within the bar
-    PLUS the reference's own distance from convergence of the reference's output."""
-    spec = maker(); B = 48
+@functools.lru_cache(maxsize=None)
+def _north_star_worst(feeder, solver):
+    """Largest |V| / angle / line-flow differences (pu, rad, pu) of the GPU at the benchmark's configuration (tolerance 1e-6) on
+    48 instances x 2 steps at the midday peak against the oracle's Newton-Raphson at the reference's settings ("ref", tolerance
+    1e-6, power_flow.py:81) and -- sweep solver -- converged to 1e-12 ("exact"), and of those two against each other."""
+    spec = P.ieee123_like() if feeder == "ieee123" else P.ieee13_like("epsilon"); B = 48
     env = P.BatchedGridEnvironment(spec, num_envs=B, solver=solver, stochastic_loads=True, weather_variation=True, jacobian="exact",
                                    tolerance=1e-6, max_iterations=100 if solver == "fbs" else 50)
     seeds = np.arange(B, dtype=np.uint64) + 77
@@ -191,12 +181,54 @@ def test_north_star_accuracy_bar_against_the_reference_algorithm_at_its_own_sett
                 if "exact" in o:
                     worst["ref_vs_exact"][q] = max(worst["ref_vs_exact"][q], np.abs(o["ref"][sl] - o["exact"][sl]).max())
     env.close()
+    return worst
+
+
+_NORTH_STAR_CASES = [("ieee123", "fbs", 1e-6),            # BASELINE config 3 (headline)
+                     ("ieee123", "nr", 1e-6),
+                     ("ieee13", "nr", 1e-6),               # BASELINE config 2
+                     ("ieee13", "fbs", 1e-6)]
+
+
+@pytest.mark.parametrize("feeder,solver,bar", _NORTH_STAR_CASES)
+def test_north_star_accuracy_bar_against_the_reference_algorithm_at_its_own_settings(feeder, solver, bar):
+    """north_star: "bus voltages and line flows within 1e-6 pu of the reference NumPy/CPU solver".  The reference's solver
+    is Newton-Raphson stopping at a 1e-6 mismatch (power_flow.py:81, 168-171); the oracle runs exactly that, the GPU runs
+    the benchmark's configuration (either solver, tolerance 1e-6) on the same instances, steps and draws.
+
+    Newton-Raphson (the reference's algorithm): the same iterates, 1e-13 -- held to the bar against the reference's own output.
+
+    The sweep solver is a different algorithm, and the reference's output at ITS tolerance is an unconverged iterate: in
+    this workload (midday peak) its line flows sit 1.3e-6 pu from the solution of the power-flow equations, so no other
+    algorithm can be promised to land within 1e-6 of it.  What the sweep solver is held to: (1) within the bar of the
+    CONVERGED solution (oracle Newton-Raphson at 1e-12) in |V|, angle and flows -- it stops on the summed mismatch, which
+    bounds every line flow's error (round 3; with the maximum alone it stopped up to 6.7e-6 away) --, and (2) within the bar
+    PLUS the reference's own distance from convergence of the reference's output.  The strict form of (2) -- the bar alone,
+    as north_star words it -- is the next test: it is expected to fail for the line flows of the headline workload and is
+    kept visible as such."""
+    worst = _north_star_worst(feeder, solver)
     if solver == "nr":
         assert max(worst["ref"].values()) < bar, worst
     else:
         assert max(worst["exact"].values()) < bar, worst
-        for q in cols:
+        for q in ("Vm", "Va", "flow"):
             assert worst["ref"][q] < bar + worst["ref_vs_exact"][q], worst
+
+
+@pytest.mark.parametrize("quantity", ["Vm", "Va", "flow"])
+@pytest.mark.parametrize("feeder", ["ieee123", "ieee13"])
+def test_sweep_solver_strictly_within_the_bar_of_the_reference_at_its_own_settings(feeder, quantity, request):
+    """The bar as north_star words it -- 1e-6 pu against the reference solver's own output (Newton-Raphson stopped at a 1e-6
+    mismatch) -- with no allowance for that output's distance from convergence.  |V| and angle pass (7e-8, 9e-8 on the
+    headline workload).  The line flows of the 123-bus workload do not: 1.29e-6 pu, of which 1.32e-6 is the reference
+    iterate's own distance from the converged solution (the sweep solver is 4.6e-8 from it).  That case is marked
+    xfail(strict): the day it passes -- or another case starts failing -- the suite says so."""
+    if feeder == "ieee123" and quantity == "flow":
+        request.applymarker(pytest.mark.xfail(strict=True, reason="documented deviation: the reference's Newton-Raphson iterate at tolerance 1e-6 is "
+                                              "itself 1.3e-6 pu from the converged line flows on this workload; the sweep solver lands 1.29e-6 pu from that iterate "
+                                              "(4.6e-8 from the converged solution)"))
+    worst = _north_star_worst(feeder, "fbs")
+    assert worst["ref"][quantity] < 1e-6, worst
 
 
 @pytest.mark.parametrize("maker", [lambda: P.ieee123_like(), lambda: P.ieee13_like("epsilon")])

@@ -168,3 +168,29 @@ def test_full_size_two_ranks_with_the_split_step_and_a_pending_gather():
     for h in hs:
         assert np.array_equal(h.allgather_obs_download(), want)
     whole.close(); grp.close()
+
+
+def test_gather_self_check_and_comm_info_through_the_loopback_transport():
+    """The self-check an N-rank bench run prints (``gather_verified``: SHA-256 of every rank's own block against the slot it
+    landed in on every rank, sharding.verify_gathered_block) rehearsed on one GPU, and gs_comm_info."""
+    from grid_fed_rl_gym_amd.sharding import block_checksum
+    spec = P.ieee123_like(); world, B = 4, 80
+    rng = np.random.default_rng(11)
+    acts = rng.uniform(-1, 1, (2, world * B, spec.action_dim))
+    seeds = np.arange(world * B, dtype=np.uint64) + 5
+    grp = _members(spec, world, B, seeds, acts)
+    hs = grp.handles
+    for t in range(2):
+        for h in hs:
+            h.step_device(t)
+        Handle.allgather_obs_shards(hs)
+    sums = [block_checksum(h.download_step()["obs"]) for h in hs]
+    assert len(set(sums)) == world                                  # the shards differ (global-index seeds), so a swap would show
+    for h in hs:
+        mine = h.allgather_obs_download()
+        assert [block_checksum(mine[q * B:(q + 1) * B]) for q in range(world)] == sums
+    for r, h in enumerate(hs):
+        info = h.comm_info()
+        assert info["transport"] == "loopback" and info["nranks"] == world and info["rank"] == r
+        assert len(info["device_uuid"]) == 32
+    grp.close()

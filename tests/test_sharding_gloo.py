@@ -103,3 +103,35 @@ def test_two_ranks_over_the_file_rendezvous_equal_single_process_without_torch()
                 assert p.wait(timeout=300) == 0
             outs[world] = np.load(out)
         assert np.array_equal(outs[1]["obs"], outs[2]["obs"]) and np.array_equal(outs[1]["reward"], outs[2]["reward"])
+
+
+def test_gather_self_check_catches_a_block_in_the_wrong_slot():
+    """``sharding.verify_gathered_block`` (what ``bench.py`` prints as ``gather_verified`` for N > 1): three ranks as threads,
+    the checksums all-gathered through a FileRendezvous each; a correct gathered block verifies on every rank, a block with
+    two slots swapped on ONE rank fails on all of them."""
+    import tempfile
+    import threading
+    from grid_fed_rl_gym_amd.rendezvous import FileRendezvous
+    from grid_fed_rl_gym_amd.sharding import verify_gathered_block
+    world, rows, D = 3, 5, 7
+    rng = np.random.default_rng(3)
+    blocks = [rng.standard_normal((rows, D)) for _ in range(world)]
+    good = np.concatenate(blocks)
+    swapped = np.concatenate([blocks[1], blocks[0], blocks[2]])
+    for bad_rank in (None, 2):
+        root = tempfile.mkdtemp()
+        out = [None] * world
+
+        def run(r):
+            rz = FileRendezvous(r, world, key=f"selfcheck_{bad_rank}", root=root, timeout=60.0)
+            full = swapped if r == bad_rank else good
+            out[r] = verify_gathered_block(full, blocks[r], r, world, rz.all_gather_bytes)
+            rz.close()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert all(o is not None for o in out)
+        assert [o["gather_verified"] for o in out] == [bad_rank is None] * world, out
+        assert out[0]["distinct_shard_checksums"] == world
+        if bad_rank is not None:
+            assert out[0]["slots_matching_per_rank"] == [3, 3, 1]
