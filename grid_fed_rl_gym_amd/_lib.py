@@ -109,6 +109,8 @@ SYMBOLS = [
     ("gs_allgather_obs", C.c_int, [_H, _dp]),
     ("gs_comm_destroy", C.c_int, [_H]),
     ("gs_comm_info", C.c_int, [_H, C.c_void_p]),
+    ("gs_mesh_schedule_dump", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_char_p, C.c_int32,
+                                        C.c_void_p, _ip, _ip, _dp]),
     ("gs_comm_init_loopback", C.c_int, [C.POINTER(_H), C.c_int32]),
     ("gs_allgather_obs_shards", C.c_int, [C.POINTER(_H), C.c_int32, _dp]),
     ("gs_allgather_obs_view", C.c_int, [_H, C.c_void_p, C.c_void_p]),
@@ -240,6 +242,70 @@ def _device_address(x, shape) -> int:
     return int(cai["data"][0])
 
 
+def _topology_of(spec: FeederSpec):
+    """gs_topology of a FeederSpec and the arrays it points into (keep them alive while the struct is in use)."""
+    keep = dict(frm=_i32(spec.frm), to=_i32(spec.to), r=_f64(spec.r), x=_f64(spec.x), rating=_f64(spec.rating),
+                bus_type=np.ascontiguousarray(spec.bus_type, dtype=np.uint8), v_set=_f64(spec.v_set),
+                load_bus=_i32(spec.load_bus), load_base=_f64(spec.load_base), load_pf=_f64(spec.load_pf),
+                gen_bus=_i32(spec.gen_bus), gen_kind=_i32(spec.gen_kind), gen_cap=_f64(spec.gen_cap),
+                gen_p0=_f64(spec.gen_p0), gen_p1=_f64(spec.gen_p1), gen_p2=_f64(spec.gen_p2),
+                bat_bus=_i32(spec.bat_bus), bat_cap=_f64(spec.bat_cap), bat_rating=_f64(spec.bat_rating),
+                bat_eff=_f64(spec.bat_eff))
+    t = gs_topology()
+    t.struct_size = C.sizeof(gs_topology)
+    t.n, t.m = spec.n, spec.m
+    t.from_bus, t.to_bus = _ptr(keep["frm"], _ip), _ptr(keep["to"], _ip)
+    t.r, t.x, t.rating = _ptr(keep["r"], _dp), _ptr(keep["x"], _dp), _ptr(keep["rating"], _dp)
+    t.bus_type, t.v_set = _ptr(keep["bus_type"], _up), _ptr(keep["v_set"], _dp)
+    t.n_loads = spec.n_loads
+    t.load_bus, t.load_base, t.load_pf = _ptr(keep["load_bus"], _ip), _ptr(keep["load_base"], _dp), _ptr(keep["load_pf"], _dp)
+    t.n_gens = spec.n_gens
+    t.gen_bus, t.gen_kind, t.gen_cap = _ptr(keep["gen_bus"], _ip), _ptr(keep["gen_kind"], _ip), _ptr(keep["gen_cap"], _dp)
+    t.gen_p0, t.gen_p1, t.gen_p2 = _ptr(keep["gen_p0"], _dp), _ptr(keep["gen_p1"], _dp), _ptr(keep["gen_p2"], _dp)
+    t.n_bats = spec.n_bats
+    t.bat_bus, t.bat_cap = _ptr(keep["bat_bus"], _ip), _ptr(keep["bat_cap"], _dp)
+    t.bat_rating, t.bat_eff = _ptr(keep["bat_rating"], _dp), _ptr(keep["bat_eff"], _dp)
+    return t, keep
+
+
+MESH_ITEM_DTYPE = np.dtype([("vk_off", "<i4"), ("vj_off", "<i4"), ("xk_off", "<i4"), ("xj_off", "<i4"), ("flags", "<i4"), ("cq_off", "<i4"),
+                            ("adj_ptr", "<i4"), ("bus", "<i4"), ("ykj_g", "<f8"), ("ykj_b", "<f8"), ("ykk_g", "<f8"), ("ykk_b", "<f8"),
+                            ("mout", "<i4", (8,)), ("cq_in", "<i4", (4,)), ("rw_in", "<i4", (4,)), ("cl_in", "<i4", (4,)),
+                            ("nbr", "<i4"), ("pos", "<i4"), ("pad", "<i4", (10,))])      # GsMeshItem, csrc/gs_internal.h
+
+
+def mesh_schedule(spec: FeederSpec, nw: int = 4, ni: int = 10, acc_cap: int = 4, region_base: int = 0, slot_bytes: int = 144,
+                  zero_z: str = "open") -> dict:
+    """gs_mesh_schedule_dump: the host-side schedule of the meshed Newton-Raphson step kernel for ``spec`` (no device needed).
+    Returns the header fields, ``why`` (when not eligible) and the tables as NumPy arrays (items: MESH_ITEM_DTYPE)."""
+    lib = load()
+    t, keep = _topology_of(spec)
+    hd = np.zeros(16, dtype=np.int32)
+    why = C.create_string_buffer(256)
+    args = (C.byref(t), ZERO_Z[zero_z], int(nw), int(ni), int(acc_cap), int(region_base), int(slot_bytes))
+    rc = lib.gs_mesh_schedule_dump(*args, _ptr(hd, _ip), why, 256, None, None, None, None)
+    if rc != GS_OK:
+        raise PowerFlowError(f"gs_mesh_schedule_dump failed ({rc}): {lib.gs_last_error(None).decode()}")
+    names = ("ok", "n_levels", "n_rows", "max_rows_per_wave", "n_pivots", "msg_units", "n_messages", "n_accumulators", "max_degree",
+             "unit_bytes", "zero_off", "dummy_off", "body_off", "region_bytes", "item_bytes", "n_adj")
+    out = {k: int(v) for k, v in zip(names, hd)}
+    out["why"] = why.value.decode(); out["nw"], out["ni"] = int(nw), int(ni)
+    if not out["ok"]:
+        return out
+    if out["item_bytes"] != MESH_ITEM_DTYPE.itemsize:
+        raise PowerFlowError(f"GsMeshItem is {out['item_bytes']} bytes in the library, {MESH_ITEM_DTYPE.itemsize} here")
+    items = np.zeros(nw * ni * 8, dtype=MESH_ITEM_DTYPE)
+    rowinfo = np.zeros((nw * ni, 4), dtype=np.int32)
+    adj_off = np.zeros(max(out["n_adj"], 1), dtype=np.int32)
+    adj_y = np.zeros((max(out["n_adj"], 1), 2))
+    rc = lib.gs_mesh_schedule_dump(*args, _ptr(hd, _ip), why, 256, items.ctypes.data_as(C.c_void_p), _ptr(rowinfo, _ip),
+                                   _ptr(adj_off, _ip), _ptr(adj_y, _dp))
+    if rc != GS_OK:
+        raise PowerFlowError(f"gs_mesh_schedule_dump failed ({rc}): {lib.gs_last_error(None).decode()}")
+    out.update(items=items.reshape(nw, ni, 8), rowinfo=rowinfo.reshape(nw, ni, 4), adj_off=adj_off, adj_y=adj_y)
+    return out
+
+
 class Handle:
     """Owns one gs_handle (one GPU, one stream).  All array arguments are NumPy, batch-major."""
 
@@ -248,27 +314,7 @@ class Handle:
         self._h = _H()
         self.spec = spec
         self.B = int(batch)
-        keep = dict(frm=_i32(spec.frm), to=_i32(spec.to), r=_f64(spec.r), x=_f64(spec.x), rating=_f64(spec.rating),
-                    bus_type=np.ascontiguousarray(spec.bus_type, dtype=np.uint8), v_set=_f64(spec.v_set),
-                    load_bus=_i32(spec.load_bus), load_base=_f64(spec.load_base), load_pf=_f64(spec.load_pf),
-                    gen_bus=_i32(spec.gen_bus), gen_kind=_i32(spec.gen_kind), gen_cap=_f64(spec.gen_cap),
-                    gen_p0=_f64(spec.gen_p0), gen_p1=_f64(spec.gen_p1), gen_p2=_f64(spec.gen_p2),
-                    bat_bus=_i32(spec.bat_bus), bat_cap=_f64(spec.bat_cap), bat_rating=_f64(spec.bat_rating),
-                    bat_eff=_f64(spec.bat_eff))
-        t = gs_topology()
-        t.struct_size = C.sizeof(gs_topology)
-        t.n, t.m = spec.n, spec.m
-        t.from_bus, t.to_bus = _ptr(keep["frm"], _ip), _ptr(keep["to"], _ip)
-        t.r, t.x, t.rating = _ptr(keep["r"], _dp), _ptr(keep["x"], _dp), _ptr(keep["rating"], _dp)
-        t.bus_type, t.v_set = _ptr(keep["bus_type"], _up), _ptr(keep["v_set"], _dp)
-        t.n_loads = spec.n_loads
-        t.load_bus, t.load_base, t.load_pf = _ptr(keep["load_bus"], _ip), _ptr(keep["load_base"], _dp), _ptr(keep["load_pf"], _dp)
-        t.n_gens = spec.n_gens
-        t.gen_bus, t.gen_kind, t.gen_cap = _ptr(keep["gen_bus"], _ip), _ptr(keep["gen_kind"], _ip), _ptr(keep["gen_cap"], _dp)
-        t.gen_p0, t.gen_p1, t.gen_p2 = _ptr(keep["gen_p0"], _dp), _ptr(keep["gen_p1"], _dp), _ptr(keep["gen_p2"], _dp)
-        t.n_bats = spec.n_bats
-        t.bat_bus, t.bat_cap = _ptr(keep["bat_bus"], _ip), _ptr(keep["bat_cap"], _dp)
-        t.bat_rating, t.bat_eff = _ptr(keep["bat_rating"], _dp), _ptr(keep["bat_eff"], _dp)
+        t, keep = _topology_of(spec)
         rc = self._lib.gs_create(C.byref(t), C.byref(cfg), self.B, int(device), int(first_instance), C.byref(self._h))
         if rc != GS_OK:
             self._h = _H()

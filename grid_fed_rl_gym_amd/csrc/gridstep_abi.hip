@@ -23,6 +23,7 @@
 #include "gs_internal.h"
 #include "kernels.h"
 #include "topology.h"
+#include "mesh_schedule.h"
 
 namespace {
 
@@ -2000,6 +2001,32 @@ int gs_comm_destroy(gs_handle* h) {
   if (h->d_gather_send) { (void)hipFree(h->d_gather_send); h->d_gather_send = nullptr; }
   if (h->d_gather_recv) { (void)hipFree(h->d_gather_recv); h->d_gather_recv = nullptr; }
   h->rank = 0; h->world = 1;
+  return GS_OK;
+}
+
+// ---- the meshed Newton-Raphson member's host schedule, without a device (mesh_schedule.h) -------------------------------
+// header[0..15]: ok, n_levels, n_rows, max_rows_per_wave, n_pivots, msg_units, n_messages, n_accumulators, max_degree,
+//                unit_bytes, zero_off, dummy_off, body_off, region_bytes, sizeof(GsMeshItem), n_adj;  why: the reason when ok == 0
+int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+                          int32_t slot_bytes, int32_t* header, char* why, int32_t why_cap, void* items, int32_t* rowinfo,
+                          int32_t* adj_off, double* adj_y) {
+  if (!topo || !header) return fail(nullptr, GS_E_INVALID, "topology / header is NULL");
+  if (topo->struct_size != (int32_t)sizeof(gs_topology)) return fail(nullptr, GS_E_INVALID, "struct_size mismatch");
+  if (nw < 1 || ni < 1 || acc_cap < 1) return fail(nullptr, GS_E_INVALID, "bad arguments");
+  HostTopology ht;
+  const std::string err = gs_compile_topology(*topo, zero_z_mode, false, true, ht);
+  if (!err.empty()) return fail(nullptr, GS_E_INVALID, "topology: %s", err.c_str());
+  MeshSchedule S;
+  gs_mesh_schedule(ht, nw, ni, 8, region_base, slot_bytes, acc_cap, S);
+  const int32_t hd[16] = {S.ok ? 1 : 0, S.n_levels, S.n_rows, S.max_rows_per_wave, S.n_pivots, S.msg_units, S.n_messages, S.n_accumulators,
+                          S.max_degree, S.unit_bytes, S.zero_off, S.dummy_off, S.body_off, S.region_bytes, (int32_t)sizeof(GsMeshItem), (int32_t)S.adj_off.size()};
+  memcpy(header, hd, sizeof hd);
+  if (why && why_cap > 0) { strncpy(why, S.why.c_str(), (size_t)why_cap - 1); why[why_cap - 1] = 0; }
+  if (!S.ok) return GS_OK;
+  if (items) memcpy(items, S.items.data(), S.items.size() * sizeof(MeshItem));
+  if (rowinfo) memcpy(rowinfo, S.rowinfo.data(), S.rowinfo.size() * sizeof(int32_t));
+  if (adj_off) memcpy(adj_off, S.adj_off.data(), S.adj_off.size() * sizeof(int32_t));
+  if (adj_y) memcpy(adj_y, S.adj_y.data(), S.adj_y.size() * sizeof(double));
   return GS_OK;
 }
 

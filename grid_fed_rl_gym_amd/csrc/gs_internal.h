@@ -394,6 +394,30 @@ struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half
   int32_t b1, level, pad1, pad2;
   double zr, zi, yr, yi;                    // branch to the parent: z = 1 / y
 };
+// ---- the meshed Newton-Raphson member (F2_NRM, mesh_schedule.h): one (wavefront, row, sub-group) of the block elimination ----
+#define GS_MESH_ACC 4             /* most accumulators per target = entries per pull list */
+struct GsMeshItem {                     // 192 bytes
+  int32_t vk_off, vj_off;               // LDS byte offsets (without the lane's share): voltage slot of the pivot bus / of neighbour j_t
+  int32_t xk_off, xj_off;               // back substitution: where lane 0 leaves x_k / where lane t finds x_jt
+  int32_t flags;                        // GS_MESH_F_*
+  int32_t cq_off;                       // CQ(k -> j_t) accumulator
+  int32_t adj_ptr, bus;                 // first entry of the pivot bus's Ybus row (lane 0); the pivot bus (-1: idle)
+  double ykj_g, ykj_b, ykk_g, ykk_b;    // Y(k, j_t) (0 where the pair is fill); Y(k, k) (lane 0; (0, -1) elsewhere: an identity-like diagonal block)
+  int32_t mout[8];                      // accumulator of M(k -> (j_t, j_t')) for t' = 0 .. g - 1 (entry t: the C part of cq_off)
+  int32_t cq_in[GS_MESH_ACC], rw_in[GS_MESH_ACC], cl_in[GS_MESH_ACC];      // pull lists (padded with the ZERO message): into (D_k, r_k), A(k, j_t), A(j_t, k)
+  int32_t nbr, pos;                     // neighbour bus (-1: none); index of the item
+  int32_t pad[10];
+};
+enum {
+  GS_MESH_F_PIVOT = 1,          // lane 0 of a group that eliminates a bus
+  GS_MESH_F_NBR = 2,            // the lane has a neighbour (blocks, T, messages)
+  GS_MESH_F_SLACKPOS = 4,       // takes part in the mismatch pass only: the slack's share of the losses sum
+  GS_MESH_F_HV0_SHIFT = 4,      // bits 4-7: first sub-group of the lane's group
+  GS_MESH_F_T_SHIFT = 8,        // bits 8-11: t
+  GS_MESH_F_G_SHIFT = 12,       // bits 12-15: group size (1, 2, 4, 8)
+  GS_MESH_F_RMW_SHIFT = 16      // bits 16-23: output t' adds to what its accumulator holds (else: first producer, plain write)
+};
+
 struct GsF2Tables {
   const GsF2Rec* recs;            // [GS_F2_WAVES * 2 * GS_F2_ITEMS]
   const int32_t* anc;             // sweeps: [n_jump][n_slots] 2^r-th ancestor of every slot on its way to the slack, ZERO beyond;
@@ -418,6 +442,10 @@ struct GsF2Tables {
   // itself (nrflat_mode 1: one workgroup, gs_create) and read by iteration 0 of every later step (mode 2), which then only
   // carries its right-hand side up and down the tree.  Mode 0 / NULL: every iteration eliminates for itself.
   double* nrflat; int32_t nrflat_mode, pad_nrflat;
+  // the meshed member: items [NW * NI * 8], rowinfo [NW * NI][4] (level | -1, g | ncq << 8 | nrw << 16 | ncl << 24, nadj, -), the
+  // Ybus rows of the pivot buses (voltage slot offset; (G, B)), and its per-wave exchange scratch in LDS
+  const GsMeshItem* mesh_items; const int32_t* mesh_rowinfo; const int32_t* mesh_adj_off; const double* mesh_adj_y;
+  int32_t off_scr, mesh_pad;
 };
 
 // gs_k_rollout_post (kernels_env.hip): bookkeeping after step t of gs_rollout

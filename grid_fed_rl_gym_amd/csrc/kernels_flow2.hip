@@ -167,7 +167,7 @@ struct F2ArgBlock { GsTables T; GsF2Tables F; GsRows R; GsSolveCfg C; GsEnvCfg E
 __device__ __forceinline__ void f2_touch_arguments() {
   const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
   unsigned sink;
-  static_assert(sizeof(F2ArgBlock) >= 0x644 && sizeof(F2ArgBlock) <= 0x680, "argument block size changed: adjust the touched lines");
+  static_assert(sizeof(F2ArgBlock) >= 0x684 && sizeof(F2ArgBlock) <= 0x6c0, "argument block size changed: adjust the touched lines");
   asm volatile(
       "s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\t"
       "s_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\ts_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0\n\t"
@@ -175,7 +175,7 @@ __device__ __forceinline__ void f2_touch_arguments() {
       "s_load_dword %0, %1, 0x300\n\ts_load_dword %0, %1, 0x340\n\ts_load_dword %0, %1, 0x380\n\ts_load_dword %0, %1, 0x3c0\n\t"
       "s_load_dword %0, %1, 0x400\n\ts_load_dword %0, %1, 0x440\n\ts_load_dword %0, %1, 0x480\n\ts_load_dword %0, %1, 0x4c0\n\t"
       "s_load_dword %0, %1, 0x500\n\ts_load_dword %0, %1, 0x540\n\ts_load_dword %0, %1, 0x580\n\ts_load_dword %0, %1, 0x5c0\n\t"
-      "s_load_dword %0, %1, 0x600\n\ts_load_dword %0, %1, 0x640\n\ts_waitcnt lgkmcnt(0)"
+      "s_load_dword %0, %1, 0x600\n\ts_load_dword %0, %1, 0x640\n\ts_load_dword %0, %1, 0x680\n\ts_waitcnt lgkmcnt(0)"
       : "=&s"(sink) : "s"(ka) : "memory");
 }
 

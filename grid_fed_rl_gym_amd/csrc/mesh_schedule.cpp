@@ -1,0 +1,262 @@
+// mesh_schedule.cpp -- see mesh_schedule.h.  Pure host C++.
+#include "mesh_schedule.h"
+
+#include <algorithm>
+#include <map>
+#include <set>
+#include <utility>
+
+namespace {
+
+int pow2ceil(int x) { int p = 1; while (p < x) p *= 2; return p; }
+
+struct Target {                          // what a message adds to: the diagonal block + right-hand side of a bus, or an off-diagonal block
+  int cons = -1;                         // the pivot that pulls it
+  int units = 0;                         // 16-byte-per-lane units: CQ 3, M 2
+  std::map<int, int> per_level;          // producers per level so far
+  std::vector<int> acc;                  // accumulator ids, by rank inside a level
+};
+
+struct Acc { int units = 0, first = 1 << 30, cons_level = 0, off = -1; };
+
+}  // namespace
+
+void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region_base, int slot_bytes, int acc_cap, MeshSchedule& S) {
+  S = MeshSchedule();
+  S.NW = NW; S.NI = NI; S.IW = IW; S.HV = 64 / IW;
+  const int n = ht.n, HV = S.HV;
+  S.unit_bytes = 16 * IW; S.zero_off = 0; S.dummy_off = 3 * S.unit_bytes; S.body_off = 6 * S.unit_bytes;
+  auto fail = [&](const std::string& w) { S.ok = false; S.why = w; };
+  if (HV != 8) return fail("the meshed member is built for 8 instances per workgroup");
+  if (acc_cap < 1) acc_cap = 1;
+  if (acc_cap > GS_MESH_ACC) acc_cap = GS_MESH_ACC;
+  std::vector<char> active(n);
+  for (int i = 0; i < n; ++i) active[i] = ht.th_free[i] || ht.vm_free[i];
+
+  // ---- minimum-degree elimination on the active buses (ties: lowest index), as topology.cpp orders the first-generation LU ----
+  std::vector<std::set<int>> g(n);
+  for (int i = 0; i < n; ++i)
+    for (int p = ht.row_ptr[i]; p < ht.row_ptr[i + 1]; ++p) {
+      const int j = ht.col[p];
+      if (j != i && active[i] && active[j]) g[i].insert(j);
+    }
+  std::vector<int> order, pos_of(n, -1);
+  std::vector<std::vector<int>> nbrs(n);
+  {
+    std::vector<char> gone(n, 0);
+    for (int step = 0; step < ht.n_active; ++step) {
+      int k = -1; size_t best = (size_t)-1;
+      for (int i = 0; i < n; ++i) if (active[i] && !gone[i] && g[i].size() < best) { best = g[i].size(); k = i; }
+      if (k < 0) break;
+      pos_of[k] = (int)order.size(); order.push_back(k);
+      nbrs[k].assign(g[k].begin(), g[k].end());
+      for (int i : nbrs[k]) for (int j : nbrs[k]) if (i != j) g[i].insert(j);
+      for (int j : nbrs[k]) g[j].erase(k);
+      gone[k] = 1;
+      S.max_degree = std::max(S.max_degree, (int)nbrs[k].size());
+    }
+  }
+  S.n_pivots = (int)order.size();
+  if (S.max_degree > HV) return fail("a pivot of the block LU has more than " + std::to_string(HV) + " neighbours when it is eliminated");
+
+  // ---- targets, levels (a pivot is delayed until none of its targets has acc_cap producers in its level), accumulators ----
+  std::map<std::pair<int, int>, Target> targets;          // (i, i): CQ of bus i; (i, j): block (i, j)
+  auto target_of = [&](int i, int j) -> Target& {
+    Target& t = targets[{i, j}];
+    if (t.cons < 0) { t.cons = (i == j) ? i : (pos_of[i] < pos_of[j] ? i : j); t.units = (i == j) ? 3 : 2; }
+    return t;
+  };
+  std::vector<int> level(n, 0), ready(n, 0);
+  std::vector<Acc> accs;
+  struct Msg { int prod, i, j, acc, rmw; };
+  std::vector<Msg> msgs;
+  for (int k : order) {
+    int lv = ready[k];
+    for (bool again = true; again;) {
+      again = false;
+      for (int i : nbrs[k]) for (int j : nbrs[k]) {
+        Target& t = target_of(i, j);
+        auto it = t.per_level.find(lv);
+        if (it != t.per_level.end() && it->second >= acc_cap) { ++lv; again = true; }
+      }
+    }
+    level[k] = lv;
+    for (int i : nbrs[k]) {
+      ready[i] = std::max(ready[i], lv + 1);
+      for (int j : nbrs[k]) {
+        Target& t = target_of(i, j);
+        const int rank = t.per_level[lv]++;
+        if (rank >= (int)t.acc.size()) { t.acc.push_back((int)accs.size()); Acc a; a.units = t.units; accs.push_back(a); }
+        msgs.push_back({k, i, j, t.acc[rank], 0});
+      }
+    }
+    S.n_levels = std::max(S.n_levels, lv + 1);
+  }
+  if (S.n_levels < 1) S.n_levels = 1;
+  for (auto& m : msgs) accs[m.acc].first = std::min(accs[m.acc].first, level[m.prod]);
+  for (auto& m : msgs) m.rmw = level[m.prod] > accs[m.acc].first ? 1 : 0;
+  for (auto& kv : targets) for (int a : kv.second.acc) accs[a].cons_level = level[kv.second.cons];
+  for (auto& m : msgs)
+    if (level[m.prod] >= accs[m.acc].cons_level) return fail("internal: a message is produced at or after its consumer's level");
+  S.n_messages = (int)msgs.size(); S.n_accumulators = (int)accs.size();
+
+  // ---- LDS units of the accumulators: live from the first producer's level through the consumer's; reusable by producers of later levels ----
+  {
+    std::vector<int> by_first(accs.size());
+    for (size_t a = 0; a < accs.size(); ++a) by_first[a] = (int)a;
+    std::stable_sort(by_first.begin(), by_first.end(), [&](int x, int y) { return accs[x].first < accs[y].first; });
+    std::vector<int> free_from;                               // per unit: the first level whose producers may write it again
+    int top = 0;
+    for (int a : by_first) {
+      const int u = accs[a].units, f = accs[a].first;
+      int at = -1;
+      for (int o = 0; o + u <= top && at < 0; ++o) {          // lowest run of u units that are all free by level f
+        bool fits = true;
+        for (int q = 0; q < u; ++q) if (free_from[o + q] > f) { fits = false; break; }
+        if (fits) at = o;
+      }
+      if (at < 0) {                                           // extend, taking along a free tail
+        at = top;
+        while (at > 0 && top - at + 1 <= u - 1 && free_from[at - 1] <= f) --at;
+        top = at + u; free_from.resize(top, 0);
+      }
+      accs[a].off = at;
+      for (int q = 0; q < u; ++q) free_from[at + q] = accs[a].cons_level + 1;
+    }
+    S.msg_units = std::max(top, n);                          // the x slots of the back substitution share the body: one unit per bus
+  }
+  S.region_bytes = S.body_off + S.msg_units * S.unit_bytes;
+  const int ZERO = region_base + S.zero_off, DUMMY = region_base + S.dummy_off, BODY = region_base + S.body_off;
+  auto acc_addr = [&](int a) { return BODY + accs[a].off * S.unit_bytes; };
+
+  // ---- pull lists and outputs ----
+  std::vector<std::vector<int>> cq_in(n);
+  std::map<std::pair<int, int>, std::vector<int>> rw_in, cl_in;     // (pivot, neighbour) -> accumulator addresses of A(pivot, nbr) / A(nbr, pivot)
+  for (auto& kv : targets) {
+    const int i = kv.first.first, j = kv.first.second;
+    for (int a : kv.second.acc) {
+      if (i == j) cq_in[i].push_back(acc_addr(a));
+      else if (kv.second.cons == i) rw_in[{i, j}].push_back(acc_addr(a));
+      else cl_in[{j, i}].push_back(acc_addr(a));
+    }
+  }
+  std::map<std::tuple<int, int, int>, std::pair<int, int>> out_of;   // (producer, i, j) -> (address, rmw)
+  for (auto& m : msgs) out_of[{m.prod, m.i, m.j}] = {acc_addr(m.acc), m.rmw};
+
+  // ---- groups -> rows (one level per row, groups by size so that they sit aligned) -> waves ----
+  struct Group { int k, d, g, level, slackpos; };
+  std::vector<Group> groups;
+  for (int k : order) { const int d = (int)nbrs[k].size(); groups.push_back({k, d, pow2ceil(std::max(d, 1)), level[k], 0}); }
+  groups.push_back({ht.slack, 0, 1, 0, 1});                 // the slack bus: its share of the losses sum in the mismatch pass
+  struct Row { int level; std::vector<std::pair<int, int>> lanes; int fill; };    // lanes: (group index, t) or (-1, 0)
+  std::vector<Row> rows;
+  std::vector<int> rows_of_level(S.n_levels, 0);
+  for (int L = 0; L < S.n_levels; ++L) {
+    std::vector<int> gl;
+    for (size_t q = 0; q < groups.size(); ++q) if (groups[q].level == L) gl.push_back((int)q);
+    std::stable_sort(gl.begin(), gl.end(), [&](int a, int b) { return groups[a].g > groups[b].g; });
+    int cur = -1;
+    for (int q : gl) {
+      if (cur < 0 || rows[cur].fill + groups[q].g > HV) { rows.push_back({L, std::vector<std::pair<int, int>>(HV, {-1, 0}), 0}); cur = (int)rows.size() - 1; ++rows_of_level[L]; }
+      for (int t = 0; t < groups[q].g; ++t) rows[cur].lanes[rows[cur].fill + t] = {q, t};
+      rows[cur].fill += groups[q].g;
+    }
+  }
+  S.n_rows = (int)rows.size();
+  std::vector<std::vector<int>> wave_rows(NW);
+  {
+    const int cap = (S.n_rows + NW - 1) / NW;
+    int prev = 0;
+    for (size_t r = 0; r < rows.size(); ++r) {
+      int w = 0;
+      for (int v = 1; v < NW; ++v) if (wave_rows[v].size() < wave_rows[w].size()) w = v;
+      // a level of one row goes where the previous one went while that wave has room: the sequential tail of the elimination
+      // then stays inside one wavefront
+      if (rows_of_level[rows[r].level] == 1 && (int)wave_rows[prev].size() < cap) w = prev;
+      wave_rows[w].push_back((int)r); prev = w;
+    }
+    for (auto& v : wave_rows) S.max_rows_per_wave = std::max(S.max_rows_per_wave, (int)v.size());
+  }
+  if (S.max_rows_per_wave > NI) return fail("the elimination needs " + std::to_string(S.max_rows_per_wave) + " rows per wavefront (limit " + std::to_string(NI) + ")");
+
+  // ---- items ----
+  const int V_ONE = (n + 1) * slot_bytes, V_ZERO = n * slot_bytes;
+  S.rowinfo.assign((size_t)NW * NI * 4, 0);
+  S.items.assign((size_t)NW * NI * HV, MeshItem{});
+  for (int w = 0; w < NW; ++w)
+    for (int j = 0; j < NI; ++j) {
+      int32_t* ri = &S.rowinfo[((size_t)w * NI + j) * 4];
+      ri[0] = -1; ri[1] = 1; ri[2] = 0; ri[3] = 0;
+      const bool have = j < (int)wave_rows[w].size();
+      const Row* row = have ? &rows[wave_rows[w][j]] : nullptr;
+      int g_row = 1, ncq = 0, nrw = 0, ncl = 0, nadj = 0;
+      if (have) {
+        ri[0] = row->level;
+        for (int hv = 0; hv < HV; ++hv) {
+          const auto [q, t] = row->lanes[hv];
+          if (q < 0) continue;
+          const Group& G = groups[q];
+          g_row = std::max(g_row, G.g);
+          if (t == 0) {
+            nadj = std::max(nadj, ht.row_ptr[G.k + 1] - ht.row_ptr[G.k]);
+            if (!G.slackpos) ncq = std::max(ncq, (int)cq_in[G.k].size());
+          }
+          if (t < G.d) {
+            const int jn = nbrs[G.k][t];
+            auto a = rw_in.find({G.k, jn}); if (a != rw_in.end()) nrw = std::max(nrw, (int)a->second.size());
+            auto c = cl_in.find({G.k, jn}); if (c != cl_in.end()) ncl = std::max(ncl, (int)c->second.size());
+          }
+        }
+        if (ncq > GS_MESH_ACC || nrw > GS_MESH_ACC || ncl > GS_MESH_ACC) return fail("internal: pull list too long");
+        ri[1] = g_row | (ncq << 8) | (nrw << 16) | (ncl << 24); ri[2] = nadj;
+      }
+      for (int hv = 0; hv < HV; ++hv) {
+        MeshItem& it = S.items[((size_t)w * NI + j) * HV + hv];
+        it.pos = (int32_t)(((size_t)w * NI + j) * HV + hv);
+        it.vk_off = V_ONE; it.vj_off = V_ONE; it.xk_off = DUMMY; it.xj_off = ZERO; it.cq_off = DUMMY;
+        it.flags = (hv << MESH_F_HV0_SHIFT) | (1 << MESH_F_G_SHIFT);
+        it.ykj_g = 0.0; it.ykj_b = 0.0; it.ykk_g = 0.0; it.ykk_b = -1.0;       // an idle lane's diagonal block comes out as the identity
+        for (int q = 0; q < 8; ++q) it.mout[q] = DUMMY;
+        it.bus = -1; it.nbr = -1;
+        it.adj_ptr = (int32_t)S.adj_off.size();
+        int q = -1, t = 0;
+        if (have) { q = row->lanes[hv].first; t = row->lanes[hv].second; }
+        const Group* G = q >= 0 ? &groups[q] : nullptr;
+        // pull lists (padded with the ZERO message) and the pivot bus's Ybus row (padded with the ZERO voltage slot)
+        std::vector<int> lcq, lrw, lcl;
+        if (G) {
+          const int hv0 = hv - t;
+          it.flags = (hv0 << MESH_F_HV0_SHIFT) | (t << MESH_F_T_SHIFT) | (G->g << MESH_F_G_SHIFT);
+          it.bus = G->k; it.vk_off = G->k * slot_bytes;
+          if (t == 0) {
+            it.flags |= G->slackpos ? MESH_F_SLACKPOS : MESH_F_PIVOT;
+            if (!G->slackpos) { it.xk_off = BODY + G->k * S.unit_bytes; it.ykk_g = ht.Gd[G->k]; it.ykk_b = ht.Bd[G->k]; lcq = cq_in[G->k]; }
+          }
+          if (t < G->d) {
+            const int jn = nbrs[G->k][t];
+            it.flags |= MESH_F_NBR; it.nbr = jn;
+            it.vj_off = jn * slot_bytes; it.xj_off = BODY + jn * S.unit_bytes;
+            for (int p = ht.row_ptr[G->k]; p < ht.row_ptr[G->k + 1]; ++p) if (ht.col[p] == jn) { it.ykj_g = ht.G[p]; it.ykj_b = ht.B[p]; }
+            auto a = rw_in.find({G->k, jn}); if (a != rw_in.end()) lrw = a->second;
+            auto c = cl_in.find({G->k, jn}); if (c != cl_in.end()) lcl = c->second;
+            int rmw = 0;
+            for (int t2 = 0; t2 < G->d; ++t2) {
+              const auto o = out_of.at({G->k, jn, nbrs[G->k][t2]});
+              it.mout[t2] = o.first; rmw |= o.second << t2;
+              if (t2 == t) it.cq_off = o.first;
+            }
+            it.flags |= rmw << MESH_F_RMW_SHIFT;
+          }
+        }
+        lcq.resize(GS_MESH_ACC, ZERO); lrw.resize(GS_MESH_ACC, ZERO); lcl.resize(GS_MESH_ACC, ZERO);
+        for (int u = 0; u < GS_MESH_ACC; ++u) { it.cq_in[u] = lcq[u]; it.rw_in[u] = lrw[u]; it.cl_in[u] = lcl[u]; }
+        int have_adj = 0;
+        if (G && t == 0)
+          for (int p = ht.row_ptr[G->k]; p < ht.row_ptr[G->k + 1]; ++p, ++have_adj) {
+            S.adj_off.push_back(ht.col[p] * slot_bytes); S.adj_y.push_back(ht.G[p]); S.adj_y.push_back(ht.B[p]);
+          }
+        for (; have_adj < nadj; ++have_adj) { S.adj_off.push_back(V_ZERO); S.adj_y.push_back(0.0); S.adj_y.push_back(0.0); }
+      }
+    }
+  S.ok = true;
+}

@@ -333,6 +333,15 @@ int gs_timing_enable(gs_handle* h, int32_t on);
  * (block 0 / wave 0; phases: prologue, init, mismatch, bottom-up, flag, top-down, final mismatch,
  * epilogue), later calls return the sums accumulated since the previous call and clear them. */
 int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n);
+/* The host-side schedule of the meshed Newton-Raphson step kernel (gs_k_step_nr_mesh2; csrc/mesh_schedule.h) for a topology,
+ * built WITHOUT a device: the block elimination that replaces np.linalg.solve (power_flow.py:186-190) as per-(wavefront, row,
+ * sub-group) items, pull lists and Ybus rows.  header[16]: ok, n_levels, n_rows, max_rows_per_wave, n_pivots, msg_units,
+ * n_messages, n_accumulators, max_degree, unit_bytes, zero_off, dummy_off, body_off, region_bytes, item_bytes, n_adj.  Call once
+ * with the arrays NULL for the sizes (items: nw * ni * 8 records of item_bytes; rowinfo: nw * ni * 4; adj_y: 2 * n_adj), then
+ * with buffers.  tests/test_mesh_schedule.py replays the tables in NumPy against a dense solve. */
+int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+                          int32_t slot_bytes, int32_t* header, char* why, int32_t why_cap, void* items, int32_t* rowinfo,
+                          int32_t* adj_off, double* adj_y);
 /* Diagnostic: (start, end) of each of the first n_blocks workgroups of the last step launch, in ticks of the GPU's 100 MHz
  * real-time clock (second-generation step kernels; arm with gs_debug_stamps while GS_STAMP_BLOCK_TIMES is set). */
 int gs_debug_block_times(gs_handle* h, uint64_t* out, int32_t n_blocks);
