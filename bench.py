@@ -53,7 +53,7 @@ WORKLOADS = {
 }
 KERNEL_NAMES = {"nr_tree": "nr_tree", "nr_sparse_lu": "nr_lu", "nr_dense_mfma": "nr_dense_mfma", "nr_sparse_lds": "nr_sparse_lds", "fbs": "fbs", "nr_dense_pivot": "nr_dense",
                 "nr_tree_lds": "nr_tree_lds", "fbs_lds": "fbs_lds", "fbs_flow": "fbs_flow", "fbs_flow2": "fbs_flow2", "fbs_flow2h": "fbs_flow2h", "fbs_flow2s": "fbs_flow2s", "nr_flow2s": "nr_flow2s",
-                "nr_flow2": "nr_flow2"}
+                "nr_flow2": "nr_flow2", "nr_mesh2": "nr_mesh2"}
 
 
 def make_feeder(name):
@@ -69,7 +69,7 @@ _COMMON_SOURCES = ["gs_internal.h", "env_device.h", "fastmath.h", "kernels.h", "
 KERNEL_SOURCES = {
     "ieee123_b8192:fbs": ["kernels_flow2.hip"], "ieee123_b8192:nr": ["kernels_flow2.hip"], "ieee13_b4096:nr": ["kernels_flow2.hip"],
     "ieee8500_3ph_b1024:fbs3": ["gridstep3.hip", "gridstep3_resident.h"],
-    "meshed_loops26_b8192:nr": ["kernels_solve.hip"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
+    "meshed_loops26_b8192:nr": ["kernels_flow2.hip", "mesh_schedule.cpp", "mesh_schedule.h"], "meshed_scalable_b8192:nr": ["kernels_dense.hip", "kernels_solve.hip"],
 }
 
 

@@ -114,6 +114,8 @@ struct gs_handle {
   // launched the same way
   GsSparseArgs SA{}; int sparse_grid = 0; size_t sparse_lds = 0;
   bool nr2 = false;         // ... and likewise the Newton-Raphson step of a radial all-PQ feeder (gs_k_step_nr_flow2) instead of kernel 4
+  bool nrm = false;         // ... and of a meshed all-PQ feeder whose block LU stays narrow (gs_k_step_nr_mesh2, mesh_schedule.h) instead of kernel 1
+  std::string mesh_why; int mesh_levels = 0, mesh_rows = 0, mesh_units = 0, mesh_messages = 0, mesh_accs = 0;
   unsigned long long* d_stamps = nullptr;
   bool was_reset = false;
   std::vector<void*> allocs;
@@ -364,7 +366,7 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     if (h->lean) { h->rows_stale = true; h->last_obs = obs_out; }
     const GsFusedChecks fc = fused_checks_args(h);
     const GsRolloutStep rsv = rs ? *rs : GsRolloutStep{};
-    if (h->nr2 || h->flow2) {        // 64 / IW workgroups per 64-instance slab group, each with its own IW instances
+    if (h->nr2 || h->flow2 || h->nrm) {        // 64 / IW workgroups per 64-instance slab group, each with its own IW instances
       const int per_group = 64 / h->f2_iw, n_wg = h->groups * per_group;
       const dim3 b2(64 * h->f2_nw);
       // (two half-grid launches on two streams, see gs_handle::split_ok; the halves are whole 64-instance slab groups)
@@ -380,7 +382,8 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
       f2a.wg_offset = 0; f2b.wg_offset = n_first;
 #define GS_F2(k) do { hipLaunchKernelGGL(k, dim3(n_first), b2, h->F2.lds_bytes, h->stream, h->T, f2a, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc, rsv); \
                       if (n_first < n_wg) hipLaunchKernelGGL(k, dim3(n_wg - n_first), b2, h->F2.lds_bytes, h->stream2, h->T, f2b, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc, rsv); } while (0)
-      if (h->nr2) {
+      if (h->nrm) { if (fc.enabled) GS_F2(gs_k_stepc_nr_mesh2); else GS_F2(gs_k_step_nr_mesh2); }
+      else if (h->nr2) {
         if (h->f2_small) { if (fc.enabled) GS_F2(gs_k_stepc_nr_flow2s); else GS_F2(gs_k_step_nr_flow2s); }
         else { if (fc.enabled) GS_F2(gs_k_stepc_nr_flow2); else GS_F2(gs_k_step_nr_flow2); }
       } else {
@@ -572,7 +575,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     for (const void* f : {(const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2, (const void*)gs_k_step_nr_flow2,
                           (const void*)gs_k_stepc_nr_flow2, (const void*)gs_k_step_fbs_flow2s, (const void*)gs_k_stepc_fbs_flow2s,
                           (const void*)gs_k_step_nr_flow2s, (const void*)gs_k_stepc_nr_flow2s, (const void*)gs_k_step_fbs_flow2h,
-                          (const void*)gs_k_stepc_fbs_flow2h, (const void*)gs_k_step_fbs_flow2x, (const void*)gs_k_stepc_fbs_flow2x})      // no static LDS in these
+                          (const void*)gs_k_stepc_fbs_flow2h, (const void*)gs_k_step_fbs_flow2x, (const void*)gs_k_stepc_fbs_flow2x,
+                          (const void*)gs_k_step_nr_mesh2, (const void*)gs_k_stepc_nr_mesh2})      // no static LDS in these
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", 160 * 1024));
   }
@@ -942,6 +946,49 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     }
   }
 
+  // -- Newton-Raphson on a meshed feeder: the block LU as rows of lane items (mesh_schedule.h), 8 instances per workgroup
+  std::vector<GsMeshItem> mesh_items; std::vector<int32_t> mesh_rowinfo, mesh_adj_off; std::vector<double> mesh_adj_y;
+  if (h->solve_kernel == 1 && !ht.is_forest) {
+    std::string& why = h->mesh_why;
+    const int NW = GS_F2M_WAVES, NI = GS_F2M_ITEMS, IW = GS_F2S_IW, HV = 64 / IW;
+    bool all_pq = true;
+    for (int i = 0; i < ht.n; ++i) if (i != ht.slack && !(ht.th_free[i] && ht.vm_free[i])) all_pq = false;
+    GsF2Tables& F = h->F2;
+    MeshSchedule S;
+    if (getenv("GS_NO_FLOW2") || getenv("GS_NO_MESH2")) why = "disabled by GS_NO_FLOW2 / GS_NO_MESH2";
+    else if (cfg->jacobian_mode != GS_JACOBIAN_EXACT) why = "as-coded Jacobian";
+    else if (!all_pq) why = "a bus other than the slack is not a PQ bus";
+    else if (ht.fixed_v[ht.slack] == 0) why = "no typed slack bus";
+    else if (max_dev > 2) why = "more than two devices of a kind at one bus";
+    else if (ht.n < 2 || ht.m < 1) why = "trivial network";
+    else {
+      const int off_tile = (int)up16((size_t)nsl * (IW + 1) * 16);          // where f2_layout puts the region (below)
+      gs_mesh_schedule(ht, NW, NI, IW, off_tile, (IW + 1) * 16, GS_MESH_ACC, S);
+      if (!S.ok) why = S.why;
+    }
+    if (why.empty()) {
+      size_t off = f2_layout(F, NW, IW, (size_t)S.region_bytes, 0, 0);
+      F.off_scr = (int32_t)off; off += (size_t)NW * HV * 3 * 16 * IW;       // exchange scratch: 3 units per sub-group and wave
+      F.lds_bytes = (int32_t)off;
+      if (off > 160 * 1024) why = "LDS tables do not fit";
+    }
+    if (why.empty()) {
+      h->nrm = true; h->f2_small = false; h->f2_iw = IW; h->f2_nw = NW; h->f2_npos = NW * HV * NI;
+      h->mesh_levels = S.n_levels; h->mesh_rows = S.n_rows; h->mesh_units = S.msg_units; h->mesh_messages = S.n_messages; h->mesh_accs = S.n_accumulators;
+      F.n_jump = 0; F.n_levels = S.n_levels; F.pos_off = 0; F.n_anc_ints = 0; F.ring_zero = 0;
+      GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY; idle.level = -1;
+      f2recs.assign((size_t)NW * HV * NI, idle);
+      for (int w = 0; w < NW; ++w) for (int j = 0; j < NI; ++j) for (int hh = 0; hh < HV; ++hh) {
+        const GsMeshItem& it = S.items[((size_t)w * NI + j) * HV + hh];
+        if (!(it.flags & GS_MESH_F_PIVOT)) continue;
+        GsF2Rec& r = f2recs[((size_t)w * HV + hh) * NI + j];        // position of (wave, sub-group, row) in the frame's numbering
+        r.bus = it.bus; r.parent = SL_ONE; r.flags = 1; r.last = it.bus; r.level = S.rowinfo[((size_t)w * NI + j) * 4];
+        f2_devices(r, it.bus);
+      }
+      mesh_items = S.items; mesh_rowinfo = S.rowinfo; mesh_adj_off = S.adj_off; mesh_adj_y = S.adj_y;
+    }
+  }
+
   // ---- level schedule of the sparse block LU for this handle's W waves (kernels_solve.hip, linsolve_lu) ----
   std::vector<int32_t> lu_a_ptr, lu_a, lu_b_ptr, lu_b, lu_c_ptr, lu_c, lu_r_ptr, lu_r;
   if (ht.has_lu) {
@@ -1073,8 +1120,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     }
   }
   // a step as two half-grid launches on two streams: only where each half still gives every CU a workgroup
-  h->lean = (h->flow2 || h->nr2) && !getenv("GS_EAGER_ROWS");
-  if ((h->flow2 || h->nr2) && 2 * (size_t)h->F2.lds_bytes <= 160 * 1024 && !getenv("GS_NO_SPLIT") && h->groups * (64 / h->f2_iw) >= 512 &&
+  h->lean = (h->flow2 || h->nr2 || h->nrm) && !getenv("GS_EAGER_ROWS");
+  if ((h->flow2 || h->nr2 || h->nrm) && 2 * (size_t)h->F2.lds_bytes <= 160 * 1024 && !getenv("GS_NO_SPLIT") && h->groups * (64 / h->f2_iw) >= 512 &&
       h->groups >= 2) {
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1083,7 +1130,11 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     h->split_ok = true;
   }
 
-  if (h->flow2 || h->nr2) {
+  if (h->nrm) {
+    if ((rc = dev_upload(h, &h->F2.mesh_items, mesh_items)) || (rc = dev_upload(h, &h->F2.mesh_rowinfo, mesh_rowinfo)) ||
+        (rc = dev_upload(h, &h->F2.mesh_adj_off, mesh_adj_off)) || (rc = dev_upload(h, &h->F2.mesh_adj_y, mesh_adj_y))) return bail(rc);
+  }
+  if (h->flow2 || h->nr2 || h->nrm) {
     // buses with a voltage set point, for the kernels' flat start (the slack; the first entry travels inside the argument block)
     std::vector<int32_t> fs_slot; std::vector<double> fs_val;
     for (int i = 0; i < ht.n; ++i) if (ht.fixed_v[i]) { fs_slot.push_back(i); fs_val.push_back(ht.v_set[i]); }
@@ -1331,12 +1382,14 @@ int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
            "{\"kernel\": \"%s\", \"n\": %d, \"m\": %d, \"nnz\": %d, \"forest\": %s, \"levels\": %d, \"max_level_width\": %d, "
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
            "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d, "
-           "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"step_launches\": %d, \"solve_kernel\": \"%s\", \"flow2\": \"%s\"}",
-           h->flow2 ? (h->f2_small ? "fbs_flow2s" : h->f2_wide ? "fbs_flow2x" : h->f2_half ? "fbs_flow2h" : "fbs_flow2") : h->nr2 ? (h->f2_small ? "nr_flow2s" : "nr_flow2") : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
-           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, (h->flow2 || h->nr2) ? h->f2_nw : h->W, h->groups,
+           "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"step_launches\": %d, \"solve_kernel\": \"%s\", \"flow2\": \"%s\", "
+           "\"mesh2\": \"%s\", \"mesh_levels\": %d, \"mesh_rows\": %d, \"mesh_message_units\": %d, \"mesh_messages\": %d, \"mesh_accumulators\": %d}",
+           h->flow2 ? (h->f2_small ? "fbs_flow2s" : h->f2_wide ? "fbs_flow2x" : h->f2_half ? "fbs_flow2h" : "fbs_flow2") : h->nrm ? "nr_mesh2" : h->nr2 ? (h->f2_small ? "nr_flow2s" : "nr_flow2") : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
+           h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, (h->flow2 || h->nr2 || h->nrm) ? h->f2_nw : h->W, h->groups,
            h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim,
-           (h->flow2 || h->nr2) ? h->f2_iw : 64, (h->flow2 || h->nr2) ? (64 / h->f2_iw) * h->groups : h->groups, (h->flow2 || h->nr2) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576, h->split_ok ? 2 : 1,
-           kn[h->solve_kernel], (h->flow2 || h->nr2) ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()));
+           (h->flow2 || h->nr2 || h->nrm) ? h->f2_iw : 64, (h->flow2 || h->nr2 || h->nrm) ? (64 / h->f2_iw) * h->groups : h->groups, (h->flow2 || h->nr2 || h->nrm) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576, h->split_ok ? 2 : 1,
+           kn[h->solve_kernel], (h->flow2 || h->nr2 || h->nrm) ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()),
+           h->nrm ? "on" : (h->mesh_why.empty() ? "n/a" : h->mesh_why.c_str()), h->mesh_levels, h->mesh_rows, h->mesh_units, h->mesh_messages, h->mesh_accs);
   return GS_OK;
 }
 
@@ -1586,7 +1639,7 @@ int gs_rollout(gs_handle* h, int32_t T, int32_t policy, uint64_t policy_seed, co
   // was built in round 2 and is bit-identical, but slower: inlined into a loop the step's ~1 KB argument block stays live
   // across iterations (230 spilled registers); as an out-of-line call reading its arguments from memory the block lands in
   // scratch (59 M env-steps/s against 150 M for a launch per step).)
-  const bool fused = h->flow2 || h->nr2;
+  const bool fused = h->flow2 || h->nr2 || h->nrm;
   for (int t = 0; t < T; ++t) {
     double* nxt = ro.obs_seq + (size_t)(t + 1) * B * D;
     GsRolloutStep rs{ro.rew, ro.done, ro.obs_seq + (size_t)t * B * D, h->map_obs, h->d_cst, ro.term_count, ro.term_idx, ro.term_obs, ro.term_cap, h->obs_dim, t, 1};

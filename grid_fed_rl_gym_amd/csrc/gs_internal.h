@@ -386,6 +386,8 @@ struct GsPackArgs {
 #define GS_F2S_ITEMS 1
 #define GS_F2NS_WAVES 4           /* Newton-Raphson: 4 waves x 1 item, each a group of 8 buses of one level (2 x 2: 124 M env-steps/s on config 2; 4 x 1: 147 M -- the load draws get waves of their own) */
 #define GS_F2NS_ITEMS 1
+#define GS_F2M_WAVES 4            /* the meshed Newton-Raphson member: 4 waves x up to 10 rows of 8 sub-groups */
+#define GS_F2M_ITEMS 10
 #define GS_F2_CHILDREN 8          /* children per bus in the Newton-Raphson kernel's LDS child tables */
 struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half) * GS_F2_ITEMS + item); 96 bytes
   int32_t bus, parent, flags, last;         // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); last: the bus at the LAST position of this bus's subtree

@@ -46,6 +46,10 @@ __global__ void gs_k_step_nr_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCf
                                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS);
 __global__ void gs_k_stepc_nr_flow2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
                                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS);
+__global__ void gs_k_step_nr_mesh2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS);
+__global__ void gs_k_stepc_nr_mesh2(GsTables T, GsF2Tables F, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
+                                    const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC, GsRolloutStep RS);
 __global__ void gs_k_pre_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,
                                   const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC);
 __global__ void gs_k_post_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg E, double* __restrict__ slab, int B,

@@ -244,7 +244,7 @@ struct F2Stamp {
 // SOLVER: 0 forward/backward sweep, 1 Newton-Raphson.  NW wavefronts per workgroup, NI buses per half wave (NW * 2 * NI = 128
 // positions): the sweep kernel runs 16 x 4, Newton-Raphson -- whose bus state (voltage, the T and s of the elimination)
 // lives in registers across its two sweeps -- 8 x 8, i.e. twice the registers per wave.
-enum { F2_FBS = 0, F2_NR = 1 };
+enum { F2_FBS = 0, F2_NR = 1, F2_NRM = 2 };      // NRM: Newton-Raphson on a meshed feeder (block LU with fill-in, mesh_schedule.h)
 template <int SOLVER, int CHK, int NW, int NI, int IW>
 __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, const GsRows& R, const GsSolveCfg& C, const GsEnvCfg& E,
                                         double* __restrict__ slab, int B, const double* __restrict__ actions, double total_load,
@@ -271,7 +271,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // vector lane) instead.
   int n = T.n, m = T.m, nsl = F.n_slots;
   int o_env = F.off_env, o_tile = F.off_tile, o_red = F.off_red, o_atom = F.off_atom, o_anc = F.off_anc, o_z = F.off_z, o_prof = F.off_prof;
-  int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl * 4 : F.n_anc_ints;  // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
+  int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl * 4 : SOLVER == F2_NRM ? 0 : F.n_anc_ints;  // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
   const int32_t* anc_g = F.anc; const double* zbus_g = F.zbus;
   F2_KEEP(n); F2_KEEP(m); F2_KEEP(nsl); F2_KEEP(o_env); F2_KEEP(o_tile); F2_KEEP(o_red); F2_KEEP(o_atom); F2_KEEP(o_anc); F2_KEEP(o_z);
   F2_KEEP(o_prof); F2_KEEP(n_tab); F2_KEEP(anc_g); F2_KEEP(zbus_g);
@@ -297,7 +297,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // round trips in a row, 9 k cycles = 13 % of the launch before the first useful instruction)
   double told = ROW(R.TIME), kold = ROW(R.STEP);
   uint64_t seed = lane_seed(S, R);
-  const int n_z = (SOLVER == F2_FBS ? 2 : 4) * nsl;                        // z per bus; Newton-Raphson (G_ip, B_ip, G_ii, B_ii) per bus
+  const int n_z = SOLVER == F2_NRM ? 0 : (SOLVER == F2_FBS ? 2 : 4) * nsl;                        // z per bus; Newton-Raphson (G_ip, B_ip, G_ii, B_ii) per bus
   const int tab0 = (int)threadIdx.x < n_tab ? anc_g[threadIdx.x] : 0;
   const double z0 = (int)threadIdx.x < n_z ? zbus_g[threadIdx.x] : 0.0;
   // (the load profile's 24 factors too: read from the module's table where it is used, every draw wave waited a round trip
@@ -386,11 +386,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   int ibus[NI], ilast[NI];
   unsigned roots = 0u;                   // bit j: item j hangs off the slack bus
   f2_i4 rdev[NI][2]; int rdev_b1[NI];    // devices at the bus (GsF2Rec: nl, l0, l1, ng | g0, g1, nb, b0 | b1)
+  if constexpr (SOLVER != F2_NRM) {      // (the meshed member, with more rows than it has registers for their records, reads them in the injection pass)
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const f2_i4 a = *(const f2_i4*)&rec0[j].bus;
     ibus[j] = a.x; ilast[j] = a.w; roots |= (a.z & 2) ? (1u << j) : 0u;
     rdev[j][0] = *(const f2_i4*)&rec0[j].nl; rdev[j][1] = *(const f2_i4*)&rec0[j].g0; rdev_b1[j] = rec0[j].b1;
+  }
   }
   const int nb = T.n_bats, ng = T.n_gens, nl_ = T.n_loads;
   if (wave == 0) {
@@ -475,6 +477,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   double Pj[NI], IR[NI], II[NI], JR[NI], JI[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
+    if constexpr (SOLVER == F2_NRM) { rdev[j][0] = *(const f2_i4*)&rec0[j].nl; rdev[j][1] = *(const f2_i4*)&rec0[j].g0; rdev_b1[j] = rec0[j].b1; }
     const int nl = rdev[j][0].x, l0 = rdev[j][0].y, l1 = rdev[j][0].z, ngj = rdev[j][0].w, g0 = rdev[j][1].x, g1 = rdev[j][1].y,
               nbj = rdev[j][1].z, b0 = rdev[j][1].w, b1 = rdev_b1[j];
     double ls = 0.0, gs = 0.0;
@@ -489,7 +492,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   }
   stp.hit(F2_ST_PROLOGUE);
   f2_lds_sync();                     // the load powers (tile region) have been read: the region becomes the solver's second buffer
-  if (wave == 0) f2_st2((unsigned)o_tile + f2_slot(SL_ZERO, l), make_double2(0.0, 0.0));      // "no ancestor" reads as 0 in both buffers
+  if constexpr (SOLVER != F2_NRM) {
+    if (wave == 0) f2_st2((unsigned)o_tile + f2_slot(SL_ZERO, l), make_double2(0.0, 0.0));      // "no ancestor" reads as 0 in both buffers
+  }
 
   F2State st; st.mm = INFINITY; st.iters = 0; st.conv = 0; st.status = GS_STATUS_MAX_ITER; st.done = !valid;
   double psum = 0.0;
@@ -829,6 +834,271 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     stale = true;
   }
   if (stale) { (void)mismatch(false); }       // iteration cap reached after an update: the losses sum at the final voltages
+  } else if constexpr (SOLVER == F2_NRM) {
+  // ================= Newton-Raphson on a MESHED feeder (power_flow.py:143-193; the linear solve of :186-190 as a block LU) =================
+  // mesh_schedule.h describes the elimination: pull model, accumulating messages, a pivot of degree d on a group of d
+  // sub-groups of one wavefront row.  Here: 8 instances per workgroup, NW wavefronts, each walking its rows (at most NI) in
+  // level order; a row is 8 sub-groups = 8 lane items (GsMeshItem, read from global memory: the tables are the same for every
+  // workgroup and stay in the L2).  LDS: the voltage slots (as everywhere in this file); the region behind them = the ZERO
+  // message, a DUMMY to write to, and the body -- accumulators during the elimination, the x slots during the back
+  // substitution --; a scratch of 3 units per sub-group and wave for the exchanges inside a group (D^-1 and s from lane 0, every
+  // lane's T, the partial sums of the back substitution: LDS executes a wave's instructions in order, so a write followed by a
+  // read of the same wave needs no barrier).  Registers: T of every row's item and s / x of its pivot (NI x 6 doubles), P_spec.
+  static_assert(IW == 8, "the meshed member is laid out for 8 instances per workgroup");
+  constexpr unsigned UB = 16u * IW;                              // a unit: 16 bytes per instance
+  const unsigned l16 = (unsigned)l << 4;
+  const unsigned R_ZERO = (unsigned)o_tile;                      // region: ZERO (3 units) | DUMMY (3 units) | body
+  const unsigned scr = (unsigned)F.off_scr + (unsigned)wave * (HV * 3u * UB), scr_me = scr + (unsigned)hv * (3u * UB) + l16;
+  const GS_CONST int32_t* const rinfo = (const GS_CONST int32_t*)F.mesh_rowinfo + (size_t)wave * NI * 4;      // wave-uniform: scalar loads
+  const GsMeshItem* const items = F.mesh_items + (size_t)wave * NI * HV + hv;                                  // row j: items[j * HV]
+  const int NL = F.n_levels;
+  if (threadIdx.x < 3 * IW) f2_st2(R_ZERO + (threadIdx.x >> 3) * UB + ((threadIdx.x & 7u) << 4), make_double2(0.0, 0.0));   // (first read: behind the first check's barrier)
+  double T00[NI], T01[NI], T10[NI], T11[NI], sx0[NI], sx1[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; sx0[j] = 0.0; sx1[j] = 0.0; }
+  // row j of the register arrays, j wave-uniform: a scalar compare-and-branch chain around the moves (the asm keeps the compiler
+  // from turning it into 2 (NI - 1) selects per value)
+#define F2_ROW_CASE(Q, STMT) case Q: if constexpr (Q < NI) { constexpr int RQ = Q < NI ? Q : 0; STMT; asm volatile("" ::: "memory"); } break;
+#define F2_ROW(j, STMT) switch (j) { F2_ROW_CASE(0, STMT) F2_ROW_CASE(1, STMT) F2_ROW_CASE(2, STMT) F2_ROW_CASE(3, STMT) F2_ROW_CASE(4, STMT) F2_ROW_CASE(5, STMT) \
+                                     F2_ROW_CASE(6, STMT) F2_ROW_CASE(7, STMT) F2_ROW_CASE(8, STMT) F2_ROW_CASE(9, STMT) F2_ROW_CASE(10, STMT) F2_ROW_CASE(11, STMT) default: break; }
+  static_assert(NI <= 12, "F2_ROW covers 12 rows");
+  // (Y V)_k over the Ybus row of the item's bus, CSR order; a lane that is not a pivot's lane 0 has a row of (ZERO slot, 0) entries
+  auto calc_pq = [&](const GsMeshItem* it, int nadj, double2 vk, double& pc, double& qc) {
+    const int ap = it->adj_ptr;
+    const int32_t* ao = F.mesh_adj_off + ap; const double2* ay = (const double2*)F.mesh_adj_y + ap;
+    double ir = 0.0, ii = 0.0;
+#pragma unroll 4
+    for (int u = 0; u < nadj; ++u) {
+      const double2 y = ay[u];
+      const double2 v = f2_ld2((unsigned)ao[u] + l16);
+      ir += __builtin_fma(y.x, v.x, -(y.y * v.y)); ii += __builtin_fma(y.x, v.y, y.y * v.x);
+    }
+    pc = __builtin_fma(vk.x, ir, vk.y * ii); qc = __builtin_fma(vk.y, ir, -(vk.x * ii));        // S = V conj(I) (power_flow.py:150-157)
+  };
+  auto mismatch = [&]() -> double {
+    double lmax = 0.0, bad = 0.0, ps = 0.0;
+#pragma nounroll
+    for (int j = 0; j < NI; ++j) {
+      const int lev = rinfo[4 * j];
+      if (lev < 0) break;                                        // a wave's rows are the first of its NI
+      const int nadj = rinfo[4 * j + 2];
+      const GsMeshItem* it = items + (size_t)j * HV;
+      const int fl = it->flags;
+      const double2 vk = f2_ld2((unsigned)it->vk_off + l16);
+      double pc, qc;
+      calc_pq(it, nadj, vk, pc, qc);
+      double Pk = 0.0;
+      F2_ROW(j, Pk = Pj[RQ]);
+      const double dP = Pk - pc, dQ = 0.0 - qc;                  // power_flow.py:159-165
+      if (fl & GS_MESH_F_PIVOT) { lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ))); bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad)); }
+      if (fl & (GS_MESH_F_PIVOT | GS_MESH_F_SLACKPOS)) ps += pc;                                    // total losses = sum of P_calc over ALL buses (:198-200)
+    }
+    if (bad != bad) lmax = INFINITY;
+    psum = ps;
+    return lmax;
+  };
+  bool stale = true;
+  for (int it_ = 0; it_ < C.max_iterations; ++it_) {
+    const double lm = mismatch();
+    stp.hit(F2_ST_MISMATCH);
+    const double mm = wg_max(lm);
+    stp.hit(F2_ST_FLAG);
+    f2_check(st, mm, mm, it_, C.tolerance);
+    stale = false;
+    if (__all(st.done)) break;
+    // ---------------- elimination, level by level ----------------
+    int sing = 0;
+    {
+      int lv = 0;
+#pragma nounroll
+      for (int j = 0; j < NI; ++j) {
+        const int lev = rinfo[4 * j];
+        if (lev < 0) break;
+        const int pk = rinfo[4 * j + 1], nadj = rinfo[4 * j + 2];
+        const int g_row = pk & 255, ncq = (pk >> 8) & 255, nrw = (pk >> 16) & 255, ncl = (pk >> 24) & 255;
+        const GsMeshItem* it = items + (size_t)j * HV;
+        // everything that does not depend on the messages comes before the wait for the row's level
+        const f2_i4 h0 = *(const f2_i4*)&it->vk_off, h1 = *(const f2_i4*)&it->flags;        // vk, vj, xk, xj | flags, cq_off, adj_ptr, bus
+        const double2 ykj = *(const double2*)&it->ykj_g, ykk = *(const double2*)&it->ykk_g;
+        const f2_i4 mo0 = *(const f2_i4*)&it->mout[0], mo1 = *(const f2_i4*)&it->mout[4];
+        const f2_i4 icq = *(const f2_i4*)&it->cq_in[0], irw = *(const f2_i4*)&it->rw_in[0], icl = *(const f2_i4*)&it->cl_in[0];
+        const int fl = h1.x;
+        const bool pivot = (fl & GS_MESH_F_PIVOT) != 0;
+        const unsigned hv0 = ((unsigned)fl >> GS_MESH_F_HV0_SHIFT) & 15u, tl = ((unsigned)fl >> GS_MESH_F_T_SHIFT) & 15u;
+        const double2 vk = f2_ld2((unsigned)h0.x + l16), vj = f2_ld2((unsigned)h0.y + l16);
+        double pc, qc;
+        calc_pq(it, nadj, vk, pc, qc);
+        if (!pivot) { pc = 0.0; qc = 0.0; }                       // (the slack's position: its row is there for the mismatch pass only)
+        double Pk = 0.0;
+        F2_ROW(j, Pk = Pj[RQ]);
+        const double v2 = __builtin_fma(vk.x, vk.x, vk.y * vk.y), rvk = f2_rsq(v2), vmk = v2 * rvk;
+        const double rvj = f2_rsq(__builtin_fma(vj.x, vj.x, vj.y * vj.y));
+        // diagonal block (power_flow.py:247-248 exact sign, 259-260, 270-271, 283-284) and right-hand side (:159-165)
+        double d00 = -qc - v2 * ykk.y, d01 = pc * rvk + vmk * ykk.x, d10 = pc - v2 * ykk.x, d11 = qc * rvk - vmk * ykk.y;
+        double r0 = Pk - pc, r1 = 0.0 - qc;
+        // the branch's two off-diagonal blocks (power_flow.py:251, 263, 274, 287): row k column j, row j column k
+        const double a = vk.x * vj.x + vk.y * vj.y, bk = vk.y * vj.x - vk.x * vj.y, bj = -bk;
+        const double gsk = ykj.x * bk - ykj.y * a, gck = ykj.x * a + ykj.y * bk;
+        const double gsj = ykj.x * bj - ykj.y * a, gcj = ykj.x * a + ykj.y * bj;
+        double a00 = gsk, a01 = gck * rvj, a10 = -gck, a11 = gsk * rvj;             // A(k, j)
+        double c00 = gsj, c01 = gcj * rvk, c10 = -gcj, c11 = gsj * rvk;             // A(j, k)
+        while (lv < lev) { f2_lds_sync(); ++lv; }
+        // ---- pull: what earlier pivots addressed to this one
+#pragma unroll
+        for (int u = 0; u < GS_MESH_ACC; ++u) {
+          if (u < ncq) {
+            const unsigned o = (unsigned)icq[u] + l16;
+            const double2 m0 = f2_ld2(o), m1 = f2_ld2(o + UB), mq = f2_ld2(o + 2u * UB);
+            d00 += m0.x; d01 += m0.y; d10 += m1.x; d11 += m1.y; r0 += mq.x; r1 += mq.y;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GS_MESH_ACC; ++u) {
+          if (u < nrw) { const unsigned o = (unsigned)irw[u] + l16; const double2 m0 = f2_ld2(o), m1 = f2_ld2(o + UB); a00 += m0.x; a01 += m0.y; a10 += m1.x; a11 += m1.y; }
+        }
+#pragma unroll
+        for (int u = 0; u < GS_MESH_ACC; ++u) {
+          if (u < ncl) { const unsigned o = (unsigned)icl[u] + l16; const double2 m0 = f2_ld2(o), m1 = f2_ld2(o + UB); c00 += m0.x; c01 += m0.y; c10 += m1.x; c11 += m1.y; }
+        }
+        // ---- the pivot: D^-1, s (every lane on the diagonal block it holds; only a group's lane 0 holds the real one)
+        const double det = d00 * d11 - d01 * d10;
+        if (pivot && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;          // power_flow.py:188-190: only an exactly singular matrix raises
+        const double rdet = f2_rcp(det);
+        double i00 = d11 * rdet, i01 = -d01 * rdet, i10 = -d10 * rdet, i11 = d00 * rdet;
+        double s0 = i00 * r0 + i01 * r1, s1 = i10 * r0 + i11 * r1;
+        if (g_row > 1) {                                          // the group's lanes take D^-1 and s from its lane 0
+          f2_st2(scr_me, make_double2(i00, i01)); f2_st2(scr_me + UB, make_double2(i10, i11)); f2_st2(scr_me + 2u * UB, make_double2(s0, s1));
+          const unsigned o = scr + hv0 * (3u * UB) + l16;
+          const double2 q0 = f2_ld2(o), q1 = f2_ld2(o + UB), q2 = f2_ld2(o + 2u * UB);
+          i00 = q0.x; i01 = q0.y; i10 = q1.x; i11 = q1.y; s0 = q2.x; s1 = q2.y;
+        }
+        const double t00 = i00 * a00 + i01 * a10, t01 = i00 * a01 + i01 * a11, t10 = i10 * a00 + i11 * a10, t11 = i10 * a01 + i11 * a11;      // T(k, j) = D^-1 A(k, j)
+        F2_ROW(j, (T00[RQ] = t00, T01[RQ] = t01, T10[RQ] = t10, T11[RQ] = t11, sx0[RQ] = s0, sx1[RQ] = s1));
+        if (g_row > 1) { f2_st2(scr_me, make_double2(t00, t01)); f2_st2(scr_me + UB, make_double2(t10, t11)); }
+        // ---- what this pivot sends on: row j_t of its messages.  q first (it needs nothing from the group)
+        {
+          const bool rmw = ((fl >> (GS_MESH_F_RMW_SHIFT + tl)) & 1) != 0;
+          const unsigned o = (unsigned)h1.y + 2u * UB + l16;
+          const double2 old = f2_ld2(rmw ? o : R_ZERO + l16);
+          f2_st2(o, make_double2(old.x - (c00 * s0 + c01 * s1), old.y - (c10 * s0 + c11 * s1)));
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 8; ++t2) {
+          if (t2 < g_row) {
+            double u00 = t00, u01 = t01, u10 = t10, u11 = t11;
+            if (g_row > 1) {
+              const unsigned o = scr + ((hv0 + (unsigned)t2) & 7u) * (3u * UB) + l16;
+              const double2 q0 = f2_ld2(o), q1 = f2_ld2(o + UB);
+              u00 = q0.x; u01 = q0.y; u10 = q1.x; u11 = q1.y;
+            }
+            const unsigned o = (unsigned)(t2 < 4 ? mo0[t2 & 3] : mo1[t2 & 3]) + l16;
+            const bool rmw = ((fl >> (GS_MESH_F_RMW_SHIFT + t2)) & 1) != 0;
+            const unsigned ro = rmw ? o : R_ZERO + l16;
+            const double2 o0 = f2_ld2(ro), o1 = f2_ld2(ro + UB);
+            f2_st2(o, make_double2(o0.x - (c00 * u00 + c01 * u10), o0.y - (c00 * u01 + c01 * u11)));
+            f2_st2(o + UB, make_double2(o1.x - (c10 * u00 + c11 * u10), o1.y - (c10 * u01 + c11 * u11)));
+          }
+        }
+      }
+      while (lv < NL) { f2_lds_sync(); ++lv; }
+    }
+    stp.hit(F2_ST_BOTTOM_UP);
+    if (sing) atomicOr(icell + 15 * IW + l, 1u);                 // read behind the back substitution, whose barriers publish it
+    stp.hit(F2_ST_INIT);
+    // ---------------- back substitution: x_k = s_k - sum_j T(k, j) x_j, levels downwards; the x slots share the messages' body ----------------
+    {
+      int lv = NL - 1;
+#pragma nounroll
+      for (int j = NI - 1; j >= 0; --j) {
+        const int lev = rinfo[4 * j];
+        if (lev < 0) continue;
+        const int g_row = rinfo[4 * j + 1] & 255;
+        const GsMeshItem* it = items + (size_t)j * HV;
+        const int xk_off = it->xk_off, xj_off = it->xj_off, fl = it->flags;
+        double t00 = 0.0, t01 = 0.0, t10 = 0.0, t11 = 0.0, s0 = 0.0, s1 = 0.0;
+        F2_ROW(j, (t00 = T00[RQ], t01 = T01[RQ], t10 = T10[RQ], t11 = T11[RQ], s0 = sx0[RQ], s1 = sx1[RQ]));
+        while (lv > lev) { f2_lds_sync(); --lv; }
+        const double2 xj = f2_ld2((unsigned)xj_off + l16);
+        double p0 = t00 * xj.x + t01 * xj.y, p1 = t10 * xj.x + t11 * xj.y;
+        if (g_row > 1) {                                          // a group's partial sums, added by its lane 0 in lane order
+          f2_st2(scr_me, make_double2(p0, p1));
+          const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+          for (int t2 = 0; t2 < 8; ++t2) {
+            if (t2 < g_row) {
+              const double2 q = f2_ld2(scr + (((unsigned)hv + (unsigned)t2) & 7u) * (3u * UB) + l16);
+              if ((unsigned)t2 < gl) { a0 += q.x; a1 += q.y; }
+            }
+          }
+          p0 = a0; p1 = a1;
+        }
+        const double x0 = s0 - p0, x1 = s1 - p1;
+        if (fl & GS_MESH_F_PIVOT) f2_st2((unsigned)xk_off + l16, make_double2(x0, x1));
+        F2_ROW(j, (sx0[RQ] = x0, sx1[RQ] = x1));
+      }
+      while (lv > 0) { f2_lds_sync(); --lv; }
+    }
+    {
+      const unsigned sa = icell[15 * IW + l];
+      if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+    }
+    const bool upd = !st.done;
+    stp.hit(F2_ST_TOP_DOWN);
+    // corrections (power_flow.py:315-327) as a rotation and scaling of (e, f): see the radial member above
+    if (__any(upd)) {
+      double kcs[16];
+      {
+        const GS_CONST double* kc0 = (const GS_CONST double*)kF2Series;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) kcs[q] = kc0[q];
+      }
+#pragma nounroll
+      for (int j = 0; j < NI; ++j) {
+        const int lev = rinfo[4 * j];
+        if (lev < 0) break;
+        const GsMeshItem* it = items + (size_t)j * HV;
+        const int vk_off = it->vk_off, fl = it->flags;
+        double x0 = 0.0, x1 = 0.0;
+        F2_ROW(j, (x0 = sx0[RQ], x1 = sx1[RQ]));
+        if (upd && (fl & GS_MESH_F_PIVOT)) {
+          const double2 v = f2_ld2((unsigned)vk_off + l16);
+          const double v2 = __builtin_fma(v.x, v.x, v.y * v.y), rvm0 = f2_rsq(v2), vm0 = v2 * rvm0;
+          const double dth = C.alpha * x0, vmn = vm0 + C.alpha * x1;
+          const bool big = __any(fabs(dth) > 0.5);
+          double h = dth;
+          if (big) {
+            const double k = rint(dth * 0.15915494309189535);
+            h = __builtin_fma(-k, 6.283185307179586, dth);
+            h = __builtin_fma(-k, 2.4492935982947064e-16, h);
+            h *= 0.125;
+          }
+          const double* kc = kcs;
+          const double z = h * h;
+          double sp = kc[0];
+          sp = __builtin_fma(sp, z, kc[1]); sp = __builtin_fma(sp, z, kc[2]); sp = __builtin_fma(sp, z, kc[3]);
+          sp = __builtin_fma(sp, z, kc[4]); sp = __builtin_fma(sp, z, kc[5]); sp = __builtin_fma(sp, z, kc[6]); sp = __builtin_fma(sp, z, kc[7]);
+          double sn = h - h * z * sp;
+          double cp = kc[8];
+          cp = __builtin_fma(cp, z, kc[9]); cp = __builtin_fma(cp, z, kc[10]); cp = __builtin_fma(cp, z, kc[11]);
+          cp = __builtin_fma(cp, z, kc[12]); cp = __builtin_fma(cp, z, kc[13]); cp = __builtin_fma(cp, z, kc[14]); cp = __builtin_fma(cp, z, kc[15]);
+          double cs = __builtin_fma(z, cp, 1.0);
+          if (big) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const double c2 = __builtin_fma(cs, cs, -(sn * sn)), s2 = 2.0 * cs * sn; cs = c2; sn = s2; }
+          }
+          const double ratio = vmn * rvm0;
+          f2_st2((unsigned)vk_off + l16, make_double2(ratio * (v.x * cs - v.y * sn), ratio * (v.x * sn + v.y * cs)));
+        }
+      }
+    }
+    f2_lds_sync();                   // the new voltages are read by the neighbours' lanes in the next mismatch
+    stp.hit(14);
+    stale = true;
+  }
+  if (stale) { (void)mismatch(); }          // iteration cap reached after an update: the losses sum at the final voltages
+#undef F2_ROW
+#undef F2_ROW_CASE
   } else {
   // ================= the sweeps =================
   // The algorithm is the one of fbs_loop_flow (kernels_solve.hip): flat start, mismatch S_spec - V conj(I) evaluated on
@@ -1330,3 +1600,6 @@ F2_KERNELS(nr_flow2s, F2_NR, GS_F2NS_WAVES, GS_F2NS_ITEMS, GS_F2S_IW)          /
 F2_KERNELS_OCC(fbs_flow2h, F2_FBS, GS_F2H_WAVES, GS_F2H_ITEMS, GS_F2H_IW, __attribute__((amdgpu_waves_per_eu(4, 4))))
 // up to 256 buses below the slack: eight buses per sub-group (twice the registers: two waves per SIMD), one workgroup per CU
 F2_KERNELS(fbs_flow2x, F2_FBS, GS_F2X_WAVES, GS_F2X_ITEMS, GS_F2H_IW)
+// Newton-Raphson on a meshed feeder (a few loops on a tree): 8 instances per workgroup, 4 wavefronts, up to GS_F2M_ITEMS rows each,
+// two workgroups per CU (two waves per SIMD: 256 registers)
+F2_KERNELS_OCC(nr_mesh2, F2_NRM, GS_F2M_WAVES, GS_F2M_ITEMS, GS_F2S_IW, __attribute__((amdgpu_waves_per_eu(2, 2))))

@@ -1,0 +1,156 @@
+"""GPU parity of the meshed Newton-Raphson member of the second-generation step kernels (gs_k_step_nr_mesh2: the block LU of
+a feeder with a few loops as rows of lane items, accumulating messages in LDS; csrc/mesh_schedule.h, kernels_flow2.hip) --
+the kind of network the reference's own IEEE123Bus generates (26 cycles, feeders/ieee_feeders.py:236-330) and solves densely
+(np.linalg.solve, environments/power_flow.py:186-190).  Through the C ABI: against the NumPy oracle's environment (dense
+Newton-Raphson, exact Jacobian) on seeded batches, against the first-generation sparse-LU kernel it replaces, under an
+iteration cap, and for an instance's independence of the batch it runs in."""
+import numpy as np
+import pytest
+
+import grid_fed_rl_gym_amd as P
+from tests.test_gpu_env import _oracle_rollout
+
+pytestmark = pytest.mark.gpu
+
+MESHED = [(lambda: P.random_meshed(123, 26, seed=1), 44),      # the benchmark's feeder: 26 loops on 123 buses
+          (lambda: P.random_meshed(60, 10, seed=2), 70),
+          (lambda: P.random_meshed(20, 4, seed=1), 9),         # one partial workgroup more than a slab group's worth of them
+          (lambda: P.random_meshed(123, 26, seed=5), 20)]      # a wider core: bigger message region, one workgroup per CU
+
+
+def _env(spec, B, **kw):
+    base = dict(num_envs=B, solver="nr", stochastic_loads=True, weather_variation=True, jacobian="exact", tolerance=1e-9, max_iterations=50)
+    base.update(kw)
+    return P.BatchedGridEnvironment(spec, **base)
+
+
+@pytest.mark.parametrize("maker,B", MESHED)
+def test_meshed_environment_steps_equal_the_oracle(maker, B):
+    spec = maker()
+    assert not spec.is_radial()
+    T = 3
+    rng = np.random.default_rng(91)
+    actions = rng.uniform(-1, 1, (T, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 300
+    t0 = 11.5 * 3600.0
+    env = _env(spec, B, first_instance=500)
+    d = env.handle.describe()
+    assert d["kernel"] == "nr_mesh2", d
+    env.reset(seed=seeds)
+    st = env.get_state(); st[:, env.state_column("time")] = t0; env.set_state(st)
+    cfg = dict(stochastic_loads=True, weather_variation=True, power_base=spec.base_power_va, solver="nr", tolerance=1e-9, max_iterations=50,
+               jacobian_mode="exact", zero_z="open")
+    ref = _oracle_rollout(spec, cfg, actions, seeds, first_instance=500, t0=t0)
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(actions[t])
+        assert info["power_flow_converged"].all()
+        for b in range(B):
+            o, r, te, tr, inf = ref[b][t]
+            assert np.max(np.abs(obs[b] - o) / np.maximum(1.0, np.abs(o))) < 1e-8, (t, b, int(np.argmax(np.abs(obs[b] - o))))
+            assert abs(rew[b] - r) <= 1e-7 * max(1.0, abs(r)) and bool(term[b]) == te and bool(trunc[b]) == tr
+            assert int(info["iterations"][b]) == int(inf["iterations"]), (t, b)
+            assert abs(info["total_losses"][b] - inf["total_losses"]) < 1e-8
+    env.close()
+
+
+@pytest.mark.parametrize("maker,B", MESHED[:3])
+def test_meshed_member_equals_the_first_generation_sparse_lu_kernel(maker, B, monkeypatch):
+    """Steps with stochastic loads and weather, the fused post-step checks, a masked reset, a checkpoint round trip and a device
+    rollout with in-place resets: observations within 1e-10 of the slab-row sparse LU (the same pivots in the same order, sums
+    associated differently), every discrete output equal."""
+    from grid_fed_rl_gym_amd.safety import PostStepChecks
+    spec = maker()
+    kw = dict(episode_length=6)
+    rng = np.random.default_rng(17)
+    acts = rng.uniform(-1, 1, (5, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 40
+    mask = (rng.random(B) < 0.3).astype(np.uint8)
+    outs = {}
+    for which in ("mesh2", "sparse_lu"):
+        if which == "sparse_lu":
+            monkeypatch.setenv("GS_NO_MESH2", "1")
+        env = _env(spec, B, **kw)
+        monkeypatch.delenv("GS_NO_MESH2", raising=False)
+        assert env.handle.describe()["kernel"] == ("nr_mesh2" if which == "mesh2" else "nr_sparse_lu")
+        got = []
+        h = env.handle
+        env.reset(seed=seeds); h.upload_actions(acts)
+        for k in range(2):
+            h.step_device(k)
+        got.append(h.download_step()); got.append(env.last_solution())
+        ck = PostStepChecks(env, fused=True)
+        h.step_device(2)
+        got.append(ck.download()); got.append(h.download_step())
+        ck.close()
+        h.reset(seeds + np.uint64(1), mask, want_obs=False)
+        env.set_state(env.get_state())
+        h.step_device(3)
+        got.append(h.download_step())
+        h.rollout(9, "random", seed=5)
+        got.append(h.rollout_download())
+        outs[which] = got
+        env.close()
+    for k, (a, b) in enumerate(zip(outs["mesh2"], outs["sparse_lu"])):
+        for q in a:
+            x, y = np.asarray(a[q]), np.asarray(b[q])
+            if x.dtype.kind == "f":
+                assert np.max(np.abs(x - y) / np.maximum(1.0, np.abs(y)), initial=0.0) < 1e-10, (k, q)
+            else:
+                assert np.array_equal(x, y), (k, q)
+    assert outs["mesh2"][-1]["n_terminal"] > 0
+
+
+@pytest.mark.parametrize("cap", [1, 2])
+def test_meshed_member_under_an_iteration_cap_matches_the_oracle(cap):
+    spec = P.random_meshed(60, 10, seed=2); B, T = 21, 2
+    rng = np.random.default_rng(11)
+    actions = rng.uniform(-1, 1, (T, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 5
+    env = _env(spec, B, max_iterations=cap, first_instance=40)
+    assert env.handle.describe()["kernel"] == "nr_mesh2"
+    env.reset(seed=seeds)
+    cfg = dict(stochastic_loads=True, weather_variation=True, power_base=spec.base_power_va, solver="nr", tolerance=1e-9, max_iterations=cap,
+               jacobian_mode="exact", zero_z="open")
+    ref = _oracle_rollout(spec, cfg, actions, seeds, first_instance=40)
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(actions[t])
+        assert not info["power_flow_converged"].any() and (info["iterations"] == cap).all() and (info["status"] == 1).all()
+        for b in range(B):
+            o, r, te, tr, inf = ref[b][t]
+            assert np.max(np.abs(obs[b] - o) / np.maximum(1.0, np.abs(o))) < 1e-9, (t, b)
+    env.close()
+
+
+def test_meshed_member_at_bench_size_is_independent_of_the_batch_and_solves_the_equations():
+    """B = 8192 on the benchmark's feeder: every instance converged; the voltages satisfy S = V conj(Y V) with the oracle's dense
+    Ybus at the injections the step built; and the same instances (global-index seeds) in two smaller handles give the same
+    observations bit for bit."""
+    from oracle import oracle_np as O
+    spec = P.random_meshed(123, 26, seed=1); B = 8192
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(-1, 1, (2, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 9
+    env = _env(spec, B, tolerance=1e-8)
+    d = env.handle.describe()
+    assert d["kernel"] == "nr_mesh2" and d["workgroups"] == 1024
+    env.reset(seed=seeds)
+    for t in range(2):
+        obs, rew, term, trunc, info = env.step(acts[t])
+    assert info["power_flow_converged"].all() and info["iterations"].max() <= 6
+    n = spec.n
+    Y = O.admittance_matrix(n, spec.frm, spec.to, spec.r, spec.x)
+    sol = env.last_solution()
+    for b in (0, 77, 4095, 8191):
+        V = sol["bus_voltages"][b] * np.exp(1j * sol["bus_angles"][b])
+        S = V * np.conj(Y @ V)
+        assert np.max(np.abs(S[1:].imag)) < 1e-7                      # Q_spec = 0 at every PQ bus
+        assert abs(S.real.sum() - info["total_losses"][b]) < 1e-9
+    parts = []
+    for lo, hi in ((0, 5000), (5000, B)):
+        e2 = _env(spec, hi - lo, tolerance=1e-8, first_instance=lo)
+        e2.reset(seed=seeds[lo:hi])
+        for t in range(2):
+            o2, *_ = e2.step(acts[t, lo:hi])
+        parts.append(o2); e2.close()
+    np.testing.assert_array_equal(np.vstack(parts), obs)
+    env.close()
