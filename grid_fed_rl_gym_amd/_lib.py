@@ -109,6 +109,7 @@ SYMBOLS = [
     ("gs_allgather_obs", C.c_int, [_H, _dp]),
     ("gs_comm_destroy", C.c_int, [_H]),
     ("gs_comm_info", C.c_int, [_H, C.c_void_p]),
+    ("gs_mesh_schedule_dump_packed", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip, _ip, _dp, _ip]),
     ("gs_mesh_schedule_dump", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_char_p, C.c_int32,
                                         C.c_void_p, _ip, _ip, _dp]),
     ("gs_comm_init_loopback", C.c_int, [C.POINTER(_H), C.c_int32]),
@@ -303,6 +304,19 @@ def mesh_schedule(spec: FeederSpec, nw: int = 4, ni: int = 10, acc_cap: int = 4,
     if rc != GS_OK:
         raise PowerFlowError(f"gs_mesh_schedule_dump failed ({rc}): {lib.gs_last_error(None).decode()}")
     out.update(items=items.reshape(nw, ni, 8), rowinfo=rowinfo.reshape(nw, ni, 4), adj_off=adj_off, adj_y=adj_y)
+    # the packed form the kernel reads
+    cnt = np.zeros(4, dtype=np.int32)
+    rc = lib.gs_mesh_schedule_dump_packed(*args, _ptr(cnt, _ip), None, None, None, None)
+    if rc != GS_OK:
+        raise PowerFlowError(f"gs_mesh_schedule_dump_packed failed ({rc}): {lib.gs_last_error(None).decode()}")
+    packed = np.zeros((nw * ni * 8, int(cnt[3])), dtype=np.int32)
+    rowinfo_p = np.zeros((nw * ni, 4), dtype=np.int32)
+    ytab = np.zeros((int(cnt[1]) // 2, 2))
+    adj_ent = np.zeros(int(cnt[2]), dtype=np.int32)
+    rc = lib.gs_mesh_schedule_dump_packed(*args, _ptr(cnt, _ip), _ptr(packed, _ip), _ptr(rowinfo_p, _ip), _ptr(ytab, _dp), _ptr(adj_ent, _ip))
+    if rc != GS_OK:
+        raise PowerFlowError(f"gs_mesh_schedule_dump_packed failed ({rc}): {lib.gs_last_error(None).decode()}")
+    out.update(n_pairs=int(cnt[0]), packed=packed.reshape(nw, ni, 8, -1), rowinfo_packed=rowinfo_p.reshape(nw, ni, 4), ytab=ytab, adj_ent=adj_ent)
     return out
 
 

@@ -735,14 +735,14 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   std::vector<GsF2Rec> f2recs; std::vector<int32_t> f2anc; std::vector<double> f2z;
   auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   // LDS carve-up shared by the members of the family; returns the total
-  auto f2_layout = [&](GsF2Tables& F, int NW, int IW, size_t second_region_min, size_t n_table_ints, int zcols) {
+  auto f2_layout = [&](GsF2Tables& F, int NW, int IW, size_t second_region_min, size_t n_table_ints, int zcols, size_t z_bytes = 0) {
     const int nsl = ht.n + 3;
     const size_t SB = (size_t)(IW + 1) * 16;
     size_t off = up16((size_t)nsl * SB);
     F.off_tile = (int32_t)off;
     off += up16(std::max<size_t>({(size_t)nsl * SB, second_region_min, (size_t)ht.m * SB, (size_t)(topo->n_loads + 4) * IW * sizeof(double)}));
     F.off_anc = (int32_t)off; off += up16(n_table_ints * 4);
-    F.off_z = (int32_t)off; off += up16((size_t)nsl * zcols * 8);
+    F.off_z = (int32_t)off; off += up16(std::max((size_t)nsl * zcols * 8, z_bytes));
     F.off_prof = (int32_t)off; off += up16(24 * sizeof(double));
     F.env_genp = 0; F.env_curt = topo->n_gens; F.env_batp = 2 * topo->n_gens; F.env_soc = 2 * topo->n_gens + topo->n_bats;
     F.off_env = (int32_t)off; off += up16((size_t)(2 * topo->n_gens + 2 * topo->n_bats + 1) * IW * sizeof(double));
@@ -947,7 +947,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   }
 
   // -- Newton-Raphson on a meshed feeder: the block LU as rows of lane items (mesh_schedule.h), 8 instances per workgroup
-  std::vector<GsMeshItem> mesh_items; std::vector<int32_t> mesh_rowinfo, mesh_adj_off; std::vector<double> mesh_adj_y;
+  std::vector<int32_t> mesh_items, mesh_rowinfo;
   if (h->solve_kernel == 1 && !ht.is_forest) {
     std::string& why = h->mesh_why;
     const int NW = GS_F2M_WAVES, NI = GS_F2M_ITEMS, IW = GS_F2S_IW, HV = 64 / IW;
@@ -967,15 +967,19 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       if (!S.ok) why = S.why;
     }
     if (why.empty()) {
-      size_t off = f2_layout(F, NW, IW, (size_t)S.region_bytes, 0, 0);
-      F.off_scr = (int32_t)off; off += (size_t)NW * HV * 3 * 16 * IW;       // exchange scratch: 3 units per sub-group and wave
+      // ints staged at off_anc: every bus's neighbour list; doubles at off_z: the Ybus entries of the pairs, then of the diagonal per slot
+      size_t off = f2_layout(F, NW, IW, (size_t)S.region_bytes, S.adj_ent.size(), 0, S.ytab.size() * sizeof(double));
+      F.off_scr = (int32_t)off; off += (size_t)NW * 16 * 16 * IW;           // exchange scratch: 16 units per wave
+      F.mesh_off_p = (int32_t)off; off += (size_t)nsl * IW * sizeof(double);   // P_spec by voltage slot
       F.lds_bytes = (int32_t)off;
       if (off > 160 * 1024) why = "LDS tables do not fit";
     }
     if (why.empty()) {
       h->nrm = true; h->f2_small = false; h->f2_iw = IW; h->f2_nw = NW; h->f2_npos = NW * HV * NI;
       h->mesh_levels = S.n_levels; h->mesh_rows = S.n_rows; h->mesh_units = S.msg_units; h->mesh_messages = S.n_messages; h->mesh_accs = S.n_accumulators;
-      F.n_jump = 0; F.n_levels = S.n_levels; F.pos_off = 0; F.n_anc_ints = 0; F.ring_zero = 0;
+      F.n_jump = 0; F.n_levels = S.n_levels; F.pos_off = 0; F.n_anc_ints = (int32_t)S.adj_ent.size(); F.ring_zero = 0;
+      F.mesh_nz = (int32_t)S.ytab.size(); F.mesh_pairs = S.n_pairs;
+      f2anc = S.adj_ent; f2z = S.ytab;
       GsF2Rec idle{}; idle.bus = SL_DUMMY; idle.parent = SL_ONE; idle.last = SL_DUMMY; idle.level = -1;
       f2recs.assign((size_t)NW * HV * NI, idle);
       for (int w = 0; w < NW; ++w) for (int j = 0; j < NI; ++j) for (int hh = 0; hh < HV; ++hh) {
@@ -985,7 +989,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
         r.bus = it.bus; r.parent = SL_ONE; r.flags = 1; r.last = it.bus; r.level = S.rowinfo[((size_t)w * NI + j) * 4];
         f2_devices(r, it.bus);
       }
-      mesh_items = S.items; mesh_rowinfo = S.rowinfo; mesh_adj_off = S.adj_off; mesh_adj_y = S.adj_y;
+      mesh_items = S.packed; mesh_rowinfo = S.rowinfo_packed;
     }
   }
 
@@ -1131,8 +1135,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   }
 
   if (h->nrm) {
-    if ((rc = dev_upload(h, &h->F2.mesh_items, mesh_items)) || (rc = dev_upload(h, &h->F2.mesh_rowinfo, mesh_rowinfo)) ||
-        (rc = dev_upload(h, &h->F2.mesh_adj_off, mesh_adj_off)) || (rc = dev_upload(h, &h->F2.mesh_adj_y, mesh_adj_y))) return bail(rc);
+    if ((rc = dev_upload(h, &h->F2.mesh_items, mesh_items)) || (rc = dev_upload(h, &h->F2.mesh_rowinfo, mesh_rowinfo))) return bail(rc);
   }
   if (h->flow2 || h->nr2 || h->nrm) {
     // buses with a voltage set point, for the kernels' flat start (the slack; the first entry travels inside the argument block)
@@ -2080,6 +2083,25 @@ int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t 
   if (rowinfo) memcpy(rowinfo, S.rowinfo.data(), S.rowinfo.size() * sizeof(int32_t));
   if (adj_off) memcpy(adj_off, S.adj_off.data(), S.adj_off.size() * sizeof(int32_t));
   if (adj_y) memcpy(adj_y, S.adj_y.data(), S.adj_y.size() * sizeof(double));
+  return GS_OK;
+}
+
+// The same schedule in the form the kernel reads (GS_MESH_W_*): counts[4] = n_pairs, ytab doubles, adj_ent entries, item words
+int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+                                 int32_t slot_bytes, int32_t* counts, int32_t* packed, int32_t* rowinfo, double* ytab, int32_t* adj_ent) {
+  if (!topo || !counts) return fail(nullptr, GS_E_INVALID, "topology / counts is NULL");
+  if (topo->struct_size != (int32_t)sizeof(gs_topology)) return fail(nullptr, GS_E_INVALID, "struct_size mismatch");
+  HostTopology ht;
+  const std::string err = gs_compile_topology(*topo, zero_z_mode, false, true, ht);
+  if (!err.empty()) return fail(nullptr, GS_E_INVALID, "topology: %s", err.c_str());
+  MeshSchedule S;
+  gs_mesh_schedule(ht, nw, ni, 8, region_base, slot_bytes, acc_cap, S);
+  if (!S.ok) return fail(nullptr, GS_E_TOPOLOGY, "%s", S.why.c_str());
+  counts[0] = S.n_pairs; counts[1] = (int32_t)S.ytab.size(); counts[2] = (int32_t)S.adj_ent.size(); counts[3] = GS_MESH_WORDS;
+  if (packed) memcpy(packed, S.packed.data(), S.packed.size() * sizeof(int32_t));
+  if (rowinfo) memcpy(rowinfo, S.rowinfo_packed.data(), S.rowinfo_packed.size() * sizeof(int32_t));
+  if (ytab) memcpy(ytab, S.ytab.data(), S.ytab.size() * sizeof(double));
+  if (adj_ent) memcpy(adj_ent, S.adj_ent.data(), S.adj_ent.size() * sizeof(int32_t));
   return GS_OK;
 }
 

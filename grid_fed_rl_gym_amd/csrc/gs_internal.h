@@ -386,8 +386,8 @@ struct GsPackArgs {
 #define GS_F2S_ITEMS 1
 #define GS_F2NS_WAVES 4           /* Newton-Raphson: 4 waves x 1 item, each a group of 8 buses of one level (2 x 2: 124 M env-steps/s on config 2; 4 x 1: 147 M -- the load draws get waves of their own) */
 #define GS_F2NS_ITEMS 1
-#define GS_F2M_WAVES 4            /* the meshed Newton-Raphson member: 4 waves x up to 10 rows of 8 sub-groups */
-#define GS_F2M_ITEMS 10
+#define GS_F2M_WAVES 4            /* the meshed Newton-Raphson member: 4 waves x up to 9 rows of 8 sub-groups */
+#define GS_F2M_ITEMS 9
 #define GS_F2_CHILDREN 8          /* children per bus in the Newton-Raphson kernel's LDS child tables */
 struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half) * GS_F2_ITEMS + item); 96 bytes
   int32_t bus, parent, flags, last;         // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); last: the bus at the LAST position of this bus's subtree
@@ -420,6 +420,21 @@ enum {
   GS_MESH_F_RMW_SHIFT = 16      // bits 16-23: output t' adds to what its accumulator holds (else: first producer, plain write)
 };
 
+// The same item as the kernel reads it: 16 words.  Offsets are slot / unit numbers (a voltage slot is (IW + 1) * 16 bytes, a unit of
+// the message region 16 * IW bytes; unit 0 = the ZERO message, 3 = DUMMY, 6 + i = the body's unit i; x slot of bus b = unit 6 + b).
+enum {
+  // words 0-3: what a row needs BEFORE its level's messages (read a row ahead)
+  GS_MESH_W_BUS_NBR = 0,        // pivot bus slot | neighbour slot << 16 (idle: the ONE slot)
+  GS_MESH_W_FLAGS = 1,          // GS_MESH_F_* in bits 0-23; bits 24-31: neighbour entries of the pivot bus (lane 0 of a pivot / the slack's position; 0 elsewhere)
+  GS_MESH_W_PAIR_CQ = 2,        // Ybus pair of (bus, neighbour) (n_pairs: none) | unit of CQ(k -> j_t) << 16
+  GS_MESH_W_DIAG_ADJ = 3,       // slot whose diagonal Ybus entry the lane uses | first neighbour entry of the pivot bus << 16
+  // words 4-15: what it needs after them (read at the row's start)
+  GS_MESH_W_CQIN = 4,           // 2 words cq_in, then 2 words rw_in, 2 words cl_in: units, two per word
+  GS_MESH_W_MOUT = 10,          // 4 words: units of M(k -> (j_t, j_t')), two per word
+  GS_MESH_WORDS = 16
+};
+#define GS_MESH_F_NADJ_SHIFT 24
+
 struct GsF2Tables {
   const GsF2Rec* recs;            // [GS_F2_WAVES * 2 * GS_F2_ITEMS]
   const int32_t* anc;             // sweeps: [n_jump][n_slots] 2^r-th ancestor of every slot on its way to the slack, ZERO beyond;
@@ -446,8 +461,9 @@ struct GsF2Tables {
   double* nrflat; int32_t nrflat_mode, pad_nrflat;
   // the meshed member: items [NW * NI * 8], rowinfo [NW * NI][4] (level | -1, g | ncq << 8 | nrw << 16 | ncl << 24, nadj, -), the
   // Ybus rows of the pivot buses (voltage slot offset; (G, B)), and its per-wave exchange scratch in LDS
-  const GsMeshItem* mesh_items; const int32_t* mesh_rowinfo; const int32_t* mesh_adj_off; const double* mesh_adj_y;
-  int32_t off_scr, mesh_pad;
+  const int32_t* mesh_items; const int32_t* mesh_rowinfo;      // packed items (GS_MESH_W_*), [NW * NI * 8][16]
+  int32_t off_scr, mesh_nz;                                    // exchange scratch; doubles of the Ybus tables staged at off_z (pairs, then diagonal per slot)
+  int32_t mesh_pairs, mesh_off_p;                              // P_spec by voltage slot, [slot][8 instances] doubles
 };
 
 // gs_k_rollout_post (kernels_env.hip): bookkeeping after step t of gs_rollout

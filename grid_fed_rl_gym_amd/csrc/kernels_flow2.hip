@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <limits.h>
+#include <type_traits>
 
 #include "../../include/gridstep.h"
 #include "gs_internal.h"
@@ -271,7 +272,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // vector lane) instead.
   int n = T.n, m = T.m, nsl = F.n_slots;
   int o_env = F.off_env, o_tile = F.off_tile, o_red = F.off_red, o_atom = F.off_atom, o_anc = F.off_anc, o_z = F.off_z, o_prof = F.off_prof;
-  int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl * 4 : SOLVER == F2_NRM ? 0 : F.n_anc_ints;  // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
+  int n_tab = SOLVER == F2_FBS ? F.n_jump * nsl * 4 : F.n_anc_ints;  // sweeps: ancestor table; Newton-Raphson: child tables + per-position indices
   const int32_t* anc_g = F.anc; const double* zbus_g = F.zbus;
   F2_KEEP(n); F2_KEEP(m); F2_KEEP(nsl); F2_KEEP(o_env); F2_KEEP(o_tile); F2_KEEP(o_red); F2_KEEP(o_atom); F2_KEEP(o_anc); F2_KEEP(o_z);
   F2_KEEP(o_prof); F2_KEEP(n_tab); F2_KEEP(anc_g); F2_KEEP(zbus_g);
@@ -297,7 +298,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // round trips in a row, 9 k cycles = 13 % of the launch before the first useful instruction)
   double told = ROW(R.TIME), kold = ROW(R.STEP);
   uint64_t seed = lane_seed(S, R);
-  const int n_z = SOLVER == F2_NRM ? 0 : (SOLVER == F2_FBS ? 2 : 4) * nsl;                        // z per bus; Newton-Raphson (G_ip, B_ip, G_ii, B_ii) per bus
+  const int n_z = SOLVER == F2_NRM ? F.mesh_nz : (SOLVER == F2_FBS ? 2 : 4) * nsl;                        // z per bus; Newton-Raphson (G_ip, B_ip, G_ii, B_ii) per bus
   const int tab0 = (int)threadIdx.x < n_tab ? anc_g[threadIdx.x] : 0;
   const double z0 = (int)threadIdx.x < n_z ? zbus_g[threadIdx.x] : 0.0;
   // (the load profile's 24 factors too: read from the module's table where it is used, every draw wave waited a round trip
@@ -488,6 +489,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     if (nbj > 0) { const double bp = env_lds[(F.env_batp + b0) * IW + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
     if (nbj > 1) { const double bp = env_lds[(F.env_batp + b1) * IW + l]; if (bp > 0.0) gs += bp; else if (bp < 0.0) ls += fabs(bp); }
     Pj[j] = (0.0 - gs_div_by(ls, E.power_base, E.inv_power_base)) + gs_div_by(gs, E.power_base, E.inv_power_base);
+    if constexpr (SOLVER == F2_NRM) {      // (the meshed member keeps P_spec by bus in LDS: its rows' registers are taken by the elimination)
+      f2_st((unsigned)F.mesh_off_p + 64u * (unsigned)rec0[j].bus + ((unsigned)l << 3), Pj[j]);
+    }
     IR[j] = 0.0; II[j] = 0.0; JR[j] = 0.0; JI[j] = 0.0;
   }
   stp.hit(F2_ST_PROLOGUE);
@@ -838,57 +842,84 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // ================= Newton-Raphson on a MESHED feeder (power_flow.py:143-193; the linear solve of :186-190 as a block LU) =================
   // mesh_schedule.h describes the elimination: pull model, accumulating messages, a pivot of degree d on a group of d
   // sub-groups of one wavefront row.  Here: 8 instances per workgroup, NW wavefronts, each walking its rows (at most NI) in
-  // level order; a row is 8 sub-groups = 8 lane items (GsMeshItem, read from global memory: the tables are the same for every
-  // workgroup and stay in the L2).  LDS: the voltage slots (as everywhere in this file); the region behind them = the ZERO
-  // message, a DUMMY to write to, and the body -- accumulators during the elimination, the x slots during the back
-  // substitution --; a scratch of 3 units per sub-group and wave for the exchanges inside a group (D^-1 and s from lane 0, every
-  // lane's T, the partial sums of the back substitution: LDS executes a wave's instructions in order, so a write followed by a
-  // read of the same wave needs no barrier).  Registers: T of every row's item and s / x of its pivot (NI x 6 doubles), P_spec.
+  // level order; a row is 8 sub-groups = 8 lane items of 16 words (GS_MESH_W_*), read from global memory ONE ROW AHEAD (the
+  // table is the same for every workgroup: it stays in the L1 / L2; read where it is used, a row cost two dependent round
+  // trips of ~1 k cycles -- 400 k cycles per step).  LDS: the voltage slots (as everywhere in this file); the Ybus entries
+  // of the connected pairs and of the diagonal, and every bus's neighbour list (staged by the frame at off_z / off_anc);
+  // the region behind the slots = the ZERO message, a DUMMY to write to, and the body -- accumulators during the
+  // elimination, the x slots during the back substitution --; a scratch of 3 units per sub-group and wave for the exchanges
+  // inside a group (D^-1 and s from lane 0, every lane's T, the partial sums of the back substitution: LDS executes a wave's
+  // instructions in order, so a write followed by a read of the same wave needs no barrier).  Registers: T of every row's
+  // item and s / x of its pivot (NI x 6 doubles), P_spec.
   static_assert(IW == 8, "the meshed member is laid out for 8 instances per workgroup");
   constexpr unsigned UB = 16u * IW;                              // a unit: 16 bytes per instance
   const unsigned l16 = (unsigned)l << 4;
-  const unsigned R_ZERO = (unsigned)o_tile;                      // region: ZERO (3 units) | DUMMY (3 units) | body
-  const unsigned scr = (unsigned)F.off_scr + (unsigned)wave * (HV * 3u * UB), scr_me = scr + (unsigned)hv * (3u * UB) + l16;
+  const unsigned R0l = (unsigned)o_tile + l16;                   // unit u of the region, this lane's share: R0l + u * UB
+  // this wave's exchange scratch, 16 units, used three ways one after the other: (D^-1, s) of a group's lane 0 at 3 units per group
+  // slot (hv0 / 2: groups of two or more start on even sub-groups), every lane's T at 2 units per sub-group, the back
+  // substitution's partial sums at 1 unit per sub-group
+  const unsigned scr = (unsigned)F.off_scr + (unsigned)wave * (16u * UB) + l16;
+  const unsigned o_ptab = (unsigned)F.mesh_off_p + ((unsigned)l << 3);
+  const unsigned o_pair = (unsigned)o_z, o_diag = (unsigned)o_z + 16u * (unsigned)(F.mesh_pairs + 1);
   const GS_CONST int32_t* const rinfo = (const GS_CONST int32_t*)F.mesh_rowinfo + (size_t)wave * NI * 4;      // wave-uniform: scalar loads
-  const GsMeshItem* const items = F.mesh_items + (size_t)wave * NI * HV + hv;                                  // row j: items[j * HV]
+  const f2_i4* const items = (const f2_i4*)F.mesh_items + ((size_t)wave * NI * HV + hv) * 4;                   // row j: items[j * HV * 4 + 0..3]
   const int NL = F.n_levels;
-  if (threadIdx.x < 3 * IW) f2_st2(R_ZERO + (threadIdx.x >> 3) * UB + ((threadIdx.x & 7u) << 4), make_double2(0.0, 0.0));   // (first read: behind the first check's barrier)
+  const unsigned null_ent = (unsigned)F.n_anc_ints - 1u;
+  if (threadIdx.x < 3 * IW) f2_st2((unsigned)o_tile + (threadIdx.x >> 3) * UB + ((threadIdx.x & 7u) << 4), make_double2(0.0, 0.0));   // the ZERO message (first read: behind the first check's barrier)
   double T00[NI], T01[NI], T10[NI], T11[NI], sx0[NI], sx1[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) { T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; sx0[j] = 0.0; sx1[j] = 0.0; }
   // row j of the register arrays, j wave-uniform: a scalar compare-and-branch chain around the moves (the asm keeps the compiler
   // from turning it into 2 (NI - 1) selects per value)
-#define F2_ROW_CASE(Q, STMT) case Q: if constexpr (Q < NI) { constexpr int RQ = Q < NI ? Q : 0; STMT; asm volatile("" ::: "memory"); } break;
+#define F2_ROW_CASE(Q, STMT) case Q: if constexpr (Q < NI) { constexpr int RQ = Q < NI ? Q : 0; STMT; asm volatile(""); } break;
 #define F2_ROW(j, STMT) switch (j) { F2_ROW_CASE(0, STMT) F2_ROW_CASE(1, STMT) F2_ROW_CASE(2, STMT) F2_ROW_CASE(3, STMT) F2_ROW_CASE(4, STMT) F2_ROW_CASE(5, STMT) \
                                      F2_ROW_CASE(6, STMT) F2_ROW_CASE(7, STMT) F2_ROW_CASE(8, STMT) F2_ROW_CASE(9, STMT) F2_ROW_CASE(10, STMT) F2_ROW_CASE(11, STMT) default: break; }
   static_assert(NI <= 12, "F2_ROW covers 12 rows");
-  // (Y V)_k over the Ybus row of the item's bus, CSR order; a lane that is not a pivot's lane 0 has a row of (ZERO slot, 0) entries
-  auto calc_pq = [&](const GsMeshItem* it, int nadj, double2 vk, double& pc, double& qc) {
-    const int ap = it->adj_ptr;
-    const int32_t* ao = F.mesh_adj_off + ap; const double2* ay = (const double2*)F.mesh_adj_y + ap;
+  // an item's words 0-3 (what a row needs before its level's messages) are read a row ahead, words 4-15 at the row's start
+  auto load_item = [&](int j) -> f2_i4 { return items[(size_t)j * (HV * 4)]; };
+  auto lo16 = [](int w) -> unsigned { return (unsigned)w & 0xffffu; };
+  auto hi16 = [](int w) -> unsigned { return (unsigned)w >> 16; };
+  auto unit_at = [&](unsigned u) -> unsigned { return R0l + u * UB; };
+  auto vslot = [&](unsigned slot) -> unsigned { return __umul24(slot, SB) + l16; };
+  // (Y V)_k over the neighbours of the item's bus (the LDS neighbour list: pair | other bus << 16), then the diagonal; S = V conj(I)
+  auto calc_pq = [&](const f2_i4& it, int nadj, double2 vk, double& pc, double& qc) {
+    const unsigned ap = hi16(it.w), cnt = (unsigned)it.y >> GS_MESH_F_NADJ_SHIFT;
+    const double2 yd = f2_ld2(o_diag + 16u * lo16(it.w));
+    // (no predicate on the lane's own count: beyond it a lane reads the list's last entry -- no branch, the ZERO slot -- so that the
+    // reads of four entries go out together; with `if (u < cnt)` every entry was two LDS round trips of its own)
     double ir = 0.0, ii = 0.0;
-#pragma unroll 4
-    for (int u = 0; u < nadj; ++u) {
-      const double2 y = ay[u];
-      const double2 v = f2_ld2((unsigned)ao[u] + l16);
-      ir += __builtin_fma(y.x, v.x, -(y.y * v.y)); ii += __builtin_fma(y.x, v.y, y.y * v.x);
+    for (int u0 = 0; u0 < nadj; u0 += 4) {
+      int e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = *F2_P(const int, (unsigned)o_anc + 4u * ((unsigned)(u0 + q) < cnt ? ap + (unsigned)(u0 + q) : null_ent));
+      double2 y[4], v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { y[q] = f2_ld2(o_pair + 16u * lo16(e[q])); v[q] = f2_ld2(vslot(hi16(e[q]))); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ir += __builtin_fma(y[q].x, v[q].x, -(y[q].y * v[q].y)); ii += __builtin_fma(y[q].x, v[q].y, y[q].y * v[q].x); }
     }
-    pc = __builtin_fma(vk.x, ir, vk.y * ii); qc = __builtin_fma(vk.y, ir, -(vk.x * ii));        // S = V conj(I) (power_flow.py:150-157)
+    if (cnt) { ir += __builtin_fma(yd.x, vk.x, -(yd.y * vk.y)); ii += __builtin_fma(yd.x, vk.y, yd.y * vk.x); }
+    pc = __builtin_fma(vk.x, ir, vk.y * ii); qc = __builtin_fma(vk.y, ir, -(vk.x * ii));        // power_flow.py:150-157
   };
   auto mismatch = [&]() -> double {
     double lmax = 0.0, bad = 0.0, ps = 0.0;
+    f2_i4 nxt = load_item(0);
 #pragma nounroll
     for (int j = 0; j < NI; ++j) {
       const int lev = rinfo[4 * j];
       if (lev < 0) break;                                        // a wave's rows are the first of its NI
       const int nadj = rinfo[4 * j + 2];
-      const GsMeshItem* it = items + (size_t)j * HV;
-      const int fl = it->flags;
-      const double2 vk = f2_ld2((unsigned)it->vk_off + l16);
+      const f2_i4 it = nxt;
+      if (j + 1 < NI) nxt = load_item(j + 1);
+      const int fl = it.y;
+      const double2 vk = f2_ld2(vslot(lo16(it.x)));
       double pc, qc;
       calc_pq(it, nadj, vk, pc, qc);
-      double Pk = 0.0;
-      F2_ROW(j, Pk = Pj[RQ]);
+#ifdef F2_MESH_P_REG
+      double Pk = 0.0; F2_ROW(j, Pk = Pj[RQ]);
+#else
+      const double Pk = f2_ld(o_ptab + 64u * lo16(it.x));
+#endif
       const double dP = Pk - pc, dQ = 0.0 - qc;                  // power_flow.py:159-165
       if (fl & GS_MESH_F_PIVOT) { lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ))); bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad)); }
       if (fl & (GS_MESH_F_PIVOT | GS_MESH_F_SLACKPOS)) ps += pc;                                    // total losses = sum of P_calc over ALL buses (:198-200)
@@ -910,27 +941,31 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     int sing = 0;
     {
       int lv = 0;
+      f2_i4 nxt = load_item(0);
 #pragma nounroll
       for (int j = 0; j < NI; ++j) {
         const int lev = rinfo[4 * j];
         if (lev < 0) break;
         const int pk = rinfo[4 * j + 1], nadj = rinfo[4 * j + 2];
         const int g_row = pk & 255, ncq = (pk >> 8) & 255, nrw = (pk >> 16) & 255, ncl = (pk >> 24) & 255;
-        const GsMeshItem* it = items + (size_t)j * HV;
+        const f2_i4 it = nxt;
+        const f2_i4* const late = items + (size_t)j * (HV * 4) + 1;
+        const f2_i4 pl0 = late[0], pl1 = late[1], pl2 = late[2];      // words 4-15: cq_in (2), rw_in (2) | cl_in (2), mout 0-3 (2) | mout 4-7 (2), -
+        if (j + 1 < NI) nxt = load_item(j + 1);
         // everything that does not depend on the messages comes before the wait for the row's level
-        const f2_i4 h0 = *(const f2_i4*)&it->vk_off, h1 = *(const f2_i4*)&it->flags;        // vk, vj, xk, xj | flags, cq_off, adj_ptr, bus
-        const double2 ykj = *(const double2*)&it->ykj_g, ykk = *(const double2*)&it->ykk_g;
-        const f2_i4 mo0 = *(const f2_i4*)&it->mout[0], mo1 = *(const f2_i4*)&it->mout[4];
-        const f2_i4 icq = *(const f2_i4*)&it->cq_in[0], irw = *(const f2_i4*)&it->rw_in[0], icl = *(const f2_i4*)&it->cl_in[0];
-        const int fl = h1.x;
+        const int fl = it.y;
         const bool pivot = (fl & GS_MESH_F_PIVOT) != 0;
         const unsigned hv0 = ((unsigned)fl >> GS_MESH_F_HV0_SHIFT) & 15u, tl = ((unsigned)fl >> GS_MESH_F_T_SHIFT) & 15u;
-        const double2 vk = f2_ld2((unsigned)h0.x + l16), vj = f2_ld2((unsigned)h0.y + l16);
+        const double2 vk = f2_ld2(vslot(lo16(it.x))), vj = f2_ld2(vslot(hi16(it.x)));
+        const double2 ykj = f2_ld2(o_pair + 16u * lo16(it.z)), ykk = f2_ld2(o_diag + 16u * lo16(it.w));
         double pc, qc;
         calc_pq(it, nadj, vk, pc, qc);
         if (!pivot) { pc = 0.0; qc = 0.0; }                       // (the slack's position: its row is there for the mismatch pass only)
-        double Pk = 0.0;
-        F2_ROW(j, Pk = Pj[RQ]);
+#ifdef F2_MESH_P_REG
+        double Pk = 0.0; F2_ROW(j, Pk = Pj[RQ]);
+#else
+        const double Pk = f2_ld(o_ptab + 64u * lo16(it.x));
+#endif
         const double v2 = __builtin_fma(vk.x, vk.x, vk.y * vk.y), rvk = f2_rsq(v2), vmk = v2 * rvk;
         const double rvj = f2_rsq(__builtin_fma(vj.x, vj.x, vj.y * vj.y));
         // diagonal block (power_flow.py:247-248 exact sign, 259-260, 270-271, 283-284) and right-hand side (:159-165)
@@ -943,62 +978,76 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         double a00 = gsk, a01 = gck * rvj, a10 = -gck, a11 = gsk * rvj;             // A(k, j)
         double c00 = gsj, c01 = gcj * rvk, c10 = -gcj, c11 = gsj * rvk;             // A(j, k)
         while (lv < lev) { f2_lds_sync(); ++lv; }
-        // ---- pull: what earlier pivots addressed to this one
-#pragma unroll
-        for (int u = 0; u < GS_MESH_ACC; ++u) {
-          if (u < ncq) {
-            const unsigned o = (unsigned)icq[u] + l16;
-            const double2 m0 = f2_ld2(o), m1 = f2_ld2(o + UB), mq = f2_ld2(o + 2u * UB);
-            d00 += m0.x; d01 += m0.y; d10 += m1.x; d11 += m1.y; r0 += mq.x; r1 += mq.y;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < GS_MESH_ACC; ++u) {
-          if (u < nrw) { const unsigned o = (unsigned)irw[u] + l16; const double2 m0 = f2_ld2(o), m1 = f2_ld2(o + UB); a00 += m0.x; a01 += m0.y; a10 += m1.x; a11 += m1.y; }
-        }
-#pragma unroll
-        for (int u = 0; u < GS_MESH_ACC; ++u) {
-          if (u < ncl) { const unsigned o = (unsigned)icl[u] + l16; const double2 m0 = f2_ld2(o), m1 = f2_ld2(o + UB); c00 += m0.x; c01 += m0.y; c10 += m1.x; c11 += m1.y; }
-        }
+        // ---- pull: what earlier pivots addressed to this one (lists of units, two per word; entries beyond a list name the ZERO
+        // message).  The first two entries of every list unconditionally, their reads together (a wave-uniform `if` per entry was a
+        // round trip per entry, on the row's critical path); the other two only in rows that have such lists
+        auto pull_cq = [&](int w) {
+          const unsigned q0 = unit_at(lo16(w)), q1 = unit_at(hi16(w));
+          const double2 m00 = f2_ld2(q0), m01 = f2_ld2(q0 + UB), m0q = f2_ld2(q0 + 2u * UB), m10 = f2_ld2(q1), m11 = f2_ld2(q1 + UB), m1q = f2_ld2(q1 + 2u * UB);
+          d00 += m00.x; d01 += m00.y; d10 += m01.x; d11 += m01.y; r0 += m0q.x; r1 += m0q.y;
+          d00 += m10.x; d01 += m10.y; d10 += m11.x; d11 += m11.y; r0 += m1q.x; r1 += m1q.y;
+        };
+        auto pull_rc = [&](int wr, int wc) {
+          const unsigned w0 = unit_at(lo16(wr)), w1 = unit_at(hi16(wr)), e0 = unit_at(lo16(wc)), e1 = unit_at(hi16(wc));
+          const double2 r00 = f2_ld2(w0), r01 = f2_ld2(w0 + UB), r10 = f2_ld2(w1), r11 = f2_ld2(w1 + UB);
+          const double2 l00 = f2_ld2(e0), l01 = f2_ld2(e0 + UB), l10 = f2_ld2(e1), l11 = f2_ld2(e1 + UB);
+          a00 += r00.x; a01 += r00.y; a10 += r01.x; a11 += r01.y; a00 += r10.x; a01 += r10.y; a10 += r11.x; a11 += r11.y;
+          c00 += l00.x; c01 += l00.y; c10 += l01.x; c11 += l01.y; c00 += l10.x; c01 += l10.y; c10 += l11.x; c11 += l11.y;
+        };
+        pull_cq(pl0.x);
+        if (ncq > 2) pull_cq(pl0.y);
+        pull_rc(pl0.z, pl1.x);
+        if ((nrw | ncl) > 2) pull_rc(pl0.w, pl1.y);
         // ---- the pivot: D^-1, s (every lane on the diagonal block it holds; only a group's lane 0 holds the real one)
         const double det = d00 * d11 - d01 * d10;
         if (pivot && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;          // power_flow.py:188-190: only an exactly singular matrix raises
         const double rdet = f2_rcp(det);
         double i00 = d11 * rdet, i01 = -d01 * rdet, i10 = -d10 * rdet, i11 = d00 * rdet;
         double s0 = i00 * r0 + i01 * r1, s1 = i10 * r0 + i11 * r1;
-        if (g_row > 1) {                                          // the group's lanes take D^-1 and s from its lane 0
-          f2_st2(scr_me, make_double2(i00, i01)); f2_st2(scr_me + UB, make_double2(i10, i11)); f2_st2(scr_me + 2u * UB, make_double2(s0, s1));
-          const unsigned o = scr + hv0 * (3u * UB) + l16;
+        const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
+        if (g_row > 1 && gl > 1) {                                // the lanes of a group of two or more take D^-1 and s from its lane 0
+          const unsigned o = scr + (hv0 >> 1) * (3u * UB);
+          if (tl == 0) { f2_st2(o, make_double2(i00, i01)); f2_st2(o + UB, make_double2(i10, i11)); f2_st2(o + 2u * UB, make_double2(s0, s1)); }
+          // (what the other lanes of the wave wrote: the compiler, which sees one lane, may not move the reads over the conditional
+          // write to the same address -- it did, and every lane but lane 0 read the slot before it was written)
+          asm volatile("" ::: "memory");
           const double2 q0 = f2_ld2(o), q1 = f2_ld2(o + UB), q2 = f2_ld2(o + 2u * UB);
           i00 = q0.x; i01 = q0.y; i10 = q1.x; i11 = q1.y; s0 = q2.x; s1 = q2.y;
         }
         const double t00 = i00 * a00 + i01 * a10, t01 = i00 * a01 + i01 * a11, t10 = i10 * a00 + i11 * a10, t11 = i10 * a01 + i11 * a11;      // T(k, j) = D^-1 A(k, j)
         F2_ROW(j, (T00[RQ] = t00, T01[RQ] = t01, T10[RQ] = t10, T11[RQ] = t11, sx0[RQ] = s0, sx1[RQ] = s1));
-        if (g_row > 1) { f2_st2(scr_me, make_double2(t00, t01)); f2_st2(scr_me + UB, make_double2(t10, t11)); }
+        if (g_row > 1) { const unsigned o = scr + (unsigned)hv * (2u * UB); f2_st2(o, make_double2(t00, t01)); f2_st2(o + UB, make_double2(t10, t11)); asm volatile("" ::: "memory"); }
         // ---- what this pivot sends on: row j_t of its messages.  q first (it needs nothing from the group)
         {
           const bool rmw = ((fl >> (GS_MESH_F_RMW_SHIFT + tl)) & 1) != 0;
-          const unsigned o = (unsigned)h1.y + 2u * UB + l16;
-          const double2 old = f2_ld2(rmw ? o : R_ZERO + l16);
+          const unsigned o = unit_at(hi16(it.z)) + 2u * UB;
+          const double2 old = f2_ld2(rmw ? o : R0l);
           f2_st2(o, make_double2(old.x - (c00 * s0 + c01 * s1), old.y - (c10 * s0 + c11 * s1)));
         }
+        // the M blocks, G outputs at a time: every read of the batch (the group's T from the scratch, what the accumulators hold) goes
+        // out before the first product (one output per wave-uniform `if` was a round trip per output)
+        auto send = [&](auto gc, int t_first) {
+          constexpr int G = decltype(gc)::value;
+          double2 ta[G], tb[G], oa[G], ob[G]; unsigned oo[G];
 #pragma unroll
-        for (int t2 = 0; t2 < 8; ++t2) {
-          if (t2 < g_row) {
-            double u00 = t00, u01 = t01, u10 = t10, u11 = t11;
-            if (g_row > 1) {
-              const unsigned o = scr + ((hv0 + (unsigned)t2) & 7u) * (3u * UB) + l16;
-              const double2 q0 = f2_ld2(o), q1 = f2_ld2(o + UB);
-              u00 = q0.x; u01 = q0.y; u10 = q1.x; u11 = q1.y;
-            }
-            const unsigned o = (unsigned)(t2 < 4 ? mo0[t2 & 3] : mo1[t2 & 3]) + l16;
-            const bool rmw = ((fl >> (GS_MESH_F_RMW_SHIFT + t2)) & 1) != 0;
-            const unsigned ro = rmw ? o : R_ZERO + l16;
-            const double2 o0 = f2_ld2(ro), o1 = f2_ld2(ro + UB);
-            f2_st2(o, make_double2(o0.x - (c00 * u00 + c01 * u10), o0.y - (c00 * u01 + c01 * u11)));
-            f2_st2(o + UB, make_double2(o1.x - (c10 * u00 + c11 * u10), o1.y - (c10 * u01 + c11 * u11)));
+          for (int q = 0; q < G; ++q) {
+            const int t2 = t_first + q;
+            const int w = t2 < 2 ? pl1.z : t2 < 4 ? pl1.w : t2 < 6 ? pl2.x : pl2.y;      // words 10 .. 13
+            oo[q] = unit_at((t2 & 1) ? hi16(w) : lo16(w));
+            const unsigned ro = ((fl >> (GS_MESH_F_RMW_SHIFT + t2)) & 1) ? oo[q] : R0l;
+            oa[q] = f2_ld2(ro); ob[q] = f2_ld2(ro + UB);
+            if (g_row > 1) { const unsigned o = scr + ((hv0 + (unsigned)t2) & 7u) * (2u * UB); ta[q] = f2_ld2(o); tb[q] = f2_ld2(o + UB); }
+            else { ta[q] = make_double2(t00, t01); tb[q] = make_double2(t10, t11); }
           }
-        }
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            f2_st2(oo[q], make_double2(oa[q].x - (c00 * ta[q].x + c01 * tb[q].x), oa[q].y - (c00 * ta[q].y + c01 * tb[q].y)));
+            f2_st2(oo[q] + UB, make_double2(ob[q].x - (c10 * ta[q].x + c11 * tb[q].x), ob[q].y - (c10 * ta[q].y + c11 * tb[q].y)));
+          }
+        };
+        if (g_row == 1) send(std::integral_constant<int, 1>{}, 0);
+        else if (g_row == 2) send(std::integral_constant<int, 2>{}, 0);
+        else { send(std::integral_constant<int, 4>{}, 0); if (g_row > 4) send(std::integral_constant<int, 4>{}, 4); }
       }
       while (lv < NL) { f2_lds_sync(); ++lv; }
     }
@@ -1008,33 +1057,38 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     // ---------------- back substitution: x_k = s_k - sum_j T(k, j) x_j, levels downwards; the x slots share the messages' body ----------------
     {
       int lv = NL - 1;
+      f2_i4 ia_next = items[(size_t)(NI - 1) * (HV * 4)];         // bus | nbr, flags: the item's first 16 bytes, a row ahead
 #pragma nounroll
       for (int j = NI - 1; j >= 0; --j) {
         const int lev = rinfo[4 * j];
+        const f2_i4 ia = ia_next;
+        if (j > 0) ia_next = items[(size_t)(j - 1) * (HV * 4)];
         if (lev < 0) continue;
         const int g_row = rinfo[4 * j + 1] & 255;
-        const GsMeshItem* it = items + (size_t)j * HV;
-        const int xk_off = it->xk_off, xj_off = it->xj_off, fl = it->flags;
+        const int fl = ia.y;
         double t00 = 0.0, t01 = 0.0, t10 = 0.0, t11 = 0.0, s0 = 0.0, s1 = 0.0;
         F2_ROW(j, (t00 = T00[RQ], t01 = T01[RQ], t10 = T10[RQ], t11 = T11[RQ], s0 = sx0[RQ], s1 = sx1[RQ]));
         while (lv > lev) { f2_lds_sync(); --lv; }
-        const double2 xj = f2_ld2((unsigned)xj_off + l16);
+        const double2 xj = f2_ld2((fl & GS_MESH_F_NBR) ? unit_at(6u + hi16(ia.x)) : R0l);
         double p0 = t00 * xj.x + t01 * xj.y, p1 = t10 * xj.x + t11 * xj.y;
         if (g_row > 1) {                                          // a group's partial sums, added by its lane 0 in lane order
-          f2_st2(scr_me, make_double2(p0, p1));
+          f2_st2(scr + (unsigned)hv * UB, make_double2(p0, p1));
+          asm volatile("" ::: "memory");
           const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
           double a0 = 0.0, a1 = 0.0;
+          auto gsum = [&](auto gc) {                              // all reads first, then the sum in lane order
+            constexpr int G = decltype(gc)::value;
+            double2 q[G];
 #pragma unroll
-          for (int t2 = 0; t2 < 8; ++t2) {
-            if (t2 < g_row) {
-              const double2 q = f2_ld2(scr + (((unsigned)hv + (unsigned)t2) & 7u) * (3u * UB) + l16);
-              if ((unsigned)t2 < gl) { a0 += q.x; a1 += q.y; }
-            }
-          }
+            for (int t2 = 0; t2 < G; ++t2) q[t2] = f2_ld2(scr + (((unsigned)hv + (unsigned)t2) & 7u) * UB);
+#pragma unroll
+            for (int t2 = 0; t2 < G; ++t2) { if ((unsigned)t2 < gl) { a0 += q[t2].x; a1 += q[t2].y; } }
+          };
+          if (g_row == 2) gsum(std::integral_constant<int, 2>{}); else if (g_row <= 4) gsum(std::integral_constant<int, 4>{}); else gsum(std::integral_constant<int, 8>{});
           p0 = a0; p1 = a1;
         }
         const double x0 = s0 - p0, x1 = s1 - p1;
-        if (fl & GS_MESH_F_PIVOT) f2_st2((unsigned)xk_off + l16, make_double2(x0, x1));
+        if (fl & GS_MESH_F_PIVOT) f2_st2(unit_at(6u + lo16(ia.x)), make_double2(x0, x1));
         F2_ROW(j, (sx0[RQ] = x0, sx1[RQ] = x1));
       }
       while (lv > 0) { f2_lds_sync(); --lv; }
@@ -1053,16 +1107,19 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
 #pragma unroll
         for (int q = 0; q < 16; ++q) kcs[q] = kc0[q];
       }
+      f2_i4 ia_next = items[0];
 #pragma nounroll
       for (int j = 0; j < NI; ++j) {
         const int lev = rinfo[4 * j];
         if (lev < 0) break;
-        const GsMeshItem* it = items + (size_t)j * HV;
-        const int vk_off = it->vk_off, fl = it->flags;
+        const f2_i4 ia = ia_next;
+        if (j + 1 < NI) ia_next = items[(size_t)(j + 1) * (HV * 4)];
+        const int fl = ia.y;
+        const unsigned vo = vslot(lo16(ia.x));
         double x0 = 0.0, x1 = 0.0;
         F2_ROW(j, (x0 = sx0[RQ], x1 = sx1[RQ]));
         if (upd && (fl & GS_MESH_F_PIVOT)) {
-          const double2 v = f2_ld2((unsigned)vk_off + l16);
+          const double2 v = f2_ld2(vo);
           const double v2 = __builtin_fma(v.x, v.x, v.y * v.y), rvm0 = f2_rsq(v2), vm0 = v2 * rvm0;
           const double dth = C.alpha * x0, vmn = vm0 + C.alpha * x1;
           const bool big = __any(fabs(dth) > 0.5);
@@ -1088,7 +1145,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
             for (int q = 0; q < 3; ++q) { const double c2 = __builtin_fma(cs, cs, -(sn * sn)), s2 = 2.0 * cs * sn; cs = c2; sn = s2; }
           }
           const double ratio = vmn * rvm0;
-          f2_st2((unsigned)vk_off + l16, make_double2(ratio * (v.x * cs - v.y * sn), ratio * (v.x * sn + v.y * cs)));
+          f2_st2(vo, make_double2(ratio * (v.x * cs - v.y * sn), ratio * (v.x * sn + v.y * cs)));
         }
       }
     }

@@ -170,9 +170,14 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
     for (size_t r = 0; r < rows.size(); ++r) {
       int w = 0;
       for (int v = 1; v < NW; ++v) if (wave_rows[v].size() < wave_rows[w].size()) w = v;
-      // a level of one row goes where the previous one went while that wave has room: the sequential tail of the elimination
-      // then stays inside one wavefront
-      if (rows_of_level[rows[r].level] == 1 && (int)wave_rows[prev].size() < cap) w = prev;
+      // consecutive levels of one row each (the sequential tail of the elimination) go to DIFFERENT waves in turn: everything a
+      // row does before it needs its level's messages -- its item, the voltages, P / Q calculated, the original blocks -- then
+      // runs while another wave is still on the level before
+      if (rows_of_level[rows[r].level] == 1) {
+        int v = (prev + 1) % NW;
+        for (int q = 0; q < NW && (int)wave_rows[v].size() >= cap; ++q) v = (v + 1) % NW;
+        if ((int)wave_rows[v].size() < cap) w = v;
+      }
       wave_rows[w].push_back((int)r); prev = w;
     }
     for (auto& v : wave_rows) S.max_rows_per_wave = std::max(S.max_rows_per_wave, (int)v.size());
@@ -258,5 +263,62 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
         for (; have_adj < nadj; ++have_adj) { S.adj_off.push_back(V_ZERO); S.adj_y.push_back(0.0); S.adj_y.push_back(0.0); }
       }
     }
+  // ---- the packed form the kernel reads ----
+  {
+    std::map<std::pair<int, int>, int> pair_of;
+    for (int i = 0; i < n; ++i)
+      for (int p = ht.row_ptr[i]; p < ht.row_ptr[i + 1]; ++p) {
+        const int j = ht.col[p];
+        if (j <= i) continue;
+        pair_of[{i, j}] = S.n_pairs++;
+        S.ytab.push_back(ht.G[p]); S.ytab.push_back(ht.B[p]);
+      }
+    S.ytab.push_back(0.0); S.ytab.push_back(0.0);                                   // entry n_pairs: no branch
+    for (int i = 0; i < n; ++i) { S.ytab.push_back(ht.Gd[i]); S.ytab.push_back(ht.Bd[i]); }
+    for (int q = 0; q < 3; ++q) { S.ytab.push_back(0.0); S.ytab.push_back(-1.0); }   // ZERO, ONE, DUMMY slots
+    std::vector<int> adj_ptr(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+      adj_ptr[i] = (int)S.adj_ent.size();
+      for (int p = ht.row_ptr[i]; p < ht.row_ptr[i + 1]; ++p) {
+        const int j = ht.col[p];
+        if (j == i) continue;
+        S.adj_ent.push_back(pair_of.at({std::min(i, j), std::max(i, j)}) | (j << 16));
+      }
+    }
+    adj_ptr[n] = (int)S.adj_ent.size();
+    S.adj_ent.push_back(S.n_pairs | (n << 16));            // the last entry: no branch, the ZERO voltage slot (what a lane reads beyond its bus's neighbours)
+    if (S.n_pairs >= 65535 || S.adj_ent.size() >= 65535 || n + 3 >= 65535 || 6 + S.msg_units >= 65535) return fail("internal: a packed field overflows 16 bits");
+    const int U = S.unit_bytes;
+    auto unit_of = [&](int addr) { return (addr - region_base) / U; };
+    S.packed.assign(S.items.size() * GS_MESH_WORDS, 0);
+    S.rowinfo_packed = S.rowinfo;
+    for (size_t q = 0; q < S.items.size(); ++q) {
+      const MeshItem& it = S.items[q];
+      int32_t* w = &S.packed[q * GS_MESH_WORDS];
+      const int bus = it.vk_off / slot_bytes, nbr = it.vj_off / slot_bytes;
+      w[GS_MESH_W_BUS_NBR] = bus | (nbr << 16);
+      w[GS_MESH_W_FLAGS] = it.flags;
+      int pair = S.n_pairs;
+      if ((it.flags & MESH_F_NBR) && (it.ykj_g != 0.0 || it.ykj_b != 0.0)) pair = pair_of.at({std::min(bus, nbr), std::max(bus, nbr)});
+      w[GS_MESH_W_PAIR_CQ] = pair | (unit_of(it.cq_off) << 16);
+      for (int t = 0; t < 8; t += 2) w[GS_MESH_W_MOUT + t / 2] = unit_of(it.mout[t]) | (unit_of(it.mout[t + 1]) << 16);
+      for (int u = 0; u < GS_MESH_ACC; u += 2) {
+        w[GS_MESH_W_CQIN + u / 2] = unit_of(it.cq_in[u]) | (unit_of(it.cq_in[u + 1]) << 16);
+        w[GS_MESH_W_CQIN + 2 + u / 2] = unit_of(it.rw_in[u]) | (unit_of(it.rw_in[u + 1]) << 16);
+        w[GS_MESH_W_CQIN + 4 + u / 2] = unit_of(it.cl_in[u]) | (unit_of(it.cl_in[u + 1]) << 16);
+      }
+      const bool lane0 = (it.flags & (MESH_F_PIVOT | MESH_F_SLACKPOS)) != 0;
+      const int dslot = lane0 ? bus : n + 1;                  // (the slack's position needs its true diagonal entry for P calculated)
+      w[GS_MESH_W_DIAG_ADJ] = dslot | ((lane0 ? adj_ptr[bus] : 0) << 16);
+      const int nadj_lane = lane0 ? adj_ptr[bus + 1] - adj_ptr[bus] : 0;
+      if (nadj_lane > 255) return fail("a bus has more than 255 neighbours");
+      w[GS_MESH_W_FLAGS] |= nadj_lane << GS_MESH_F_NADJ_SHIFT;
+      if (lane0) {
+        int32_t* ri = &S.rowinfo_packed[(q / HV) * 4];
+        if (nadj_lane > ri[3]) ri[3] = nadj_lane;
+      }
+    }
+    for (size_t r = 0; r < S.rowinfo_packed.size() / 4; ++r) { S.rowinfo_packed[4 * r + 2] = S.rowinfo_packed[4 * r + 3]; S.rowinfo_packed[4 * r + 3] = 0; }
+  }
   S.ok = true;
 }

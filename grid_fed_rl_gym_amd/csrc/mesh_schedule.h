@@ -51,6 +51,15 @@ struct MeshSchedule {
   std::vector<MeshItem> items;           // [NW * NI * 8]
   std::vector<int32_t> adj_off;          // per pivot lane: the Ybus row of its bus in CSR order (diagonal included), padded to nadj of its row
   std::vector<double> adj_y;             // (G, B) per entry
+  // What the kernel reads: the same items packed into 16 words each (GS_MESH_W_*, gs_internal.h; read from global memory a row
+  // ahead), and three small tables it keeps in LDS -- the off-diagonal Ybus entry of every connected pair of buses (entry n_pairs:
+  // zero), the diagonal entry of every voltage slot ((0, -1) for the slots that are not buses: an identity-like diagonal block for
+  // idle lanes), and every bus's neighbours as (pair | other bus << 16).  rowinfo[.][2] (nadj) counts off-diagonal entries here.
+  int n_pairs = 0;
+  std::vector<int32_t> packed;           // [NW * NI * 8][16]
+  std::vector<double> ytab;              // [(n_pairs + 1) + (n + 3)][2]
+  std::vector<int32_t> adj_ent;          // per bus contiguous
+  std::vector<int32_t> rowinfo_packed;   // rowinfo with nadj = most off-diagonal neighbours of a pivot bus in the row
 };
 
 // region_base: LDS byte offset of the region (GsF2Tables::off_tile); slot_bytes: bytes of a voltage slot ((IW + 1) * 16).

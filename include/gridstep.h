@@ -342,6 +342,12 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n);
 int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
                           int32_t slot_bytes, int32_t* header, char* why, int32_t why_cap, void* items, int32_t* rowinfo,
                           int32_t* adj_off, double* adj_y);
+/* The same schedule as the kernel reads it: 16 words per item (GS_MESH_W_*, csrc/gs_internal.h), rowinfo with the neighbour count
+ * of the packed form, the Ybus table it stages in LDS ((n_pairs + 1) off-diagonal entries, then the diagonal entry of every
+ * voltage slot) and the neighbour lists.  counts[4]: n_pairs, doubles of ytab, entries of adj_ent, words per item; arrays may be
+ * NULL (first call).  GS_E_TOPOLOGY if the feeder is not eligible. */
+int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+                                 int32_t slot_bytes, int32_t* counts, int32_t* packed, int32_t* rowinfo, double* ytab, int32_t* adj_ent);
 /* Diagnostic: (start, end) of each of the first n_blocks workgroups of the last step launch, in ticks of the GPU's 100 MHz
  * real-time clock (second-generation step kernels; arm with gs_debug_stamps while GS_STAMP_BLOCK_TIMES is set). */
 int gs_debug_block_times(gs_handle* h, uint64_t* out, int32_t n_blocks);

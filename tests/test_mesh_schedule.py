@@ -206,3 +206,52 @@ def test_schedule_limits_and_refusals():
     assert not S["ok"] and "neighbours" in S["why"]
     S = _lib.mesh_schedule(spec, ni=4)
     assert not S["ok"] and "rows per wavefront" in S["why"]
+
+
+@pytest.mark.parametrize("name,maker", FEEDERS)
+def test_packed_items_say_what_the_verbose_items_say(name, maker):
+    """The 16-word items the kernel reads (GS_MESH_W_*) against the verbose records the replay above walks: every offset as a slot /
+    unit number, the Ybus pair of every neighbour lane, the diagonal entry, and the neighbour list of every pivot bus."""
+    spec = maker(); n = spec.n
+    base = (n + 3) * SLOT
+    S = _lib.mesh_schedule(spec, nw=4, ni=16, acc_cap=4, region_base=base, slot_bytes=SLOT)
+    assert S["ok"]
+    U = S["unit_bytes"]
+    Y = O.admittance_matrix(n, spec.frm, spec.to, spec.r, spec.x)
+    unit = lambda off: (int(off) - base) // U
+    ytab, ent, npairs = S["ytab"], S["adj_ent"], S["n_pairs"]
+    for w in range(4):
+        for j in range(16):
+            ri, rp = S["rowinfo"][w, j], S["rowinfo_packed"][w, j]
+            assert ri[0] == rp[0] and ri[1] == rp[1]
+            for hv in range(8):
+                it, p = S["items"][w, j, hv], S["packed"][w, j, hv]
+                bus, nbr = int(p[0]) & 0xffff, (int(p[0]) >> 16) & 0xffff
+                assert bus * SLOT == it["vk_off"] and nbr * SLOT == it["vj_off"]
+                fl = int(p[1]) & 0xffffff
+                assert fl == int(it["flags"])
+                pair, cq = int(p[2]) & 0xffff, (int(p[2]) >> 16) & 0xffff
+                assert cq == unit(it["cq_off"])
+                assert tuple(ytab[pair]) == (float(it["ykj_g"]), float(it["ykj_b"]))
+                dslot, ap = int(p[3]) & 0xffff, (int(p[3]) >> 16) & 0xffff
+                nadj = (int(p[1]) >> 24) & 255
+                if fl & (F_PIVOT | F_SLACKPOS):
+                    assert dslot == bus and tuple(ytab[npairs + 1 + dslot]) == (Y[bus, bus].real, Y[bus, bus].imag)
+                    got = sorted((int(e) >> 16, tuple(ytab[int(e) & 0xffff])) for e in ent[ap:ap + nadj])
+                    want = sorted((k, (Y[bus, k].real, Y[bus, k].imag)) for k in range(n) if k != bus and Y[bus, k] != 0)
+                    assert got == want and nadj <= rp[2]
+                else:
+                    assert nadj == 0 and tuple(ytab[npairs + 1 + dslot]) == (0.0, -1.0)
+                if fl & F_PIVOT:
+                    assert unit(it["xk_off"]) == 6 + bus
+                if fl & F_NBR:
+                    assert unit(it["xj_off"]) == 6 + nbr
+                lists = [it["cq_in"], it["rw_in"], it["cl_in"]]
+                for q in range(3):
+                    for u in range(4):
+                        word = int(p[4 + 2 * q + u // 2]); got = (word >> 16) & 0xffff if u & 1 else word & 0xffff
+                        assert got == unit(lists[q][u])
+                for t in range(8):
+                    word = int(p[10 + t // 2]); got = (word >> 16) & 0xffff if t & 1 else word & 0xffff
+                    assert got == unit(it["mout"][t])
+    assert (int(ent[-1]) & 0xffff) == npairs and (int(ent[-1]) >> 16) == n          # the list's last entry: no branch, the ZERO slot
