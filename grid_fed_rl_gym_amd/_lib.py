@@ -109,8 +109,8 @@ SYMBOLS = [
     ("gs_allgather_obs", C.c_int, [_H, _dp]),
     ("gs_comm_destroy", C.c_int, [_H]),
     ("gs_comm_info", C.c_int, [_H, C.c_void_p]),
-    ("gs_mesh_schedule_dump_packed", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip, _ip, _dp, _ip]),
-    ("gs_mesh_schedule_dump", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_char_p, C.c_int32,
+    ("gs_mesh_schedule_dump_packed", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip, _ip, _dp, _ip]),
+    ("gs_mesh_schedule_dump", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_char_p, C.c_int32,
                                         C.c_void_p, _ip, _ip, _dp]),
     ("gs_comm_init_loopback", C.c_int, [C.POINTER(_H), C.c_int32]),
     ("gs_allgather_obs_shards", C.c_int, [C.POINTER(_H), C.c_int32, _dp]),
@@ -276,14 +276,14 @@ MESH_ITEM_DTYPE = np.dtype([("vk_off", "<i4"), ("vj_off", "<i4"), ("xk_off", "<i
 
 
 def mesh_schedule(spec: FeederSpec, nw: int = 4, ni: int = 10, acc_cap: int = 4, region_base: int = 0, slot_bytes: int = 144,
-                  zero_z: str = "open") -> dict:
+                  zero_z: str = "open", unit_budget: int = 0) -> dict:
     """gs_mesh_schedule_dump: the host-side schedule of the meshed Newton-Raphson step kernel for ``spec`` (no device needed).
     Returns the header fields, ``why`` (when not eligible) and the tables as NumPy arrays (items: MESH_ITEM_DTYPE)."""
     lib = load()
     t, keep = _topology_of(spec)
     hd = np.zeros(16, dtype=np.int32)
     why = C.create_string_buffer(256)
-    args = (C.byref(t), ZERO_Z[zero_z], int(nw), int(ni), int(acc_cap), int(region_base), int(slot_bytes))
+    args = (C.byref(t), ZERO_Z[zero_z], int(nw), int(ni), int(acc_cap), int(unit_budget), int(region_base), int(slot_bytes))
     rc = lib.gs_mesh_schedule_dump(*args, _ptr(hd, _ip), why, 256, None, None, None, None)
     if rc != GS_OK:
         raise PowerFlowError(f"gs_mesh_schedule_dump failed ({rc}): {lib.gs_last_error(None).decode()}")

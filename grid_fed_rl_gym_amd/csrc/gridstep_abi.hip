@@ -963,7 +963,12 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     else if (ht.n < 2 || ht.m < 1) why = "trivial network";
     else {
       const int off_tile = (int)up16((size_t)nsl * (IW + 1) * 16);          // where f2_layout puts the region (below)
-      gs_mesh_schedule(ht, NW, NI, IW, off_tile, (IW + 1) * 16, GS_MESH_ACC, S);
+      // message units that leave room for a second workgroup on the CU: 80 KB less everything else the workgroup keeps in LDS
+      // (an estimate: the Ybus tables' size is known only from the schedule; f2_layout below decides)
+      const size_t fixed = up16((size_t)nsl * (IW + 1) * 16) + (size_t)6 * 16 * IW + (size_t)NW * 16 * 16 * IW + (size_t)nsl * IW * 8 +
+                           (size_t)(ht.nnz + 8) * 8 + (size_t)(ht.nnz + nsl + 4) * 16 + 4096;
+      const int unit_budget = fixed < 80 * 1024 ? (int)((80 * 1024 - fixed) / (16 * IW)) : 1;
+      gs_mesh_schedule(ht, NW, NI, IW, off_tile, (IW + 1) * 16, GS_MESH_ACC, unit_budget, S);
       if (!S.ok) why = S.why;
     }
     if (why.empty()) {
@@ -2063,7 +2068,7 @@ int gs_comm_destroy(gs_handle* h) {
 // ---- the meshed Newton-Raphson member's host schedule, without a device (mesh_schedule.h) -------------------------------
 // header[0..15]: ok, n_levels, n_rows, max_rows_per_wave, n_pivots, msg_units, n_messages, n_accumulators, max_degree,
 //                unit_bytes, zero_off, dummy_off, body_off, region_bytes, sizeof(GsMeshItem), n_adj;  why: the reason when ok == 0
-int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t unit_budget, int32_t region_base,
                           int32_t slot_bytes, int32_t* header, char* why, int32_t why_cap, void* items, int32_t* rowinfo,
                           int32_t* adj_off, double* adj_y) {
   if (!topo || !header) return fail(nullptr, GS_E_INVALID, "topology / header is NULL");
@@ -2073,7 +2078,7 @@ int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t 
   const std::string err = gs_compile_topology(*topo, zero_z_mode, false, true, ht);
   if (!err.empty()) return fail(nullptr, GS_E_INVALID, "topology: %s", err.c_str());
   MeshSchedule S;
-  gs_mesh_schedule(ht, nw, ni, 8, region_base, slot_bytes, acc_cap, S);
+  gs_mesh_schedule(ht, nw, ni, 8, region_base, slot_bytes, acc_cap, unit_budget, S);
   const int32_t hd[16] = {S.ok ? 1 : 0, S.n_levels, S.n_rows, S.max_rows_per_wave, S.n_pivots, S.msg_units, S.n_messages, S.n_accumulators,
                           S.max_degree, S.unit_bytes, S.zero_off, S.dummy_off, S.body_off, S.region_bytes, (int32_t)sizeof(GsMeshItem), (int32_t)S.adj_off.size()};
   memcpy(header, hd, sizeof hd);
@@ -2087,7 +2092,7 @@ int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t 
 }
 
 // The same schedule in the form the kernel reads (GS_MESH_W_*): counts[4] = n_pairs, ytab doubles, adj_ent entries, item words
-int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t unit_budget, int32_t region_base,
                                  int32_t slot_bytes, int32_t* counts, int32_t* packed, int32_t* rowinfo, double* ytab, int32_t* adj_ent) {
   if (!topo || !counts) return fail(nullptr, GS_E_INVALID, "topology / counts is NULL");
   if (topo->struct_size != (int32_t)sizeof(gs_topology)) return fail(nullptr, GS_E_INVALID, "struct_size mismatch");
@@ -2095,7 +2100,7 @@ int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, i
   const std::string err = gs_compile_topology(*topo, zero_z_mode, false, true, ht);
   if (!err.empty()) return fail(nullptr, GS_E_INVALID, "topology: %s", err.c_str());
   MeshSchedule S;
-  gs_mesh_schedule(ht, nw, ni, 8, region_base, slot_bytes, acc_cap, S);
+  gs_mesh_schedule(ht, nw, ni, 8, region_base, slot_bytes, acc_cap, unit_budget, S);
   if (!S.ok) return fail(nullptr, GS_E_TOPOLOGY, "%s", S.why.c_str());
   counts[0] = S.n_pairs; counts[1] = (int32_t)S.ytab.size(); counts[2] = (int32_t)S.adj_ent.size(); counts[3] = GS_MESH_WORDS;
   if (packed) memcpy(packed, S.packed.data(), S.packed.size() * sizeof(int32_t));

@@ -387,7 +387,7 @@ struct GsPackArgs {
 #define GS_F2NS_WAVES 4           /* Newton-Raphson: 4 waves x 1 item, each a group of 8 buses of one level (2 x 2: 124 M env-steps/s on config 2; 4 x 1: 147 M -- the load draws get waves of their own) */
 #define GS_F2NS_ITEMS 1
 #define GS_F2M_WAVES 4            /* the meshed Newton-Raphson member: 4 waves x up to 9 rows of 8 sub-groups */
-#define GS_F2M_ITEMS 9
+#define GS_F2M_ITEMS 10
 #define GS_F2_CHILDREN 8          /* children per bus in the Newton-Raphson kernel's LDS child tables */
 struct GsF2Rec {                  // one preorder position p = ((wave * 2 + half) * GS_F2_ITEMS + item); 96 bytes
   int32_t bus, parent, flags, last;         // slot indices; flags: bit0 active, bit1 root (parent is the slack bus); last: the bus at the LAST position of this bus's subtree
@@ -408,7 +408,7 @@ struct GsMeshItem {                     // 192 bytes
   int32_t mout[8];                      // accumulator of M(k -> (j_t, j_t')) for t' = 0 .. g - 1 (entry t: the C part of cq_off)
   int32_t cq_in[GS_MESH_ACC], rw_in[GS_MESH_ACC], cl_in[GS_MESH_ACC];      // pull lists (padded with the ZERO message): into (D_k, r_k), A(k, j_t), A(j_t, k)
   int32_t nbr, pos;                     // neighbour bus (-1: none); index of the item
-  int32_t pad[10];
+  int32_t pad[10];                      // pad[0]: the group's slot in the (D^-1, s) exchange (GS_MESH_W_GSLOT)
 };
 enum {
   GS_MESH_F_PIVOT = 1,          // lane 0 of a group that eliminates a bus
@@ -431,6 +431,7 @@ enum {
   // words 4-15: what it needs after them (read at the row's start)
   GS_MESH_W_CQIN = 4,           // 2 words cq_in, then 2 words rw_in, 2 words cl_in: units, two per word
   GS_MESH_W_MOUT = 10,          // 4 words: units of M(k -> (j_t, j_t')), two per word
+  GS_MESH_W_GSLOT = 14,         // which of the row's groups of two or more lanes this lane's is (0 .. 3): its slot in the (D^-1, s) exchange
   GS_MESH_WORDS = 16
 };
 #define GS_MESH_F_NADJ_SHIFT 24

@@ -856,8 +856,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const unsigned l16 = (unsigned)l << 4;
   const unsigned R0l = (unsigned)o_tile + l16;                   // unit u of the region, this lane's share: R0l + u * UB
   // this wave's exchange scratch, 16 units, used three ways one after the other: (D^-1, s) of a group's lane 0 at 3 units per group
-  // slot (hv0 / 2: groups of two or more start on even sub-groups), every lane's T at 2 units per sub-group, the back
-  // substitution's partial sums at 1 unit per sub-group
+  // of two or more lanes (at most four in a row), every lane's T at 2 units per sub-group, the back substitution's partial sums at
+  // 1 unit per sub-group
   const unsigned scr = (unsigned)F.off_scr + (unsigned)wave * (16u * UB) + l16;
   const unsigned o_ptab = (unsigned)F.mesh_off_p + ((unsigned)l << 3);
   const unsigned o_pair = (unsigned)o_z, o_diag = (unsigned)o_z + 16u * (unsigned)(F.mesh_pairs + 1);
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         double s0 = i00 * r0 + i01 * r1, s1 = i10 * r0 + i11 * r1;
         const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
         if (g_row > 1 && gl > 1) {                                // the lanes of a group of two or more take D^-1 and s from its lane 0
-          const unsigned o = scr + (hv0 >> 1) * (3u * UB);
+          const unsigned o = scr + (unsigned)pl2.z * (3u * UB);      // the group's slot (GS_MESH_W_GSLOT): at most four groups of two or more in a row
           if (tl == 0) { f2_st2(o, make_double2(i00, i01)); f2_st2(o + UB, make_double2(i10, i11)); f2_st2(o + 2u * UB, make_double2(s0, s1)); }
           // (what the other lanes of the wave wrote: the compiler, which sees one lane, may not move the reads over the conditional
           // write to the same address -- it did, and every lane but lane 0 read the slot before it was written)

@@ -8,7 +8,7 @@
 
 namespace {
 
-int pow2ceil(int x) { int p = 1; while (p < x) p *= 2; return p; }
+
 
 struct Target {                          // what a message adds to: the diagonal block + right-hand side of a bus, or an off-diagonal block
   int cons = -1;                         // the pivot that pulls it
@@ -21,7 +21,7 @@ struct Acc { int units = 0, first = 1 << 30, cons_level = 0, off = -1; };
 
 }  // namespace
 
-void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region_base, int slot_bytes, int acc_cap, MeshSchedule& S) {
+void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region_base, int slot_bytes, int acc_cap, int unit_budget, MeshSchedule& S) {
   S = MeshSchedule();
   S.NW = NW; S.NI = NI; S.IW = IW; S.HV = 64 / IW;
   const int n = ht.n, HV = S.HV;
@@ -59,40 +59,124 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
   S.n_pivots = (int)order.size();
   if (S.max_degree > HV) return fail("a pivot of the block LU has more than " + std::to_string(HV) + " neighbours when it is eliminated");
 
-  // ---- targets, levels (a pivot is delayed until none of its targets has acc_cap producers in its level), accumulators ----
+  // ---- levels.  First as early as the dependencies allow, a pivot delayed only while one of its targets already has acc_cap
+  // producers in the level.  Then pivots are moved LATER inside their windows while that helps: a message occupies its accumulator
+  // from its producer's level to its consumer's, so a leaf eliminated eight levels before the bus it reports to holds 48 bytes
+  // per instance for nothing; what is minimised is, in this order, the excess of the peak over `unit_budget`, the excess of the
+  // row count over `row_budget`, the levels' critical path (rows per level / waves), the peak, and the sum of squares of the
+  // per-level occupancy.  (The benchmark's 123-bus feeder with 26 loops: 392 -> 289 units, i.e. two workgroups per CU.)
+  auto target_cons = [&](int i, int j) { return (i == j) ? i : (pos_of[i] < pos_of[j] ? i : j); };
+  std::vector<int> level(n, 0);
+  {
+    std::vector<int> ready(n, 0);
+    std::map<std::pair<int, int>, std::map<int, int>> cnt;
+    for (int k : order) {
+      int lv = ready[k];
+      for (bool again = true; again;) {
+        again = false;
+        for (int i : nbrs[k]) for (int j : nbrs[k]) {
+          auto& pl = cnt[{i, j}];
+          auto it = pl.find(lv);
+          if (it != pl.end() && it->second >= acc_cap) { ++lv; again = true; }
+        }
+      }
+      level[k] = lv;
+      for (int i : nbrs[k]) { ready[i] = std::max(ready[i], lv + 1); for (int j : nbrs[k]) ++cnt[{i, j}][lv]; }
+    }
+  }
+  struct Score { long long over_units, over_rows, critical, peak, sumsq; int maxA; };
+  auto better = [](const Score& a, const Score& b) {
+    if (a.over_units != b.over_units) return a.over_units < b.over_units;
+    if (a.over_rows != b.over_rows) return a.over_rows < b.over_rows;
+    if (a.critical != b.critical) return a.critical < b.critical;
+    if (a.peak != b.peak) return a.peak < b.peak;
+    return a.sumsq < b.sumsq;
+  };
+  auto pack_rows = [&](const std::vector<int>& lev, int NLv, std::vector<int>* rows_per_level) {
+    int total = 0;
+    for (int L = 0; L < NLv; ++L) {
+      std::vector<int> sizes;
+      for (int k : order) if (lev[k] == L) sizes.push_back(std::max(1, (int)nbrs[k].size()));
+      if (L == 0) sizes.push_back(1);                                       // the slack's position
+      std::sort(sizes.begin(), sizes.end(), std::greater<int>());
+      std::vector<int> bins;
+      for (int g : sizes) {
+        bool put = false;
+        for (int& b : bins) if (b + g <= HV) { b += g; put = true; break; }
+        if (!put) bins.push_back(g);
+      }
+      if (rows_per_level) rows_per_level->push_back((int)bins.size());
+      total += (int)bins.size();
+    }
+    return total;
+  };
+  auto evaluate = [&](const std::vector<int>& lev) {
+    int NLv = 0;
+    for (int k : order) NLv = std::max(NLv, lev[k] + 1);
+    std::map<std::pair<int, int>, std::map<int, int>> cnt;
+    for (int k : order) for (int i : nbrs[k]) for (int j : nbrs[k]) ++cnt[{i, j}][lev[k]];
+    std::vector<long long> live(NLv + 1, 0);
+    Score sc{0, 0, 0, 0, 0, 0};
+    for (auto& kv : cnt) {
+      const int i = kv.first.first, j = kv.first.second, units = (i == j) ? 3 : 2, cl = lev[target_cons(i, j)];
+      int A = 0;
+      for (auto& pl : kv.second) A = std::max(A, pl.second);
+      sc.maxA = std::max(sc.maxA, A);
+      for (int a = 0; a < A; ++a) {
+        int first = 1 << 30;
+        for (auto& pl : kv.second) if (pl.second > a) first = std::min(first, pl.first);
+        for (int L = first; L <= cl && L <= NLv; ++L) live[L] += units;
+      }
+    }
+    for (long long x : live) { sc.peak = std::max(sc.peak, x); sc.sumsq += x * x; }
+    std::vector<int> rpl;
+    const int rows = pack_rows(lev, NLv, &rpl);
+    for (int r : rpl) sc.critical += (r + NW - 1) / NW;
+    sc.over_units = std::max<long long>(0, sc.peak - unit_budget);
+    sc.over_rows = std::max(0, rows - NW * NI);
+    return sc;
+  };
+  if (unit_budget > 0) {
+    Score best = evaluate(level);
+    for (int round = 0; round < 6; ++round) {
+      bool improved = false;
+      for (int k : order) {
+        int hi = level[k];
+        if (!nbrs[k].empty()) { hi = 1 << 30; for (int i : nbrs[k]) hi = std::min(hi, level[i] - 1); }
+        const int keep = level[k];
+        int pick = keep;
+        for (int cand = keep + 1; cand <= hi; ++cand) {
+          level[k] = cand;
+          const Score sc = evaluate(level);
+          if (sc.maxA <= acc_cap && better(sc, best)) { best = sc; pick = cand; improved = true; }
+        }
+        level[k] = pick;
+      }
+      if (!improved) break;
+    }
+  }
+  for (int k : order) S.n_levels = std::max(S.n_levels, level[k] + 1);
+  if (S.n_levels < 1) S.n_levels = 1;
+
+  // ---- targets and accumulators: the producers of a target in one level get accumulators of their own (by rank); an accumulator's
+  // first producer writes, the later ones (later levels) add ----
   std::map<std::pair<int, int>, Target> targets;          // (i, i): CQ of bus i; (i, j): block (i, j)
   auto target_of = [&](int i, int j) -> Target& {
     Target& t = targets[{i, j}];
-    if (t.cons < 0) { t.cons = (i == j) ? i : (pos_of[i] < pos_of[j] ? i : j); t.units = (i == j) ? 3 : 2; }
+    if (t.cons < 0) { t.cons = target_cons(i, j); t.units = (i == j) ? 3 : 2; }
     return t;
   };
-  std::vector<int> level(n, 0), ready(n, 0);
   std::vector<Acc> accs;
   struct Msg { int prod, i, j, acc, rmw; };
   std::vector<Msg> msgs;
-  for (int k : order) {
-    int lv = ready[k];
-    for (bool again = true; again;) {
-      again = false;
-      for (int i : nbrs[k]) for (int j : nbrs[k]) {
-        Target& t = target_of(i, j);
-        auto it = t.per_level.find(lv);
-        if (it != t.per_level.end() && it->second >= acc_cap) { ++lv; again = true; }
-      }
+  for (int k : order)
+    for (int i : nbrs[k]) for (int j : nbrs[k]) {
+      Target& t = target_of(i, j);
+      const int rank = t.per_level[level[k]]++;
+      if (rank >= acc_cap) return fail("internal: more producers of one target in a level than accumulators");
+      if (rank >= (int)t.acc.size()) { t.acc.push_back((int)accs.size()); Acc a; a.units = t.units; accs.push_back(a); }
+      msgs.push_back({k, i, j, t.acc[rank], 0});
     }
-    level[k] = lv;
-    for (int i : nbrs[k]) {
-      ready[i] = std::max(ready[i], lv + 1);
-      for (int j : nbrs[k]) {
-        Target& t = target_of(i, j);
-        const int rank = t.per_level[lv]++;
-        if (rank >= (int)t.acc.size()) { t.acc.push_back((int)accs.size()); Acc a; a.units = t.units; accs.push_back(a); }
-        msgs.push_back({k, i, j, t.acc[rank], 0});
-      }
-    }
-    S.n_levels = std::max(S.n_levels, lv + 1);
-  }
-  if (S.n_levels < 1) S.n_levels = 1;
   for (auto& m : msgs) accs[m.acc].first = std::min(accs[m.acc].first, level[m.prod]);
   for (auto& m : msgs) m.rmw = level[m.prod] > accs[m.acc].first ? 1 : 0;
   for (auto& kv : targets) for (int a : kv.second.acc) accs[a].cons_level = level[kv.second.cons];
@@ -143,23 +227,26 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
   std::map<std::tuple<int, int, int>, std::pair<int, int>> out_of;   // (producer, i, j) -> (address, rmw)
   for (auto& m : msgs) out_of[{m.prod, m.i, m.j}] = {acc_addr(m.acc), m.rmw};
 
-  // ---- groups -> rows (one level per row, groups by size so that they sit aligned) -> waves ----
-  struct Group { int k, d, g, level, slackpos; };
+  // ---- groups -> rows (one level per row; first fit by decreasing size, a group = consecutive sub-groups) -> waves ----
+  struct Group { int k, d, g, level, slackpos, gslot; };
   std::vector<Group> groups;
-  for (int k : order) { const int d = (int)nbrs[k].size(); groups.push_back({k, d, pow2ceil(std::max(d, 1)), level[k], 0}); }
-  groups.push_back({ht.slack, 0, 1, 0, 1});                 // the slack bus: its share of the losses sum in the mismatch pass
-  struct Row { int level; std::vector<std::pair<int, int>> lanes; int fill; };    // lanes: (group index, t) or (-1, 0)
+  for (int k : order) { const int d = (int)nbrs[k].size(); groups.push_back({k, d, std::max(d, 1), level[k], 0, 0}); }
+  groups.push_back({ht.slack, 0, 1, 0, 1, 0});              // the slack bus: its share of the losses sum in the mismatch pass
+  struct Row { int level; std::vector<std::pair<int, int>> lanes; int fill; int n_multi; };    // lanes: (group index, t) or (-1, 0)
   std::vector<Row> rows;
   std::vector<int> rows_of_level(S.n_levels, 0);
   for (int L = 0; L < S.n_levels; ++L) {
     std::vector<int> gl;
     for (size_t q = 0; q < groups.size(); ++q) if (groups[q].level == L) gl.push_back((int)q);
     std::stable_sort(gl.begin(), gl.end(), [&](int a, int b) { return groups[a].g > groups[b].g; });
-    int cur = -1;
+    const size_t first_row = rows.size();
     for (int q : gl) {
-      if (cur < 0 || rows[cur].fill + groups[q].g > HV) { rows.push_back({L, std::vector<std::pair<int, int>>(HV, {-1, 0}), 0}); cur = (int)rows.size() - 1; ++rows_of_level[L]; }
-      for (int t = 0; t < groups[q].g; ++t) rows[cur].lanes[rows[cur].fill + t] = {q, t};
-      rows[cur].fill += groups[q].g;
+      size_t r = first_row;
+      while (r < rows.size() && rows[r].fill + groups[q].g > HV) ++r;
+      if (r == rows.size()) { rows.push_back({L, std::vector<std::pair<int, int>>(HV, {-1, 0}), 0, 0}); ++rows_of_level[L]; }
+      for (int t = 0; t < groups[q].g; ++t) rows[r].lanes[rows[r].fill + t] = {q, t};
+      rows[r].fill += groups[q].g;
+      if (groups[q].g > 1) groups[q].gslot = rows[r].n_multi++;             // (at most four groups of two or more in a row of eight)
     }
   }
   S.n_rows = (int)rows.size();
@@ -232,6 +319,7 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
         if (G) {
           const int hv0 = hv - t;
           it.flags = (hv0 << MESH_F_HV0_SHIFT) | (t << MESH_F_T_SHIFT) | (G->g << MESH_F_G_SHIFT);
+          it.pad[0] = G->gslot;
           it.bus = G->k; it.vk_off = G->k * slot_bytes;
           if (t == 0) {
             it.flags |= G->slackpos ? MESH_F_SLACKPOS : MESH_F_PIVOT;
@@ -307,6 +395,7 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
         w[GS_MESH_W_CQIN + 2 + u / 2] = unit_of(it.rw_in[u]) | (unit_of(it.rw_in[u + 1]) << 16);
         w[GS_MESH_W_CQIN + 4 + u / 2] = unit_of(it.cl_in[u]) | (unit_of(it.cl_in[u + 1]) << 16);
       }
+      w[GS_MESH_W_GSLOT] = it.pad[0];
       const bool lane0 = (it.flags & (MESH_F_PIVOT | MESH_F_SLACKPOS)) != 0;
       const int dslot = lane0 ? bus : n + 1;                  // (the slack's position needs its true diagonal entry for P calculated)
       w[GS_MESH_W_DIAG_ADJ] = dslot | ((lane0 ? adj_ptr[bus] : 0) << 16);

@@ -13,7 +13,7 @@
 //         CQ(k -> i) = (-A_ik T_ki, -A_ik s_k)     M(k -> (i, j)) = -A_ik T_kj  (i != j)            i, j in N(k)
 //     to whoever eliminates the target first.  Back substitution: x_k = s_k - sum_j T_kj x_j.  No block is ever read, modified
 //     and written by two parties; original Jacobian blocks are never stored (formed from the voltages where they are needed).
-//   * A pivot of degree d takes a GROUP of g = 2^ceil(log2 d) sub-groups of ONE wavefront row (8 sub-groups of 8 instances):
+//   * A pivot of degree d takes a GROUP of max(d, 1) consecutive sub-groups of ONE wavefront row (8 sub-groups of 8 instances):
 //     lane t handles neighbour j_t (both blocks, T, row j_t's messages), lane 0 also the diagonal.  T stays in the registers
 //     of the lane that formed it until the back substitution; everything else is a message in LDS.
 //   * Messages ACCUMULATE: the producers of one target at different levels add into the same slot (a level barrier apart);
@@ -63,5 +63,6 @@ struct MeshSchedule {
 };
 
 // region_base: LDS byte offset of the region (GsF2Tables::off_tile); slot_bytes: bytes of a voltage slot ((IW + 1) * 16).
-// acc_cap: most accumulators per target (1 .. GS_MESH_ACC, the pull lists' capacity).
-void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region_base, int slot_bytes, int acc_cap, MeshSchedule& out);
+// acc_cap: most accumulators per target (1 .. GS_MESH_ACC, the pull lists' capacity).  unit_budget: the message units the level
+// assignment tries to stay below (what lets two workgroups share a CU); 0: levels as early as possible, no search.
+void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region_base, int slot_bytes, int acc_cap, int unit_budget, MeshSchedule& out);

@@ -336,17 +336,18 @@ int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n);
 /* The host-side schedule of the meshed Newton-Raphson step kernel (gs_k_step_nr_mesh2; csrc/mesh_schedule.h) for a topology,
  * built WITHOUT a device: the block elimination that replaces np.linalg.solve (power_flow.py:186-190) as per-(wavefront, row,
  * sub-group) items, pull lists and Ybus rows.  header[16]: ok, n_levels, n_rows, max_rows_per_wave, n_pivots, msg_units,
- * n_messages, n_accumulators, max_degree, unit_bytes, zero_off, dummy_off, body_off, region_bytes, item_bytes, n_adj.  Call once
+ * n_messages, n_accumulators, max_degree, unit_bytes, zero_off, dummy_off, body_off, region_bytes, item_bytes, n_adj.  unit_budget:
+ * the message units the level assignment tries to stay below (0: levels as early as possible).  Call once
  * with the arrays NULL for the sizes (items: nw * ni * 8 records of item_bytes; rowinfo: nw * ni * 4; adj_y: 2 * n_adj), then
  * with buffers.  tests/test_mesh_schedule.py replays the tables in NumPy against a dense solve. */
-int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t unit_budget, int32_t region_base,
                           int32_t slot_bytes, int32_t* header, char* why, int32_t why_cap, void* items, int32_t* rowinfo,
                           int32_t* adj_off, double* adj_y);
 /* The same schedule as the kernel reads it: 16 words per item (GS_MESH_W_*, csrc/gs_internal.h), rowinfo with the neighbour count
  * of the packed form, the Ybus table it stages in LDS ((n_pairs + 1) off-diagonal entries, then the diagonal entry of every
  * voltage slot) and the neighbour lists.  counts[4]: n_pairs, doubles of ytab, entries of adj_ent, words per item; arrays may be
  * NULL (first call).  GS_E_TOPOLOGY if the feeder is not eligible. */
-int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t region_base,
+int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t unit_budget, int32_t region_base,
                                  int32_t slot_bytes, int32_t* counts, int32_t* packed, int32_t* rowinfo, double* ytab, int32_t* adj_ent);
 /* Diagnostic: (start, end) of each of the first n_blocks workgroups of the last step launch, in ticks of the GPU's 100 MHz
  * real-time clock (second-generation step kernels; arm with gs_debug_stamps while GS_STAMP_BLOCK_TIMES is set). */

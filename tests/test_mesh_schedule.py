@@ -164,12 +164,12 @@ FEEDERS = [("loops26", lambda: P.random_meshed(123, 26)), ("radial123", lambda: 
 
 
 @pytest.mark.parametrize("name,maker", FEEDERS)
-@pytest.mark.parametrize("acc_cap", [4, 1])
-def test_replay_of_the_schedule_solves_the_newton_step(name, maker, acc_cap):
+@pytest.mark.parametrize("acc_cap,budget", [(4, 0), (1, 0), (4, 200), (2, 1)])
+def test_replay_of_the_schedule_solves_the_newton_step(name, maker, acc_cap, budget):
     spec = maker()
     region_base = (spec.n + 3) * SLOT + 16
     region_base += (-region_base) % 16
-    S = _lib.mesh_schedule(spec, nw=4, ni=16, acc_cap=acc_cap, region_base=region_base, slot_bytes=SLOT)
+    S = _lib.mesh_schedule(spec, nw=4, ni=16, acc_cap=acc_cap, region_base=region_base, slot_bytes=SLOT, unit_budget=budget)
     assert S["ok"], S["why"]
     S["region_base"] = region_base
     n = spec.n
@@ -255,3 +255,23 @@ def test_packed_items_say_what_the_verbose_items_say(name, maker):
                     word = int(p[10 + t // 2]); got = (word >> 16) & 0xffff if t & 1 else word & 0xffff
                     assert got == unit(it["mout"][t])
     assert (int(ent[-1]) & 0xffff) == npairs and (int(ent[-1]) >> 16) == n          # the list's last entry: no branch, the ZERO slot
+
+
+def test_level_search_lowers_the_peak_of_the_message_region():
+    """Pivots delayed inside their windows (unit_budget > 0): the benchmark's feeder needs a quarter fewer message units, in the
+    same number of levels; the packed items carry each group's exchange slot, at most four groups of two or more lanes per row."""
+    spec = P.random_meshed(123, 26, seed=1)
+    early = _lib.mesh_schedule(spec, ni=12, unit_budget=0)
+    late = _lib.mesh_schedule(spec, ni=12, unit_budget=290)
+    assert early["ok"] and late["ok"]
+    assert late["msg_units"] <= 0.8 * early["msg_units"] and late["n_levels"] == early["n_levels"] and late["n_rows"] <= early["n_rows"]
+    p = late["packed"].reshape(-1, 16)
+    multi = ((p[:, 1] >> 12) & 15) > 1
+    assert p[multi, 14].max() <= 3 and p[:, 14].min() >= 0
+    rows = late["packed"].reshape(-1, 8, 16)
+    for r in rows:                                      # the lanes of one group share a slot, different groups of a row do not
+        g = {}
+        for hv in range(8):
+            if ((r[hv, 1] >> 12) & 15) > 1 and r[hv, 1] & 3:
+                g.setdefault(int((r[hv, 1] >> 4) & 15), set()).add(int(r[hv, 14]))
+        assert all(len(v) == 1 for v in g.values()) and len({next(iter(v)) for v in g.values()}) == len(g)
