@@ -952,7 +952,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const f2_i4* const late = items + (size_t)j * (HV * 4) + 1;
         const f2_i4 pl0 = late[0], pl1 = late[1], pl2 = late[2];      // words 4-15: cq_in (2), rw_in (2) | cl_in (2), mout 0-3 (2) | mout 4-7 (2), -
         if (j + 1 < NI) nxt = load_item(j + 1);
-        // everything that does not depend on the messages comes before the wait for the row's level
+        // The barrier that publishes this wave's previous row FIRST: the waves take the tail's levels in turn, and a wave that went
+        // from its row straight into the next row's preparations kept the wave of the next level waiting for exactly that long
+        // (per level: one row's whole work instead of its message-dependent half).  Then everything that does not depend on the
+        // messages, before the wait for the row's level: it runs while another wave is on the levels in between
+        if (j > 0 && lv < lev) { f2_lds_sync(); ++lv; }
         const int fl = it.y;
         const bool pivot = (fl & GS_MESH_F_PIVOT) != 0;
         const unsigned hv0 = ((unsigned)fl >> GS_MESH_F_HV0_SHIFT) & 15u, tl = ((unsigned)fl >> GS_MESH_F_T_SHIFT) & 15u;
@@ -999,11 +1003,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         pull_rc(pl0.z, pl1.x);
         if ((nrw | ncl) > 2) pull_rc(pl0.w, pl1.y);
         // ---- the pivot: D^-1, s (every lane on the diagonal block it holds; only a group's lane 0 holds the real one)
-        const double det = d00 * d11 - d01 * d10;
+        const double det = __builtin_fma(d00, d11, -(d01 * d10));
         if (pivot && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;          // power_flow.py:188-190: only an exactly singular matrix raises
         const double rdet = f2_rcp(det);
         double i00 = d11 * rdet, i01 = -d01 * rdet, i10 = -d10 * rdet, i11 = d00 * rdet;
-        double s0 = i00 * r0 + i01 * r1, s1 = i10 * r0 + i11 * r1;
+        double s0 = __builtin_fma(i00, r0, i01 * r1), s1 = __builtin_fma(i10, r0, i11 * r1);
         const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
         if (g_row > 1 && gl > 1) {                                // the lanes of a group of two or more take D^-1 and s from its lane 0
           const unsigned o = scr + (unsigned)pl2.z * (3u * UB);      // the group's slot (GS_MESH_W_GSLOT): at most four groups of two or more in a row
@@ -1014,15 +1018,16 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           const double2 q0 = f2_ld2(o), q1 = f2_ld2(o + UB), q2 = f2_ld2(o + 2u * UB);
           i00 = q0.x; i01 = q0.y; i10 = q1.x; i11 = q1.y; s0 = q2.x; s1 = q2.y;
         }
-        const double t00 = i00 * a00 + i01 * a10, t01 = i00 * a01 + i01 * a11, t10 = i10 * a00 + i11 * a10, t11 = i10 * a01 + i11 * a11;      // T(k, j) = D^-1 A(k, j)
+        const double t00 = __builtin_fma(i00, a00, i01 * a10), t01 = __builtin_fma(i00, a01, i01 * a11), t10 = __builtin_fma(i10, a00, i11 * a10),
+                     t11 = __builtin_fma(i10, a01, i11 * a11);                                                     // T(k, j) = D^-1 A(k, j)
         F2_ROW(j, (T00[RQ] = t00, T01[RQ] = t01, T10[RQ] = t10, T11[RQ] = t11, sx0[RQ] = s0, sx1[RQ] = s1));
-        if (g_row > 1) { const unsigned o = scr + (unsigned)hv * (2u * UB); f2_st2(o, make_double2(t00, t01)); f2_st2(o + UB, make_double2(t10, t11)); asm volatile("" ::: "memory"); }
+        if (g_row > 1) { unsigned hvx = (unsigned)hv; F2_OPAQUE(hvx); const unsigned o = scr + hvx * (2u * UB); f2_st2(o, make_double2(t00, t01)); f2_st2(o + UB, make_double2(t10, t11)); asm volatile("" ::: "memory"); }
         // ---- what this pivot sends on: row j_t of its messages.  q first (it needs nothing from the group)
         {
           const bool rmw = ((fl >> (GS_MESH_F_RMW_SHIFT + tl)) & 1) != 0;
           const unsigned o = unit_at(hi16(it.z)) + 2u * UB;
           const double2 old = f2_ld2(rmw ? o : R0l);
-          f2_st2(o, make_double2(old.x - (c00 * s0 + c01 * s1), old.y - (c10 * s0 + c11 * s1)));
+          f2_st2(o, make_double2(__builtin_fma(-c00, s0, __builtin_fma(-c01, s1, old.x)), __builtin_fma(-c10, s0, __builtin_fma(-c11, s1, old.y))));
         }
         // the M blocks, G outputs at a time: every read of the batch (the group's T from the scratch, what the accumulators hold) goes
         // out before the first product (one output per wave-uniform `if` was a round trip per output)
@@ -1041,13 +1046,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           }
 #pragma unroll
           for (int q = 0; q < G; ++q) {
-            f2_st2(oo[q], make_double2(oa[q].x - (c00 * ta[q].x + c01 * tb[q].x), oa[q].y - (c00 * ta[q].y + c01 * tb[q].y)));
-            f2_st2(oo[q] + UB, make_double2(ob[q].x - (c10 * ta[q].x + c11 * tb[q].x), ob[q].y - (c10 * ta[q].y + c11 * tb[q].y)));
+            f2_st2(oo[q], make_double2(__builtin_fma(-c00, ta[q].x, __builtin_fma(-c01, tb[q].x, oa[q].x)), __builtin_fma(-c00, ta[q].y, __builtin_fma(-c01, tb[q].y, oa[q].y))));
+            f2_st2(oo[q] + UB, make_double2(__builtin_fma(-c10, ta[q].x, __builtin_fma(-c11, tb[q].x, ob[q].x)), __builtin_fma(-c10, ta[q].y, __builtin_fma(-c11, tb[q].y, ob[q].y))));
           }
         };
+        // (two at a time: four of them are 64 registers of reads in flight, in a kernel that has none to spare)
         if (g_row == 1) send(std::integral_constant<int, 1>{}, 0);
-        else if (g_row == 2) send(std::integral_constant<int, 2>{}, 0);
-        else { send(std::integral_constant<int, 4>{}, 0); if (g_row > 4) send(std::integral_constant<int, 4>{}, 4); }
+        else { for (int t0 = 0; t0 < g_row; t0 += 2) send(std::integral_constant<int, 2>{}, t0); }
       }
       while (lv < NL) { f2_lds_sync(); ++lv; }
     }
@@ -1064,27 +1069,33 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const f2_i4 ia = ia_next;
         if (j > 0) ia_next = items[(size_t)(j - 1) * (HV * 4)];
         if (lev < 0) continue;
+        if (lv < NL - 1 && lv > lev) { f2_lds_sync(); --lv; }     // (publish this wave's previous row first, as in the elimination)
         const int g_row = rinfo[4 * j + 1] & 255;
         const int fl = ia.y;
         double t00 = 0.0, t01 = 0.0, t10 = 0.0, t11 = 0.0, s0 = 0.0, s1 = 0.0;
         F2_ROW(j, (t00 = T00[RQ], t01 = T01[RQ], t10 = T10[RQ], t11 = T11[RQ], s0 = sx0[RQ], s1 = sx1[RQ]));
         while (lv > lev) { f2_lds_sync(); --lv; }
         const double2 xj = f2_ld2((fl & GS_MESH_F_NBR) ? unit_at(6u + hi16(ia.x)) : R0l);
-        double p0 = t00 * xj.x + t01 * xj.y, p1 = t10 * xj.x + t11 * xj.y;
+        double p0 = __builtin_fma(t00, xj.x, t01 * xj.y), p1 = __builtin_fma(t10, xj.x, t11 * xj.y);
         if (g_row > 1) {                                          // a group's partial sums, added by its lane 0 in lane order
-          f2_st2(scr + (unsigned)hv * UB, make_double2(p0, p1));
+          // (the sub-group index through an opaque copy: the eight read addresses below do not depend on the row, the compiler
+          // computed them once in front of the loop, had no registers for them, and every one came back from scratch memory behind a
+          // wait for ALL outstanding loads -- the next row's item among them: most of the back substitution's time)
+          unsigned hvx = (unsigned)hv; F2_OPAQUE(hvx);
+          f2_st2(scr + hvx * UB, make_double2(p0, p1));
           asm volatile("" ::: "memory");
           const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
           double a0 = 0.0, a1 = 0.0;
-          auto gsum = [&](auto gc) {                              // all reads first, then the sum in lane order
+          auto gsum = [&](auto gc, int t_first) {                 // all reads of a batch first, then the sum in lane order
             constexpr int G = decltype(gc)::value;
             double2 q[G];
 #pragma unroll
-            for (int t2 = 0; t2 < G; ++t2) q[t2] = f2_ld2(scr + (((unsigned)hv + (unsigned)t2) & 7u) * UB);
+            for (int t2 = 0; t2 < G; ++t2) q[t2] = f2_ld2(scr + ((hvx + (unsigned)(t_first + t2)) & 7u) * UB);
 #pragma unroll
-            for (int t2 = 0; t2 < G; ++t2) { if ((unsigned)t2 < gl) { a0 += q[t2].x; a1 += q[t2].y; } }
+            for (int t2 = 0; t2 < G; ++t2) { if ((unsigned)(t_first + t2) < gl) { a0 += q[t2].x; a1 += q[t2].y; } }
           };
-          if (g_row == 2) gsum(std::integral_constant<int, 2>{}); else if (g_row <= 4) gsum(std::integral_constant<int, 4>{}); else gsum(std::integral_constant<int, 8>{});
+          if (g_row == 2) gsum(std::integral_constant<int, 2>{}, 0);
+          else { gsum(std::integral_constant<int, 4>{}, 0); if (g_row > 4) gsum(std::integral_constant<int, 4>{}, 4); }
           p0 = a0; p1 = a1;
         }
         const double x0 = s0 - p0, x1 = s1 - p1;
