@@ -1325,7 +1325,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   }
   // Newton-Raphson on the second-generation frame: the constants of the flat-start elimination (GsF2Tables::nrflat), written by
   // ONE workgroup of the step kernel itself on the zeroed state of group 0, then group 0 is cleared again.  GS_NR_NO_FLAT=1: off.
-  if (h->nr2 && h->f2_npos > 0 && !getenv("GS_NR_NO_FLAT")) {
+  if ((h->nr2 || h->nrm) && h->f2_npos > 0 && !getenv("GS_NR_NO_FLAT")) {
     double* tab = nullptr;
     if ((rc = dev_alloc(h, &tab, (size_t)h->f2_npos * 16))) return bail(rc);
     if (hipMemset(tab, 0, (size_t)h->f2_npos * 16 * sizeof(double)) != hipSuccess ||
@@ -1335,7 +1335,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     GsSolveCfg sc = h->SC; sc.stamps = nullptr;
     const dim3 b2(64 * h->f2_nw);
     const int Bc = std::min(h->B, h->f2_iw);
-    if (h->f2_small) hipLaunchKernelGGL(gs_k_step_nr_flow2s, dim3(1), b2, h->F2.lds_bytes, h->stream, h->T, cap, h->R, sc, h->EC, h->slab, Bc, h->d_in, h->total_load, pa, fc, rsv);
+    if (h->nrm) hipLaunchKernelGGL(gs_k_step_nr_mesh2, dim3(1), b2, h->F2.lds_bytes, h->stream, h->T, cap, h->R, sc, h->EC, h->slab, Bc, h->d_in, h->total_load, pa, fc, rsv);
+    else if (h->f2_small) hipLaunchKernelGGL(gs_k_step_nr_flow2s, dim3(1), b2, h->F2.lds_bytes, h->stream, h->T, cap, h->R, sc, h->EC, h->slab, Bc, h->d_in, h->total_load, pa, fc, rsv);
     else hipLaunchKernelGGL(gs_k_step_nr_flow2, dim3(1), b2, h->F2.lds_bytes, h->stream, h->T, cap, h->R, sc, h->EC, h->slab, Bc, h->d_in, h->total_load, pa, fc, rsv);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
         hipMemset(h->slab, 0, (size_t)R.total * GS_LANES * sizeof(double)) != hipSuccess)

@@ -901,7 +901,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     if (cnt) { ir += __builtin_fma(yd.x, vk.x, -(yd.y * vk.y)); ii += __builtin_fma(yd.x, vk.y, yd.y * vk.x); }
     pc = __builtin_fma(vk.x, ir, vk.y * ii); qc = __builtin_fma(vk.y, ir, -(vk.x * ii));        // power_flow.py:150-157
   };
-  auto mismatch = [&]() -> double {
+  // Iteration 0 of every solve starts from the flat start, where the Jacobian -- and with it every pivot's D^-1, T(k, j) and the
+  // column block A(j, k) its messages are formed with, P and Q calculated -- does not depend on the instance.  The handle keeps them
+  // in a table, 16 doubles per item (D^-1, T, A(j, k), P calc, Q calc), written ONCE by one workgroup of this kernel (nrflat_mode 1,
+  // gs_create); iteration 0 of every later step (mode 2) only carries its right-hand side through: the q parts of the CQ messages
+  // up, x down.  Mode 0: every iteration eliminates for itself (GS_NR_NO_FLAT=1).
+  const bool flat_use = F.nrflat != nullptr && F.nrflat_mode == 2, flat_cap = F.nrflat != nullptr && F.nrflat_mode == 1;
+  double* const flat_tab = F.nrflat + ((size_t)wave * NI * HV + hv) * 16;      // row j: flat_tab + j * HV * 16
+  auto mismatch = [&](bool flat_it, bool capture) -> double {
     double lmax = 0.0, bad = 0.0, ps = 0.0;
     f2_i4 nxt = load_item(0);
 #pragma nounroll
@@ -914,12 +921,10 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       const int fl = it.y;
       const double2 vk = f2_ld2(vslot(lo16(it.x)));
       double pc, qc;
-      calc_pq(it, nadj, vk, pc, qc);
-#ifdef F2_MESH_P_REG
-      double Pk = 0.0; F2_ROW(j, Pk = Pj[RQ]);
-#else
+      if (flat_it) { const double2 c = *(const double2*)(flat_tab + (size_t)j * (HV * 16) + 12); pc = c.x; qc = c.y; }
+      else calc_pq(it, nadj, vk, pc, qc);
+      if (capture && l == 0) { double* tb = flat_tab + (size_t)j * (HV * 16); tb[12] = pc; tb[13] = qc; tb[14] = 0.0; tb[15] = 0.0; }
       const double Pk = f2_ld(o_ptab + 64u * lo16(it.x));
-#endif
       const double dP = Pk - pc, dQ = 0.0 - qc;                  // power_flow.py:159-165
       if (fl & GS_MESH_F_PIVOT) { lmax = fmax(lmax, fmax(fabs(dP), fabs(dQ))); bad = __builtin_fma(dP, 0.0, __builtin_fma(dQ, 0.0, bad)); }
       if (fl & (GS_MESH_F_PIVOT | GS_MESH_F_SLACKPOS)) ps += pc;                                    // total losses = sum of P_calc over ALL buses (:198-200)
@@ -930,13 +935,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   };
   bool stale = true;
   for (int it_ = 0; it_ < C.max_iterations; ++it_) {
-    const double lm = mismatch();
+    const bool flat_it = flat_use && it_ == 0;
+    const double lm = mismatch(flat_it, flat_cap && it_ == 0);      // (capture: the first mismatch of the capture launch is the flat-start one)
     stp.hit(F2_ST_MISMATCH);
     const double mm = wg_max(lm);
     stp.hit(F2_ST_FLAG);
     f2_check(st, mm, mm, it_, C.tolerance);
     stale = false;
-    if (__all(st.done)) break;
+    if (__all(st.done) && !(flat_cap && it_ == 0)) break;        // (the capture launch always runs its first elimination)
     // ---------------- elimination, level by level ----------------
     int sing = 0;
     {
@@ -958,6 +964,38 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         // messages, before the wait for the row's level: it runs while another wave is on the levels in between
         if (j > 0 && lv < lev) { f2_lds_sync(); ++lv; }
         const int fl = it.y;
+        double t00, t01, t10, t11, s0, s1;                        // what the row leaves in its registers: T(k, j_t) and the pivot's s
+        if (flat_it) {
+          // iteration 0 with the handle's flat-start table: s = D^-1 (r + the q parts addressed to this pivot); q to row j_t = -A(j_t, k) s
+          const double* tb = flat_tab + (size_t)j * (HV * 16);
+          const double2 iv0 = *(const double2*)tb, iv1 = *(const double2*)(tb + 2), tt0 = *(const double2*)(tb + 4), tt1 = *(const double2*)(tb + 6),
+                        cc0 = *(const double2*)(tb + 8), cc1 = *(const double2*)(tb + 10), pq = *(const double2*)(tb + 12);
+          const double Pk = f2_ld(o_ptab + 64u * lo16(it.x));
+          double r0 = Pk - pq.x, r1 = 0.0 - pq.y;
+          const unsigned tl = ((unsigned)fl >> GS_MESH_F_T_SHIFT) & 15u, gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
+          while (lv < lev) { f2_lds_sync(); ++lv; }
+          {
+            const double2 m0 = f2_ld2(unit_at(lo16(pl0.x)) + 2u * UB), m1 = f2_ld2(unit_at(hi16(pl0.x)) + 2u * UB);
+            r0 += m0.x; r1 += m0.y; r0 += m1.x; r1 += m1.y;
+          }
+          if (ncq > 2) {
+            const double2 m0 = f2_ld2(unit_at(lo16(pl0.y)) + 2u * UB), m1 = f2_ld2(unit_at(hi16(pl0.y)) + 2u * UB);
+            r0 += m0.x; r1 += m0.y; r0 += m1.x; r1 += m1.y;
+          }
+          s0 = __builtin_fma(iv0.x, r0, iv0.y * r1); s1 = __builtin_fma(iv1.x, r0, iv1.y * r1);
+          if (g_row > 1 && gl > 1) {
+            const unsigned o = scr + (unsigned)pl2.z * (3u * UB);
+            if (tl == 0) f2_st2(o, make_double2(s0, s1));
+            asm volatile("" ::: "memory");
+            const double2 q = f2_ld2(o);
+            s0 = q.x; s1 = q.y;
+          }
+          t00 = tt0.x; t01 = tt0.y; t10 = tt1.x; t11 = tt1.y;
+          const bool rmw = ((fl >> (GS_MESH_F_RMW_SHIFT + tl)) & 1) != 0;
+          const unsigned o = unit_at(hi16(it.z)) + 2u * UB;
+          const double2 old = f2_ld2(rmw ? o : R0l);
+          f2_st2(o, make_double2(__builtin_fma(-cc0.x, s0, __builtin_fma(-cc0.y, s1, old.x)), __builtin_fma(-cc1.x, s0, __builtin_fma(-cc1.y, s1, old.y))));
+        } else {
         const bool pivot = (fl & GS_MESH_F_PIVOT) != 0;
         const unsigned hv0 = ((unsigned)fl >> GS_MESH_F_HV0_SHIFT) & 15u, tl = ((unsigned)fl >> GS_MESH_F_T_SHIFT) & 15u;
         const double2 vk = f2_ld2(vslot(lo16(it.x))), vj = f2_ld2(vslot(hi16(it.x)));
@@ -965,11 +1003,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         double pc, qc;
         calc_pq(it, nadj, vk, pc, qc);
         if (!pivot) { pc = 0.0; qc = 0.0; }                       // (the slack's position: its row is there for the mismatch pass only)
-#ifdef F2_MESH_P_REG
-        double Pk = 0.0; F2_ROW(j, Pk = Pj[RQ]);
-#else
         const double Pk = f2_ld(o_ptab + 64u * lo16(it.x));
-#endif
         const double v2 = __builtin_fma(vk.x, vk.x, vk.y * vk.y), rvk = f2_rsq(v2), vmk = v2 * rvk;
         const double rvj = f2_rsq(__builtin_fma(vj.x, vj.x, vj.y * vj.y));
         // diagonal block (power_flow.py:247-248 exact sign, 259-260, 270-271, 283-284) and right-hand side (:159-165)
@@ -1007,7 +1041,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         if (pivot && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;          // power_flow.py:188-190: only an exactly singular matrix raises
         const double rdet = f2_rcp(det);
         double i00 = d11 * rdet, i01 = -d01 * rdet, i10 = -d10 * rdet, i11 = d00 * rdet;
-        double s0 = __builtin_fma(i00, r0, i01 * r1), s1 = __builtin_fma(i10, r0, i11 * r1);
+        s0 = __builtin_fma(i00, r0, i01 * r1); s1 = __builtin_fma(i10, r0, i11 * r1);
         const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
         if (g_row > 1 && gl > 1) {                                // the lanes of a group of two or more take D^-1 and s from its lane 0
           const unsigned o = scr + (unsigned)pl2.z * (3u * UB);      // the group's slot (GS_MESH_W_GSLOT): at most four groups of two or more in a row
@@ -1018,9 +1052,13 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           const double2 q0 = f2_ld2(o), q1 = f2_ld2(o + UB), q2 = f2_ld2(o + 2u * UB);
           i00 = q0.x; i01 = q0.y; i10 = q1.x; i11 = q1.y; s0 = q2.x; s1 = q2.y;
         }
-        const double t00 = __builtin_fma(i00, a00, i01 * a10), t01 = __builtin_fma(i00, a01, i01 * a11), t10 = __builtin_fma(i10, a00, i11 * a10),
-                     t11 = __builtin_fma(i10, a01, i11 * a11);                                                     // T(k, j) = D^-1 A(k, j)
-        F2_ROW(j, (T00[RQ] = t00, T01[RQ] = t01, T10[RQ] = t10, T11[RQ] = t11, sx0[RQ] = s0, sx1[RQ] = s1));
+        t00 = __builtin_fma(i00, a00, i01 * a10); t01 = __builtin_fma(i00, a01, i01 * a11); t10 = __builtin_fma(i10, a00, i11 * a10);
+        t11 = __builtin_fma(i10, a01, i11 * a11);                                                                  // T(k, j) = D^-1 A(k, j)
+        if (flat_cap && it_ == 0 && l == 0) {      // capture launch: this item's constants of the flat-start elimination
+          double* tb = flat_tab + (size_t)j * (HV * 16);
+          tb[0] = i00; tb[1] = i01; tb[2] = i10; tb[3] = i11; tb[4] = t00; tb[5] = t01; tb[6] = t10; tb[7] = t11;
+          tb[8] = c00; tb[9] = c01; tb[10] = c10; tb[11] = c11;
+        }
         if (g_row > 1) { unsigned hvx = (unsigned)hv; F2_OPAQUE(hvx); const unsigned o = scr + hvx * (2u * UB); f2_st2(o, make_double2(t00, t01)); f2_st2(o + UB, make_double2(t10, t11)); asm volatile("" ::: "memory"); }
         // ---- what this pivot sends on: row j_t of its messages.  q first (it needs nothing from the group)
         {
@@ -1053,6 +1091,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         // (two at a time: four of them are 64 registers of reads in flight, in a kernel that has none to spare)
         if (g_row == 1) send(std::integral_constant<int, 1>{}, 0);
         else { for (int t0 = 0; t0 < g_row; t0 += 2) send(std::integral_constant<int, 2>{}, t0); }
+        }
+        F2_ROW(j, (T00[RQ] = t00, T01[RQ] = t01, T10[RQ] = t10, T11[RQ] = t11, sx0[RQ] = s0, sx1[RQ] = s1));
       }
       while (lv < NL) { f2_lds_sync(); ++lv; }
     }
@@ -1164,7 +1204,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     stp.hit(14);
     stale = true;
   }
-  if (stale) { (void)mismatch(); }          // iteration cap reached after an update: the losses sum at the final voltages
+  if (stale) { (void)mismatch(false, false); }          // iteration cap reached after an update: the losses sum at the final voltages
 #undef F2_ROW
 #undef F2_ROW_CASE
   } else {

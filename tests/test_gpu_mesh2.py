@@ -154,3 +154,31 @@ def test_meshed_member_at_bench_size_is_independent_of_the_batch_and_solves_the_
         parts.append(o2); e2.close()
     np.testing.assert_array_equal(np.vstack(parts), obs)
     env.close()
+
+
+@pytest.mark.parametrize("maker,B", MESHED[:2])
+def test_flat_start_table_of_the_meshed_member_changes_nothing_beyond_rounding(maker, B, monkeypatch):
+    """Iteration 0 of every solve starts from the flat start, where every pivot's D^-1, T and column blocks do not depend on the
+    instance: the handle keeps them in a table (written once by the step kernel itself) and iteration 0 only carries the right-hand
+    side through.  Against a handle that eliminates for itself every time (GS_NR_NO_FLAT=1): equal iteration counts and flags,
+    observations within 1e-12."""
+    spec = maker()
+    rng = np.random.default_rng(23)
+    acts = rng.uniform(-1, 1, (3, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 11
+    outs = []
+    for no_flat in (False, True):
+        if no_flat:
+            monkeypatch.setenv("GS_NR_NO_FLAT", "1")
+        env = _env(spec, B)
+        monkeypatch.delenv("GS_NR_NO_FLAT", raising=False)
+        assert env.handle.describe()["kernel"] == "nr_mesh2"
+        env.reset(seed=seeds)
+        got = []
+        for t in range(3):
+            obs, rew, term, trunc, info = env.step(acts[t])
+            got.append((obs.copy(), rew.copy(), info["iterations"].copy(), info["power_flow_converged"].copy(), info["total_losses"].copy()))
+        outs.append(got); env.close()
+    for (o1, r1, i1, c1, l1), (o2, r2, i2, c2, l2) in zip(*outs):
+        assert np.array_equal(i1, i2) and np.array_equal(c1, c2) and c1.all()
+        assert np.max(np.abs(o1 - o2) / np.maximum(1.0, np.abs(o2))) < 1e-12 and np.max(np.abs(l1 - l2)) < 1e-12
