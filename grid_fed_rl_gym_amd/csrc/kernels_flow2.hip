@@ -855,9 +855,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   constexpr unsigned UB = 16u * IW;                              // a unit: 16 bytes per instance
   const unsigned l16 = (unsigned)l << 4;
   const unsigned R0l = (unsigned)o_tile + l16;                   // unit u of the region, this lane's share: R0l + u * UB
-  // this wave's exchange scratch, 16 units, used three ways one after the other: (D^-1, s) of a group's lane 0 at 3 units per group
-  // of two or more lanes (at most four in a row), every lane's T at 2 units per sub-group, the back substitution's partial sums at
-  // 1 unit per sub-group
+  // this wave's exchange scratch, 16 units, used two ways one after the other: every lane's T at 2 units per sub-group, the back
+  // substitution's partial sums at 1 unit per sub-group
   const unsigned scr = (unsigned)F.off_scr + (unsigned)wave * (16u * UB) + l16;
   const unsigned o_ptab = (unsigned)F.mesh_off_p + ((unsigned)l << 3);
   const unsigned o_pair = (unsigned)o_z, o_diag = (unsigned)o_z + 16u * (unsigned)(F.mesh_pairs + 1);
@@ -944,7 +943,6 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     stale = false;
     if (__all(st.done) && !(flat_cap && it_ == 0)) break;        // (the capture launch always runs its first elimination)
     // ---------------- elimination, level by level ----------------
-    int sing = 0;
     {
       int lv = 0;
       f2_i4 nxt = load_item(0);
@@ -953,16 +951,16 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const int lev = rinfo[4 * j];
         if (lev < 0) break;
         const int pk = rinfo[4 * j + 1], nadj = rinfo[4 * j + 2];
+        const int lev_next = j + 1 < NI ? rinfo[4 * (j + 1)] : -1;
         const int g_row = pk & 255, ncq = (pk >> 8) & 255, nrw = (pk >> 16) & 255, ncl = (pk >> 24) & 255;
         const f2_i4 it = nxt;
         const f2_i4* const late = items + (size_t)j * (HV * 4) + 1;
         const f2_i4 pl0 = late[0], pl1 = late[1], pl2 = late[2];      // words 4-15: cq_in (2), rw_in (2) | cl_in (2), mout 0-3 (2) | mout 4-7 (2), -
         if (j + 1 < NI) nxt = load_item(j + 1);
-        // The barrier that publishes this wave's previous row FIRST: the waves take the tail's levels in turn, and a wave that went
-        // from its row straight into the next row's preparations kept the wave of the next level waiting for exactly that long
-        // (per level: one row's whole work instead of its message-dependent half).  Then everything that does not depend on the
-        // messages, before the wait for the row's level: it runs while another wave is on the levels in between
-        if (j > 0 && lv < lev) { f2_lds_sync(); ++lv; }
+        // (The barrier that publishes a row comes right behind the row's last message, below: a wave that went from its row into
+        // the register-file store and the next row's preparations first kept the wave of the next level waiting for exactly that
+        // long.)  Everything that does not depend on the messages comes before the wait for the row's level: it runs while
+        // another wave is on the levels in between
         const int fl = it.y;
         double t00, t01, t10, t11, s0, s1;                        // what the row leaves in its registers: T(k, j_t) and the pivot's s
         if (flat_it) {
@@ -972,7 +970,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
                         cc0 = *(const double2*)(tb + 8), cc1 = *(const double2*)(tb + 10), pq = *(const double2*)(tb + 12);
           const double Pk = f2_ld(o_ptab + 64u * lo16(it.x));
           double r0 = Pk - pq.x, r1 = 0.0 - pq.y;
-          const unsigned tl = ((unsigned)fl >> GS_MESH_F_T_SHIFT) & 15u, gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
+          const unsigned tl = ((unsigned)fl >> GS_MESH_F_T_SHIFT) & 15u;
           while (lv < lev) { f2_lds_sync(); ++lv; }
           {
             const double2 m0 = f2_ld2(unit_at(lo16(pl0.x)) + 2u * UB), m1 = f2_ld2(unit_at(hi16(pl0.x)) + 2u * UB);
@@ -982,14 +980,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
             const double2 m0 = f2_ld2(unit_at(lo16(pl0.y)) + 2u * UB), m1 = f2_ld2(unit_at(hi16(pl0.y)) + 2u * UB);
             r0 += m0.x; r1 += m0.y; r0 += m1.x; r1 += m1.y;
           }
-          s0 = __builtin_fma(iv0.x, r0, iv0.y * r1); s1 = __builtin_fma(iv1.x, r0, iv1.y * r1);
-          if (g_row > 1 && gl > 1) {
-            const unsigned o = scr + (unsigned)pl2.z * (3u * UB);
-            if (tl == 0) f2_st2(o, make_double2(s0, s1));
-            asm volatile("" ::: "memory");
-            const double2 q = f2_ld2(o);
-            s0 = q.x; s1 = q.y;
-          }
+          s0 = __builtin_fma(iv0.x, r0, iv0.y * r1); s1 = __builtin_fma(iv1.x, r0, iv1.y * r1);      // (every lane of the group: the same s)
           t00 = tt0.x; t01 = tt0.y; t10 = tt1.x; t11 = tt1.y;
           const bool rmw = ((fl >> (GS_MESH_F_RMW_SHIFT + tl)) & 1) != 0;
           const unsigned o = unit_at(hi16(it.z)) + 2u * UB;
@@ -1001,8 +992,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const double2 vk = f2_ld2(vslot(lo16(it.x))), vj = f2_ld2(vslot(hi16(it.x)));
         const double2 ykj = f2_ld2(o_pair + 16u * lo16(it.z)), ykk = f2_ld2(o_diag + 16u * lo16(it.w));
         double pc, qc;
-        calc_pq(it, nadj, vk, pc, qc);
-        if (!pivot) { pc = 0.0; qc = 0.0; }                       // (the slack's position: its row is there for the mismatch pass only)
+        calc_pq(it, nadj, vk, pc, qc);                            // (every lane of a group: the pivot bus's)
         const double Pk = f2_ld(o_ptab + 64u * lo16(it.x));
         const double v2 = __builtin_fma(vk.x, vk.x, vk.y * vk.y), rvk = f2_rsq(v2), vmk = v2 * rvk;
         const double rvj = f2_rsq(__builtin_fma(vj.x, vj.x, vj.y * vj.y));
@@ -1032,26 +1022,20 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           a00 += r00.x; a01 += r00.y; a10 += r01.x; a11 += r01.y; a00 += r10.x; a01 += r10.y; a10 += r11.x; a11 += r11.y;
           c00 += l00.x; c01 += l00.y; c10 += l01.x; c11 += l01.y; c00 += l10.x; c01 += l10.y; c10 += l11.x; c11 += l11.y;
         };
+        // (the six reads of (D, r) first: the inverse starts on them while the eight of the off-diagonal blocks are still under way;
+        // all fourteen at once were 40 more spilled registers and no faster)
         pull_cq(pl0.x);
         if (ncq > 2) pull_cq(pl0.y);
         pull_rc(pl0.z, pl1.x);
         if ((nrw | ncl) > 2) pull_rc(pl0.w, pl1.y);
-        // ---- the pivot: D^-1, s (every lane on the diagonal block it holds; only a group's lane 0 holds the real one)
+        // ---- the pivot: D^-1, s (every lane of the group for itself)
         const double det = __builtin_fma(d00, d11, -(d01 * d10));
-        if (pivot && (!(det != 0.0) || !(fabs(det) < INFINITY))) sing = 1;          // power_flow.py:188-190: only an exactly singular matrix raises
+        // power_flow.py:188-190: only an exactly singular matrix raises.  Posted at once: the barriers of the levels that follow
+        // publish it, and the back substitution knows before its first row whether the step will be applied
+        if (pivot && (!(det != 0.0) || !(fabs(det) < INFINITY))) atomicOr(icell + 15 * IW + l, 1u);
         const double rdet = f2_rcp(det);
         double i00 = d11 * rdet, i01 = -d01 * rdet, i10 = -d10 * rdet, i11 = d00 * rdet;
         s0 = __builtin_fma(i00, r0, i01 * r1); s1 = __builtin_fma(i10, r0, i11 * r1);
-        const unsigned gl = ((unsigned)fl >> GS_MESH_F_G_SHIFT) & 15u;
-        if (g_row > 1 && gl > 1) {                                // the lanes of a group of two or more take D^-1 and s from its lane 0
-          const unsigned o = scr + (unsigned)pl2.z * (3u * UB);      // the group's slot (GS_MESH_W_GSLOT): at most four groups of two or more in a row
-          if (tl == 0) { f2_st2(o, make_double2(i00, i01)); f2_st2(o + UB, make_double2(i10, i11)); f2_st2(o + 2u * UB, make_double2(s0, s1)); }
-          // (what the other lanes of the wave wrote: the compiler, which sees one lane, may not move the reads over the conditional
-          // write to the same address -- it did, and every lane but lane 0 read the slot before it was written)
-          asm volatile("" ::: "memory");
-          const double2 q0 = f2_ld2(o), q1 = f2_ld2(o + UB), q2 = f2_ld2(o + 2u * UB);
-          i00 = q0.x; i01 = q0.y; i10 = q1.x; i11 = q1.y; s0 = q2.x; s1 = q2.y;
-        }
         t00 = __builtin_fma(i00, a00, i01 * a10); t01 = __builtin_fma(i00, a01, i01 * a11); t10 = __builtin_fma(i10, a00, i11 * a10);
         t11 = __builtin_fma(i10, a01, i11 * a11);                                                                  // T(k, j) = D^-1 A(k, j)
         if (flat_cap && it_ == 0 && l == 0) {      // capture launch: this item's constants of the flat-start elimination
@@ -1092,12 +1076,23 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         if (g_row == 1) send(std::integral_constant<int, 1>{}, 0);
         else { for (int t0 = 0; t0 < g_row; t0 += 2) send(std::integral_constant<int, 2>{}, t0); }
         }
+        if (lev_next != lev) { f2_lds_sync(); ++lv; }             // the row's messages are out; the wave's next row (if any) is of a later level
         F2_ROW(j, (T00[RQ] = t00, T01[RQ] = t01, T10[RQ] = t10, T11[RQ] = t11, sx0[RQ] = s0, sx1[RQ] = s1));
       }
       while (lv < NL) { f2_lds_sync(); ++lv; }
     }
     stp.hit(F2_ST_BOTTOM_UP);
-    if (sing) atomicOr(icell + 15 * IW + l, 1u);                 // read behind the back substitution, whose barriers publish it
+    {  // exact singularity anywhere in the instance: stop it where it is (status 2), as the reference's LinAlgError break does
+      const unsigned sa = icell[15 * IW + l];
+      if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
+    }
+    const bool upd = !st.done;
+    double kcs[16];                  // the series of the voltage rotation, in scalar registers for the whole pass
+    {
+      const GS_CONST double* kc0 = (const GS_CONST double*)kF2Series;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) kcs[q] = kc0[q];
+    }
     stp.hit(F2_ST_INIT);
     // ---------------- back substitution: x_k = s_k - sum_j T(k, j) x_j, levels downwards; the x slots share the messages' body ----------------
     {
@@ -1109,7 +1104,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         const f2_i4 ia = ia_next;
         if (j > 0) ia_next = items[(size_t)(j - 1) * (HV * 4)];
         if (lev < 0) continue;
-        if (lv < NL - 1 && lv > lev) { f2_lds_sync(); --lv; }     // (publish this wave's previous row first, as in the elimination)
+        const int lev_next = j > 0 ? rinfo[4 * (j - 1)] : -1;     // (the rows of a wave are its first ones: j - 1 exists whenever j > 0)
         const int g_row = rinfo[4 * j + 1] & 255;
         const int fl = ia.y;
         double t00 = 0.0, t01 = 0.0, t10 = 0.0, t11 = 0.0, s0 = 0.0, s1 = 0.0;
@@ -1140,36 +1135,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
         }
         const double x0 = s0 - p0, x1 = s1 - p1;
         if (fl & GS_MESH_F_PIVOT) f2_st2(unit_at(6u + lo16(ia.x)), make_double2(x0, x1));
-        F2_ROW(j, (sx0[RQ] = x0, sx1[RQ] = x1));
-      }
-      while (lv > 0) { f2_lds_sync(); --lv; }
-    }
-    {
-      const unsigned sa = icell[15 * IW + l];
-      if (!st.done && sa) { st.status = GS_STATUS_SINGULAR; st.done = true; }
-    }
-    const bool upd = !st.done;
-    stp.hit(F2_ST_TOP_DOWN);
-    // corrections (power_flow.py:315-327) as a rotation and scaling of (e, f): see the radial member above
-    if (__any(upd)) {
-      double kcs[16];
-      {
-        const GS_CONST double* kc0 = (const GS_CONST double*)kF2Series;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) kcs[q] = kc0[q];
-      }
-      f2_i4 ia_next = items[0];
-#pragma nounroll
-      for (int j = 0; j < NI; ++j) {
-        const int lev = rinfo[4 * j];
-        if (lev < 0) break;
-        const f2_i4 ia = ia_next;
-        if (j + 1 < NI) ia_next = items[(size_t)(j + 1) * (HV * 4)];
-        const int fl = ia.y;
-        const unsigned vo = vslot(lo16(ia.x));
-        double x0 = 0.0, x1 = 0.0;
-        F2_ROW(j, (x0 = sx0[RQ], x1 = sx1[RQ]));
+        if (lev_next != lev && lv > 0) { f2_lds_sync(); --lv; }   // x is out: the barrier before everything else the row still does
+        // corrections (power_flow.py:315-327) as a rotation and scaling of (e, f), see the radial member above -- here, behind the
+        // barrier, while the level below is at work (nobody reads a voltage before the next mismatch; as a pass of its own the
+        // update was 10 k cycles per iteration)
         if (upd && (fl & GS_MESH_F_PIVOT)) {
+          const unsigned vo = vslot(lo16(ia.x));
           const double2 v = f2_ld2(vo);
           const double v2 = __builtin_fma(v.x, v.x, v.y * v.y), rvm0 = f2_rsq(v2), vm0 = v2 * rvm0;
           const double dth = C.alpha * x0, vmn = vm0 + C.alpha * x1;
@@ -1199,7 +1170,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           f2_st2(vo, make_double2(ratio * (v.x * cs - v.y * sn), ratio * (v.x * sn + v.y * cs)));
         }
       }
+      while (lv > 0) { f2_lds_sync(); --lv; }
     }
+    stp.hit(F2_ST_TOP_DOWN);
     f2_lds_sync();                   // the new voltages are read by the neighbours' lanes in the next mismatch
     stp.hit(14);
     stale = true;

@@ -289,10 +289,8 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
           if (q < 0) continue;
           const Group& G = groups[q];
           g_row = std::max(g_row, G.g);
-          if (t == 0) {
-            nadj = std::max(nadj, ht.row_ptr[G.k + 1] - ht.row_ptr[G.k]);
-            if (!G.slackpos) ncq = std::max(ncq, (int)cq_in[G.k].size());
-          }
+          nadj = std::max(nadj, ht.row_ptr[G.k + 1] - ht.row_ptr[G.k]);
+          if (!G.slackpos) ncq = std::max(ncq, (int)cq_in[G.k].size());
           if (t < G.d) {
             const int jn = nbrs[G.k][t];
             auto a = rw_in.find({G.k, jn}); if (a != rw_in.end()) nrw = std::max(nrw, (int)a->second.size());
@@ -321,10 +319,11 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
           it.flags = (hv0 << MESH_F_HV0_SHIFT) | (t << MESH_F_T_SHIFT) | (G->g << MESH_F_G_SHIFT);
           it.pad[0] = G->gslot;
           it.bus = G->k; it.vk_off = G->k * slot_bytes;
-          if (t == 0) {
-            it.flags |= G->slackpos ? MESH_F_SLACKPOS : MESH_F_PIVOT;
-            if (!G->slackpos) { it.xk_off = BODY + G->k * S.unit_bytes; it.ykk_g = ht.Gd[G->k]; it.ykk_b = ht.Bd[G->k]; lcq = cq_in[G->k]; }
-          }
+          // every lane of the group forms the pivot's D_k, r_k, D_k^-1 and s_k for itself (the same instructions on the same
+          // operands as lane 0: nothing to exchange): all of them carry the diagonal entry, the pull list and the Ybus row
+          if (t == 0) it.flags |= G->slackpos ? MESH_F_SLACKPOS : MESH_F_PIVOT;
+          it.ykk_g = ht.Gd[G->k]; it.ykk_b = ht.Bd[G->k];
+          if (!G->slackpos) { if (t == 0) it.xk_off = BODY + G->k * S.unit_bytes; lcq = cq_in[G->k]; }
           if (t < G->d) {
             const int jn = nbrs[G->k][t];
             it.flags |= MESH_F_NBR; it.nbr = jn;
@@ -344,7 +343,7 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
         lcq.resize(GS_MESH_ACC, ZERO); lrw.resize(GS_MESH_ACC, ZERO); lcl.resize(GS_MESH_ACC, ZERO);
         for (int u = 0; u < GS_MESH_ACC; ++u) { it.cq_in[u] = lcq[u]; it.rw_in[u] = lrw[u]; it.cl_in[u] = lcl[u]; }
         int have_adj = 0;
-        if (G && t == 0)
+        if (G)
           for (int p = ht.row_ptr[G->k]; p < ht.row_ptr[G->k + 1]; ++p, ++have_adj) {
             S.adj_off.push_back(ht.col[p] * slot_bytes); S.adj_y.push_back(ht.G[p]); S.adj_y.push_back(ht.B[p]);
           }
@@ -396,8 +395,8 @@ void gs_mesh_schedule(const HostTopology& ht, int NW, int NI, int IW, int region
         w[GS_MESH_W_CQIN + 4 + u / 2] = unit_of(it.cl_in[u]) | (unit_of(it.cl_in[u + 1]) << 16);
       }
       w[GS_MESH_W_GSLOT] = it.pad[0];
-      const bool lane0 = (it.flags & (MESH_F_PIVOT | MESH_F_SLACKPOS)) != 0;
-      const int dslot = lane0 ? bus : n + 1;                  // (the slack's position needs its true diagonal entry for P calculated)
+      const bool lane0 = it.bus >= 0;                          // (every lane of a group carries its pivot's diagonal entry and Ybus row)
+      const int dslot = lane0 ? bus : n + 1;
       w[GS_MESH_W_DIAG_ADJ] = dslot | ((lane0 ? adj_ptr[bus] : 0) << 16);
       const int nadj_lane = lane0 ? adj_ptr[bus + 1] - adj_ptr[bus] : 0;
       if (nadj_lane > 255) return fail("a bus has more than 255 neighbours");

@@ -14,8 +14,9 @@
 //     to whoever eliminates the target first.  Back substitution: x_k = s_k - sum_j T_kj x_j.  No block is ever read, modified
 //     and written by two parties; original Jacobian blocks are never stored (formed from the voltages where they are needed).
 //   * A pivot of degree d takes a GROUP of max(d, 1) consecutive sub-groups of ONE wavefront row (8 sub-groups of 8 instances):
-//     lane t handles neighbour j_t (both blocks, T, row j_t's messages), lane 0 also the diagonal.  T stays in the registers
-//     of the lane that formed it until the back substitution; everything else is a message in LDS.
+//     lane t handles neighbour j_t (both blocks, T, row j_t's messages); every lane of the group forms D_k, r_k, D_k^-1 and s_k for
+//     itself (same instructions, same operands: nothing to exchange), lane 0 is the one that counts.  T stays in the registers of
+//     the lane that formed it until the back substitution; everything else is a message in LDS.
 //   * Messages ACCUMULATE: the producers of one target at different levels add into the same slot (a level barrier apart);
 //     producers of the same level get accumulators of their own.  A target's pull list is then 1-4 entries whatever its
 //     history, and the LDS footprint is the active submatrix, not the list of updates.

@@ -76,12 +76,12 @@ def _replay(spec, S, V, P_spec, rng):
             for hv in range(8):                                   # everything before the exchange of D^-1 and s
                 it = items[w, j, hv]; fl = int(it["flags"])
                 ek, fk = rd(int(it["vk_off"])); ej, fj = rd(int(it["vj_off"]))
-                pc, qc = yv(it, nadj) if fl & F_PIVOT else (0.0, 0.0)
+                pc, qc = yv(it, nadj) if int(it["bus"]) >= 0 else (0.0, 0.0)     # every lane of a group: the pivot bus's
                 vm2 = ek * ek + fk * fk; vm = np.sqrt(vm2); rvk = 1.0 / vm; rvj = 1.0 / np.sqrt(ej * ej + fj * fj)
                 G, B, Gd, Bd = float(it["ykj_g"]), float(it["ykj_b"]), float(it["ykk_g"]), float(it["ykk_b"])
                 D = np.array([[-qc - vm2 * Bd, pc * rvk + vm * Gd], [pc - vm2 * Gd, qc * rvk - vm * Bd]])
                 bus = int(it["bus"])
-                r = np.array([(P_spec[bus] if fl & F_PIVOT else 0.0) - pc, 0.0 - qc])
+                r = np.array([(P_spec[bus] if bus >= 0 else 0.0) - pc, 0.0 - qc])
                 a = ek * ej + fk * fj; bk = fk * ej - ek * fj; bj = -bk
                 gs, gc = G * bk - B * a, G * a + B * bk
                 Akj = np.array([[gs, gc * rvj], [-gc, gs * rvj]])
@@ -89,7 +89,7 @@ def _replay(spec, S, V, P_spec, rng):
                 Ajk = np.array([[gs2, gc2 * rvk], [-gc2, gs2 * rvk]])
                 for u in range(ncq):
                     o = int(it["cq_in"][u]); c0, c1, q = rd(o), rd(o + U), rd(o + 2 * U)
-                    if fl & F_PIVOT: D += np.array([c0, c1]); r += q
+                    D += np.array([c0, c1]); r += q                 # (every lane of the group: its lists are the pivot's)
                 for u in range(nrw):
                     o = int(it["rw_in"][u]); Akj += np.array([rd(o), rd(o + U)])
                 for u in range(ncl):
@@ -106,7 +106,9 @@ def _replay(spec, S, V, P_spec, rng):
             for hv in range(8):
                 L = lane[hv]; fl = L["fl"]
                 hv0 = (fl >> 4) & 15
-                Dinv, s = scratch[("d", hv0)] if g_row > 1 else (L["Dinv"], L["s"])
+                Dinv, s = L["Dinv"], L["s"]                         # formed by the lane itself ...
+                if int(L["it"]["bus"]) >= 0 and not fl & F_SLACKPOS:    # ... and equal to what the group's lane 0 formed
+                    assert np.array_equal(Dinv, scratch[("d", hv0)][0]) and np.array_equal(s, scratch[("d", hv0)][1])
                 L["Dg"], L["sg"] = Dinv, s
                 L["T"] = Dinv @ L["Akj"]
                 scratch[("t", hv)] = L["T"]
@@ -235,7 +237,7 @@ def test_packed_items_say_what_the_verbose_items_say(name, maker):
                 assert tuple(ytab[pair]) == (float(it["ykj_g"]), float(it["ykj_b"]))
                 dslot, ap = int(p[3]) & 0xffff, (int(p[3]) >> 16) & 0xffff
                 nadj = (int(p[1]) >> 24) & 255
-                if fl & (F_PIVOT | F_SLACKPOS):
+                if int(it["bus"]) >= 0:
                     assert dslot == bus and tuple(ytab[npairs + 1 + dslot]) == (Y[bus, bus].real, Y[bus, bus].imag)
                     got = sorted((int(e) >> 16, tuple(ytab[int(e) & 0xffff])) for e in ent[ap:ap + nadj])
                     want = sorted((k, (Y[bus, k].real, Y[bus, k].imag)) for k in range(n) if k != bus and Y[bus, k] != 0)
