@@ -560,9 +560,12 @@ def main():
                             "GB_per_s_of_observations": B * fs.obs_dim * 8 / med / 1e9, "what": what}
             except Exception as e:
                 m[label] = {"error": str(e)}
+        nd_cols = fs.obs_dim - 2 * fs.n_loads
         host_io("with_host_io", f"BatchedGridEnvironment.step() as it is by default; per step: actions [B][{fs.action_dim}] f64 host->device ({B * fs.action_dim * 8} B), "
-                                f"observations [B][{fs.obs_dim}] f64 device->host ({B * fs.obs_dim * 8} B), reward / flags / info arrays (~{B * 70} B); the arrays returned "
-                                "are views of page-locked buffer sets, a set reused only when the caller holds nothing of it any more")
+                                f"observations [B][{fs.obs_dim}] f64: the {nd_cols} changing columns device->host ({B * nd_cols * 8} B, written by a kernel straight into the "
+                                f"page-locked array; the {2 * fs.n_loads} constant columns -- static load powers -- were put there once, gs_host_obs_bind), "
+                                f"reward / flags / info arrays (~{B * 70} B); the arrays returned are views of page-locked buffer sets, a set reused only when the caller "
+                                "holds nothing of it any more (GB_per_s_of_observations counts the whole array the caller sees)")
         saved, h._recycle = getattr(h, "_recycle", None), None
         host_io("with_host_io_fresh_arrays", "recycle_host_buffers=False: a freshly allocated pageable NumPy array per output and step (rounds 1-3's default)")
         h._recycle = saved

@@ -109,6 +109,8 @@ SYMBOLS = [
     ("gs_allgather_obs", C.c_int, [_H, _dp]),
     ("gs_comm_destroy", C.c_int, [_H]),
     ("gs_comm_info", C.c_int, [_H, C.c_void_p]),
+    ("gs_host_obs_bind", C.c_int, [_H, _dp]),
+    ("gs_host_obs_unbind", C.c_int, [_H, _dp]),
     ("gs_mesh_schedule_dump_packed", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip, _ip, _dp, _ip]),
     ("gs_mesh_schedule_dump", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_char_p, C.c_int32,
                                         C.c_void_p, _ip, _ip, _dp]),
@@ -481,6 +483,9 @@ class Handle:
     def _free_pinned(self) -> None:
         self._pinned = None
         rec = getattr(self, "_recycle", None)
+        if rec and getattr(self, "_h", None) and self._h.value:
+            for st in rec["sets"]:
+                self._unbind_obs(st)
         self._recycle = None
         keep = set()
         if rec:       # a set the caller still holds arrays of is not freed: those arrays stay valid (the memory goes with the process)
@@ -537,8 +542,43 @@ class Handle:
         rec["sets"].append(st)
         return st
 
+    # -- constant observation columns of a recycled / pinned set: written once (gs_host_obs_bind), not moved again ------------
+    def _const_block(self):
+        s = self.spec
+        c0 = 2 * s.n + 2 * s.m + 1
+        return c0, c0 + 2 * s.n_loads
+
+    def _bind_obs(self, st) -> None:
+        """Called once a set's observation array holds a whole observation: from now on downloads into it move the changing
+        columns only.  A caller that edits returned arrays IN PLACE would spoil the constant columns for the set's next use: a
+        sample of them is checked before every reuse (``_obs_intact``), and a spoilt set is bound again."""
+        obs = st["roots"].get("obs") if st else None
+        c0, c1 = self._const_block()
+        if obs is None or c1 <= c0 or os.environ.get("GS_HOST_FULL_OBS"):
+            return
+        if self._lib.gs_host_obs_bind(self._h, _ptr(obs, _dp)) != GS_OK:
+            return
+        rng = np.random.default_rng(12345)
+        k = min(128, obs.shape[0] * (c1 - c0))
+        rows, cols = rng.integers(0, obs.shape[0], k), rng.integers(c0, c1, k)
+        st["probe"] = (rows, cols, obs[rows, cols].copy())
+
+    def _obs_intact(self, st) -> bool:
+        pr = st.get("probe")
+        if pr is None:
+            return True
+        rows, cols, vals = pr
+        return bool(np.array_equal(st["roots"]["obs"][rows, cols], vals))
+
+    def _unbind_obs(self, st) -> None:
+        if st.pop("probe", None) is not None:
+            self._lib.gs_host_obs_unbind(self._h, _ptr(st["roots"]["obs"], _dp))
+
     def _step_buffers(self, want_obs=True):
         st = self._recycled_set(want_obs) if getattr(self, "_recycle", None) else None
+        self._cur_set = st
+        if st is not None and not self._obs_intact(st):
+            self._unbind_obs(st)                   # (this download writes whole rows again; bound anew behind it)
         if getattr(self, "_pinned", None):
             out = dict(self._pinned[self._pinned_turn])
             self._pinned_turn = (self._pinned_turn + 1) % len(self._pinned)
@@ -561,7 +601,13 @@ class Handle:
         out, info = self._step_buffers()
         self._check(self._lib.gs_step(self._h, _ptr(a, _dp), _ptr(out["obs"], _dp), _ptr(out["reward"], _dp),
                                       _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
+        self._after_download()
         return out
+
+    def _after_download(self) -> None:
+        st = getattr(self, "_cur_set", None)
+        if st is not None and st["roots"].get("obs") is not None and "probe" not in st and st["ptrs"]:
+            self._bind_obs(st)
 
     def upload_actions(self, actions) -> None:
         a = _f64(actions)
@@ -596,6 +642,8 @@ class Handle:
         out, info = self._step_buffers(want_obs)
         self._check(self._lib.gs_download_step(self._h, _ptr(out["obs"], _dp), _ptr(out["reward"], _dp),
                                                _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
+        if want_obs:
+            self._after_download()
         return out
 
     # -- rollout collection ------------------------------------------------------------------

@@ -128,6 +128,9 @@ struct gs_handle {
   double* d_obs2[2] = {nullptr, nullptr}; int obs_cur = 0;
   hipStream_t comm_stream = nullptr; hipEvent_t ev_step = nullptr, ev_gather[2] = {nullptr, nullptr}; bool gather_pending[2] = {false, false};
   int obs_skip0 = 0, obs_skip1 = 0;   // the block of per-instance constants inside an observation
+  // host observation arrays whose constant columns are in place (gs_host_obs_bind): gs_step / gs_download_step copy only the
+  // changing columns into these -- two strided copies instead of one whole block, 36 % fewer bytes over PCIe on the 123-bus feeder
+  std::vector<const double*> bound_obs; std::vector<double*> bound_dev;     // (the device's address of a page-locked array, or NULL: strided copies)
   double* d_actions = nullptr; int n_action_batches = 0;
   // gs_rollout: [T + 1][B][obs_dim] observation sequence, [T][B][A] actions, [T][B] rewards / done flags, and the side
   // list of terminal observations (the rows the in-place resets replaced)
@@ -1503,11 +1506,67 @@ int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* termina
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   GS_ENTER(h);
   if (obs) {
-    HIPCHK(h, hipMemcpyAsync(obs, h->d_obs2[h->obs_cur], (size_t)h->B * h->obs_dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const double* src = h->d_obs2[h->obs_cur];
+    const size_t pitch = (size_t)h->obs_dim * sizeof(double);
+    const auto bit = std::find(h->bound_obs.begin(), h->bound_obs.end(), obs);
+    const bool bound = h->obs_skip1 > h->obs_skip0 && bit != h->bound_obs.end();
+    double* dev = bound ? h->bound_dev[bit - h->bound_obs.begin()] : nullptr;
+    if (dev) {
+      // page-locked and mapped: a kernel on the step's stream writes the changing columns into it itself, 16 bytes per lane (measured
+      // at B = 8192 on the 123-bus feeder: 0.90 ms per env.step() against 1.10 ms for the whole block through the copy engine and
+      // 1.00 ms for the copy engine's strided copies of the same columns; kernel and copy engine side by side were no faster)
+      const int nd = h->obs_dim - (h->obs_skip1 - h->obs_skip0);
+      const bool pair = !(h->obs_dim & 1) && !(h->obs_skip0 & 1) && !(h->obs_skip1 & 1);
+      const long long work = (long long)h->B * (pair ? nd / 2 : nd);
+      hipLaunchKernelGGL(gs_k_obs_to_host, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, h->stream, src, dev, (long long)h->B, h->obs_dim, h->obs_skip0, h->obs_skip1);
+      HIPCHK(h, hipGetLastError());
+    } else if (bound) {        // the columns either side of the constant block, every row
+      if (h->obs_skip0 > 0)
+        HIPCHK(h, hipMemcpy2DAsync(obs, pitch, src, pitch, (size_t)h->obs_skip0 * sizeof(double), (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+      if (h->obs_dim > h->obs_skip1)
+        HIPCHK(h, hipMemcpy2DAsync(obs + h->obs_skip1, pitch, src + h->obs_skip1, pitch, (size_t)(h->obs_dim - h->obs_skip1) * sizeof(double), (size_t)h->B,
+                                   hipMemcpyDeviceToHost, h->stream));
+    } else {
+      HIPCHK(h, hipMemcpyAsync(obs, src, (size_t)h->B * pitch, hipMemcpyDeviceToHost, h->stream));
+    }
   }
   int rc = fetch_scalars(h);
   if (rc) return rc;
   copy_info(h, reward, terminated, truncated, info);
+  return GS_OK;
+}
+
+// A host observation array [B][obs_dim] the caller will hand to gs_step / gs_download_step again and again: its constant columns
+// (the static load powers, grid_env.py:769-770 -- they never change) are written here, once, and later downloads into the same
+// address move the changing columns only.  The caller must leave those columns alone (or bind again).
+int gs_host_obs_bind(gs_handle* h, double* obs) {
+  if (!h || !obs) return fail(h, GS_E_INVALID, "handle / obs is NULL");
+  if (!h->was_reset) return fail(h, GS_E_STATE, "gs_host_obs_bind before gs_reset");
+  GS_ENTER(h);
+  if (h->obs_skip1 > h->obs_skip0) {
+    const size_t pitch = (size_t)h->obs_dim * sizeof(double);
+    HIPCHK(h, hipMemcpy2DAsync(obs + h->obs_skip0, pitch, h->d_obs2[h->obs_cur] + h->obs_skip0, pitch, (size_t)(h->obs_skip1 - h->obs_skip0) * sizeof(double),
+                               (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  if (std::find(h->bound_obs.begin(), h->bound_obs.end(), obs) == h->bound_obs.end()) {
+    // page-locked memory the device can address (gs_host_alloc): later downloads are a kernel's own stores
+    double* dev = nullptr;
+    hipPointerAttribute_t at{};
+    if (!getenv("GS_HOST_OBS_2D") && hipPointerGetAttributes(&at, obs) == hipSuccess && at.type == hipMemoryTypeHost) {
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, obs, 0) == hipSuccess) dev = (double*)dp;
+    }
+    (void)hipGetLastError();
+    h->bound_obs.push_back(obs); h->bound_dev.push_back(dev);
+  }
+  return GS_OK;
+}
+
+int gs_host_obs_unbind(gs_handle* h, double* obs) {
+  if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
+  auto it = std::find(h->bound_obs.begin(), h->bound_obs.end(), (const double*)obs);
+  if (it != h->bound_obs.end()) { h->bound_dev.erase(h->bound_dev.begin() + (it - h->bound_obs.begin())); h->bound_obs.erase(it); }
   return GS_OK;
 }
 

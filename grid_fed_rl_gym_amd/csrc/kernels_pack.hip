@@ -98,6 +98,30 @@ gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long 
   else dst[idx] = src[r * D + c];
 }
 
+// The changing columns of the observation block written STRAIGHT into a page-locked host array of the same layout (gs_host_obs_bind:
+// its constant columns are in place): dst[r][c] = src[r][c] for c outside [skip0, skip1).  16 bytes per thread where the rows allow it;
+// the stores go over PCIe as whole bursts (a strided hipMemcpy2D moved the same bytes at 32 GB/s, this at the link's rate).
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_obs_to_host(const double* __restrict__ src, double* __restrict__ dst, long long rows, int D, int skip0, int skip1) {
+  const int gap = skip1 - skip0, nd = D - gap;
+  if (!(D & 1) && !(skip0 & 1) && !(skip1 & 1)) {            // every run starts on a 16-byte boundary: two columns per thread
+    const int nd2 = nd >> 1;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * nd2) return;
+    const long long r = idx / nd2;
+    const int j = 2 * (int)(idx - r * nd2), c = j < skip0 ? j : j + gap;
+    typedef double gs_d2 __attribute__((ext_vector_type(2)));
+    const gs_d2 v = *(const gs_d2*)(src + r * D + c);
+    __builtin_nontemporal_store(v, (gs_d2*)(dst + r * D + c));
+  } else {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * nd) return;
+    const long long r = idx / nd;
+    const int j = (int)(idx - r * nd), c = j < skip0 ? j : j + gap;
+    dst[r * D + c] = src[r * D + c];
+  }
+}
+
 // out[q] = row (row0 + q) of lane `lane` of group 0, q < count (gs_create: the handle's flat-start LU blocks, read off the
 // rows one ordinary factorisation left there)
 extern "C" __global__ void __launch_bounds__(256)

@@ -216,6 +216,13 @@ int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches);
 int gs_step_device(gs_handle* h, int32_t action_batch_index);
 int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated,
                      uint8_t* truncated, const gs_info_view* info);
+/* Host observation arrays that are handed to gs_step / gs_download_step again and again (the recycled page-locked sets of the
+ * Python environment): gs_host_obs_bind writes the constant columns of the observation -- the static load powers of
+ * grid_env.py:769-770, a third of the row on the 123-bus feeder -- into `obs` once and remembers the address; later downloads
+ * into that address move the changing columns only (two strided copies), the same bytes as a whole-row download would leave.
+ * The caller must not modify the constant columns of a bound array (bind again if it did).  After gs_reset. */
+int gs_host_obs_bind(gs_handle* h, double* obs);
+int gs_host_obs_unbind(gs_handle* h, double* obs);
 
 /* A consumer that lives on the same GPU (a policy network) steps the environment without any host copy: it reads the
  * observation block and the reward / flag arrays through device pointers and hands back a device pointer to its actions.

@@ -125,13 +125,36 @@ def env_step(net: Net, cfg: orc_cfg, state, actions) -> dict:
     return out
 
 
+def cpu_share() -> dict:
+    """CPUs this process may actually use: the affinity mask, capped by the container's CPU quota (cgroup v2 ``cpu.max``, v1
+    ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us``).  A GPU box exposes every host thread in the mask but grants a share of them
+    per GPU: a pool sized by the mask alone is time-sliced inside the quota (round 3 measured 256 threads three times SLOWER
+    than 16 for exactly that reason)."""
+    mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = mask if quota is None else max(1, min(mask, int(quota + 0.999)))
+    return {"affinity_mask": mask, "cgroup_quota_cpus": quota, "usable": usable}
+
+
 def bench_env_steps(fs, env_kwargs, budget_s=15.0, threads=None) -> dict:
     """cpu_baseline leg of bench.py: the C/OpenMP port on all host cores (or on `threads`), bounded sample."""
     net = Net(fs)
     # the GPU box exposes all host threads but grants a 16-core share per GPU; never oversubscribe
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else lib().orc_max_threads()
-    if threads == "all":                      # every CPU this process may run on (BASELINE.md section 3: "at 1 core and at all cores")
-        threads = max(1, avail)
+    share = cpu_share()
+    if threads == "all":                      # every CPU this process may USE (BASELINE.md section 3: "at 1 core and at all cores"): mask capped by the cgroup quota
+        threads = max(1, share["usable"])
     threads = max(1, min(lib().orc_max_threads(), avail, 16)) if threads is None else int(threads)
     cfg = config(solver=env_kwargs["solver"], jacobian="exact", max_iterations=env_kwargs["max_iterations"],
                  tolerance=env_kwargs["tolerance"], stochastic_loads=env_kwargs["stochastic_loads"],
@@ -146,7 +169,7 @@ def bench_env_steps(fs, env_kwargs, budget_s=15.0, threads=None) -> dict:
         env_step(net, cfg, state, rng.uniform(-1, 1, (B, net.action_dim)))
         n_done += B
     dt = time.perf_counter() - t0
-    return {"value": n_done / dt, "unit": "env_steps/s", "cores": threads, "kind": "port",
+    return {"value": n_done / dt, "unit": "env_steps/s", "cores": threads, "kind": "port", "cpu_share": share,
             "sample": f"C/OpenMP oracle ({'dense Newton-Raphson as the reference codes it' if env_kwargs['solver'] == 'nr' else 'forward/backward sweep, dense mismatch'}), {n_done} env-steps of the same workload "
                       f"(batches of {B}) in {dt:.1f} s on {threads} threads"}
 

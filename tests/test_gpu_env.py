@@ -759,3 +759,35 @@ def test_step_outputs_are_recycled_only_when_the_caller_has_let_go():
     held = o1[:2]
     env.close(); ref.close()
     assert np.array_equal(held, o2[:2])       # an array held across close() stays readable
+
+
+def test_recycled_observation_arrays_download_the_changing_columns_only_and_stay_whole():
+    """A recycled page-locked observation array gets its constant columns (the static load powers, grid_env.py:769-770) once
+    (gs_host_obs_bind); later steps move the changing columns only -- and return, bit for bit, what a whole-row download into a
+    fresh array returns.  Also after the caller edited a returned array IN PLACE (the constant columns of that set are spoilt:
+    the sampled check notices and the set is bound again), after a masked reset, and for download_step()."""
+    fs = P.ieee123_like(); B = 200
+    env = P.BatchedGridEnvironment(fs, num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True)
+    ref = P.BatchedGridEnvironment(fs, num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True, recycle_host_buffers=False)
+    seeds = np.arange(B, dtype=np.uint64) + 3
+    env.reset(seed=seeds); ref.reset(seed=seeds)
+    rng = np.random.default_rng(1)
+    acts = rng.uniform(-1, 1, (10, B, fs.action_dim))
+    c0 = 2 * fs.n + 2 * fs.m + 1; c1 = c0 + 2 * fs.n_loads
+    bound_seen = False
+    for k in range(10):
+        o1, r1, *_ = env.step(acts[k]); o2, r2, *_ = ref.step(acts[k])
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2), k
+        assert (o1[:, c0:c1] != 0).any()
+        st = env.handle._cur_set
+        bound_seen |= st is not None and "probe" in st
+        if k == 4:
+            o1 *= 0.5                             # a caller normalising in place: the set's constant columns are gone
+        if k == 6:
+            m = (rng.random(B) < 0.4).astype(np.uint8)
+            env.handle.reset(seeds + np.uint64(9), m, want_obs=False); ref.handle.reset(seeds + np.uint64(9), m, want_obs=False)
+        del o1, r1
+    assert bound_seen
+    d1 = env.handle.download_step(); d2 = ref.handle.download_step()
+    assert np.array_equal(d1["obs"], d2["obs"])
+    env.close(); ref.close()
