@@ -83,6 +83,7 @@ POLICY = {"uploaded": 0, "random": 1}
 _H = C.c_void_p
 SYMBOLS = [
     ("gs_version", C.c_int, []),
+    ("gs_build_experiments", C.c_int, []),
     ("gs_device_count", C.c_int, []),
     ("gs_last_error", C.c_char_p, [_H]),
     ("gs_create", C.c_int, [C.POINTER(gs_topology), C.POINTER(gs_config), C.c_int32, C.c_int32, C.c_int64, C.POINTER(_H)]),
@@ -154,6 +155,11 @@ def load() -> C.CDLL:
         raise PowerFlowError(f"libgridstep ABI {lib.gs_version()} != binding {GS_ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def experiments() -> bool:
+    """True if libgridstep.so was built with ``make EXPERIMENTS=1`` (gs_build_experiments)."""
+    return bool(load().gs_build_experiments())
 
 
 def _f64(a) -> np.ndarray:

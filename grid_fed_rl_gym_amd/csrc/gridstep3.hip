@@ -36,6 +36,11 @@
 #include <vector>
 
 #include "../../include/gridstep.h"
+#if defined(GS_BUILD_EXPERIMENTS)        /* gs_internal.h: switches that exist to measure alternatives */
+#define GS_EXPERIMENT_ENV(name) getenv(name)
+#else
+#define GS_EXPERIMENT_ENV(name) ((const char*)nullptr)
+#endif
 
 namespace {
 
@@ -602,7 +607,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     return bail(rc);
   // level messages through LDS when two parities of the widest level fit beside three other resident workgroups
   h->lds_bytes = 2 * 2 * h->max_width * (int)sizeof(double);
-  if (h->lds_bytes > 38 * 1024 || getenv("GS3_NO_LDS")) h->lds_bytes = 0;
+  if (h->lds_bytes > 38 * 1024 || GS_EXPERIMENT_ENV("GS3_NO_LDS")) h->lds_bytes = 0;
   h->rows = h->lds_bytes ? C_COUNT : C_COUNT_NOLDS;
   h->ns_store = ns;
   // Resident layout (gridstep3_resident.h) when the conductors fit in one CU: ns + 1 LDS entries beside 1 KB of scratch,
@@ -611,7 +616,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     int lds_max = 0;
     (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     lds_max = std::max(lds_max, 64 * 1024);
-    if (const char* e = getenv("GS3_RESIDENT_LDS")) lds_max = atoi(e);
+    if (const char* e = GS_EXPERIMENT_ENV("GS3_RESIDENT_LDS")) lds_max = atoi(e);
     int K = 0;
     for (int k : {3, 9, 19}) if (!K && (ns + k - 1) / k <= 512) K = k;
     const int nthr = K ? std::max(64, ((ns + K - 1) / K + 63) / 64 * 64) : 0;
@@ -686,7 +691,7 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
     rmz_a.insert(rmz_a.end(), rmz_b.begin(), rmz_b.end());
     for (int ph = 0; ph < 3; ++ph) { R.vsr[ph] = T.vsr[ph]; R.vsi[ph] = T.vsi[ph]; R.off[ph] = pre[(size_t)t->source * 3 + ph]; }
     R.off[3] = ns;
-    if (getenv("GS3_STAMPS")) { if ((rc = alloc3(h, &R.stamps, 16))) return bail(rc); (void)hipMemset(R.stamps, 0, 16 * sizeof(long long)); }
+    if (GS_EXPERIMENT_ENV("GS3_STAMPS")) { if ((rc = alloc3(h, &R.stamps, 16))) return bail(rc); (void)hipMemset(R.stamps, 0, 16 * sizeof(long long)); }
     if ((rc = upload3(h, &R.pk, rpk)) || (rc = upload3(h, &R.zd, rzd)) || (rc = upload3(h, &R.mut, rmut)) || (rc = upload3(h, &R.mz, rmz_a))) return bail(rc);
     src_of = rsrc; slot_of = rslot;
     if (hipFuncSetAttribute((const void*)resident_kernel(K, h->resident_mk), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes) != hipSuccess)
@@ -694,13 +699,13 @@ int gs3_create(const gs3_topology* t, double tolerance, int32_t max_iterations, 
   }
   { const int32_t* q = nullptr; if ((rc = upload3(h, &q, src_of))) return bail(rc); h->d_src_of = const_cast<int32_t*>(q); }
   { const int32_t* q = nullptr; if ((rc = upload3(h, &q, slot_of))) return bail(rc); h->d_slot_of = const_cast<int32_t*>(q); }
-  if (const char* e = getenv("GS3_PREFETCH")) h->prefetch = std::max(1, std::min(3, atoi(e)));
-  if (const char* e = getenv("GS3_THREADS")) if (!h->resident_k) h->threads = std::max(64, std::min(256, atoi(e) / 64 * 64));
+  if (const char* e = GS_EXPERIMENT_ENV("GS3_PREFETCH")) h->prefetch = std::max(1, std::min(3, atoi(e)));
+  if (const char* e = GS_EXPERIMENT_ENV("GS3_THREADS")) if (!h->resident_k) h->threads = std::max(64, std::min(256, atoi(e) / 64 * 64));
   const size_t bn3 = (size_t)batch * n * 3;
   // Instances of the resident layout start 256 x (37 mod 128) bytes apart: with a stride that is a multiple of 16 KB all
   // workgroups, which run in step, would ask the same few memory channels for the same row at the same time.
   h->inst_stride = (size_t)h->rows * h->ns_store;
-  if (h->resident_k && !getenv("GS3_NO_STRIDE_PAD")) {
+  if (h->resident_k && !GS_EXPERIMENT_ENV("GS3_NO_STRIDE_PAD")) {
     size_t units = (h->inst_stride * sizeof(double2) + 255) / 256;
     while (units % 128 != 37) ++units;
     h->inst_stride = units * 256 / sizeof(double2);

@@ -203,7 +203,7 @@ int dev_alloc(gs_handle* h, X** p, size_t count) {
   const size_t bytes = std::max<size_t>(count, 1) * sizeof(X);
   // Tables (a few hundred bytes to a few KB each, forty of them) share 2 MB chunks: as allocations of their own each sat on a
   // page of its own, and a workgroup's first touch of every one of them was an address-translation miss at kernel start.
-  if (bytes <= GS_ARENA_SMALL && !getenv("GS_NO_TABLE_ARENA")) {
+  if (bytes <= GS_ARENA_SMALL && !GS_EXPERIMENT_ENV("GS_NO_TABLE_ARENA")) {
     const size_t need = (bytes + 255) & ~(size_t)255;
     if (h->arena_left < need) {
       hipError_t e = hipMalloc(&q, GS_ARENA_CHUNK);
@@ -331,10 +331,12 @@ int launch_solve(gs_handle* h) {
     hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
     hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   }
+#if defined(GS_BUILD_EXPERIMENTS)
   else if (h->solve_kernel == 8) {
     hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64 * h->SA.waves), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
     hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   }
+#endif
   else if (h->solve_kernel == 5) GS_SOLVE(gs_k_fbs_lds);
   else if (h->solve_kernel == 6) GS_SOLVE(gs_k_fbs_flow);
   else GS_SOLVE(gs_k_fbs);
@@ -363,7 +365,7 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
     }
     GsPackArgs pa{h->map_obs, h->d_cst, obs_out, h->obs_dim, (int)std::max<size_t>(1, std::min<size_t>(3, (h->dyn_lds - 49152) / (64 * 65 * sizeof(double)))), 0, 0,
                   h->obs_skip0, h->obs_skip1};
-    pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !getenv("GS_PACK_BY_COLUMN");
+    pa.pair_ok = !(h->obs_dim & 1) && !((h->obs_skip1 - h->obs_skip0) & 1) && pa.tiles_per_pass >= 2 && !GS_EXPERIMENT_ENV("GS_PACK_BY_COLUMN");
     pa.early_pass0 = 2 * h->n + 2 * h->m >= 64 * pa.tiles_per_pass;   // the frequency column (grid_env.py:766) lies beyond the first pass
     pa.lean = h->lean ? 1 : 0;
     if (h->lean) { h->rows_stale = true; h->last_obs = obs_out; }
@@ -393,7 +395,9 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
         if (h->f2_small) { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2s); else GS_F2(gs_k_step_fbs_flow2s); }
         else if (h->f2_wide) { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2x); else GS_F2(gs_k_step_fbs_flow2x); }
         else if (h->f2_half) { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2h); else GS_F2(gs_k_step_fbs_flow2h); }
+#if defined(GS_BUILD_EXPERIMENTS)
         else { if (fc.enabled) GS_F2(gs_k_stepc_fbs_flow2); else GS_F2(gs_k_step_fbs_flow2); }
+#endif
       }
 #undef GS_F2
       HIPCHK(h, hipGetLastError());
@@ -405,11 +409,13 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
       hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
       if (fc.enabled) GS_STEP(gs_k_postc_nr_dmfma); else GS_STEP(gs_k_post_nr_dmfma);
     } else
+#if defined(GS_BUILD_EXPERIMENTS)
     if (h->solve_kernel == 8) {      // prologue | sparse LU in LDS, one wavefront per instance | epilogue + observation pack
       GS_STEP(gs_k_pre_nr_dmfma);
       hipLaunchKernelGGL(gs_k_nr_sparse_lds, dim3(h->sparse_grid), dim3(64 * h->SA.waves), h->sparse_lds, h->stream, h->SA, h->slab, h->B);
       if (fc.enabled) GS_STEP(gs_k_postc_nr_dmfma); else GS_STEP(gs_k_post_nr_dmfma);
     } else
+#endif
     if (fc.enabled) {
       if (h->solve_kernel == 0) GS_STEP(gs_k_stepc_nr_tree);
       else if (h->solve_kernel == 4) GS_STEP(gs_k_stepc_nr_tree_lds);
@@ -460,6 +466,14 @@ extern "C" {
 
 int gs_version(void) { return GS_ABI_VERSION; }
 
+int gs_build_experiments(void) {
+#if defined(GS_BUILD_EXPERIMENTS)
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int gs_device_count(void) {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;
@@ -506,7 +520,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     if (!ht.fbs_ok) { int rc = fail(nullptr, GS_E_TOPOLOGY, "FBS: %s", ht.fbs_why.c_str()); delete h; return rc; }
     h->solve_kernel = 2;
     const size_t msg_bytes = (size_t)2 * ht.max_level_width * 6 * GS_LANES * sizeof(double);
-    if (msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) { h->solve_kernel = 5; h->dyn_lds = msg_bytes; }
+    if (msg_bytes + 24576 <= 160 * 1024 && !GS_EXPERIMENT_ENV("GS_NO_LDS_TREE")) { h->solve_kernel = 5; h->dyn_lds = msg_bytes; }
     // dataflow sweeps: one 16-byte-per-lane message slot and one flag word per bus in LDS, at most 8 buses per wave
     // (their state lives in registers); flat start only
     const size_t flow_bytes = (size_t)ht.n * 2 * GS_LANES * sizeof(double) + (size_t)ht.n * sizeof(int32_t);
@@ -525,7 +539,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
                                                        : (ht.is_forest ? GS_LINSOLVE_TREE : GS_LINSOLVE_SPARSE_LU);
     // meshed network whose sparse block LU would fill in (more than a quarter of all blocks): dense LU on the matrix cores
     const int na_ = ht.n_active;
-    const bool mfma_fits = cfg->jacobian_mode == GS_JACOBIAN_EXACT && na_ >= 1 && 2 * na_ <= 256 && !getenv("GS_NO_DENSE_MFMA");
+    const bool mfma_fits = cfg->jacobian_mode == GS_JACOBIAN_EXACT && na_ >= 1 && 2 * na_ <= 256 && !GS_EXPERIMENT_ENV("GS_NO_DENSE_MFMA");
     if (ls == GS_LINSOLVE_DENSE_MFMA && !mfma_fits) {
       int rc = fail(nullptr, GS_E_TOPOLOGY, "dense_mfma needs the exact Jacobian and at most 128 non-slack buses (have %d)", na_); delete h; return rc; }
     if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && mfma_fits && (long long)ht.lu_n_slots * 4 > (long long)na_ * na_)
@@ -534,17 +548,21 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     // (one instance: its blocks + 7 doubles per bus; the shared schedule is about 2.5 x the blocks in bytes: two instances at least)
     const size_t sparse_need = ((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)7 * ht.n) * sizeof(double);
     const bool sparse_fits = ht.has_lu && !ht.is_forest && ht.lu_n_piv > 0 && ht.n <= 256 && sparse_need <= 32 * 1024;
+#if !defined(GS_BUILD_EXPERIMENTS)
+    if (ls == GS_LINSOLVE_SPARSE_LDS) {
+      int rc = fail(nullptr, GS_E_INVALID, "linear_solver sparse_lds is an experiment (measured, never AUTO's choice): build the library with `make EXPERIMENTS=1`"); delete h; return rc; }
+#endif
     if (ls == GS_LINSOLVE_SPARSE_LDS && !sparse_fits) {
       int rc = fail(nullptr, GS_E_TOPOLOGY, "sparse_lds needs a meshed network of at most 256 buses whose block LU fits 32 KB of LDS (%zu bytes here)", sparse_need); delete h; return rc; }
     // (AUTO does not take it: measured on the 123-bus feeder with 26 loops it reaches 12.9 M env-steps/s against the slab-row
     // kernel's 17.7 M -- four instances per CU, each a chain of 7-to-40-lane steps, lose to 64 instances per workgroup on full
     // lanes, bytes or not; DESIGN.md section 7.  GS_SPARSE_LDS_AUTO=1 makes AUTO take it, for measurements.)
-    if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && sparse_fits && getenv("GS_SPARSE_LDS_AUTO"))
+    if (cfg->linear_solver == GS_LINSOLVE_AUTO && ls == GS_LINSOLVE_SPARSE_LU && sparse_fits && GS_EXPERIMENT_ENV("GS_SPARSE_LDS_AUTO"))
       ls = GS_LINSOLVE_SPARSE_LDS;
     h->solve_kernel = (ls == GS_LINSOLVE_TREE) ? 0 : (ls == GS_LINSOLVE_SPARSE_LU) ? 1 : (ls == GS_LINSOLVE_DENSE_MFMA) ? 7 : (ls == GS_LINSOLVE_SPARSE_LDS) ? 8 : 3;
     // forest sweeps through LDS messages when two adjacent levels fit next to the 24 KB static block
     const size_t msg_bytes = (size_t)2 * ht.max_level_width * 6 * GS_LANES * sizeof(double);
-    if (h->solve_kernel == 0 && msg_bytes + 24576 <= 160 * 1024 && !getenv("GS_NO_LDS_TREE")) h->solve_kernel = 4;
+    if (h->solve_kernel == 0 && msg_bytes + 24576 <= 160 * 1024 && !GS_EXPERIMENT_ENV("GS_NO_LDS_TREE")) h->solve_kernel = 4;
     if (h->solve_kernel == 4) h->dyn_lds = msg_bytes;
   } else { int rc = fail(nullptr, GS_E_INVALID, "unknown solver_kind %d", cfg->solver_kind); delete h; return rc; }
   // the epilogue's cross-wave partials need 48 KB; the observation pack stages two or three 64-column tiles behind them
@@ -575,7 +593,11 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", max_dyn));
-    for (const void* f : {(const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2, (const void*)gs_k_step_nr_flow2,
+    for (const void* f : {
+#if defined(GS_BUILD_EXPERIMENTS)
+                          (const void*)gs_k_step_fbs_flow2, (const void*)gs_k_stepc_fbs_flow2,
+#endif
+                          (const void*)gs_k_step_nr_flow2,
                           (const void*)gs_k_stepc_nr_flow2, (const void*)gs_k_step_fbs_flow2s, (const void*)gs_k_stepc_fbs_flow2s,
                           (const void*)gs_k_step_nr_flow2s, (const void*)gs_k_stepc_nr_flow2s, (const void*)gs_k_step_fbs_flow2h,
                           (const void*)gs_k_stepc_fbs_flow2h, (const void*)gs_k_step_fbs_flow2x, (const void*)gs_k_stepc_fbs_flow2x,
@@ -807,7 +829,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const bool small = N <= GS_F2S_WAVES * (64 / GS_F2S_IW) * GS_F2S_ITEMS && !getenv("GS_NO_FLOW2_SMALL");
     // default: 16 instances per workgroup, two workgroups per CU (GS_FLOW2_IW=32 asks for the 32-instance member, one per CU)
     const bool wide = !small && N > GS_F2_WAVES * 2 * GS_F2_ITEMS;          // 129 ... 256 buses: eight buses per sub-group
-    const bool half = !small && !wide && !(getenv("GS_FLOW2_IW") && atoi(getenv("GS_FLOW2_IW")) == 32);
+    const bool half = !small && !wide && !(GS_EXPERIMENT_ENV("GS_FLOW2_IW") && atoi(GS_EXPERIMENT_ENV("GS_FLOW2_IW")) == 32);
     const int NW = small ? GS_F2S_WAVES : wide ? GS_F2X_WAVES : half ? GS_F2H_WAVES : GS_F2_WAVES,
               NI = small ? GS_F2S_ITEMS : wide ? GS_F2X_ITEMS : half ? GS_F2H_ITEMS : GS_F2_ITEMS,
               IW = small ? GS_F2S_IW : (wide || half) ? GS_F2H_IW : 32;
@@ -1198,7 +1220,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     while (c1 < (int)mo.size() && mo[c1] < 0) ++c1;
     bool one_block = true;
     for (int c = c1; c < (int)mo.size(); ++c) one_block = one_block && mo[c] >= 0;
-    if (one_block && !getenv("GS_PACK_ALL_COLUMNS")) { h->obs_skip0 = c0; h->obs_skip1 = c1; }
+    if (one_block && !GS_EXPERIMENT_ENV("GS_PACK_ALL_COLUMNS")) { h->obs_skip0 = c0; h->obs_skip1 = c1; }
   }
   if ((int)mo.size() != h->obs_dim || (int)mst.size() != h->state_dim)
     return bail(fail(nullptr, GS_E_INVALID, "internal: layout map size mismatch"));
@@ -1227,6 +1249,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       (rc = dev_alloc(h, &h->d_mask, (size_t)h->B)))
     return bail(rc);
   h->h_f.resize((size_t)SF_COUNT * h->Bp); h->h_i.resize((size_t)SI_COUNT * h->Bp); h->h_u.resize((size_t)SU_COUNT * h->Bp);
+#if defined(GS_BUILD_EXPERIMENTS)
   // ---- sparse block LU in LDS (kernels_sparse.hip): the level schedule without the split over waves, the flat-start factors ----
   if (h->solve_kernel == 8) {
     GsSparseArgs& Sp = h->SA;
@@ -1278,7 +1301,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     const size_t shared_bytes = ((((size_t)Sp.dpack_n + 1) & ~(size_t)1) * 8 + (size_t)Sp.ipack_n * 4 + 15) & ~(size_t)15;
     Sp.wave_bytes = (int32_t)((((size_t)4 * (ht.lu_n_slots + ht.n) + (size_t)7 * ht.n) * sizeof(double) + 15) & ~(size_t)15);
     int waves = (int)((160 * 1024 - 512 - (long long)shared_bytes) / Sp.wave_bytes);
-    if (const char* e = getenv("GS_SPARSE_LDS_WAVES")) waves = std::min(waves, atoi(e));
+    if (const char* e = GS_EXPERIMENT_ENV("GS_SPARSE_LDS_WAVES")) waves = std::min(waves, atoi(e));
     waves = std::max(0, std::min(4, waves));
     if (waves < 1 || ht.n > 256)
       return bail(fail(nullptr, GS_E_TOPOLOGY, "sparse_lds: the schedule (%zu bytes) and one instance (%d bytes) do not fit the LDS, or more than 256 buses", shared_bytes, Sp.wave_bytes));
@@ -1301,6 +1324,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       Sp.flat = flat;
     }
   }
+#endif
   // Sparse block LU: iteration 0 of every solve factors the flat-start Jacobian, which is the same for every instance.  One
   // ordinary solve of group 0, capped at one iteration, leaves those factors in the rows of lane 0; they are kept as a table
   // of wave-uniform scalars (GsTables::lu_flat) and iteration 0 then only carries its right-hand side through
@@ -1553,7 +1577,7 @@ int gs_host_obs_bind(gs_handle* h, double* obs) {
     // page-locked memory the device can address (gs_host_alloc): later downloads are a kernel's own stores
     double* dev = nullptr;
     hipPointerAttribute_t at{};
-    if (!getenv("GS_HOST_OBS_2D") && hipPointerGetAttributes(&at, obs) == hipSuccess && at.type == hipMemoryTypeHost) {
+    if (!GS_EXPERIMENT_ENV("GS_HOST_OBS_2D") && hipPointerGetAttributes(&at, obs) == hipSuccess && at.type == hipMemoryTypeHost) {
       void* dp = nullptr;
       if (hipHostGetDevicePointer(&dp, obs, 0) == hipSuccess) dev = (double*)dp;
     }

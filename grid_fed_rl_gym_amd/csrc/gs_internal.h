@@ -13,6 +13,18 @@
 #pragma once
 #include <stdint.h>
 
+// Switches that exist to MEASURE alternatives (kernel members AUTO never takes, table layouts, launch shapes) are read only by a
+// library built with `make EXPERIMENTS=1` (-DGS_BUILD_EXPERIMENTS); the default build answers them with "not set" and does not
+// carry the kernels only they can reach (gs_k_nr_sparse_lds, the 32-instance sweep member).  What stays readable in every build
+// are the switches the parity tests compare builds of one handle with: GS_NO_FLOW2, GS_NO_FLOW, GS_NO_FLOW2_SMALL, GS_NO_SPLIT,
+// GS_EAGER_ROWS, GS_NR_NO_FLAT, GS_LU_NO_FLAT, GS_DENSE_NO_FLAT, GS_NO_MESH2, GS3_NO_RESIDENT, GS3_DENSE_MUTUAL, GS_WAVES, and
+// the two that arm the in-kernel clocks bench.py reads (GS_STAMP_WAVE, GS_STAMP_BLOCK_TIMES).
+#if defined(GS_BUILD_EXPERIMENTS)
+#define GS_EXPERIMENT_ENV(name) getenv(name)
+#else
+#define GS_EXPERIMENT_ENV(name) ((const char*)nullptr)
+#endif
+
 #define GS_LANES 64
 // Slab layout inside a 64-instance group: rows come in PAIRS that share 1 KB, lane-interleaved --
 //   double index of (row, lane) = (row / 2) * 128 + lane * 2 + (row % 2)

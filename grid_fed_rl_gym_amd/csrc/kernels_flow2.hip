@@ -1670,7 +1670,9 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_step<SOLVER, 1, NW, NI, IW>(A->T, A->F, A->R, A->C, A->E, A->slab, A->B, A->actions, A->total_load, A->PA, A->FC, A->RS); \
   }
 #define F2_KERNELS(name, SOLVER, NW, NI, IW) F2_KERNELS_OCC(name, SOLVER, NW, NI, IW, )
-F2_KERNELS(fbs_flow2, F2_FBS, 16, 4, 32)       // up to 128 buses below the slack
+#if defined(GS_BUILD_EXPERIMENTS)
+F2_KERNELS(fbs_flow2, F2_FBS, 16, 4, 32)       // up to 128 buses below the slack, 32 instances per workgroup (GS_FLOW2_IW=32; the 16-instance member is the default)
+#endif
 F2_KERNELS(nr_flow2, F2_NR, 8, 8, 32)
 F2_KERNELS(fbs_flow2s, F2_FBS, GS_F2S_WAVES, GS_F2S_ITEMS, GS_F2S_IW)        // up to 16 buses: 8 instances per workgroup, eight buses per wavefront
 F2_KERNELS(nr_flow2s, F2_NR, GS_F2NS_WAVES, GS_F2NS_ITEMS, GS_F2S_IW)          // up to 4 groups of 8 same-level buses

@@ -152,6 +152,10 @@ typedef struct gs_handle gs_handle;
 
 /* ---- library ------------------------------------------------------------------------- */
 int gs_version(void);
+/* 1 if the library was built with `make EXPERIMENTS=1`: the kernel members and environment switches that exist to measure
+ * alternatives (linear_solver sparse_lds, the 32-instance sweep member, table-layout and launch-shape switches) are present.
+ * The default build carries what AUTO can reach and the switches the parity tests compare handles with (csrc/gs_internal.h). */
+int gs_build_experiments(void);
 int gs_device_count(void);
 /* text of the last error on this thread (handle may be NULL for creation errors) */
 const char* gs_last_error(const gs_handle* h);

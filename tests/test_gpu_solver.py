@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import grid_fed_rl_gym_amd as P
+from grid_fed_rl_gym_amd import _lib
 from oracle import oracle_np as O
 from tests.helpers import golden, golden_names, net_of
 
@@ -183,8 +184,8 @@ def test_linear_solver_paths_agree(name):
     for ls in ("tree", "sparse_lu", "sparse_lds", "dense_pivot", "dense_mfma"):
         if ls == "tree" and not spec.is_radial():
             continue
-        if ls == "sparse_lds" and (spec.is_radial() or name == "solve_scal123"):
-            continue                                     # (meshed networks only; the 123-bus dense graph's 8600 blocks do not fit LDS)
+        if ls == "sparse_lds" and (spec.is_radial() or name == "solve_scal123" or not _lib.experiments()):
+            continue                                     # (meshed networks only; the 123-bus dense graph's 8600 blocks do not fit LDS; an experiment: `make EXPERIMENTS=1`)
         if ls == "dense_pivot" and spec.n > 100 and not spec.is_radial():
             continue                                     # (the lane-per-instance pivoted LU on a 244 x 244 matrix: minutes)
         s = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, jacobian="exact", linear_solver=ls)
@@ -296,6 +297,16 @@ def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_t
         check(sol, k, d, f"B{k}_", 1e-9)
 
 
+def test_sparse_lds_is_refused_with_a_reason_in_the_default_build():
+    if _lib.experiments():
+        pytest.skip("library built with EXPERIMENTS=1")
+    q = P.BatchedNewtonRaphsonSolver(linear_solver="sparse_lds")
+    with pytest.raises(P.PowerFlowError, match="EXPERIMENTS=1"):
+        q.solve_batch(P.random_meshed(10, 3, seed=1), np.zeros((2, 10)))
+    q.close()
+
+
+@pytest.mark.skipif("not _lib.experiments()", reason="linear_solver sparse_lds is an experiment: `make EXPERIMENTS=1`")
 def test_sparse_lu_in_lds_handles_the_edge_cases(monkeypatch):
     """linear_solver="sparse_lds": the sparse block LU with an instance's blocks in LDS, one wavefront per instance
     (kernels_sparse.hip; an alternative AUTO does not take).  Against the slab-row sparse LU: a ragged batch larger than the persistent grid's stride pattern, a zero-load instance (one iteration),
