@@ -2,7 +2,7 @@
 # All rocprofv3 summaries of a round's final build: kernel-trace stats + FETCH_SIZE / WRITE_SIZE passes per workload.
 #   ROUND=r03v3 tools/profile_round.sh            (on the GPU box, through gpurun; then tools/collect_round.sh here)
 R=$GRAFT_REPO_ROOT
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 run() {   # tag, bench args, steps
   TAG=${ROUND}_$1 BENCH_ARGS="$2" tools/profile.sh || echo "profile $1 failed"
 }
