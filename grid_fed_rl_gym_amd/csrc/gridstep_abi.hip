@@ -130,7 +130,8 @@ struct gs_handle {
   int obs_skip0 = 0, obs_skip1 = 0;   // the block of per-instance constants inside an observation
   // host observation arrays whose constant columns are in place (gs_host_obs_bind): gs_step / gs_download_step copy only the
   // changing columns into these -- two strided copies instead of one whole block, 36 % fewer bytes over PCIe on the 123-bus feeder
-  std::vector<const double*> bound_obs; std::vector<double*> bound_dev;     // (the device's address of a page-locked array, or NULL: strided copies)
+  std::vector<const double*> bound_obs;
+  hipEvent_t ev_scalars = nullptr;
   double* d_actions = nullptr; int n_action_batches = 0;
   // gs_rollout: [T + 1][B][obs_dim] observation sequence, [T][B][A] actions, [T][B] rewards / done flags, and the side
   // list of terminal observations (the rows the in-place resets replaced)
@@ -150,7 +151,11 @@ struct gs_handle {
   std::vector<double> line_x;
   bool fb_ready = false; GsFallbackArgs FB{};
   double *fb_load = nullptr, *fb_gen = nullptr, *fb_tl = nullptr, *fb_tg = nullptr; uint8_t* fb_mask = nullptr; int32_t* fb_applied = nullptr;
-  std::vector<double> h_f; std::vector<int32_t> h_i; std::vector<uint8_t> h_u;
+  // host copies of the per-instance scalars: ONE page-locked block the device addresses -- gs_k_scalars stores into it itself (three
+  // copies through the runtime's staging buffer cost 80 us of a 0.9 ms env.step()); hd_*: the same block as the device sees it
+  void* h_pin = nullptr;
+  double* h_f = nullptr; int32_t* h_i = nullptr; uint8_t* h_u = nullptr; uint32_t* h_v4 = nullptr;
+  double* hd_f = nullptr; int32_t* hd_i = nullptr; uint8_t* hd_u = nullptr; uint32_t* hd_v4 = nullptr;
   // timing
   bool timing = false;
   bool timing_span = false, span_open = false; hipEvent_t span_a = nullptr, span_b = nullptr; int span_kid = 0; int64_t span_launches[8] = {0};
@@ -308,14 +313,11 @@ int unpack_from_host(gs_handle* h, const int32_t* map, int C, const double* host
   return launch_unpack(h, map, C, h->d_in);
 }
 
-int fetch_scalars(gs_handle* h) {
+int fetch_scalars(gs_handle* h, bool sync = true) {
   hipLaunchKernelGGL(gs_k_scalars, dim3(h->groups), dim3(64), 0, h->stream, h->rows_f, (int)SF_COUNT, h->rows_i,
-                     (int)SI_COUNT, h->rows_u, (int)SU_COUNT, h->R.total, h->slab, h->sc_f, h->sc_i, h->sc_u, h->Bp);
+                     (int)SI_COUNT, h->rows_u, (int)SU_COUNT, h->R.total, h->slab, h->hd_f, h->hd_i, h->hd_u, h->Bp, h->hd_v4, (int)SU_VF0);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(h->h_f.data(), h->sc_f, h->h_f.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->h_i.data(), h->sc_i, h->h_i.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->h_u.data(), h->sc_u, h->h_u.size(), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return GS_OK;
 }
 
@@ -440,7 +442,7 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
 
 void copy_info(gs_handle* h, double* reward, uint8_t* term, uint8_t* trunc, const gs_info_view* info) {
   const int B = h->B, Bp = h->Bp;
-  const double* f = h->h_f.data(); const int32_t* i32 = h->h_i.data(); const uint8_t* u = h->h_u.data();
+  const double* f = h->h_f; const int32_t* i32 = h->h_i; const uint8_t* u = h->h_u;
   if (reward) memcpy(reward, f + (size_t)SF_REWARD * Bp, B * sizeof(double));
   if (term) memcpy(term, u + (size_t)SU_TERM * Bp, B);
   if (trunc) memcpy(trunc, u + (size_t)SU_TRUNC * Bp, B);
@@ -449,9 +451,7 @@ void copy_info(gs_handle* h, double* reward, uint8_t* term, uint8_t* trunc, cons
   if (info->max_voltage) memcpy(info->max_voltage, f + (size_t)SF_VMAX * Bp, B * sizeof(double));
   if (info->min_voltage) memcpy(info->min_voltage, f + (size_t)SF_VMIN * Bp, B * sizeof(double));
   if (info->total_losses) memcpy(info->total_losses, f + (size_t)SF_LOSSES * Bp, B * sizeof(double));
-  if (info->violations)
-    for (int b = 0; b < B; ++b)
-      for (int v = 0; v < 4; ++v) info->violations[(size_t)b * 4 + v] = u[(size_t)(SU_VF0 + v) * Bp + b];
+  if (info->violations) memcpy(info->violations, h->h_v4, (size_t)B * 4);      // (the four flags of an instance, interleaved by the kernel)
   if (info->constraint_violations) memcpy(info->constraint_violations, i32 + (size_t)SI_VIOL * Bp, B * sizeof(int32_t));
   if (info->current_step) memcpy(info->current_step, i32 + (size_t)SI_STEP * Bp, B * sizeof(int32_t));
   if (info->episode_reward) memcpy(info->episode_reward, f + (size_t)SF_EPREW * Bp, B * sizeof(double));
@@ -1248,7 +1248,19 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       (rc = dev_alloc(h, &h->sc_u, (size_t)SU_COUNT * h->Bp)) || (rc = dev_alloc(h, &h->d_seeds, (size_t)h->B)) ||
       (rc = dev_alloc(h, &h->d_mask, (size_t)h->B)))
     return bail(rc);
-  h->h_f.resize((size_t)SF_COUNT * h->Bp); h->h_i.resize((size_t)SI_COUNT * h->Bp); h->h_u.resize((size_t)SU_COUNT * h->Bp);
+  {
+    const size_t nf = (size_t)SF_COUNT * h->Bp * sizeof(double), ni = (size_t)SI_COUNT * h->Bp * sizeof(int32_t), nv = (size_t)h->Bp * sizeof(uint32_t),
+                 nu = (size_t)SU_COUNT * h->Bp;
+    void* dp = nullptr;
+    if (hipHostMalloc(&h->h_pin, nf + ni + nv + nu, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, h->h_pin, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return bail(fail(nullptr, GS_E_NOMEM, "hipHostMalloc(%zu bytes, mapped) for the per-instance scalars failed", nf + ni + nv + nu));
+    }
+    memset(h->h_pin, 0, nf + ni + nv + nu);
+    char* hp = (char*)h->h_pin; char* dv = (char*)dp;
+    h->h_f = (double*)hp; h->h_i = (int32_t*)(hp + nf); h->h_v4 = (uint32_t*)(hp + nf + ni); h->h_u = (uint8_t*)(hp + nf + ni + nv);
+    h->hd_f = (double*)dv; h->hd_i = (int32_t*)(dv + nf); h->hd_v4 = (uint32_t*)(dv + nf + ni); h->hd_u = (uint8_t*)(dv + nf + ni + nv);
+  }
 #if defined(GS_BUILD_EXPERIMENTS)
   // ---- sparse block LU in LDS (kernels_sparse.hip): the level schedule without the split over waves, the flat-start factors ----
   if (h->solve_kernel == 8) {
@@ -1387,6 +1399,7 @@ void gs_destroy(gs_handle* h) {
   if (h->ev_peer2) (void)hipEventDestroy(h->ev_peer2);
   if (h->ev_step) (void)hipEventDestroy(h->ev_step);
   if (h->ev_full) (void)hipEventDestroy(h->ev_full);
+  if (h->ev_scalars) (void)hipEventDestroy(h->ev_scalars);
   for (int k = 0; k < 2; ++k) if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   for (auto& t : h->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1396,6 +1409,7 @@ void gs_destroy(gs_handle* h) {
   for (void* p : {(void*)h->ro.obs_seq, (void*)h->ro.act, (void*)h->ro.rew, (void*)h->ro.done, (void*)h->ro.term_count,
                   (void*)h->ro.term_idx, (void*)h->ro.term_obs})
     if (p) (void)hipFree(p);
+  if (h->h_pin) (void)hipHostFree(h->h_pin);
   if (h->d_obs_full) (void)hipFree(h->d_obs_full);
   if (h->d_gather_send) (void)hipFree(h->d_gather_send);
   if (h->d_gather_recv) (void)hipFree(h->d_gather_recv);
@@ -1473,11 +1487,11 @@ int gs_download_solution(gs_handle* h, const gs_solution_view* out) {
   if ((rc = pack_to_host(h, h->map_load, h->m, out->line_loadings))) return rc;
   if ((rc = fetch_scalars(h))) return rc;
   const int B = h->B, Bp = h->Bp;
-  if (out->losses) memcpy(out->losses, h->h_f.data() + (size_t)SF_LOSSES * Bp, B * sizeof(double));
-  if (out->max_mismatch) memcpy(out->max_mismatch, h->h_f.data() + (size_t)SF_MAXMIS * Bp, B * sizeof(double));
-  if (out->iterations) memcpy(out->iterations, h->h_i.data() + (size_t)SI_ITERS * Bp, B * sizeof(int32_t));
-  if (out->status) memcpy(out->status, h->h_i.data() + (size_t)SI_STATUS * Bp, B * sizeof(int32_t));
-  if (out->converged) memcpy(out->converged, h->h_u.data() + (size_t)SU_CONV * Bp, B);
+  if (out->losses) memcpy(out->losses, h->h_f + (size_t)SF_LOSSES * Bp, B * sizeof(double));
+  if (out->max_mismatch) memcpy(out->max_mismatch, h->h_f + (size_t)SF_MAXMIS * Bp, B * sizeof(double));
+  if (out->iterations) memcpy(out->iterations, h->h_i + (size_t)SI_ITERS * Bp, B * sizeof(int32_t));
+  if (out->status) memcpy(out->status, h->h_i + (size_t)SI_STATUS * Bp, B * sizeof(int32_t));
+  if (out->converged) memcpy(out->converged, h->h_u + (size_t)SU_CONV * Bp, B);
   return GS_OK;
 }
 
@@ -1529,34 +1543,38 @@ int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* termina
                      const gs_info_view* info) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   GS_ENTER(h);
-  if (obs) {
-    const double* src = h->d_obs2[h->obs_cur];
-    const size_t pitch = (size_t)h->obs_dim * sizeof(double);
-    const auto bit = std::find(h->bound_obs.begin(), h->bound_obs.end(), obs);
-    const bool bound = h->obs_skip1 > h->obs_skip0 && bit != h->bound_obs.end();
-    double* dev = bound ? h->bound_dev[bit - h->bound_obs.begin()] : nullptr;
-    if (dev) {
-      // page-locked and mapped: a kernel on the step's stream writes the changing columns into it itself, 16 bytes per lane (measured
-      // at B = 8192 on the 123-bus feeder: 0.90 ms per env.step() against 1.10 ms for the whole block through the copy engine and
-      // 1.00 ms for the copy engine's strided copies of the same columns; kernel and copy engine side by side were no faster)
-      const int nd = h->obs_dim - (h->obs_skip1 - h->obs_skip0);
-      const bool pair = !(h->obs_dim & 1) && !(h->obs_skip0 & 1) && !(h->obs_skip1 & 1);
-      const long long work = (long long)h->B * (pair ? nd / 2 : nd);
-      hipLaunchKernelGGL(gs_k_obs_to_host, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, h->stream, src, dev, (long long)h->B, h->obs_dim, h->obs_skip0, h->obs_skip1);
-      HIPCHK(h, hipGetLastError());
-    } else if (bound) {        // the columns either side of the constant block, every row
-      if (h->obs_skip0 > 0)
-        HIPCHK(h, hipMemcpy2DAsync(obs, pitch, src, pitch, (size_t)h->obs_skip0 * sizeof(double), (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
-      if (h->obs_dim > h->obs_skip1)
-        HIPCHK(h, hipMemcpy2DAsync(obs + h->obs_skip1, pitch, src + h->obs_skip1, pitch, (size_t)(h->obs_dim - h->obs_skip1) * sizeof(double), (size_t)h->B,
-                                   hipMemcpyDeviceToHost, h->stream));
-    } else {
-      HIPCHK(h, hipMemcpyAsync(obs, src, (size_t)h->B * pitch, hipMemcpyDeviceToHost, h->stream));
-    }
+  if (!obs) {
+    int rc = fetch_scalars(h);
+    if (rc) return rc;
+    copy_info(h, reward, terminated, truncated, info);
+    return GS_OK;
   }
-  int rc = fetch_scalars(h);
+  // the scalars first (half a megabyte the kernel stores into the handle's page-locked block itself), then the observation block
+  // behind them: the caller's reward / flag / info arrays are filled while the block is still crossing the link
+  if (!h->ev_scalars) HIPCHK(h, hipEventCreateWithFlags(&h->ev_scalars, hipEventDisableTiming));
+  int rc = fetch_scalars(h, false);
   if (rc) return rc;
+  HIPCHK(h, hipEventRecord(h->ev_scalars, h->stream));
+  const double* src = h->d_obs2[h->obs_cur];
+  const size_t D = (size_t)h->obs_dim, pitch = D * sizeof(double), s0 = (size_t)h->obs_skip0, s1 = (size_t)h->obs_skip1, B = (size_t)h->B;
+  const bool bound = s1 > s0 && std::find(h->bound_obs.begin(), h->bound_obs.end(), obs) != h->bound_obs.end();
+  if (bound) {
+    // The constants are in place (gs_host_obs_bind).  What changes is, in memory order, ONE run per row boundary: the columns of row r
+    // behind the constant block and those of row r + 1 in front of it -- a single pitched copy of B - 1 runs of obs_dim - (skip1 -
+    // skip0) doubles, plus the head of row 0 and the tail of row B - 1.  Measured at B = 8192 on the 123-bus feeder, per env.step():
+    // this 0.78 ms; a kernel storing the same columns into the mapped array 0.82 ms (its stores cross the link 64 bytes at a time);
+    // two pitched copies, one either side of the constants, 1.00 ms; the whole block 1.10 ms.
+    if (s0 > 0) HIPCHK(h, hipMemcpyAsync(obs, src, s0 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (B > 1)
+      HIPCHK(h, hipMemcpy2DAsync(obs + s1, pitch, src + s1, pitch, (D - (s1 - s0)) * sizeof(double), B - 1, hipMemcpyDeviceToHost, h->stream));
+    if (D > s1)
+      HIPCHK(h, hipMemcpyAsync(obs + (B - 1) * D + s1, src + (B - 1) * D + s1, (D - s1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    HIPCHK(h, hipMemcpyAsync(obs, src, B * pitch, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipEventSynchronize(h->ev_scalars));
   copy_info(h, reward, terminated, truncated, info);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return GS_OK;
 }
 
@@ -1573,24 +1591,14 @@ int gs_host_obs_bind(gs_handle* h, double* obs) {
                                (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
-  if (std::find(h->bound_obs.begin(), h->bound_obs.end(), obs) == h->bound_obs.end()) {
-    // page-locked memory the device can address (gs_host_alloc): later downloads are a kernel's own stores
-    double* dev = nullptr;
-    hipPointerAttribute_t at{};
-    if (!GS_EXPERIMENT_ENV("GS_HOST_OBS_2D") && hipPointerGetAttributes(&at, obs) == hipSuccess && at.type == hipMemoryTypeHost) {
-      void* dp = nullptr;
-      if (hipHostGetDevicePointer(&dp, obs, 0) == hipSuccess) dev = (double*)dp;
-    }
-    (void)hipGetLastError();
-    h->bound_obs.push_back(obs); h->bound_dev.push_back(dev);
-  }
+  if (std::find(h->bound_obs.begin(), h->bound_obs.end(), obs) == h->bound_obs.end()) h->bound_obs.push_back(obs);
   return GS_OK;
 }
 
 int gs_host_obs_unbind(gs_handle* h, double* obs) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   auto it = std::find(h->bound_obs.begin(), h->bound_obs.end(), (const double*)obs);
-  if (it != h->bound_obs.end()) { h->bound_dev.erase(h->bound_dev.begin() + (it - h->bound_obs.begin())); h->bound_obs.erase(it); }
+  if (it != h->bound_obs.end()) h->bound_obs.erase(it);
   return GS_OK;
 }
 
@@ -1624,7 +1632,7 @@ int gs_step_device_view(gs_handle* h, gs_step_device_out* out, void* consumer_st
   if (!h->was_reset) return fail(h, GS_E_STATE, "gs_step_device_view before gs_reset");
   GS_ENTER(h);
   hipLaunchKernelGGL(gs_k_scalars, dim3(h->groups), dim3(64), 0, h->stream, h->rows_f, (int)SF_COUNT, h->rows_i,
-                     (int)SI_COUNT, h->rows_u, (int)SU_COUNT, h->R.total, h->slab, h->sc_f, h->sc_i, h->sc_u, h->Bp);
+                     (int)SI_COUNT, h->rows_u, (int)SU_COUNT, h->R.total, h->slab, h->sc_f, h->sc_i, h->sc_u, h->Bp, (uint32_t*)nullptr, 0);
   HIPCHK(h, hipGetLastError());
   if (consumer_stream) {
     if (!h->ev_peer2) HIPCHK(h, hipEventCreateWithFlags(&h->ev_peer2, hipEventDisableTiming));

@@ -71,12 +71,11 @@ __global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restr
 __global__ void gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,
                             const double* __restrict__ in, int B, int stride);
 __global__ void gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long long rows, int D, int skip0, int skip1, int expand);
-__global__ void gs_k_obs_to_host(const double* __restrict__ src, double* __restrict__ dst, long long rows, int D, int skip0, int skip1);
 __global__ void gs_k_gather_lane(int row0, int count, int lane, const double* __restrict__ slab, double* __restrict__ out);
 __global__ void gs_k_fill_rows(int row0, int stride, int count, int rows_total, double* __restrict__ slab, double value);
 __global__ void gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__ ri, int ni,
                              const int32_t* __restrict__ ru, int nu, int rows_total, const double* __restrict__ slab,
-                             double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp);
+                             double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp, uint32_t* __restrict__ ov4, int vf0);
 __global__ void gs_k_checks(GsChecksCfg C, const double* __restrict__ slab, const double* __restrict__ freq_override,
                             double* __restrict__ prev, int32_t* __restrict__ state, int32_t* __restrict__ out_i,
                             double* __restrict__ out_f, uint8_t* __restrict__ bus_mask, uint8_t* __restrict__ line_mask, int B, int Bp);

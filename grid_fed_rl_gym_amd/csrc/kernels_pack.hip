@@ -73,13 +73,19 @@ gs_k_fill_rows(int row0, int stride, int count, int rows_total, double* __restri
 extern "C" __global__ void __launch_bounds__(64)
 gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__ ri, int ni,
              const int32_t* __restrict__ ru, int nu, int rows_total, const double* __restrict__ slab,
-             double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp) {
+             double* __restrict__ of, int32_t* __restrict__ oi, uint8_t* __restrict__ ou, int Bp, uint32_t* __restrict__ ov4, int vf0) {
   const int b = blockIdx.x * GS_LANES + threadIdx.x;
   const double* S = slab + (size_t)blockIdx.x * rows_total * GS_LANES;
   const int ln = threadIdx.x;
   for (int k = 0; k < nf; ++k) of[(size_t)k * Bp + b] = S[GS_ELEM(rf[k], ln)];
   for (int k = 0; k < ni; ++k) oi[(size_t)k * Bp + b] = (int32_t)S[GS_ELEM(ri[k], ln)];
-  for (int k = 0; k < nu; ++k) ou[(size_t)k * Bp + b] = (S[GS_ELEM(ru[k], ln)] != 0.0) ? 1 : 0;
+  uint32_t v4 = 0;
+  for (int k = 0; k < nu; ++k) {
+    const uint32_t f = (S[GS_ELEM(ru[k], ln)] != 0.0) ? 1u : 0u;
+    ou[(size_t)k * Bp + b] = (uint8_t)f;
+    if (k >= vf0 && k < vf0 + 4) v4 |= f << (8 * (k - vf0));
+  }
+  if (ov4) ov4[b] = v4;      // the four flag arrays ru[vf0 .. vf0 + 3] once more, as the bytes of one word per instance ([B][4] on the host)
 }
 
 // Observation blocks with / without their block of per-instance constants (columns [skip0, skip1): the static load
@@ -96,30 +102,6 @@ gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long 
   const int j = (int)(idx - r * nd), c = j < skip0 ? j : j + gap;
   if (expand) dst[r * D + c] = src[idx];
   else dst[idx] = src[r * D + c];
-}
-
-// The changing columns of the observation block written STRAIGHT into a page-locked host array of the same layout (gs_host_obs_bind:
-// its constant columns are in place): dst[r][c] = src[r][c] for c outside [skip0, skip1).  16 bytes per thread where the rows allow it;
-// the stores go over PCIe as whole bursts (a strided hipMemcpy2D moved the same bytes at 32 GB/s, this at the link's rate).
-extern "C" __global__ void __launch_bounds__(256)
-gs_k_obs_to_host(const double* __restrict__ src, double* __restrict__ dst, long long rows, int D, int skip0, int skip1) {
-  const int gap = skip1 - skip0, nd = D - gap;
-  if (!(D & 1) && !(skip0 & 1) && !(skip1 & 1)) {            // every run starts on a 16-byte boundary: two columns per thread
-    const int nd2 = nd >> 1;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * nd2) return;
-    const long long r = idx / nd2;
-    const int j = 2 * (int)(idx - r * nd2), c = j < skip0 ? j : j + gap;
-    typedef double gs_d2 __attribute__((ext_vector_type(2)));
-    const gs_d2 v = *(const gs_d2*)(src + r * D + c);
-    __builtin_nontemporal_store(v, (gs_d2*)(dst + r * D + c));
-  } else {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * nd) return;
-    const long long r = idx / nd;
-    const int j = (int)(idx - r * nd), c = j < skip0 ? j : j + gap;
-    dst[r * D + c] = src[r * D + c];
-  }
 }
 
 // out[q] = row (row0 + q) of lane `lane` of group 0, q < count (gs_create: the handle's flat-start LU blocks, read off the

@@ -152,9 +152,14 @@ class BatchedGridEnvironment:
             a = a[None, :]
         if a.shape != (self.num_envs, self.action_dim):
             raise InvalidActionError(f"actions must have shape ({self.num_envs}, {self.action_dim}), got {a.shape}")
-        bad = ~np.isfinite(a).all(axis=1)
-        if bad.any():
-            a = np.where(bad[:, None], 0.0, a)
+        # a non-finite action counts as "no action" (zeros) for its instance.  One pass decides the common case: a finite sum means
+        # every entry is finite (NaN and +-inf survive any sum); the per-row test runs only when the sum is not.
+        if np.isfinite(np.add.reduce(a, axis=None)):
+            bad = np.zeros(self.num_envs, dtype=bool)
+        else:
+            bad = ~np.isfinite(a).all(axis=1)
+            if bad.any():
+                a = np.where(bad[:, None], 0.0, a)
         out = self._h.step(a)
         info = self._base_info(out["current_step"], out["episode_reward"], out["constraint_violations"])
         v = out["violations"].astype(bool)

@@ -223,7 +223,8 @@ int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* termina
 /* Host observation arrays that are handed to gs_step / gs_download_step again and again (the recycled page-locked sets of the
  * Python environment): gs_host_obs_bind writes the constant columns of the observation -- the static load powers of
  * grid_env.py:769-770, a third of the row on the 123-bus feeder -- into `obs` once and remembers the address; later downloads
- * into that address move the changing columns only (two strided copies), the same bytes as a whole-row download would leave.
+ * into that address move the changing columns only (one pitched copy: in memory order the changing columns of row r behind the
+ * constants and those of row r + 1 in front of them are one run), the same bytes as a whole-row download would leave.
  * The caller must not modify the constant columns of a bound array (bind again if it did).  After gs_reset. */
 int gs_host_obs_bind(gs_handle* h, double* obs);
 int gs_host_obs_unbind(gs_handle* h, double* obs);
