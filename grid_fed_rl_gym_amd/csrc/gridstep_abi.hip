@@ -109,7 +109,7 @@ struct gs_handle {
   bool lean = false, rows_stale = false; const double* last_obs = nullptr;
   // solve_kernel 7: Newton-Raphson with the dense block LU on the matrix cores (kernels_dense.hip), a launch of its own between
   // the two halves of the step / solve
-  GsDenseArgs DA{}; int dense_grid = 0; size_t dense_lds = 0;
+  GsDenseArgs DA{}; int dense_grid = 0; size_t dense_lds = 0; bool dense_blockrow = true;
   // solve_kernel 8: Newton-Raphson with the sparse block LU of an instance in the LDS of a one-wave workgroup (kernels_sparse.hip),
   // launched the same way
   GsSparseArgs SA{}; int sparse_grid = 0; size_t sparse_lds = 0;
@@ -321,6 +321,12 @@ int fetch_scalars(gs_handle* h, bool sync = true) {
   return GS_OK;
 }
 
+#define GS_DENSE_LAUNCH(h, grid, args, nb)                                                                                          \
+  do {                                                                                                                              \
+    if ((h)->dense_blockrow) hipLaunchKernelGGL(gs_k_nr_dense_mfma2, dim3(grid), dim3(256), (h)->dense_lds, (h)->stream, args, (h)->slab, nb); \
+    else hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(grid), dim3(256), (h)->dense_lds, (h)->stream, args, (h)->slab, nb);          \
+  } while (0)
+
 int launch_solve(gs_handle* h) {
   LaunchTimer lt(h, GS_K_SOLVE);
   dim3 grid(h->groups), block(64 * h->W);
@@ -330,7 +336,7 @@ int launch_solve(gs_handle* h) {
   else if (h->solve_kernel == 1) GS_SOLVE(gs_k_nr_lu);
   else if (h->solve_kernel == 3) GS_SOLVE(gs_k_nr_dense);
   else if (h->solve_kernel == 7) {
-    hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
+    GS_DENSE_LAUNCH(h, h->dense_grid, h->DA, h->B);
     hipLaunchKernelGGL(gs_k_posts_nr_dmfma, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->slab, h->B);
   }
 #if defined(GS_BUILD_EXPERIMENTS)
@@ -408,7 +414,7 @@ int step_kernels(gs_handle* h, const double* d_actions, double* obs_out = nullpt
 #define GS_STEP(k) hipLaunchKernelGGL(k, grid, block, h->dyn_lds, h->stream, h->T, h->R, h->SC, h->EC, h->slab, h->B, d_actions, h->total_load, pa, fc)
     if (h->solve_kernel == 7) {      // prologue | dense Newton-Raphson, one workgroup per instance | epilogue + observation pack
       GS_STEP(gs_k_pre_nr_dmfma);
-      hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(h->dense_grid), dim3(256), h->dense_lds, h->stream, h->DA, h->slab, h->B);
+      GS_DENSE_LAUNCH(h, h->dense_grid, h->DA, h->B);
       if (fc.enabled) GS_STEP(gs_k_postc_nr_dmfma); else GS_STEP(gs_k_post_nr_dmfma);
     } else
 #if defined(GS_BUILD_EXPERIMENTS)
@@ -607,7 +613,8 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   }
 
   {
-    const hipError_t e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    hipError_t e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     if (e != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(gs_k_nr_dense_mfma): %s", hipGetErrorString(e)));
   }
 
@@ -1111,31 +1118,51 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     std::vector<int32_t> act_bus, act_of(ht.n, -1);
     for (int i = 0; i < ht.n; ++i) if (ht.th_free[i] || ht.vm_free[i]) { act_of[i] = (int32_t)act_bus.size(); act_bus.push_back(i); }
     const int na = (int)act_bus.size(), NB = (2 * na + 63) / 64;
-    std::vector<int32_t> ent_ptr(NB + 1, 0), ent;
+    // (panel by panel, block row by block row inside a panel: the panel form reads a panel's range, the block-row form a block's)
+    std::vector<int32_t> ent_ptr(NB + 1, 0), bent_ptr((size_t)NB * NB + 1, 0), ent;
+    std::vector<GsDenseEntry> bent;
     for (int pnl = 0; pnl < NB; ++pnl) {
       ent_ptr[pnl] = (int32_t)ent.size() / 3;
-      for (int i = 0; i < ht.n; ++i) {
-        if (act_of[i] < 0) continue;
-        for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
-          const int j = ht.col[q];
-          if (act_of[j] < 0 || (2 * act_of[j]) / 64 != pnl) continue;
-          ent.push_back(i); ent.push_back(j); ent.push_back(q);
+      for (int blk = 0; blk < NB; ++blk) {
+        bent_ptr[(size_t)pnl * NB + blk] = (int32_t)ent.size() / 3;
+        for (int i = 0; i < ht.n; ++i) {
+          if (act_of[i] < 0 || (2 * act_of[i]) / 64 != blk) continue;
+          for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+            const int j = ht.col[q];
+            if (act_of[j] < 0 || (2 * act_of[j]) / 64 != pnl) continue;
+            ent.push_back(i); ent.push_back(j); ent.push_back(q);
+            GsDenseEntry e{};
+            e.ib = i; e.jb = j;
+            e.dst = ((2 * act_of[i] - 64 * blk) * 66 + (2 * act_of[j] - 64 * pnl)) | (ht.th_free[i] ? 1 << 16 : 0) | (ht.vm_free[i] ? 1 << 17 : 0) |
+                    (ht.th_free[j] ? 1 << 18 : 0) | (ht.vm_free[j] ? 1 << 19 : 0);
+            e.g = i == j ? ht.Gd[i] : ht.G[q]; e.b = i == j ? ht.Bd[i] : ht.B[q];
+            bent.push_back(e);
+          }
         }
       }
     }
-    ent_ptr[NB] = (int32_t)ent.size() / 3;
+    if (bent.empty()) bent.push_back(GsDenseEntry{});
+    ent_ptr[NB] = bent_ptr[(size_t)NB * NB] = (int32_t)ent.size() / 3;
     D.n = ht.n; D.na = na; D.NB = NB; D.max_it = cfg->max_iterations; D.jacobian_exact = 1; D.rows_total = h->R.total;
     D.tol = cfg->tolerance; D.alpha = cfg->acceleration_factor;
     if ((rc = dev_upload(h, &D.act_bus, act_bus)) || (rc = dev_upload(h, &D.act_of, act_of)) || (rc = dev_upload(h, &D.ent_ptr, ent_ptr)) ||
-        (rc = dev_upload(h, &D.ent, ent))) return bail(rc);
+        (rc = dev_upload(h, &D.ent, ent)) || (rc = dev_upload(h, &D.bent_ptr, bent_ptr)) || (rc = dev_upload(h, &D.bent, bent))) return bail(rc);
     D.row_ptr = T.row_ptr; D.col = T.col; D.G = T.G; D.Bv = T.Bv; D.Gd = T.Gd; D.Bd = T.Bd;
     D.th_free = T.th_free; D.vm_free = T.vm_free; D.fixed_v = T.fixed_v; D.v_set = T.v_set;
     D.R = h->R;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    h->dense_grid = std::max(1, std::min(h->B, cus));             // persistent: one workgroup per CU, instances strided over the grid
+    // persistent grid, instances strided over it.  Block-row form: two block buffers in LDS, two workgroups per CU; panel form (GS_DENSE_PANEL=1
+    // in a build with the experiments): the whole 64-column panel in LDS, one workgroup per CU
     const size_t NP = (size_t)64 * NB;
-    h->dense_lds = (NP * 66 + NP + (size_t)8 * ((ht.n + 1) & ~1) + 2 * 528 + 8) * sizeof(double);
+    h->dense_blockrow = !getenv("GS_DENSE_PANEL");
+    if (h->dense_blockrow) {
+      h->dense_grid = std::max(1, std::min(h->B, 2 * cus));
+      h->dense_lds = ((size_t)2 * 64 * 66 + NP + (size_t)8 * ((ht.n + 1) & ~1) + 8) * sizeof(double);
+    } else {
+      h->dense_grid = std::max(1, std::min(h->B, cus));
+      h->dense_lds = (NP * 66 + NP + (size_t)8 * ((ht.n + 1) & ~1) + 2 * 528 + 8) * sizeof(double);
+    }
     if (h->dense_lds > 160 * 1024 - 256) return bail(fail(nullptr, GS_E_TOPOLOGY, "dense_mfma: %zu bytes of LDS needed", h->dense_lds));
     double* scratch = nullptr;
     if ((rc = dev_alloc(h, &scratch, (size_t)h->dense_grid * NB * NB * 64 * 64))) return bail(rc);
@@ -1147,7 +1174,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       if ((rc = dev_alloc(h, &flat, (size_t)NB * NB * 64 * 64 + 8))) return bail(rc);
       GsDenseArgs once = D;
       once.flat = flat; once.mode = 1; once.max_it = 1;
-      hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(1), dim3(256), h->dense_lds, h->stream, once, h->slab, 1);
+      GS_DENSE_LAUNCH(h, 1, once, 1);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "dense_mfma: factorisation of the flat-start Jacobian failed"));
       D.flat = flat;

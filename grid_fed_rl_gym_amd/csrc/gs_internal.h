@@ -313,6 +313,13 @@ struct GsRows {
 };
 
 // gs_k_nr_dense_mfma (kernels_dense.hip): Newton-Raphson with a dense block LU on the matrix cores, one workgroup per instance
+// an entry of the Jacobian by 64 x 64 block (gs_k_nr_dense_mfma2): everything a thread needs to form one 2 x 2 block, 32 bytes
+struct GsDenseEntry {
+  int32_t ib, jb;            // row bus, column bus (equal: the diagonal block of the bus)
+  int32_t dst;               // bits 0-15: (row in the block) * 66 + column in the block; 16 th_free(ib), 17 vm_free(ib), 18 th_free(jb), 19 vm_free(jb)
+  int32_t pad;
+  double g, b;               // Ybus entry (ib, jb); the diagonal entry for ib == jb
+};
 struct GsDenseArgs {
   int32_t n, na, NB, max_it;                 // buses, active (non-slack) buses, 64-wide panels (NP = 64 NB >= 2 na), iteration cap
   int32_t jacobian_exact, rows_total, pad0, pad1;
@@ -323,6 +330,8 @@ struct GsDenseArgs {
   const int32_t* th_free; const int32_t* vm_free; const int32_t* fixed_v; const double* v_set;
   const int32_t* ent_ptr;                    // [NB + 1] Jacobian blocks whose COLUMN bus lies in panel p ...
   const int32_t* ent;                        // ... as (row bus i, column bus j, Ybus position of (i, j)) triples
+  const int32_t* bent_ptr;                   // [NB * NB + 1] the same entries by block: (panel j, block row i) at j * NB + i (gs_k_nr_dense_mfma2) ...
+  const GsDenseEntry* bent;                  // ... as records
   double* scratch;                           // [grid][(NB (NB - 1) / 2 L blocks + NB (NB - 1) / 2 U blocks + NB inverses) x 64 x 64]
   // The first Newton iteration starts from the flat start, where the Jacobian is the same for every instance: its block factors
   // are computed ONCE per handle (mode 1: one workgroup runs the factorisation below into `flat`) and iteration 0 of every solve

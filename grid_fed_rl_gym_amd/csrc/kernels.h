@@ -58,6 +58,7 @@ __global__ void gs_k_postc_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, GsEnvCfg
                                     const double* __restrict__ actions, double total_load, GsPackArgs PA, GsFusedChecks FC);
 __global__ void gs_k_posts_nr_dmfma(GsTables T, GsRows R, GsSolveCfg C, double* __restrict__ slab, int B);
 __global__ void gs_k_nr_dense_mfma(GsDenseArgs A, double* __restrict__ slab, int B);
+__global__ void gs_k_nr_dense_mfma2(GsDenseArgs A, double* __restrict__ slab, int B);
 __global__ void gs_k_nr_sparse_lds(GsSparseArgs A, double* __restrict__ slab, int B);
 __global__ void gs_k_env_reset(GsTables T, GsRows R, GsEnvCfg E, double* __restrict__ slab, int B,
                                const uint64_t* __restrict__ seeds, const uint8_t* __restrict__ mask);

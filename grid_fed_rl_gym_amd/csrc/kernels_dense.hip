@@ -33,10 +33,13 @@
 #define DLD 66                /* leading dimension of the panel in LDS (doubles): even (16-byte rows), not a multiple of 32 banks */
 
 typedef double gd_v4 __attribute__((ext_vector_type(4)));
+typedef double gd_v2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ __attribute__((aligned(16))) double gd_lds[];
 
 __device__ __forceinline__ void gd_sync() { __syncthreads(); }
+// a barrier that waits for this wavefront's LDS traffic only: global loads requested before it stay in flight
+__device__ __forceinline__ void gd_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // block maximum / OR over the 256 threads (sh: 8 doubles)
 __device__ __forceinline__ double gd_block_max(double v, double* sh) {
@@ -59,6 +62,8 @@ __device__ __forceinline__ void gd_load_a(double (&a)[16], const double* A, int 
 #pragma unroll
   for (int s = 0; s < 16; ++s) a[s] = A[(size_t)(16 * w + r) * lda + 4 * s + q];
 }
+template <bool NEG>
+__device__ __forceinline__ void gd_mfma_acc(gd_v4 (&acc)[4], const double (&a)[16], const double* B, int ldb);
 template <bool SUB>
 __device__ __forceinline__ void gd_gemm64_a(double* C, int ldc, const double (&a)[16], const double* B, int ldb) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, q = l >> 4;
@@ -67,12 +72,7 @@ __device__ __forceinline__ void gd_gemm64_a(double* C, int ldc, const double (&a
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[t][g] = SUB ? C[(16 * w + q + 4 * g) * ldc + 16 * t + r] : 0.0;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const double as = SUB ? -a[s] : a[s];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, B[(4 * s + q) * ldb + 16 * t + r], acc[t], 0, 0, 0);
-  }
+  gd_mfma_acc<SUB>(acc, a, B, ldb);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -260,6 +260,53 @@ __device__ __forceinline__ void gd_matvec64_sum(double* y, const double* M0, lon
   __syncthreads();
 }
 
+// ---- the block-row form (gs_k_nr_dense_mfma2): accumulators in registers, BOTH operands of an update from the scratch ------------
+// acc (rows 16 w .. 16 w + 15 of a 64 x 64 block, four 16 x 16 tiles in the C/D layout) -= A B: the A operands in registers (gd_load_a),
+// B a 64 x 64 block in LDS.
+// (the B operands of two k-steps -- eight LDS reads -- are requested before the eight MFMAs of the two steps before them are
+// issued: read where they are used, every pair of MFMAs waited for an LDS round trip)
+template <bool NEG>
+__device__ __forceinline__ void gd_mfma_acc(gd_v4 (&acc)[4], const double (&a)[16], const double* B, int ldb) {
+  const int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+  const double* Bq = B + q * ldb + r;
+  double b[2][2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[0][s][t] = Bq[4 * s * ldb + 16 * t];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c < 7) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[(c + 1) & 1][s][t] = Bq[4 * (2 * (c + 1) + s) * ldb + 16 * t];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const double as = NEG ? -a[2 * c + s] : a[2 * c + s];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b[c & 1][s][t], acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__device__ __forceinline__ void gd_acc_load(gd_v4 (&acc)[4], const double* C, int ldc) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[t][g] = C[(16 * w + q + 4 * g) * ldc + 16 * t + r];
+}
+__device__ __forceinline__ void gd_acc_store(const gd_v4 (&acc)[4], double* C, int ldc) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) C[(size_t)(16 * w + q + 4 * g) * ldc + 16 * t + r] = acc[t][g];
+}
+
 // diagnostic phase stamps: slots 0 mismatch, 1 panel assembly, 2 updates from earlier panels (MFMA), 3 U / D^-1 copies,
 // 4 Gauss-Jordan, 5 L = C D^-1 (MFMA) + copies + forward substitution, 6 back substitution, 7 corrections, 8 row I/O
 struct GdStamp {
@@ -272,8 +319,14 @@ struct GdStamp {
   }
 };
 
-extern "C" __global__ void __launch_bounds__(256)
-gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) {
+// BLOCKROW false: the panel form described at the top (one workgroup per CU: the panel takes 135 KB of LDS).  BLOCKROW true: the
+// same left-looking block LU one 64 x 64 block at a time -- block (i, j) is assembled in LDS, taken into MFMA accumulators,
+// updated with  -= sum_{k < min(i, j)} L_ik U_kj  from the scratch (both operands: nothing of the panel stays in LDS), and leaves as
+// U_ij (i < j, straight from the registers), as D_j^-1 (Gauss-Jordan in LDS) or as L_ij = C D_j^-1.  Two block buffers instead of a
+// panel: 78 KB of LDS, TWO workgroups per CU -- the solve is a chain of short dependent phases (sixteen-step Gauss-Jordan, block
+// substitutions, assembly) at one wavefront per SIMD, and a second instance beside it is what fills the gaps.
+template <bool BLOCKROW>
+__device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ slab_, int B_) {
   // (arguments read in place through an opaque pointer, kernels_flow2.hip F2_ARGS_IN_PLACE: no scalar words parked in vector lanes)
   struct ArgBlock { GsDenseArgs A; double* slab; int B; };
   const __attribute__((address_space(4))) char* ka_ = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -283,13 +336,16 @@ gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) {
   const int B = ((const ArgBlock*)ka_)->B;
   const int tid = threadIdx.x, n = A.n, na = A.na, NB = A.NB, NP = DB * NB;
   // LDS carve-up
-  double* panel = gd_lds;                                  // [NP][DLD]
-  double* rhs = panel + (size_t)NP * DLD;                  // [NP] right-hand side, then the solution
+  double* panel = gd_lds;                                  // [NP][DLD]   (BLOCKROW: bufC [64][DLD], bufD [64][DLD])
+  double* bufC = gd_lds; double* bufD = gd_lds + (size_t)DB * DLD;
+  double* rhs = panel + (size_t)(BLOCKROW ? 2 * DB : NP) * DLD;                  // [NP] right-hand side, then the solution
   double* ve = rhs + NP;                                   // [n] e, f, |V|, angle, P calc, Q calc, P spec, Q spec
   const int n2 = (n + 1) & ~1;                             // (keeps what follows 16-byte aligned)
   double* vf = ve + n2; double* vm = vf + n2; double* va = vm + n2; double* pc = va + n2; double* qc = pc + n2; double* ps = qc + n2; double* qs = ps + n2;
-  double* gjbuf = qs + n2;                                  // [1024] pivot row / column blocks of the Gauss-Jordan steps, two parities
-  double* red = gjbuf + GD_GJ_DOUBLES;                     // [8]
+  // [1056] pivot row / column blocks of the Gauss-Jordan steps, two parities (BLOCKROW: in bufC, which is idle while a diagonal block
+  // is inverted in bufD; the back substitution's 64 doubles likewise)
+  double* gjbuf = BLOCKROW ? bufC : qs + n2;
+  double* red = BLOCKROW ? qs + n2 : gjbuf + GD_GJ_DOUBLES;                     // [8]
   double* scr = A.scratch + (size_t)blockIdx.x * (size_t)(NB * NB) * DB * DB;
   GdStamp stp{A.stamps, 0ull};
   if (A.stamps) stp.t = __builtin_readcyclecounter();
@@ -351,6 +407,107 @@ gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) {
       } else {
       if (A.mode) scr = A.flat;
       // ---- block LU, left-looking over the panels
+      if constexpr (BLOCKROW) {
+      // (the first entry of the next block for this thread -- bus pair, place in the block, Ybus entry: 32 bytes -- is requested a block ahead)
+      GsDenseEntry pre = A.bent[min(A.bent_ptr[0] + tid, A.bent_ptr[NB * NB] - 1)];
+      for (int j = 0; j < NB; ++j)
+        for (int i = 0; i < NB; ++i) {
+          double* buf = i == j ? bufD : bufC;
+          const int q0 = A.bent_ptr[j * NB + i], q1 = A.bent_ptr[j * NB + i + 1];
+          GsDenseEntry en = pre;
+          {
+            const int nb = j * NB + i + 1;
+            if (nb < NB * NB) pre = A.bent[min(A.bent_ptr[nb] + tid, A.bent_ptr[NB * NB] - 1)];
+          }
+          __syncthreads();                                  // (whoever read this buffer last is through)
+          for (int k = tid; k < DB * (DLD / 2); k += blockDim.x) ((double2*)buf)[k] = make_double2(0.0, 0.0);
+          __syncthreads();
+          // Jacobian blocks of block (i, j) (power_flow.py:243-287); padding unknowns get a unit diagonal
+          for (int q = q0 + tid; q < q1; q += blockDim.x) {
+            if (q != q0 + tid) en = A.bent[q];
+            const int ib = en.ib, jb = en.jb;
+            const int thi = (en.dst >> 16) & 1, vfi = (en.dst >> 17) & 1, thj = (en.dst >> 18) & 1, vfj = (en.dst >> 19) & 1;
+            double b00, b01, b10, b11;
+            if (ib == jb) {
+              const double gd = en.g, bd = en.b, v = vm[ib], P = pc[ib], Q = qc[ib];
+              const double vvb = v * v * bd;
+              b00 = thi ? (A.jacobian_exact ? (-Q - vvb) : (-Q + vvb)) : 1.0;
+              b01 = (thi && vfi) ? (P / v + v * gd) : 0.0;
+              b10 = (thi && vfi) ? (P - v * v * gd) : 0.0;
+              b11 = vfi ? (Q / v - v * bd) : 1.0;
+            } else {
+              const double gg = en.g, bb0 = en.b;
+              const double a = ve[ib] * ve[jb] + vf[ib] * vf[jb];
+              const double bb = vf[ib] * ve[jb] - ve[ib] * vf[jb];
+              const double gs_bc = gg * bb - bb0 * a, gc_bs = gg * a + bb0 * bb;
+              b00 = (thi && thj) ? gs_bc : 0.0;
+              b01 = (thi && vfj) ? gc_bs / vm[jb] : 0.0;
+              b10 = (vfi && thj) ? -gc_bs : 0.0;
+              b11 = (vfi && vfj) ? gs_bc / vm[jb] : 0.0;
+            }
+            double* d0 = buf + (en.dst & 0xffff);
+            d0[0] = b00; d0[1] = b01; d0[DLD] = b10; d0[DLD + 1] = b11;
+          }
+          if (i == j)
+            for (int u = max(2 * na, DB * j) + tid; u < DB * (j + 1); u += blockDim.x) buf[(size_t)(u - DB * j) * DLD + (u - DB * j)] = 1.0;
+          __syncthreads();
+          stp.hit(1);
+          gd_v4 acc[4];
+          gd_acc_load(acc, buf, DLD);
+          const int kmax = i < j ? i : j;
+          // -= sum_k L_ik U_kj.  U_kj goes through bufC (free once the accumulators are loaded; every thread brings 16 of its doubles),
+          // L_ik straight into the A operands; U of product k + 1 is requested before product k's MFMAs are issued.
+          if (kmax > 0) {
+            const int urow = tid >> 2, ucol = 16 * (tid & 3);
+            gd_v2 un[8];
+            {
+              const double* U = gd_blk(scr, NB, 1, 0, j) + (size_t)urow * DB + ucol;
+#pragma unroll
+              for (int c = 0; c < 8; ++c) un[c] = *(const gd_v2*)(U + 2 * c);
+            }
+            for (int k = 0; k < kmax; ++k) {
+              double ac[16];
+              gd_load_a(ac, gd_blk(scr, NB, 0, i, k), DB);     // (in flight across the two barriers: they wait for LDS only)
+              gd_sync_lds();                                // bufC: the accumulators are loaded / the previous product has read its B operands
+#pragma unroll
+              for (int c = 0; c < 8; ++c) *(gd_v2*)(bufC + (size_t)urow * DLD + ucol + 2 * c) = un[c];
+              gd_sync_lds();
+              if (k + 1 < kmax) {
+                const double* U = gd_blk(scr, NB, 1, k + 1, j) + (size_t)urow * DB + ucol;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) un[c] = *(const gd_v2*)(U + 2 * c);
+              }
+              gd_mfma_acc<true>(acc, ac, bufC, DLD);
+            }
+          }
+          stp.hit(2);
+          if (i < j) {                 // U_ij: straight to the scratch (the updates of the block rows below read it from there)
+            gd_acc_store(acc, gd_blk(scr, NB, 1, i, j), DB);
+            __threadfence_block();
+            stp.hit(3);
+          } else if (i == j) {         // diagonal block: inverse in place, kept in bufD for this panel's L blocks and in the scratch
+            if (kmax > 0) gd_acc_store(acc, buf, DLD);          // (a wavefront's own rows)
+            __syncthreads();
+            stp.hit(2);
+            sing |= gd_invert64(bufD, DLD, gjbuf);
+            stp.hit(4);
+            double* Dv = gd_blk(scr, NB, 2, j, 0);
+            for (int e = tid; e < DB * DB; e += blockDim.x) Dv[e] = bufD[(size_t)(e >> 6) * DLD + (e & 63)];
+            __threadfence_block();
+          } else {                     // L_ij = C D_j^-1, in place and to the scratch; the right-hand side follows: r_i -= L_ij r_j
+            if (kmax > 0) { __syncthreads(); gd_acc_store(acc, buf, DLD); }
+            gd_gemm64<false>(bufC, DLD, bufC, DLD, bufD, DLD);
+            __syncthreads();
+            double* Lij = gd_blk(scr, NB, 0, i, j);
+            for (int e = tid; e < DB * DB; e += blockDim.x) Lij[e] = bufC[(size_t)(e >> 6) * DLD + (e & 63)];
+            gd_matvec64<false>(rhs + DB * i, bufC, DLD, rhs + DB * j);
+            __threadfence_block();
+            stp.hit(5);
+          }
+        }
+      __threadfence_block();
+      __syncthreads();
+      } else {
       for (int j = 0; j < NB; ++j) {
         for (int k = tid; k < NP * (DLD / 2); k += blockDim.x) ((double2*)panel)[k] = make_double2(0.0, 0.0);
         __syncthreads();
@@ -429,6 +586,7 @@ gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) {
         __syncthreads();
         stp.hit(5);
       }
+      }
       if (A.mode) {        // the handle's flat-start factors are in place; the flag behind them says whether a pivot was singular
         sing = gd_block_max(sing ? 1.0 : 0.0, red) != 0.0 ? 1 : 0;
         if (tid == 0) A.flat[(size_t)NB * NB * DB * DB] = sing ? 1.0 : 0.0;
@@ -487,3 +645,9 @@ gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) {
     stp.hit(8);
   }
 }
+
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) { gd_newton<false>(A_, slab_, B_); }
+
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gs_k_nr_dense_mfma2(GsDenseArgs A_, double* __restrict__ slab_, int B_) { gd_newton<true>(A_, slab_, B_); }
