@@ -800,7 +800,8 @@ def main():
                         solves = max(mm["mean_iterations"] - 1.0, 0.0)
                         tfm = fl_solve * solves * Bm / (sm["avg_launch_ms"] * 1e-3) / 1e12 if sm["avg_launch_ms"] > 0 else 0.0
                         rl = {"bound": "mfma", "achieved": tfm, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfm / FP64_VECTOR_PEAK_TFLOPS,
-                              "traffic": None, "kernel": "gs_k_nr_dense_mfma (between gs_k_pre_nr_dmfma and gs_k_post_nr_dmfma)",
+                              "traffic": None, "kernel": ("gs_k_nr_dense_mfma2" if mm["desc"].get("dense_form") == "block_row" else "gs_k_nr_dense_mfma") + " (between gs_k_pre_nr_dmfma and gs_k_post_nr_dmfma)",
+                              "dense_form": mm["desc"].get("dense_form"), "workgroups": mm["desc"].get("dense_workgroups"), "lds_bytes_per_workgroup": mm["desc"].get("dense_lds_bytes"),
                               "avg_launch_ms": sm["avg_launch_ms"], "avg_launch_method": rl["avg_launch_method"] + "; a step here is three launches (prologue, dense Newton-Raphson, epilogue): the span covers all three",
                               "algorithmic_flops_per_launch": fl_solve * solves * Bm,
                               "how": f"(2/3) N^3 + 2 N^2 = {fl_solve:.3g} flops per Newton solve at N = {N_}, {solves:.2f} solves per step (iterations - 1); the peak is the dense FP64 "

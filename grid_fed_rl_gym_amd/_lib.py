@@ -533,11 +533,18 @@ class Handle:
                 return st
         if len(rec["sets"]) >= rec["max"]:
             return None
+        # Only the observation block is page-locked and recycled: it is the 45 MB whose page faults and staged copy the sets exist to
+        # avoid.  The dozen per-instance arrays (half a megabyte together) are fresh pageable arrays every step, so a caller that keeps an
+        # `info` array does not keep a 45 MB block from being taken again -- the pool's bound is max_sets x B x obs_dim x 8 bytes of
+        # page-locked memory, reached only by a caller that keeps max_sets observation arrays alive.
         before = len(self._pinned_ptrs)
         try:
-            roots = self._alloc_step_set(self._pinned_array, want_obs)
-        except PowerFlowError:                        # no page-locked memory to be had: ordinary arrays, still reused
-            roots = self._alloc_step_set(lambda shape, dtype=np.float64: np.empty(shape, dtype=dtype), want_obs)
+            roots = {"obs": self._pinned_array((self.B, self.obs_dim))}
+        except PowerFlowError:                        # no page-locked memory to be had: an ordinary array, still reused
+            for p in self._pinned_ptrs[before:]:
+                self._lib.gs_host_free(p)
+            del self._pinned_ptrs[before:]
+            roots = {"obs": np.empty((self.B, self.obs_dim))}
         st = {"roots": roots, "want_obs": want_obs, "ptrs": {p.value for p in self._pinned_ptrs[before:]}, "anchors": [], "base": []}
         def first_array(a):
             while isinstance(a.base, np.ndarray):
@@ -581,7 +588,7 @@ class Handle:
             self._lib.gs_host_obs_unbind(self._h, _ptr(st["roots"]["obs"], _dp))
 
     def _step_buffers(self, want_obs=True):
-        st = self._recycled_set(want_obs) if getattr(self, "_recycle", None) else None
+        st = self._recycled_set(want_obs) if (getattr(self, "_recycle", None) and want_obs) else None
         self._cur_set = st
         if st is not None and not self._obs_intact(st):
             self._unbind_obs(st)                   # (this download writes whole rows again; bound anew behind it)
@@ -591,7 +598,8 @@ class Handle:
             if not want_obs:
                 out["obs"] = None
         elif st is not None:
-            out = {k: (None if r is None else r.view()) for k, r in st["roots"].items()}
+            out = self._alloc_step_set(lambda shape, dtype=np.float64: np.empty(shape, dtype=dtype), False)
+            out["obs"] = st["roots"]["obs"].view()
         else:
             out = self._alloc_step_set(lambda shape, dtype=np.float64: np.empty(shape, dtype=dtype), want_obs)
         info = gs_info_view(_ptr(out["power_flow_converged"], _up), _ptr(out["max_voltage"], _dp),

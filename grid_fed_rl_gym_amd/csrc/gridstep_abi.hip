@@ -321,10 +321,15 @@ int fetch_scalars(gs_handle* h, bool sync = true) {
   return GS_OK;
 }
 
+#if defined(GS_BUILD_EXPERIMENTS)
+#define GS_DENSE_PANEL_LAUNCH(h, grid, args, nb) hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(grid), dim3(256), (h)->dense_lds, (h)->stream, args, (h)->slab, nb)
+#else
+#define GS_DENSE_PANEL_LAUNCH(h, grid, args, nb) ((void)0)
+#endif
 #define GS_DENSE_LAUNCH(h, grid, args, nb)                                                                                          \
   do {                                                                                                                              \
     if ((h)->dense_blockrow) hipLaunchKernelGGL(gs_k_nr_dense_mfma2, dim3(grid), dim3(256), (h)->dense_lds, (h)->stream, args, (h)->slab, nb); \
-    else hipLaunchKernelGGL(gs_k_nr_dense_mfma, dim3(grid), dim3(256), (h)->dense_lds, (h)->stream, args, (h)->slab, nb);          \
+    else GS_DENSE_PANEL_LAUNCH(h, grid, args, nb);                                                                                 \
   } while (0)
 
 int launch_solve(gs_handle* h) {
@@ -613,8 +618,10 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
   }
 
   {
-    hipError_t e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    hipError_t e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+#if defined(GS_BUILD_EXPERIMENTS)
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gs_k_nr_dense_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+#endif
     if (e != hipSuccess) return bail(fail(nullptr, GS_E_HIP, "hipFuncSetAttribute(gs_k_nr_dense_mfma): %s", hipGetErrorString(e)));
   }
 
@@ -1155,7 +1162,7 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     // persistent grid, instances strided over it.  Block-row form: two block buffers in LDS, two workgroups per CU; panel form (GS_DENSE_PANEL=1
     // in a build with the experiments): the whole 64-column panel in LDS, one workgroup per CU
     const size_t NP = (size_t)64 * NB;
-    h->dense_blockrow = !getenv("GS_DENSE_PANEL");
+    h->dense_blockrow = !GS_EXPERIMENT_ENV("GS_DENSE_PANEL");
     if (h->dense_blockrow) {
       h->dense_grid = std::max(1, std::min(h->B, 2 * cus));
       h->dense_lds = ((size_t)2 * 64 * 66 + NP + (size_t)8 * ((ht.n + 1) & ~1) + 8) * sizeof(double);
@@ -1460,13 +1467,15 @@ int gs_describe(const gs_handle* h, char* buf, int32_t buflen) {
            "\"lu_slots\": %d, \"lu_orig\": %d, \"lu_pairs\": %lld, \"waves_per_group\": %d, \"groups\": %d, "
            "\"rows_per_group\": %d, \"slab_bytes\": %zu, \"obs_dim\": %d, \"action_dim\": %d, "
            "\"instances_per_workgroup\": %d, \"workgroups\": %d, \"step_lds_bytes\": %zu, \"step_launches\": %d, \"solve_kernel\": \"%s\", \"flow2\": \"%s\", "
-           "\"mesh2\": \"%s\", \"mesh_levels\": %d, \"mesh_rows\": %d, \"mesh_message_units\": %d, \"mesh_messages\": %d, \"mesh_accumulators\": %d}",
+           "\"mesh2\": \"%s\", \"mesh_levels\": %d, \"mesh_rows\": %d, \"mesh_message_units\": %d, \"mesh_messages\": %d, \"mesh_accumulators\": %d, "
+           "\"dense_form\": \"%s\", \"dense_workgroups\": %d, \"dense_lds_bytes\": %zu}",
            h->flow2 ? (h->f2_small ? "fbs_flow2s" : h->f2_wide ? "fbs_flow2x" : h->f2_half ? "fbs_flow2h" : "fbs_flow2") : h->nrm ? "nr_mesh2" : h->nr2 ? (h->f2_small ? "nr_flow2s" : "nr_flow2") : kn[h->solve_kernel], h->n, h->m, h->topo.nnz, h->topo.is_forest ? "true" : "false", h->topo.n_levels,
            h->topo.max_level_width, h->topo.lu_n_slots, h->topo.lu_n_orig, (long long)h->topo.lu_n_pairs, (h->flow2 || h->nr2 || h->nrm) ? h->f2_nw : h->W, h->groups,
            h->R.total, (size_t)h->groups * h->R.total * GS_LANES * sizeof(double), h->obs_dim, h->action_dim,
            (h->flow2 || h->nr2 || h->nrm) ? h->f2_iw : 64, (h->flow2 || h->nr2 || h->nrm) ? (64 / h->f2_iw) * h->groups : h->groups, (h->flow2 || h->nr2 || h->nrm) ? (size_t)h->F2.lds_bytes : h->dyn_lds + 24576, h->split_ok ? 2 : 1,
            kn[h->solve_kernel], (h->flow2 || h->nr2 || h->nrm) ? "on" : (h->flow2_why.empty() ? "n/a" : h->flow2_why.c_str()),
-           h->nrm ? "on" : (h->mesh_why.empty() ? "n/a" : h->mesh_why.c_str()), h->mesh_levels, h->mesh_rows, h->mesh_units, h->mesh_messages, h->mesh_accs);
+           h->nrm ? "on" : (h->mesh_why.empty() ? "n/a" : h->mesh_why.c_str()), h->mesh_levels, h->mesh_rows, h->mesh_units, h->mesh_messages, h->mesh_accs,
+           h->solve_kernel == 7 ? (h->dense_blockrow ? "block_row" : "panel") : "n/a", h->solve_kernel == 7 ? h->dense_grid : 0, h->solve_kernel == 7 ? h->dense_lds : (size_t)0);
   return GS_OK;
 }
 

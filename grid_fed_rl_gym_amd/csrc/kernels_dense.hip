@@ -230,6 +230,40 @@ __device__ __forceinline__ void gd_matvec64(double* y, const double* M, int ld, 
   __syncthreads();
 }
 
+// One block step of the back substitution, x_j = D_j^-1 (r_j - sum_{q < cnt} U_q x_q), in one pass: the row segment of D_j^-1 is requested
+// together with those of the U blocks (two dependent round trips to the scratch before), the difference goes through `tmp` (64 doubles
+// of LDS) and x_j overwrites r_j.  Same sums in the same order as gd_matvec64_sum followed by gd_matvec64<true>; two barriers, not five.
+__device__ __forceinline__ void gd_backstep(double* y, const double* U0, const double* x0, int cnt, const double* Dinv, double* tmp) {
+  const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+  double dv[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) dv[c] = Dinv[(size_t)row * DB + 16 * part + c];
+  double s = 0.0;
+  for (int q = 0; q < cnt; ++q) {
+    const double* M = U0 + (size_t)q * DB * DB + (size_t)row * DB + 16 * part;
+    const double* x = x0 + q * DB + 16 * part;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += M[c] * x[c];
+  }
+  {
+    const double s1 = __shfl_xor(s, 1);
+    const double s01 = (part & 1) ? s1 + s : s + s1;
+    const double s2 = __shfl_xor(s01, 2);
+    const double tot = (part & 2) ? s2 + s01 : s01 + s2;
+    if (part == 0) tmp[row] = cnt > 0 ? y[row] - tot : y[row];
+  }
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t += dv[c] * tmp[16 * part + c];
+  const double t1 = __shfl_xor(t, 1);
+  const double t01 = (part & 1) ? t1 + t : t + t1;
+  const double t2 = __shfl_xor(t01, 2);
+  const double tot2 = (part & 2) ? t2 + t01 : t01 + t2;
+  if (part == 0) y[row] = tot2;
+  __syncthreads();
+}
+
 // scratch block addresses (64 x 64 row-major each): L(i, j) i > j, U(j, k) k > j, Dinv(j)
 __device__ __forceinline__ double* gd_blk(double* base, int NB, int kind, int a, int b) {
   // kind 0: L(a, b), a > b -> index a (a - 1) / 2 + b (a block row of L is contiguous);  kind 1: U(a, b), b > a -> NBT +
@@ -368,18 +402,30 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
     bool stale = true;
     for (int it = 0; it < A.max_it; ++it) {
       // ---- mismatch (power_flow.py:150-171): S = V conj(Y V) by Ybus rows, entries in row order
+      // (two threads per bus, the even and the odd entries of its row, two entries in flight each: a row of the ScalableFeeder-like
+      // network has ~17 entries and every one is a round trip to the Ybus arrays; sum = even part + odd part)
       double lmax = 0.0;
-      for (int i = tid; i < n; i += blockDim.x) {
+      for (int i = tid >> 1; i < n; i += blockDim.x >> 1) {
         const double ei = ve[i], fi = vf[i];
-        double P = 0.0, Q = 0.0;
-        for (int p = A.row_ptr[i]; p < A.row_ptr[i + 1]; ++p) {
-          const int j = A.col[p];
-          const double gg = A.G[p], bb0 = A.Bv[p];
-          const double a = ei * ve[j] + fi * vf[j];
-          const double bb = fi * ve[j] - ei * vf[j];
+        double P = 0.0, Q = 0.0, P2 = 0.0, Q2 = 0.0;
+        const int r1 = A.row_ptr[i + 1];
+        for (int p = A.row_ptr[i] + (tid & 1); p < r1; p += 4) {
+          const int p2 = p + 2 < r1 ? p + 2 : p;
+          const int j = A.col[p], j2 = A.col[p2];
+          const double gg = A.G[p], bb0 = A.Bv[p], gg2 = p + 2 < r1 ? A.G[p2] : 0.0, bb2 = p + 2 < r1 ? A.Bv[p2] : 0.0;
+          const double a = ei * ve[j] + fi * vf[j], a2 = ei * ve[j2] + fi * vf[j2];
+          const double bb = fi * ve[j] - ei * vf[j], bq = fi * ve[j2] - ei * vf[j2];
           P += gg * a + bb0 * bb;
           Q += gg * bb - bb0 * a;
+          P2 += gg2 * a2 + bb2 * bq;
+          Q2 += gg2 * bq - bb2 * a2;
         }
+        P += P2; Q += Q2;
+        {
+          const double Po = __shfl_xor(P, 1), Qo = __shfl_xor(Q, 1);
+          P = (tid & 1) ? Po + P : P + Po; Q = (tid & 1) ? Qo + Q : Q + Qo;
+        }
+        if (tid & 1) continue;
         pc[i] = P; qc[i] = Q;
         const double dP = A.th_free[i] ? (ps[i] - P) : 0.0, dQ = A.vm_free[i] ? (qs[i] - Q) : 0.0;
         const int a_ = A.act_of[i];
@@ -594,13 +640,8 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
       }
       }
       // ---- back substitution: x_j = D_j^-1 (r_j - sum_{k > j} U_jk x_k); x overwrites r block by block
-      for (int j = NB - 1; j >= 0; --j) {
-        if (j + 1 < NB) gd_matvec64_sum(rhs + DB * j, gd_blk(fs, NB, 1, j, j + 1), (long)DB * DB, rhs + DB * (j + 1), DB, NB - 1 - j);
-        // x_j = Dinv r_j: through gjbuf (the product reads all of r_j)
-        if (tid < DB) gjbuf[tid] = rhs[DB * j + tid];
-        __syncthreads();
-        gd_matvec64<true>(rhs + DB * j, gd_blk(fs, NB, 2, j, 0), DB, gjbuf);
-      }
+      for (int j = NB - 1; j >= 0; --j)
+        gd_backstep(rhs + DB * j, gd_blk(fs, NB, 1, j, j + 1), rhs + DB * (j + 1), NB - 1 - j, gd_blk(fs, NB, 2, j, 0), gjbuf);
       stp.hit(6);
       sing = gd_block_max(sing ? 1.0 : 0.0, red) != 0.0 ? 1 : 0;
       if (sing) { status = GS_STATUS_SINGULAR; break; }      // power_flow.py:188-190: keep the current voltages
@@ -646,8 +687,10 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
   }
 }
 
+#if defined(GS_BUILD_EXPERIMENTS)      // the panel form, kept for A/B measurements (GS_DENSE_PANEL=1 in a library built with `make EXPERIMENTS=1`)
 extern "C" __global__ void __launch_bounds__(256)
 gs_k_nr_dense_mfma(GsDenseArgs A_, double* __restrict__ slab_, int B_) { gd_newton<false>(A_, slab_, B_); }
+#endif
 
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gs_k_nr_dense_mfma2(GsDenseArgs A_, double* __restrict__ slab_, int B_) { gd_newton<true>(A_, slab_, B_); }

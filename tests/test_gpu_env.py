@@ -751,6 +751,18 @@ def test_step_outputs_are_recycled_only_when_the_caller_has_let_go():
         seen.append(obs.__array_interface__["data"][0])
         del obs
     assert len(set(seen)) <= 2
+    # only the observation block is pooled: keeping every step's small arrays (rewards, info) does not hold its buffer back
+    hoard, seen = [], []
+    for k in range(6):
+        obs, rew, term, trunc, info = env.step(acts[k])
+        hoard.append((rew, info["iterations"], info["total_losses"], rew.copy(), info["total_losses"].copy()))
+        seen.append(obs.__array_interface__["data"][0])
+        del obs
+    assert len(set(seen)) <= 2 and len({id(h[0]) for h in hoard}) == 6
+    assert all(np.array_equal(h[0], h[3]) and np.array_equal(h[2], h[4]) for h in hoard)      # nothing kept was written again
+    env.reset(seed=5); del hoard
+    for k in range(12):
+        o1, r1, *_ = env.step(acts[k]); del o1
     # the same trajectory with fresh arrays every step
     ref = P.BatchedGridEnvironment(fs, num_envs=B, solver="nr", recycle_host_buffers=False)
     ref.reset(seed=5)

@@ -253,6 +253,28 @@ def test_dense_mfma_flat_start_factors_shared_by_the_handle_change_nothing(monke
         assert np.max(np.abs(getattr(a, f) - getattr(b, f))) < tol, f      # (flows: voltage differences times admittances of ~1e3)
 
 
+@pytest.mark.parametrize("n,B", [(70, 1100), (123, 1030)])
+def test_dense_block_row_form_with_three_and_four_block_rows_and_a_grid_smaller_than_the_batch(n, B):
+    """The block-row form of the dense LU (one 64 x 64 block at a time through two LDS buffers, two workgroups per CU) with NB = 3 and
+    NB = 4 block rows, more instances than the persistent grid has workgroups (2 x CUs) and a ragged last round: iterates of the
+    sparse block LU on the same network, which eliminates in a different order (1e-10)."""
+    fs = P.scalable_like(n, seed=5)
+    rng = np.random.default_rng(n)
+    Pd = -rng.uniform(0.0, 0.02, (B, fs.n)); Pd[:, 0] = 0.0
+    outs = []
+    for ls in ("dense_mfma", "sparse_lu"):
+        q = P.BatchedNewtonRaphsonSolver(tolerance=1e-9, max_iterations=30, linear_solver=ls)
+        outs.append(q.solve_batch(fs, Pd))
+        d = q.handle_for(fs, B).describe()
+        if ls == "dense_mfma":
+            assert d["dense_form"] == "block_row" and d["dense_workgroups"] < B
+        q.close()
+    a, b = outs
+    assert a.converged.all() and np.array_equal(a.iterations, b.iterations) and np.array_equal(a.status, b.status)
+    assert np.max(np.abs(a.bus_voltages - b.bus_voltages)) < 1e-10 and np.max(np.abs(a.bus_angles - b.bus_angles)) < 1e-10
+    assert np.max(np.abs(a.line_flows - b.line_flows)) < 1e-9
+
+
 def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_the_edge_cases():
     """AUTO: the ScalableFeeder-like graph goes to the dense block LU on the matrix cores, the 26-loop feeder stays sparse.  Edge
     cases through the dense kernel: a ragged batch (more instances than workgroups of the persistent grid would be B > 256; here
@@ -264,7 +286,8 @@ def test_dense_mfma_is_what_auto_takes_when_the_sparse_lu_fills_in_and_handles_t
     B = 70
     Pd = -rng.uniform(0.0, 0.03, (B, dense.n)); Pd[:, 0] = 0.0; Pd[5] = 0.0
     a = s.solve_batch(dense, Pd)
-    assert s.handle_for(dense, B).describe()["solve_kernel"] == "nr_dense_mfma"
+    d = s.handle_for(dense, B).describe()
+    assert d["solve_kernel"] == "nr_dense_mfma" and d["dense_form"] == "block_row" and d["dense_workgroups"] == B
     s.solve_batch(sparse, np.zeros((2, sparse.n)))
     assert s.handle_for(sparse, 2).describe()["solve_kernel"] == "nr_sparse_lu"
     s.close()
