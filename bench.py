@@ -763,6 +763,24 @@ def main():
                                           "value_first_40_regions": s2["value_first_40_regions"], "kernel": m2["desc"]["kernel"], "waves_per_group": m2["desc"]["waves_per_group"],
                                           "workgroups": m2["desc"].get("workgroups", m2["desc"]["groups"]), "mean_iterations": m2["mean_iterations"],
                                           "converged_fraction": m2["converged_fraction"], "roofline": roofline_of(m2, s2, "ieee13_b4096")}
+                # the rollout collector on the same feeder (gs_rollout: T fused steps with in-place resets, no host in between)
+                try:
+                    env2 = P.BatchedGridEnvironment(fs2, num_envs=w2["batch"], jacobian="exact", zero_z="open", device=device, **env_kwargs_of(w2["solver"]))
+                    env2.reset(seed=np.arange(w2["batch"], dtype=np.uint64))
+                    h2 = env2.handle
+                    T2 = 256
+                    h2.rollout(T2, "random", seed=1); h2.synchronize()
+                    rr = []
+                    for r in range(5):
+                        t1 = time.perf_counter()
+                        h2.rollout(T2, "random", seed=2 + r); h2.synchronize()
+                        rr.append(w2["batch"] * T2 / (time.perf_counter() - t1))
+                    med2, lo2, hi2 = quantiles(rr)
+                    result["also_config2"]["rollout"] = {"env_steps_per_s": med2, "p10_p90": [lo2, hi2], "T": T2, "policy": "random actions drawn on the device",
+                                                         "finished_episodes": h2.rollout_download(want=("terminals",))["n_terminal"]}
+                    env2.close()
+                except Exception as e:
+                    result["also_config2"]["rollout"] = {"error": str(e)}
             except Exception as e:
                 result["also_config2"] = {"error": str(e)}
             try:
@@ -807,6 +825,19 @@ def main():
                               "how": f"(2/3) N^3 + 2 N^2 = {fl_solve:.3g} flops per Newton solve at N = {N_}, {solves:.2f} solves per step (iterations - 1); the peak is the dense FP64 "
                                      "MFMA rate (= the FP64 vector rate on this part); the first solve of a step reuses the handle's flat-start factors, so the executed flops are about half",
                               "hbm_view": {"achieved_GB_per_s": rl["achieved"], "frac": rl["frac"], "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"]}}
+                        # what the matrix cores actually execute: a factorisation is 64^3 block products (padded to 64-wide blocks), the updates
+                        # sum_j sum_i min(i, j) of them plus one per off-diagonal block for the scaling; one factorisation per solve but the first
+                        NBd = (2 * (fsm.n - 1) + 63) // 64
+                        n_prod = sum(min(i, j) for j in range(NBd) for i in range(NBd)) + NBd * (NBd - 1) // 2
+                        facts = max(solves - 1.0, 0.0)
+                        ex = n_prod * 2.0 * 64 ** 3 * facts * Bm / (sm["avg_launch_ms"] * 1e-3) / 1e12 if sm["avg_launch_ms"] > 0 else 0.0
+                        rl["executed_mfma"] = {"achieved_tflops": ex, "frac": ex / FP64_VECTOR_PEAK_TFLOPS, "block_products_per_factorisation": n_prod,
+                                               "flops_per_factorisation": n_prod * 2.0 * 64 ** 3, "factorisations_per_step": facts,
+                                               "how": "64 x 64 x 64 MFMA block products issued per factorisation (updates + one per off-diagonal block), one factorisation per "
+                                                      "solve except the first of a step (flat-start table); the Gauss-Jordan inversions of the diagonal blocks, the substitutions "
+                                                      "and the assembly run on the vector units and are not counted"}
+                        rl["traffic_split"] = ("none available: FETCH_SIZE / WRITE_SIZE count the L2's fabric-side requests, Infinity-Cache hits included (MI355X guide, HBM "
+                                               "section); no gfx950 counter exposed by rocprofv3 separates the workgroups' scratch that stays in the Infinity Cache from HBM")
                     if mm["desc"]["kernel"] == "nr_sparse_lds":
                         rl["kernel"] = "gs_k_nr_sparse_lds (between gs_k_pre_nr_dmfma and gs_k_post_nr_dmfma)"
                         rl["avg_launch_method"] = rl.get("avg_launch_method", "") + "; a step here is three launches (prologue, Newton-Raphson with the sparse LU in LDS, epilogue): the span covers all three"

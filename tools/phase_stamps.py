@@ -27,6 +27,19 @@ for k in range(a.steps):
     h.step_device(k % 8)
 h.synchronize()
 s = h.debug_stamps()
+if h.describe()["kernel"] == "nr_dense_mfma":      # the dense kernel's own slots (kernels_dense.hip GdStamp), summed over the instances workgroup 0 took
+    names = ["mismatch", "assembly", "update_products_mfma", "u_blocks_to_scratch", "gauss_jordan", "l_blocks_and_forward_substitution",
+             "back_substitution", "corrections", "row_io"]
+    vals = list(s.values())
+    dense = dict(zip(names, vals[:len(names)]))
+    rest = {k: v for k, v in list(s.items())[len(names):]}
+    d = h.describe()
+    per_wg = a.batch / max(1, d.get("dense_workgroups", 1))
+    print(json.dumps({"kernel": "nr_dense_mfma", "dense_form": d.get("dense_form"), "workgroups": d.get("dense_workgroups"), "instances_per_workgroup_and_step": per_wg, "steps": a.steps,
+                      "cycles_per_instance": {k: round(v / a.steps / per_wg) for k, v in dense.items()},
+                      "total_per_instance": round(sum(dense.values()) / a.steps / per_wg),
+                      "pre_and_post_kernels_cycles_per_step_of_their_workgroup_0": {k: round(v / a.steps) for k, v in rest.items() if v}}))
+    sys.exit(0)
 tot = sum(s.values())
 print(json.dumps({"kernel": h.describe()["kernel"], "wave": int(os.environ.get("GS_STAMP_WAVE", "0")), "steps": a.steps,
                   "cycles_per_step": {k: round(v / a.steps) for k, v in s.items() if v}, "total_per_step": round(tot / a.steps)}))
