@@ -19,7 +19,8 @@ LIMITS = {
     "gs_k_step_nr_flow2": (100, 0),
     "gs_k_step_nr_flow2s": (60, 0),
     "gs_k_step_nr_lu": (80, 0),
-    "gs_k_nr_dense_mfma": (80, 0),
+    "gs_k_nr_dense_mfma2": (80, 8),        # block-row form (round 4): two workgroups per CU, 256 registers
+    "gs_k_step_nr_mesh2": (80, 24),        # meshed member (round 4): T / s of ten rows in registers, 19 spilled outside the row loops
 }
 
 
@@ -37,3 +38,5 @@ def test_step_kernels_keep_their_arguments_out_of_the_vector_lanes():
         assert 0 <= r["vspill"] <= vmax, (name, r)
     # the headline member is built for two workgroups of 8 waves on a CU: 128 registers per lane
     assert res["gs_k_step_fbs_flow2h"]["vgpr"] <= 128
+    # the dense block-row form and the meshed member are built for two workgroups of 4 waves on a CU
+    assert res["gs_k_nr_dense_mfma2"]["vgpr"] <= 256 and res["gs_k_step_nr_mesh2"]["vgpr"] <= 256
