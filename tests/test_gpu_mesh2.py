@@ -182,3 +182,48 @@ def test_flat_start_table_of_the_meshed_member_changes_nothing_beyond_rounding(m
     for (o1, r1, i1, c1, l1), (o2, r2, i2, c2, l2) in zip(*outs):
         assert np.array_equal(i1, i2) and np.array_equal(c1, c2) and c1.all()
         assert np.max(np.abs(o1 - o2) / np.maximum(1.0, np.abs(o2))) < 1e-12 and np.max(np.abs(l1 - l2)) < 1e-12
+
+
+@pytest.mark.parametrize("B", [1, 8, 13])
+def test_meshed_member_with_one_instance_a_full_workgroup_and_a_ragged_second_one(B):
+    """B = 1 (seven idle lanes per sub-group), B = 8 (exactly one workgroup), B = 13 (a second workgroup with five instances): the
+    same instances -- global-index seeds, `first_instance` -- as rows 0..B-1 of a larger batch, bit for bit."""
+    spec = P.random_meshed(60, 10, seed=2)
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, (2, 40, spec.action_dim))
+    seeds = np.arange(40, dtype=np.uint64) + 21
+    big = _env(spec, 40); big.reset(seed=seeds)
+    small = _env(spec, B); small.reset(seed=seeds[:B])
+    assert small.handle.describe()["kernel"] == "nr_mesh2"
+    for t in range(2):
+        ob, rb, *_ = big.step(acts[t]); osm, rs, *_, info = small.step(acts[t, :B])
+        assert info["power_flow_converged"].all()
+        np.testing.assert_array_equal(osm, ob[:B]); np.testing.assert_array_equal(rs, rb[:B])
+    big.close(); small.close()
+
+
+def test_networks_the_meshed_member_does_not_take_say_why_and_run_on_the_kernel_they_ran_on_before(monkeypatch):
+    """Eligibility (gs_describe "mesh2"), for handles whose linear solver is the sparse block LU: the ScalableFeeder-like graph has
+    pivots with more than eight neighbours left at their elimination; the as-coded Jacobian; a PV bus; a denser 123-bus feeder
+    needing more rows per wavefront than a lane holds T / s for; GS_NO_MESH2=1.  Every one of them runs the slab-row sparse LU as
+    before, steps, and (exact Jacobian) converges."""
+    import dataclasses
+    base = P.random_meshed(40, 6, seed=2)
+    bt = base.bus_type.copy(); bt[5] = 1
+    cases = [(P.scalable_like(40, seed=3), dict(jacobian="exact"), "neighbours"),
+             (base, dict(jacobian="as_coded"), "as-coded Jacobian"),
+             (dataclasses.replace(base, bus_type=bt), dict(jacobian="exact"), "not a PQ bus"),
+             (base, dict(jacobian="exact"), "GS_NO_MESH2")]
+    for spec, kw, word in cases:
+        if word == "GS_NO_MESH2":
+            monkeypatch.setenv("GS_NO_MESH2", "1")
+        env = P.BatchedGridEnvironment(spec, num_envs=9, solver="nr", linear_solver="sparse_lu", tolerance=1e-8, max_iterations=50, **kw)
+        monkeypatch.delenv("GS_NO_MESH2", raising=False)
+        d = env.handle.describe()
+        assert d["kernel"] == "nr_sparse_lu" and word in d["mesh2"], d["mesh2"]
+        env.reset(seed=3)
+        obs, rew, term, trunc, info = env.step(np.zeros((9, spec.action_dim)))
+        assert np.isfinite(obs).all()
+        if kw.get("jacobian") == "exact":
+            assert info["power_flow_converged"].all()
+        env.close()
