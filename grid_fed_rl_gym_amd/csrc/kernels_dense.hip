@@ -341,6 +341,119 @@ __device__ __forceinline__ void gd_acc_store(const gd_v4 (&acc)[4], double* C, i
     for (int g = 0; g < 4; ++g) C[(size_t)(16 * w + q + 4 * g) * ldc + 16 * t + r] = acc[t][g];
 }
 
+__device__ __forceinline__ int gd_invert4(double (&a)[4][4]) {      // in-place Gauss-Jordan on 4 x 4, static indices; 1: a pivot was zero / not finite
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double piv = a[k][k];
+    if (!(piv != 0.0) || !(fabs(piv) < INFINITY)) bad = 1;
+    const double p = gd_rcp(piv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j != k) a[k][j] *= p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i == k) continue;
+      const double f = a[i][k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (j != k) a[i][j] = __builtin_fma(-f, a[k][j], a[i][j]);
+      a[i][k] = -(f * p);
+    }
+    a[k][k] = p;
+  }
+  return bad;
+}
+// The inversion for the block-row kernel: the same block Gauss-Jordan with 4 x 4 pivot blocks, but the 64 x 64 block lives in MFMA
+// accumulators (wavefront w: rows 16 w .. 16 w + 15) and a step's rank-4 update  M -= C T  is ONE v_mfma_f64_16x16x4 per 16 x 16 tile.
+// The FP64 matrix rate equals the vector rate on this part, so the arithmetic costs the same pipe time -- but it is 4 instructions
+// instead of 64 multiply-adds per lane, on a pipe the neighbouring workgroup's vector instructions do not queue for, and the step
+// needs ONE barrier: the pivot row block R (4 x 64, raw) and column block C (64 x 4) are published, and every lane inverts the pivot
+// tile for itself (same instructions on the same operands), forms the entries of T = P^-1 R its B operands need (the pivot's tile
+// column: T' = I + P^-1, which leaves -C P^-1 there), and issues the four MFMAs; the lanes holding the pivot's rows then overwrite
+// them with T (P^-1 in the pivot tile).  buf: [2 parities][R as [64 columns][4] | C as [64 rows][4]] doubles.
+__device__ __forceinline__ int gd_invert64_mfma(double* D, int ld, double* buf) {
+  // (the lane's coordinates through an opaque copy: what the steps derive from them is formed where it is used, not in front of the
+  // kernel's outer loops)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int w = __builtin_amdgcn_readfirstlane(tid_ >> 6), l = tid_ & 63, r = l & 15, q = l >> 4;
+  gd_v4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[t][g] = D[(16 * w + q + 4 * g) * ld + 16 * t + r];
+  int bad = 0;
+  // (the tile of the pivot's columns is named at compile time -- four copies of the step --, the register of its rows is selected
+  // at run time: unrolled over all sixteen steps, every step's lane masks were formed up front and kept: 196 spilled scalar registers)
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq)
+#pragma nounroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int kb = 4 * tq + gq;
+      double* rowb = buf + (kb & 1) * 512, *colb = rowb + 256;
+      const int wq = tq;                                    // the wavefront holding the pivot's rows (accumulator register gq);
+      const int rq = 4 * gq;                                // tile tq, lane columns rq .. rq + 3 hold the pivot's columns
+      if (w == wq) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double v = gq == 0 ? acc[t][0] : gq == 1 ? acc[t][1] : gq == 2 ? acc[t][2] : acc[t][3];
+          rowb[(16 * t + r) * 4 + q] = v;
+        }
+      }
+      if ((r >> 2) == gq) {
+        const gd_v4 c = acc[tq];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) colb[(16 * w + q + 4 * g) * 4 + (r & 3)] = c[g];
+      }
+      __syncthreads();
+      double pi[4][4];
+      {
+        const double* pp = rowb + (16 * tq + rq) * 4;           // P[k][c] at pp[4 c + k]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const gd_v2 lo = *(const gd_v2*)(pp + 4 * c), hi = *(const gd_v2*)(pp + 4 * c + 2);
+          pi[0][c] = lo.x; pi[1][c] = lo.y; pi[2][c] = hi.x; pi[3][c] = hi.y;
+        }
+      }
+      bad |= gd_invert4(pi);
+      const double pq0 = q == 0 ? pi[0][0] : q == 1 ? pi[1][0] : q == 2 ? pi[2][0] : pi[3][0];
+      const double pq1 = q == 0 ? pi[0][1] : q == 1 ? pi[1][1] : q == 2 ? pi[2][1] : pi[3][1];
+      const double pq2 = q == 0 ? pi[0][2] : q == 1 ? pi[1][2] : q == 2 ? pi[2][2] : pi[3][2];
+      const double pq3 = q == 0 ? pi[0][3] : q == 1 ? pi[1][3] : q == 2 ? pi[2][3] : pi[3][3];      // row q of P^-1
+      const double a = -colb[(16 * w + r) * 4 + q];
+      double tt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const gd_v2 lo = *(const gd_v2*)(rowb + (16 * t + r) * 4), hi = *(const gd_v2*)(rowb + (16 * t + r) * 4 + 2);
+        double v = pq0 * lo.x;
+        v = __builtin_fma(pq1, lo.y, v); v = __builtin_fma(pq2, hi.x, v); v = __builtin_fma(pq3, hi.y, v);
+        tt[t] = v;
+      }
+      const bool pcol = (r >> 2) == gq;                     // this lane's column of tile tq is one of the pivot's
+      const int rc = r & 3;
+      const double pqc = rc == 0 ? pq0 : rc == 1 ? pq1 : rc == 2 ? pq2 : pq3;      // P^-1[q][column]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool pt = pcol && t == tq;
+        const double b = pt ? pqc + (q == rc ? 1.0 : 0.0) : tt[t];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      }
+      if (w == wq) {                                        // the pivot's rows: T, and P^-1 in the pivot tile
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double v = (pcol && t == tq) ? pqc : tt[t];
+          if (gq == 0) acc[t][0] = v; else if (gq == 1) acc[t][1] = v; else if (gq == 2) acc[t][2] = v; else acc[t][3] = v;
+        }
+      }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) D[(size_t)(16 * w + q + 4 * g) * ld + 16 * t + r] = acc[t][g];
+  __syncthreads();
+  return bad;
+}
+
 // diagnostic phase stamps: slots 0 mismatch, 1 panel assembly, 2 updates from earlier panels (MFMA), 3 U / D^-1 copies,
 // 4 Gauss-Jordan, 5 L = C D^-1 (MFMA) + copies + forward substitution, 6 back substitution, 7 corrections, 8 row I/O
 struct GdStamp {
@@ -535,7 +648,7 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
             if (kmax > 0) gd_acc_store(acc, buf, DLD);          // (a wavefront's own rows)
             __syncthreads();
             stp.hit(2);
-            sing |= gd_invert64(bufD, DLD, gjbuf);
+            sing |= gd_invert64_mfma(bufD, DLD, gjbuf);
             stp.hit(4);
             double* Dv = gd_blk(scr, NB, 2, j, 0);
             for (int e = tid; e < DB * DB; e += blockDim.x) Dv[e] = bufD[(size_t)(e >> 6) * DLD + (e & 63)];
