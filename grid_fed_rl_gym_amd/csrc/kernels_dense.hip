@@ -404,7 +404,7 @@ __device__ __forceinline__ int gd_invert64_mfma(double* D, int ld, double* buf) 
 #pragma unroll
         for (int g = 0; g < 4; ++g) colb[(16 * w + q + 4 * g) * 4 + (r & 3)] = c[g];
       }
-      __syncthreads();
+      gd_sync_lds();                                        // (one barrier per step; it waits for LDS only)
       double pi[4][4];
       {
         const double* pp = rowb + (16 * tq + rq) * 4;           // P[k][c] at pp[4 c + k]
@@ -580,7 +580,7 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
           }
           __syncthreads();                                  // (whoever read this buffer last is through)
           for (int k = tid; k < DB * (DLD / 2); k += blockDim.x) ((double2*)buf)[k] = make_double2(0.0, 0.0);
-          __syncthreads();
+          gd_sync_lds();
           // Jacobian blocks of block (i, j) (power_flow.py:243-287); padding unknowns get a unit diagonal
           for (int q = q0 + tid; q < q1; q += blockDim.x) {
             if (q != q0 + tid) en = A.bent[q];
@@ -609,7 +609,7 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
           }
           if (i == j)
             for (int u = max(2 * na, DB * j) + tid; u < DB * (j + 1); u += blockDim.x) buf[(size_t)(u - DB * j) * DLD + (u - DB * j)] = 1.0;
-          __syncthreads();
+          gd_sync_lds();
           stp.hit(1);
           gd_v4 acc[4];
           gd_acc_load(acc, buf, DLD);
