@@ -586,6 +586,25 @@ def main():
                                         "what": "as with_host_io, outputs in page-locked host buffers (gs_host_alloc), reused every other step"}
         except Exception as e:
             m["with_host_io_pinned"] = {"error": str(e)}
+        # opt-in: the observation block as float32 (the dtype the reference declares for its observation space, grid_env.py:346),
+        # rounded on the device -- never the headline, never `with_host_io`
+        try:
+            e32 = P.BatchedGridEnvironment(fs, num_envs=B, jacobian="exact", zero_z="open", device=device, obs_dtype=np.float32, **env_kwargs_of(solver))
+            e32.reset(seed=np.arange(B, dtype=np.uint64))
+            for k in range(4):
+                o32 = e32.step(actions[k % n_act]); del o32
+            ts = []
+            for k in range(10):
+                t1 = time.perf_counter()
+                o32 = e32.step(actions[k % n_act]); del o32
+                ts.append(time.perf_counter() - t1)
+            e32.close()
+            med, p10, p90 = quantiles(ts)
+            m["with_host_io_float32_observations"] = {"env_steps_per_s": B / med, "ms_per_step": 1e3 * med, "ms_per_step_p10_p90": [1e3 * p10, 1e3 * p90],
+                                                      "what": "BatchedGridEnvironment(obs_dtype=np.float32).step(): as with_host_io, the observation block rounded to float32 on the "
+                                                              "device and copied whole (opt-in; every other output unchanged)"}
+        except Exception as e:
+            m["with_host_io_float32_observations"] = {"error": str(e)}
         return m
 
     def accuracy(fs, solver):
@@ -725,7 +744,7 @@ def main():
             "converged_fraction": head_m["converged_fraction"],
             "host": host_description(),
         }
-        for k in ("post_step_checks", "rollout", "with_host_io", "with_host_io_fresh_arrays", "with_host_io_pinned"):
+        for k in ("post_step_checks", "rollout", "with_host_io", "with_host_io_fresh_arrays", "with_host_io_pinned", "with_host_io_float32_observations"):
             if k in main_m:
                 result[k] = main_m[k]
         if world > 1:

@@ -100,6 +100,8 @@ SYMBOLS = [
     ("gs_upload_actions", C.c_int, [_H, _dp, C.c_int32]),
     ("gs_step_device", C.c_int, [_H, C.c_int32]),
     ("gs_download_step", C.c_int, [_H, _dp, _dp, _up, _up, C.POINTER(gs_info_view)]),
+    ("gs_step_f32", C.c_int, [_H, _dp, C.POINTER(C.c_float), _dp, _up, _up, C.POINTER(gs_info_view)]),
+    ("gs_download_step_f32", C.c_int, [_H, C.POINTER(C.c_float), _dp, _up, _up, C.POINTER(gs_info_view)]),
     ("gs_rollout", C.c_int, [_H, C.c_int32, C.c_int32, C.c_uint64, _dp]),
     ("gs_rollout_download", C.c_int, [_H, C.POINTER(gs_rollout_view)]),
     ("gs_rollout_device_view", C.c_int, [_H, C.POINTER(gs_rollout_device)]),
@@ -336,6 +338,7 @@ class Handle:
         self._h = _H()
         self.spec = spec
         self.B = int(batch)
+        self.obs_dtype = np.dtype(np.float64)      # np.float32: step() / download_step() hand out the block rounded on the device (gs_step_f32)
         t, keep = _topology_of(spec)
         rc = self._lib.gs_create(C.byref(t), C.byref(cfg), self.B, int(device), int(first_instance), C.byref(self._h))
         if rc != GS_OK:
@@ -479,7 +482,7 @@ class Handle:
 
     def _alloc_step_set(self, new, want_obs=True):
         B = self.B
-        return dict(obs=new((B, self.obs_dim)) if want_obs else None, reward=new((B,)),
+        return dict(obs=new((B, self.obs_dim), self.obs_dtype) if want_obs else None, reward=new((B,)),
                     terminated=new((B,), np.uint8), truncated=new((B,), np.uint8),
                     power_flow_converged=new((B,), np.uint8), max_voltage=new((B,)), min_voltage=new((B,)),
                     total_losses=new((B,)), violations=new((B, 4), np.uint8),
@@ -539,12 +542,12 @@ class Handle:
         # page-locked memory, reached only by a caller that keeps max_sets observation arrays alive.
         before = len(self._pinned_ptrs)
         try:
-            roots = {"obs": self._pinned_array((self.B, self.obs_dim))}
+            roots = {"obs": self._pinned_array((self.B, self.obs_dim), self.obs_dtype)}
         except PowerFlowError:                        # no page-locked memory to be had: an ordinary array, still reused
             for p in self._pinned_ptrs[before:]:
                 self._lib.gs_host_free(p)
             del self._pinned_ptrs[before:]
-            roots = {"obs": np.empty((self.B, self.obs_dim))}
+            roots = {"obs": np.empty((self.B, self.obs_dim), dtype=self.obs_dtype)}
         st = {"roots": roots, "want_obs": want_obs, "ptrs": {p.value for p in self._pinned_ptrs[before:]}, "anchors": [], "base": []}
         def first_array(a):
             while isinstance(a.base, np.ndarray):
@@ -567,7 +570,7 @@ class Handle:
         sample of them is checked before every reuse (``_obs_intact``), and a spoilt set is bound again."""
         obs = st["roots"].get("obs") if st else None
         c0, c1 = self._const_block()
-        if obs is None or c1 <= c0:
+        if obs is None or c1 <= c0 or obs.dtype != np.float64:      # (a float32 block is converted and copied whole)
             return
         if self._lib.gs_host_obs_bind(self._h, _ptr(obs, _dp)) != GS_OK:
             return
@@ -613,6 +616,10 @@ class Handle:
         if a.shape != (self.B, self.action_dim):
             raise PowerFlowError(f"actions shape {a.shape} != ({self.B}, {self.action_dim})")
         out, info = self._step_buffers()
+        if self.obs_dtype == np.float32:
+            self._check(self._lib.gs_step_f32(self._h, _ptr(a, _dp), _ptr(out["obs"], C.POINTER(C.c_float)), _ptr(out["reward"], _dp),
+                                              _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
+            return out
         self._check(self._lib.gs_step(self._h, _ptr(a, _dp), _ptr(out["obs"], _dp), _ptr(out["reward"], _dp),
                                       _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
         self._after_download()
@@ -654,6 +661,10 @@ class Handle:
 
     def download_step(self, want_obs: bool = True) -> dict:
         out, info = self._step_buffers(want_obs)
+        if want_obs and self.obs_dtype == np.float32:
+            self._check(self._lib.gs_download_step_f32(self._h, _ptr(out["obs"], C.POINTER(C.c_float)), _ptr(out["reward"], _dp),
+                                                       _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
+            return out
         self._check(self._lib.gs_download_step(self._h, _ptr(out["obs"], _dp), _ptr(out["reward"], _dp),
                                                _ptr(out["terminated"], _up), _ptr(out["truncated"], _up), C.byref(info)))
         if want_obs:

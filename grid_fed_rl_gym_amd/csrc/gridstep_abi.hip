@@ -131,6 +131,7 @@ struct gs_handle {
   // host observation arrays whose constant columns are in place (gs_host_obs_bind): gs_step / gs_download_step copy only the
   // changing columns into these -- two strided copies instead of one whole block, 36 % fewer bytes over PCIe on the 123-bus feeder
   std::vector<const double*> bound_obs;
+  float* d_obs32 = nullptr;                // float32 copy of the observation block (gs_step_f32 / gs_download_step_f32), on first use
   hipEvent_t ev_scalars = nullptr;
   double* d_actions = nullptr; int n_action_batches = 0;
   // gs_rollout: [T + 1][B][obs_dim] observation sequence, [T][B][A] actions, [T][B] rewards / done flags, and the side
@@ -1575,10 +1576,27 @@ int gs_host_free(void* p) {
   return GS_OK;
 }
 
-int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
-                     const gs_info_view* info) {
+// obs32: the observation block rounded to float32 (the dtype the reference DECLARES for its observation space, grid_env.py:346; its
+// values are Python floats) -- converted on the device, 22 MB instead of 45 over the link at [8192][684]
+static int download_step_impl(gs_handle* h, double* obs, float* obs32, double* reward, uint8_t* terminated, uint8_t* truncated,
+                              const gs_info_view* info) {
   if (!h) return fail(nullptr, GS_E_INVALID, "handle is NULL");
   GS_ENTER(h);
+  if (obs32) {
+    if (!h->d_obs32) { int rc0 = dev_alloc(h, &h->d_obs32, (size_t)h->Bp * h->obs_dim); if (rc0) return rc0; }
+    if (!h->ev_scalars) HIPCHK(h, hipEventCreateWithFlags(&h->ev_scalars, hipEventDisableTiming));
+    int rc = fetch_scalars(h, false);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_scalars, h->stream));
+    const long long n = (long long)h->B * h->obs_dim;
+    hipLaunchKernelGGL(gs_k_obs_to_f32, dim3((unsigned)((n + 2 * 256 - 1) / (2 * 256))), dim3(256), 0, h->stream, h->d_obs2[h->obs_cur], h->d_obs32, n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(obs32, h->d_obs32, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev_scalars));
+    copy_info(h, reward, terminated, truncated, info);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GS_OK;
+  }
   if (!obs) {
     int rc = fetch_scalars(h);
     if (rc) return rc;
@@ -1612,6 +1630,15 @@ int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* termina
   copy_info(h, reward, terminated, truncated, info);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return GS_OK;
+}
+
+int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated, uint8_t* truncated, const gs_info_view* info) {
+  return download_step_impl(h, obs, nullptr, reward, terminated, truncated, info);
+}
+
+int gs_download_step_f32(gs_handle* h, float* obs, double* reward, uint8_t* terminated, uint8_t* truncated, const gs_info_view* info) {
+  if (!obs) return fail(h, GS_E_INVALID, "gs_download_step_f32: obs is NULL");
+  return download_step_impl(h, nullptr, obs, reward, terminated, truncated, info);
 }
 
 // A host observation array [B][obs_dim] the caller will hand to gs_step / gs_download_step again and again: its constant columns
@@ -1648,6 +1675,18 @@ int gs_step(gs_handle* h, const double* actions, double* obs, double* reward, ui
   int rc = step_kernels(h, h->d_in);
   if (rc) return rc;
   return gs_download_step(h, obs, reward, terminated, truncated, info);
+}
+
+int gs_step_f32(gs_handle* h, const double* actions, float* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
+                const gs_info_view* info) {
+  if (!h || (!actions && h->action_dim > 0) || !obs) return fail(h, GS_E_INVALID, "handle / actions / obs is NULL");
+  if (!h->was_reset) return fail(h, GS_E_STATE, "gs_step_f32 before gs_reset");
+  GS_ENTER(h);
+  if (h->action_dim > 0)
+    HIPCHK(h, hipMemcpyAsync(h->d_in, actions, (size_t)h->B * h->action_dim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = step_kernels(h, h->d_in);
+  if (rc) return rc;
+  return download_step_impl(h, nullptr, obs, reward, terminated, truncated, info);
 }
 
 int gs_step_device_ptr(gs_handle* h, const double* d_actions, void* producer_stream) {

@@ -72,6 +72,7 @@ __global__ void gs_k_pack(const int32_t* __restrict__ src, const double* __restr
 __global__ void gs_k_unpack(const int32_t* __restrict__ dst, int C, int rows_total, double* __restrict__ slab,
                             const double* __restrict__ in, int B, int stride);
 __global__ void gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long long rows, int D, int skip0, int skip1, int expand);
+__global__ void gs_k_obs_to_f32(const double* __restrict__ src, float* __restrict__ dst, long long n);
 __global__ void gs_k_gather_lane(int row0, int count, int lane, const double* __restrict__ slab, double* __restrict__ out);
 __global__ void gs_k_fill_rows(int row0, int stride, int count, int rows_total, double* __restrict__ slab, double value);
 __global__ void gs_k_scalars(const int32_t* __restrict__ rf, int nf, const int32_t* __restrict__ ri, int ni,

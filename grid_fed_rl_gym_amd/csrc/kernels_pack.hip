@@ -104,6 +104,21 @@ gs_k_obs_compact(const double* __restrict__ src, double* __restrict__ dst, long 
   else dst[idx] = src[r * D + c];
 }
 
+// dst[k] = (float)src[k], two entries per thread (the observation block for a caller that asked for float32: gs_step_f32)
+extern "C" __global__ void __launch_bounds__(256)
+gs_k_obs_to_f32(const double* __restrict__ src, float* __restrict__ dst, long long n) {
+  const long long k = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (k + 1 < n) {
+    typedef double gs_d2 __attribute__((ext_vector_type(2)));
+    typedef float gs_f2 __attribute__((ext_vector_type(2)));
+    const gs_d2 v = *(const gs_d2*)(src + k);
+    gs_f2 o; o.x = (float)v.x; o.y = (float)v.y;
+    __builtin_nontemporal_store(o, (gs_f2*)(dst + k));
+  } else if (k < n) {
+    dst[k] = (float)src[k];
+  }
+}
+
 // out[q] = row (row0 + q) of lane `lane` of group 0, q < count (gs_create: the handle's flat-start LU blocks, read off the
 // rows one ordinary factorisation left there)
 extern "C" __global__ void __launch_bounds__(256)

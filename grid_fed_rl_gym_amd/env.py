@@ -66,7 +66,7 @@ class BatchedGridEnvironment:
                  tolerance: float = 1e-6, max_iterations: int = 50, acceleration_factor: float = 1.0,
                  linear_solver: str = "auto", power_base: Optional[float] = None, device: int = 0,
                  first_instance: int = 0, waves_per_group: int = 0, warm_start: bool = False,
-                 pinned_host_buffers: bool = False, recycle_host_buffers: bool = True, **kwargs: Any) -> None:
+                 pinned_host_buffers: bool = False, recycle_host_buffers: bool = True, obs_dtype: Any = np.float64, **kwargs: Any) -> None:
         spec = feeder if isinstance(feeder, FeederSpec) else flatten_feeder(feeder)
         if renewable_sources is not None:
             keep = [g for g in range(spec.n_gens)
@@ -105,6 +105,14 @@ class BatchedGridEnvironment:
                                safety_penalty=self.safety_penalty, power_base=self.power_base,
                                waves_per_group=int(waves_per_group), fbs_warm_start=int(bool(warm_start) and solver == "fbs"))
         self._h = _lib.Handle(spec, cfg, self.num_envs, device, first_instance)
+        # obs_dtype=np.float32 (opt-in): step() returns the observation block in the dtype the reference DECLARES for its observation
+        # space (grid_env.py:346) -- rounded on the device, half the bytes over PCIe; reset(), step_device() and the rollout collector
+        # stay float64, and so does every parity test
+        if np.dtype(obs_dtype) not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("obs_dtype must be float64 or float32")
+        self._h.obs_dtype = np.dtype(obs_dtype)
+        if pinned_host_buffers and self._h.obs_dtype == np.float32:
+            raise ValueError("pinned_host_buffers and obs_dtype=float32 are not combined: the recycled pool (the default) serves float32")
         if pinned_host_buffers:
             # step() then returns views of two rotating page-locked buffer sets instead of fresh arrays (valid until the
             # next-but-one step): the 45 MB observation copy of a B = 8192 batch runs at the link's rate
@@ -115,6 +123,7 @@ class BatchedGridEnvironment:
             self._h.use_recycled_outputs()
         self.obs_dim, self.action_dim, self.state_dim = self._h.obs_dim, self._h.action_dim, self._h.state_dim
         big = np.finfo(np.float64).max
+        self.obs_dtype = self._h.obs_dtype
         self.single_observation_space = Box(-big, big, shape=(self.obs_dim,), dtype=np.float64)
         self.single_action_space = Box(-1.0, 1.0, shape=(self.action_dim,), dtype=np.float32)    # grid_env.py:353-358
         self.observation_space = Box(-big, big, shape=(self.num_envs, self.obs_dim), dtype=np.float64)

@@ -220,6 +220,13 @@ int gs_upload_actions(gs_handle* h, const double* actions, int32_t n_batches);
 int gs_step_device(gs_handle* h, int32_t action_batch_index);
 int gs_download_step(gs_handle* h, double* obs, double* reward, uint8_t* terminated,
                      uint8_t* truncated, const gs_info_view* info);
+/* The same with the observation block as FLOAT32 [B][obs_dim] -- the dtype the reference declares for its observation space
+ * (grid_env.py:346, `Box(..., dtype=np.float32)`; the values its step() returns are Python floats, which is what gs_step hands out).
+ * Rounded to nearest on the device; every other output as in gs_step / gs_download_step.  Opt-in: half the bytes over the link. */
+int gs_step_f32(gs_handle* h, const double* actions, float* obs, double* reward, uint8_t* terminated,
+                uint8_t* truncated, const gs_info_view* info);
+int gs_download_step_f32(gs_handle* h, float* obs, double* reward, uint8_t* terminated,
+                         uint8_t* truncated, const gs_info_view* info);
 /* Host observation arrays that are handed to gs_step / gs_download_step again and again (the recycled page-locked sets of the
  * Python environment): gs_host_obs_bind writes the constant columns of the observation -- the static load powers of
  * grid_env.py:769-770, a third of the row on the 123-bus feeder -- into `obs` once and remembers the address; later downloads

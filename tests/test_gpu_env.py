@@ -805,3 +805,32 @@ def test_recycled_observation_arrays_download_the_changing_columns_only_and_stay
     d1 = env.handle.download_step(); d2 = ref.handle.download_step()
     assert np.array_equal(d1["obs"], d2["obs"])
     env.close(); ref.close()
+
+
+def test_float32_observations_are_the_float64_block_rounded_on_the_device():
+    """obs_dtype=np.float32 (opt-in; the dtype the reference declares for its observation space, grid_env.py:346): step() and
+    download_step() return the float64 observation block rounded to nearest, every other output unchanged; the arrays come from the
+    same pool (an observation that is kept is not overwritten)."""
+    fs = P.ieee123_like(); B = 77
+    kw = dict(num_envs=B, solver="fbs", stochastic_loads=True, weather_variation=True)
+    e32 = P.BatchedGridEnvironment(fs, obs_dtype=np.float32, **kw)
+    e64 = P.BatchedGridEnvironment(fs, **kw)
+    seeds = np.arange(B, dtype=np.uint64) + 17
+    o0, _ = e32.reset(seed=seeds); e64.reset(seed=seeds)
+    assert o0.dtype == np.float64                      # reset() keeps the reference's values
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, (4, B, fs.action_dim))
+    kept = []
+    for k in range(4):
+        a32 = e32.step(acts[k]); a64 = e64.step(acts[k])
+        assert a32[0].dtype == np.float32 and a32[0].shape == (B, fs.obs_dim)
+        assert np.array_equal(a32[0], a64[0].astype(np.float32))
+        assert np.array_equal(a32[1], a64[1]) and np.array_equal(a32[2], a64[2]) and np.array_equal(a32[3], a64[3])
+        assert np.array_equal(a32[4]["total_losses"], a64[4]["total_losses"])
+        kept.append((a32[0], a32[0].copy()))
+    assert all(np.array_equal(a, c) for a, c in kept)
+    d32 = e32.handle.download_step(); d64 = e64.handle.download_step()
+    assert d32["obs"].dtype == np.float32 and np.array_equal(d32["obs"], d64["obs"].astype(np.float32))
+    with pytest.raises(ValueError):
+        P.BatchedGridEnvironment(fs, num_envs=4, obs_dtype=np.int32)
+    e32.close(); e64.close()
