@@ -713,7 +713,24 @@ def main():
         rz.close()
         return
     main_m = measure(fs, B, solver0, False, args.repeats, extras=(world == 1))
-    gather_m = measure(fs, B, solver0, True, args.repeats) if want_gather else None
+    # The exchange is the one part of an N-rank run no box of this pool could rehearse over real links: if setting it up fails the same
+    # way on every rank (no librccl, a communicator that cannot be formed), the line still goes out -- the sharded steps without the
+    # exchange, flagged -- instead of nothing.  The ranks agree on that through fixed-name rendezvous entries (not the sequence-numbered
+    # collectives, which a rank that raised half-way is out of step with).
+    gather_m, gather_error = None, None
+    if want_gather:
+        try:
+            gather_m = measure(fs, B, solver0, True, args.repeats)
+        except Exception as e:                                   # noqa: BLE001 -- reported in the line
+            gather_error = f"{type(e).__name__}: {e}"[:300]
+        try:
+            rz._put(f"gather_status.{rank}", (gather_error or "ok").encode())
+            states = [rz._get(f"gather_status.{r}", timeout=180.0).decode() for r in range(world)]
+        except Exception as e:                                   # noqa: BLE001
+            states = [f"rank {rank}: no status from a peer ({type(e).__name__})"]
+        bad = [f"rank {r}: {st}" for r, st in enumerate(states) if st != "ok"]
+        if bad:
+            gather_m, gather_error = None, "; ".join(bad)[:600]
     other = None
     if world == 1 and not args.no_secondary:
         other = measure(fs, B, "nr" if solver0 == "fbs" else "fbs", False, max(3, args.repeats // 2))
@@ -747,6 +764,9 @@ def main():
         for k in ("post_step_checks", "rollout", "with_host_io", "with_host_io_fresh_arrays", "with_host_io_pinned", "with_host_io_float32_observations"):
             if k in main_m:
                 result[k] = main_m[k]
+        if world > 1 and want_gather and gather_m is None:
+            result["obs_allgather_error"] = gather_error
+            result["gather_verified"] = False
         if world > 1:
             obs_bytes = B * (fs.obs_dim - 2 * fs.n_loads) * 8
             result["without_obs_allgather"] = {"value": plain["value"], "unit": "env_steps/s", "ms_per_step": plain["ms_per_step"],
