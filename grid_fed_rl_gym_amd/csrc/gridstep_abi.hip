@@ -1021,6 +1021,78 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     }
     if (why.empty()) {
       h->nrm = true; h->f2_small = false; h->f2_iw = IW; h->f2_nw = NW; h->f2_npos = NW * HV * NI;
+      // ---- iteration 0 as a matrix product (GsF2Tables::mesh_w): the flat-start Jacobian (power_flow.py:243-287, exact sign), inverted here
+      if (!getenv("GS_NR_NO_FLAT")) {
+        const int n_ = ht.n, sl = ht.slack, na = n_ - 1, N2 = 2 * na;
+        std::vector<double> v0(n_, 1.0);
+        if (ht.fixed_v[sl]) v0[sl] = ht.v_set[sl];
+        auto act = [&](int i) { return i < sl ? i : i - 1; };
+        std::vector<double> Pc(n_, 0.0), Qc(n_, 0.0), J((size_t)N2 * N2, 0.0);
+        for (int i = 0; i < n_; ++i)
+          for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+            const int j = ht.col[q];
+            const double g = i == j ? ht.Gd[i] : ht.G[q], bq = i == j ? ht.Bd[i] : ht.B[q];
+            Pc[i] += v0[i] * v0[j] * g; Qc[i] -= v0[i] * v0[j] * bq;
+          }
+        for (int i = 0; i < n_; ++i) {
+          if (i == sl) continue;
+          const int a = act(i);
+          const double vi = v0[i];
+          J[(size_t)(2 * a) * N2 + 2 * a] = -Qc[i] - vi * vi * ht.Bd[i];
+          J[(size_t)(2 * a) * N2 + 2 * a + 1] = Pc[i] / vi + vi * ht.Gd[i];
+          J[(size_t)(2 * a + 1) * N2 + 2 * a] = Pc[i] - vi * vi * ht.Gd[i];
+          J[(size_t)(2 * a + 1) * N2 + 2 * a + 1] = Qc[i] / vi - vi * ht.Bd[i];
+          for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+            const int j = ht.col[q];
+            if (j == i || j == sl) continue;
+            const int aj = act(j);
+            const double aa = vi * v0[j], gs_bc = -ht.B[q] * aa, gc_bs = ht.G[q] * aa;
+            J[(size_t)(2 * a) * N2 + 2 * aj] += gs_bc; J[(size_t)(2 * a) * N2 + 2 * aj + 1] += gc_bs / v0[j];
+            J[(size_t)(2 * a + 1) * N2 + 2 * aj] += -gc_bs; J[(size_t)(2 * a + 1) * N2 + 2 * aj + 1] += gs_bc / v0[j];
+          }
+        }
+        // J^-1 by Gauss-Jordan with partial pivoting on [J | I]
+        std::vector<double> Ji((size_t)N2 * N2, 0.0);
+        for (int u = 0; u < N2; ++u) Ji[(size_t)u * N2 + u] = 1.0;
+        bool ok = N2 > 0;
+        for (int c = 0; c < N2 && ok; ++c) {
+          int pr = c;
+          for (int r = c + 1; r < N2; ++r) if (std::fabs(J[(size_t)r * N2 + c]) > std::fabs(J[(size_t)pr * N2 + c])) pr = r;
+          const double pv = J[(size_t)pr * N2 + c];
+          if (!(pv != 0.0) || !std::isfinite(pv)) { ok = false; break; }
+          if (pr != c)
+            for (int k = 0; k < N2; ++k) { std::swap(J[(size_t)pr * N2 + k], J[(size_t)c * N2 + k]); std::swap(Ji[(size_t)pr * N2 + k], Ji[(size_t)c * N2 + k]); }
+          const double ip = 1.0 / pv;
+          for (int k = 0; k < N2; ++k) { J[(size_t)c * N2 + k] *= ip; Ji[(size_t)c * N2 + k] *= ip; }
+          for (int r = 0; r < N2; ++r) {
+            if (r == c) continue;
+            const double f = J[(size_t)r * N2 + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < N2; ++k) { J[(size_t)r * N2 + k] -= f * J[(size_t)c * N2 + k]; Ji[(size_t)r * N2 + k] -= f * Ji[(size_t)c * N2 + k]; }
+          }
+        }
+        if (ok) {
+          const int K = na + 1, Sst = 32;                     // (the kernel's product is unrolled over 32 k-steps of 4: K <= 128)
+          std::vector<double> wt((size_t)16 * Sst * 64, 0.0);
+          auto W = [&](int u, int k) -> double {
+            if (u >= N2 || k >= K) return 0.0;
+            if (k < na) return Ji[(size_t)u * N2 + 2 * k];
+            double c0 = 0.0;
+            for (int a2 = 0; a2 < na; ++a2) {
+              const int bus = a2 < sl ? a2 : a2 + 1;
+              c0 -= Ji[(size_t)u * N2 + 2 * a2] * Pc[bus] + Ji[(size_t)u * N2 + 2 * a2 + 1] * Qc[bus];
+            }
+            return c0;
+          };
+          if (N2 <= 256 && K <= 128) {
+            for (int t = 0; t < 16; ++t)
+              for (int s2 = 0; s2 < Sst; ++s2)
+                for (int ln = 0; ln < 64; ++ln) wt[((size_t)t * Sst + s2) * 64 + ln] = W(16 * t + (ln & 15), 4 * s2 + (ln >> 4));
+            { const int rcw = dev_upload(h, &F.mesh_w, wt); if (rcw) return bail(rcw); }
+            F.mesh_w_steps = Sst; F.mesh_slack = sl;
+          }
+        }
+      }
       h->mesh_levels = S.n_levels; h->mesh_rows = S.n_rows; h->mesh_units = S.msg_units; h->mesh_messages = S.n_messages; h->mesh_accs = S.n_accumulators;
       F.n_jump = 0; F.n_levels = S.n_levels; F.pos_off = 0; F.n_anc_ints = (int32_t)S.adj_ent.size(); F.ring_zero = 0;
       F.mesh_nz = (int32_t)S.ytab.size(); F.mesh_pairs = S.n_pairs;

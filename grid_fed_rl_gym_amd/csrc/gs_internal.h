@@ -486,6 +486,12 @@ struct GsF2Tables {
   const int32_t* mesh_items; const int32_t* mesh_rowinfo;      // packed items (GS_MESH_W_*), [NW * NI * 8][16]
   int32_t off_scr, mesh_nz;                                    // exchange scratch; doubles of the Ybus tables staged at off_z (pairs, then diagonal per slot)
   int32_t mesh_pairs, mesh_off_p;                              // P_spec by voltage slot, [slot][8 instances] doubles
+  // Iteration 0 of the meshed member as a matrix product (NULL: by elimination with the flat-start table).  At the flat start the
+  // Jacobian does not depend on the instance, so the first Newton step is a constant linear map of the instance's injections:
+  //   x = J0^-1 (S_spec - S_calc(flat)) = W [P_spec; 1]     (Q_spec = 0 at every PQ bus),
+  // W = [the angle-equation columns of J0^-1 | the constant term], (2 (n - 1)) x n, inverted ONCE on the host (gs_create) and stored in
+  // the operand order of v_mfma_f64_16x16x4: [16 row tiles][mesh_w_steps k-steps][64 lanes], A[row = lane & 15][k = lane >> 4].
+  const double* mesh_w; int32_t mesh_w_steps, mesh_slack;
 };
 
 // gs_k_rollout_post (kernels_env.hip): bookkeeping after step t of gs_rollout

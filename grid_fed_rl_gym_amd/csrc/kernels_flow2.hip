@@ -865,9 +865,6 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   const int NL = F.n_levels;
   const unsigned null_ent = (unsigned)F.n_anc_ints - 1u;
   if (threadIdx.x < 3 * IW) f2_st2((unsigned)o_tile + (threadIdx.x >> 3) * UB + ((threadIdx.x & 7u) << 4), make_double2(0.0, 0.0));   // the ZERO message (first read: behind the first check's barrier)
-  double T00[NI], T01[NI], T10[NI], T11[NI], sx0[NI], sx1[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) { T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; sx0[j] = 0.0; sx1[j] = 0.0; }
   // row j of the register arrays, j wave-uniform: a scalar compare-and-branch chain around the moves (the asm keeps the compiler
   // from turning it into 2 (NI - 1) selects per value)
 #define F2_ROW_CASE(Q, STMT) case Q: if constexpr (Q < NI) { constexpr int RQ = Q < NI ? Q : 0; STMT; asm volatile(""); } break;
@@ -933,7 +930,132 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     return lmax;
   };
   bool stale = true;
-  for (int it_ = 0; it_ < C.max_iterations; ++it_) {
+  int it_first = 0;
+  bool all_done = false;
+  // Iteration 0 with the matrix product (below) stands in FRONT of the loop and of the arrays the elimination keeps T / s in: inside
+  // the loop their 120 registers count as live across the product (the compiler cannot see through the row switch that the next
+  // elimination writes every entry before the back substitution reads it), and the product had nothing to prefetch into.
+  if (flat_use && F.mesh_w != nullptr && C.max_iterations > 0) {
+    const double lm = mismatch(true, false);
+    stp.hit(F2_ST_MISMATCH);
+    const double mm = wg_max(lm);
+    stp.hit(F2_ST_FLAG);
+    f2_check(st, mm, mm, 0, C.tolerance);
+    stale = false;
+    it_first = 1;
+    if (__all(st.done)) all_done = true;
+    else {
+      // ---------------- iteration 0 as a matrix product: x = W [P_spec; 1] on the matrix cores (GsF2Tables::mesh_w) ----------------
+      // At the flat start the first Newton step is a constant linear map of the instance's injections; carried through the levels of
+      // the elimination (q parts up, x down, the handle's table of D^-1 / T) it was 61 k of a step's 213 k cycles.  As a product:
+      // 16 row tiles x mesh_w_steps k-steps of v_mfma_f64_16x16x4, four tiles a wavefront; operand A = W (global memory, in operand
+      // order: one coalesced 512-byte read per MFMA, shared by every workgroup -> L2), operand B = P_spec of four buses x the
+      // workgroup's 8 instances from the LDS table (columns 8-15 of the tile: zero), result rows = (d theta, d|V|) of a bus.
+      {
+        typedef double f2_v4 __attribute__((ext_vector_type(4)));
+        const int ln = threadIdx.x & 63, q4 = ln >> 4, r16 = ln & 15;
+        constexpr int S = 32;                                           // k-steps of 4: n - 1 buses + the constant column <= 128 (host: zero-padded)
+        const int na_ = n - 1, sl = F.mesh_slack;
+        f2_v4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f2_v4{0.0, 0.0, 0.0, 0.0};
+        const double* wp = F.mesh_w + (size_t)wave * S * 64 + ln;       // tile wave + 4 i: + i * 4 S * 64
+        constexpr size_t tstride = (size_t)4 * S * 64;
+        // The B operands of all 32 k-steps first (LDS), then sixteen MFMAs a batch (half a tile), their A operands requested two
+        // batches ahead: W is shared by every workgroup but comes from the far side of the L2 often enough (~2 k cycles) that a k-step at
+        // a time, or four with two batches ahead, left the product waiting (56 k cycles for 128 MFMAs of 64 cycles each).
+        double bv[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+          const int a = 4 * s2 + q4;
+          const unsigned bus = (unsigned)(a < sl ? a : a + 1);
+          double b = 0.0;
+          if (r16 < IW) { if (a < na_) b = f2_ld((unsigned)F.mesh_off_p + 64u * bus + 8u * (unsigned)r16); else if (a == na_) b = 1.0; }
+          bv[s2] = b;
+        }
+        constexpr int CH = 16, NCH = 4 * S / CH;                         // 8 batches: batch c = tile c / 2, k-steps 16 (c % 2) ..
+        double ab[3][CH];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int e = 0; e < CH; ++e) ab[c][e] = wp[(size_t)(c / 2) * tstride + (size_t)(CH * (c % 2) + e) * 64];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (c + 2 < NCH) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) ab[(c + 2) % 3][e] = wp[(size_t)((c + 2) / 2) * tstride + (size_t)(CH * ((c + 2) % 2) + e) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) acc[c / 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[c % 3][e], bv[CH * (c % 2) + e], acc[c / 2], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // C/D[row = (lane >> 4) + 4 reg][col = lane & 15]: unknown u = 16 (wave + 4 i) + 4 g + q4 = 2 a + {0: angle, 1: magnitude}
+        if (r16 < IW) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int u = 16 * (wave + 4 * i) + 4 * g + q4, a = u >> 1;
+              if (a < na_) {
+                const unsigned bus = (unsigned)(a < sl ? a : a + 1);
+                *F2_P(double, (unsigned)o_tile + (6u + bus) * UB + ((unsigned)r16 << 4) + ((unsigned)(u & 1) << 3)) = acc[i][g];
+              }
+            }
+        }
+      }
+      stp.hit(14);
+      f2_lds_sync();
+      // corrections (power_flow.py:315-327) as a rotation and scaling of (e, f): the update of the back substitution below, row by row
+      {
+        const bool upd = !st.done;
+        const GS_CONST double* kc = (const GS_CONST double*)kF2Series;
+#pragma nounroll
+        for (int j = 0; j < NI; ++j) {
+          if (rinfo[4 * j] < 0) break;
+          const f2_i4 ia = items[(size_t)j * (HV * 4)];
+          if (upd && (ia.y & GS_MESH_F_PIVOT)) {
+            const double2 xk = f2_ld2(unit_at(6u + lo16(ia.x)));
+            const unsigned vo = vslot(lo16(ia.x));
+            const double2 v = f2_ld2(vo);
+            const double v2 = __builtin_fma(v.x, v.x, v.y * v.y), rvm0 = f2_rsq(v2), vm0 = v2 * rvm0;
+            const double dth = C.alpha * xk.x, vmn = vm0 + C.alpha * xk.y;
+            const bool big = __any(fabs(dth) > 0.5);
+            double h = dth;
+            if (big) {
+              const double k = rint(dth * 0.15915494309189535);
+              h = __builtin_fma(-k, 6.283185307179586, dth);
+              h = __builtin_fma(-k, 2.4492935982947064e-16, h);
+              h *= 0.125;
+            }
+            const double z = h * h;
+            double sp = kc[0];
+            sp = __builtin_fma(sp, z, kc[1]); sp = __builtin_fma(sp, z, kc[2]); sp = __builtin_fma(sp, z, kc[3]);
+            sp = __builtin_fma(sp, z, kc[4]); sp = __builtin_fma(sp, z, kc[5]); sp = __builtin_fma(sp, z, kc[6]); sp = __builtin_fma(sp, z, kc[7]);
+            double sn = h - h * z * sp;
+            double cp = kc[8];
+            cp = __builtin_fma(cp, z, kc[9]); cp = __builtin_fma(cp, z, kc[10]); cp = __builtin_fma(cp, z, kc[11]);
+            cp = __builtin_fma(cp, z, kc[12]); cp = __builtin_fma(cp, z, kc[13]); cp = __builtin_fma(cp, z, kc[14]); cp = __builtin_fma(cp, z, kc[15]);
+            double cs = __builtin_fma(z, cp, 1.0);
+            if (big) {
+#pragma unroll
+              for (int q = 0; q < 3; ++q) { const double c2 = __builtin_fma(cs, cs, -(sn * sn)), s2 = 2.0 * cs * sn; cs = c2; sn = s2; }
+            }
+            const double ratio = vmn * rvm0;
+            f2_st2(vo, make_double2(ratio * (v.x * cs - v.y * sn), ratio * (v.x * sn + v.y * cs)));
+          }
+        }
+      }
+      stp.hit(F2_ST_TOP_DOWN);
+      f2_lds_sync();                 // the new voltages are read by the neighbours' lanes in the next mismatch
+      stale = true;
+    }
+  }
+  double T00[NI], T01[NI], T10[NI], T11[NI], sx0[NI], sx1[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; sx0[j] = 0.0; sx1[j] = 0.0; }
+  if (!all_done)
+  for (int it_ = it_first; it_ < C.max_iterations; ++it_) {
     const bool flat_it = flat_use && it_ == 0;
     const double lm = mismatch(flat_it, flat_cap && it_ == 0);      // (capture: the first mismatch of the capture launch is the flat-start one)
     stp.hit(F2_ST_MISMATCH);
