@@ -936,6 +936,14 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   // the loop their 120 registers count as live across the product (the compiler cannot see through the row switch that the next
   // elimination writes every entry before the back substitution reads it), and the product had nothing to prefetch into.
   if (flat_use && F.mesh_w != nullptr && C.max_iterations > 0) {
+    // (the product's first two batches of A operands are requested here, in front of the flat-start check they do not depend on)
+    constexpr int WS = 32, WCH = 16;                                  // k-steps of 4 (host: zero-padded to 32); MFMAs a batch
+    const double* const wp = F.mesh_w + (size_t)wave * WS * 64 + (threadIdx.x & 63);      // tile wave + 4 i: + i * 4 WS * 64
+    double ab[3][WCH];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < WCH; ++e) ab[c][e] = wp[(size_t)(c / 2) * (4 * WS * 64) + (size_t)(WCH * (c % 2) + e) * 64];
     const double lm = mismatch(true, false);
     stp.hit(F2_ST_MISMATCH);
     const double mm = wg_max(lm);
@@ -954,12 +962,11 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       {
         typedef double f2_v4 __attribute__((ext_vector_type(4)));
         const int ln = threadIdx.x & 63, q4 = ln >> 4, r16 = ln & 15;
-        constexpr int S = 32;                                           // k-steps of 4: n - 1 buses + the constant column <= 128 (host: zero-padded)
+        constexpr int S = WS;                                           // k-steps of 4: n - 1 buses + the constant column <= 128
         const int na_ = n - 1, sl = F.mesh_slack;
         f2_v4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f2_v4{0.0, 0.0, 0.0, 0.0};
-        const double* wp = F.mesh_w + (size_t)wave * S * 64 + ln;       // tile wave + 4 i: + i * 4 S * 64
         constexpr size_t tstride = (size_t)4 * S * 64;
         // The B operands of all 32 k-steps first (LDS), then sixteen MFMAs a batch (half a tile), their A operands requested two
         // batches ahead: W is shared by every workgroup but comes from the far side of the L2 often enough (~2 k cycles) that a k-step at
@@ -973,12 +980,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
           if (r16 < IW) { if (a < na_) b = f2_ld((unsigned)F.mesh_off_p + 64u * bus + 8u * (unsigned)r16); else if (a == na_) b = 1.0; }
           bv[s2] = b;
         }
-        constexpr int CH = 16, NCH = 4 * S / CH;                         // 8 batches: batch c = tile c / 2, k-steps 16 (c % 2) ..
-        double ab[3][CH];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int e = 0; e < CH; ++e) ab[c][e] = wp[(size_t)(c / 2) * tstride + (size_t)(CH * (c % 2) + e) * 64];
+        constexpr int CH = WCH, NCH = 4 * S / CH;                        // 8 batches: batch c = tile c / 2, k-steps 16 (c % 2) ..
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           if (c + 2 < NCH) {
@@ -1010,7 +1012,8 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       {
         const bool upd = !st.done;
         const GS_CONST double* kc = (const GS_CONST double*)kF2Series;
-#pragma nounroll
+        // (two rows in flight: the rows are independent here, and a row alone is a chain of two LDS reads, a reciprocal square root and two series)
+#pragma unroll 2
         for (int j = 0; j < NI; ++j) {
           if (rinfo[4 * j] < 0) break;
           const f2_i4 ia = items[(size_t)j * (HV * 4)];
