@@ -907,7 +907,7 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
   auto mismatch = [&](bool flat_it, bool capture) -> double {
     double lmax = 0.0, bad = 0.0, ps = 0.0;
     f2_i4 nxt = load_item(0);
-#pragma nounroll
+#pragma unroll 2
     for (int j = 0; j < NI; ++j) {
       const int lev = rinfo[4 * j];
       if (lev < 0) break;                                        // a wave's rows are the first of its NI
@@ -1054,9 +1054,6 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
       stale = true;
     }
   }
-  double T00[NI], T01[NI], T10[NI], T11[NI], sx0[NI], sx1[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) { T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; sx0[j] = 0.0; sx1[j] = 0.0; }
   if (!all_done)
   for (int it_ = it_first; it_ < C.max_iterations; ++it_) {
     const bool flat_it = flat_use && it_ == 0;
@@ -1067,6 +1064,12 @@ __device__ __forceinline__ void f2_step(const GsTables& T, const GsF2Tables& F, 
     f2_check(st, mm, mm, it_, C.tolerance);
     stale = false;
     if (__all(st.done) && !(flat_cap && it_ == 0)) break;        // (the capture launch always runs its first elimination)
+    // T / s of the wave's rows: written by this iteration's elimination, read by its back substitution -- declared HERE, so that their
+    // 120 registers are not live across the mismatch pass above (declared in front of the loop they were: the compiler cannot see
+    // through the row switch that every entry is written before it is read)
+    double T00[NI], T01[NI], T10[NI], T11[NI], sx0[NI], sx1[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { T00[j] = 0.0; T01[j] = 0.0; T10[j] = 0.0; T11[j] = 0.0; sx0[j] = 0.0; sx1[j] = 0.0; }
     // ---------------- elimination, level by level ----------------
     {
       int lv = 0;
