@@ -227,3 +227,58 @@ def test_networks_the_meshed_member_does_not_take_say_why_and_run_on_the_kernel_
         if kw.get("jacobian") == "exact":
             assert info["power_flow_converged"].all()
         env.close()
+
+
+def _relabel(spec, perm):
+    """The same network with bus i renamed perm[i] (the slack need not be bus 0: the matrix product of iteration 0 and the
+    scheduler both index buses, not "non-slack buses")."""
+    import dataclasses
+    perm = np.asarray(perm)
+    inv = np.argsort(perm)
+    m = lambda a: perm[np.asarray(a)].astype(np.int32)
+    return dataclasses.replace(spec, name=spec.name + "_relabelled", bus_type=spec.bus_type[inv].copy(), v_set=spec.v_set[inv].copy(),
+                               frm=m(spec.frm), to=m(spec.to), load_bus=m(spec.load_bus), gen_bus=m(spec.gen_bus), bat_bus=m(spec.bat_bus),
+                               bus_ids=[spec.bus_ids[i] for i in inv])
+
+
+def test_meshed_member_with_the_slack_in_the_middle_and_with_devices_equals_the_oracle():
+    """Iteration 0 is a matrix product x = W [P_spec; 1] over the NON-slack buses in bus order: with the slack renamed to bus 7 of 40,
+    and with batteries and generators on the network (their powers enter P_spec), environment steps still equal the NumPy oracle's,
+    iteration counts included; and they equal the same handle's without the flat-start shortcuts (GS_NR_NO_FLAT=1) to 1e-12."""
+    import dataclasses, os
+    base = P.random_meshed(40, 6, seed=2)
+    perm = np.arange(40); perm[[0, 7]] = perm[[7, 0]]; perm[[3, 22]] = perm[[22, 3]]
+    spec = _relabel(base, perm)
+    spec = dataclasses.replace(spec, gen_bus=np.array([5, 31], dtype=np.int32), gen_kind=np.array([0, 1], dtype=np.int32), gen_cap=np.array([300e3, 200e3]),
+                               gen_p0=np.array([0.2, 3.0]), gen_p1=np.array([1500.0, 12.0]), gen_p2=np.array([0.0, 25.0]),
+                               bat_bus=np.array([11], dtype=np.int32), bat_cap=np.array([500e3]), bat_rating=np.array([100e3]), bat_eff=np.array([0.95]))
+    assert int(np.flatnonzero(spec.bus_type == 2)[0]) == 7
+    B, T = 19, 3
+    rng = np.random.default_rng(8)
+    actions = rng.uniform(-1, 1, (T, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 50
+    cfg = dict(stochastic_loads=True, weather_variation=True, power_base=spec.base_power_va, solver="nr", tolerance=1e-9, max_iterations=50,
+               jacobian_mode="exact", zero_z="open")
+    ref = _oracle_rollout(spec, cfg, actions, seeds, first_instance=0)
+    outs = []
+    for no_flat in (False, True):
+        if no_flat:
+            os.environ["GS_NR_NO_FLAT"] = "1"
+        try:
+            env = _env(spec, B)
+        finally:
+            os.environ.pop("GS_NR_NO_FLAT", None)
+        assert env.handle.describe()["kernel"] == "nr_mesh2"
+        env.reset(seed=seeds)
+        got = []
+        for t in range(T):
+            obs, rew, term, trunc, info = env.step(actions[t])
+            assert info["power_flow_converged"].all()
+            for b in range(B):
+                o, r, te, tr, inf = ref[b][t]
+                assert np.max(np.abs(obs[b] - o) / np.maximum(1.0, np.abs(o))) < 1e-8, (no_flat, t, b)
+                assert int(info["iterations"][b]) == int(inf["iterations"])
+            got.append(obs.copy())
+        outs.append(got); env.close()
+    for a, b in zip(*outs):
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-12
