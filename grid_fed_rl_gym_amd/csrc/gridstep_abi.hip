@@ -1258,6 +1258,64 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return bail(fail(nullptr, GS_E_HIP, "dense_mfma: factorisation of the flat-start Jacobian failed"));
       D.flat = flat;
+      // ---- and its inverse, for iteration 0 as one product (GsDenseArgs::jinv_t): the same entries as the kernel's assembly
+      // (power_flow.py:243-287, exact sign; fixed components and padding unknowns: identity rows and columns), flat start
+      if (h->dense_blockrow) {
+        const int n_ = ht.n, NPd = 64 * NB;
+        std::vector<double> v0(n_, 1.0), Pc(n_, 0.0), Qc(n_, 0.0), Jm((size_t)NPd * NPd, 0.0), Ji((size_t)NPd * NPd, 0.0);
+        for (int i = 0; i < n_; ++i) if (ht.fixed_v[i]) v0[i] = ht.v_set[i];
+        for (int i = 0; i < n_; ++i)
+          for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+            const int j = ht.col[q];
+            Pc[i] += v0[i] * v0[j] * ht.G[q]; Qc[i] -= v0[i] * v0[j] * ht.B[q];
+          }
+        for (int u = 0; u < NPd; ++u) Jm[(size_t)u * NPd + u] = 1.0;              // padding / fixed components
+        for (int i = 0; i < n_; ++i) {
+          const int a = act_of[i];
+          if (a < 0) continue;
+          const bool thi = ht.th_free[i] != 0, vfi = ht.vm_free[i] != 0;
+          const double vi = v0[i], vvb = vi * vi * ht.Bd[i];
+          Jm[(size_t)(2 * a) * NPd + 2 * a] = thi ? (-Qc[i] - vvb) : 1.0;
+          Jm[(size_t)(2 * a) * NPd + 2 * a + 1] = (thi && vfi) ? (Pc[i] / vi + vi * ht.Gd[i]) : 0.0;
+          Jm[(size_t)(2 * a + 1) * NPd + 2 * a] = (thi && vfi) ? (Pc[i] - vi * vi * ht.Gd[i]) : 0.0;
+          Jm[(size_t)(2 * a + 1) * NPd + 2 * a + 1] = vfi ? (Qc[i] / vi - vi * ht.Bd[i]) : 1.0;
+          for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+            const int j = ht.col[q];
+            if (j == i || act_of[j] < 0) continue;
+            const int aj = act_of[j];
+            const bool thj = ht.th_free[j] != 0, vfj = ht.vm_free[j] != 0;
+            const double aa = vi * v0[j], gs_bc = -ht.B[q] * aa, gc_bs = ht.G[q] * aa;
+            if (thi && thj) Jm[(size_t)(2 * a) * NPd + 2 * aj] = gs_bc;
+            if (thi && vfj) Jm[(size_t)(2 * a) * NPd + 2 * aj + 1] = gc_bs / v0[j];
+            if (vfi && thj) Jm[(size_t)(2 * a + 1) * NPd + 2 * aj] = -gc_bs;
+            if (vfi && vfj) Jm[(size_t)(2 * a + 1) * NPd + 2 * aj + 1] = gs_bc / v0[j];
+          }
+        }
+        for (int u = 0; u < NPd; ++u) Ji[(size_t)u * NPd + u] = 1.0;
+        bool ok = true;
+        for (int c = 0; c < NPd && ok; ++c) {
+          int pr = c;
+          for (int r = c + 1; r < NPd; ++r) if (std::fabs(Jm[(size_t)r * NPd + c]) > std::fabs(Jm[(size_t)pr * NPd + c])) pr = r;
+          const double pv = Jm[(size_t)pr * NPd + c];
+          if (!(pv != 0.0) || !std::isfinite(pv)) { ok = false; break; }
+          if (pr != c)
+            for (int k = 0; k < NPd; ++k) { std::swap(Jm[(size_t)pr * NPd + k], Jm[(size_t)c * NPd + k]); std::swap(Ji[(size_t)pr * NPd + k], Ji[(size_t)c * NPd + k]); }
+          const double ip = 1.0 / pv;
+          for (int k = 0; k < NPd; ++k) { Jm[(size_t)c * NPd + k] *= ip; Ji[(size_t)c * NPd + k] *= ip; }
+          for (int r = 0; r < NPd; ++r) {
+            if (r == c) continue;
+            const double f = Jm[(size_t)r * NPd + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < NPd; ++k) { Jm[(size_t)r * NPd + k] -= f * Jm[(size_t)c * NPd + k]; Ji[(size_t)r * NPd + k] -= f * Ji[(size_t)c * NPd + k]; }
+          }
+        }
+        if (ok) {
+          std::vector<double> jt((size_t)NPd * NPd);
+          for (int u = 0; u < NPd; ++u)
+            for (int c = 0; c < NPd; ++c) jt[(size_t)c * NPd + u] = Ji[(size_t)u * NPd + c];
+          if ((rc = dev_upload(h, &D.jinv_t, jt))) return bail(rc);
+        }
+      }
     }
   }
   // a step as two half-grid launches on two streams: only where each half still gives every CU a workgroup

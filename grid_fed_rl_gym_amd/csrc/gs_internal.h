@@ -337,6 +337,10 @@ struct GsDenseArgs {
   // are computed ONCE per handle (mode 1: one workgroup runs the factorisation below into `flat`) and iteration 0 of every solve
   // only substitutes with them -- a third of the factorisations of a typical three-iteration solve.
   double* flat;                              // [NB * NB blocks + 1 flag] or NULL
+  // Iteration 0 as ONE matrix-vector product (block-row form): the inverse of the flat-start Jacobian, transposed ([column][row], NP x NP,
+  // NP = 64 NB), inverted once on the host -- x = J0^-1 rhs instead of a forward and a back substitution over the flat-start factors
+  // (seven block steps of two barriers and a round trip to the table each).  NULL: the factors.
+  const double* jinv_t;
   int32_t mode, pad2;                        // 0 solve, 1 factor the flat-start Jacobian into `flat`
   unsigned long long* stamps;                // diagnostic (gs_debug_stamps): cycles per phase of workgroup 0, NULL = off
   GsRows R;

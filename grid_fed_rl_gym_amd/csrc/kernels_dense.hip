@@ -556,13 +556,40 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
         if (mm < A.tol) { conv = 1; status = GS_STATUS_OK; break; }
       }
       int sing = 0;
+      bool skip_subst = false;
       double* fs = scr;                                    // where this iteration's block factors live
       if (A.flat != nullptr && it == 0 && !A.mode) {
         // iteration 0: the flat-start factors of the handle; forward substitution r_i -= L_ij r_j from the stored blocks
         fs = A.flat;
         sing = A.flat[(size_t)NB * NB * DB * DB] != 0.0 ? 1 : 0;
-        for (int i = 1; i < NB; ++i) gd_matvec64_sum(rhs + DB * i, gd_blk(fs, NB, 0, i, 0), (long)DB * DB, rhs, DB, i);
-        stp.hit(5);
+        if constexpr (BLOCKROW) {
+          if (A.jinv_t != nullptr) {
+            // x = J0^-1 rhs as one product: thread u forms sum_c J0^-1[u][c] rhs[c] over the transposed inverse (a coalesced 8-byte
+            // column read per c, the same 512 KB for every workgroup -> L2; rhs[c] is an LDS broadcast), sixty-four columns in flight
+            double acc_x = 0.0;
+            if (tid < NP) {
+              const double* jt = A.jinv_t + tid;
+              // (NP is a multiple of 64; a round trip to the table under load is ~2 k cycles: sixteen columns in flight made the
+              // product as long as the substitutions it replaces)
+              for (int c0 = 0; c0 < NP; c0 += 64) {
+                double jv[64];
+#pragma unroll
+                for (int e = 0; e < 64; ++e) jv[e] = jt[(size_t)(c0 + e) * NP];
+#pragma unroll
+                for (int e = 0; e < 64; ++e) acc_x = __builtin_fma(jv[e], rhs[c0 + e], acc_x);
+              }
+            }
+            __syncthreads();                                 // every thread has read rhs
+            if (tid < NP) rhs[tid] = acc_x;
+            __syncthreads();
+            stp.hit(6);
+            skip_subst = true;
+          }
+        }
+        if (!skip_subst) {
+          for (int i = 1; i < NB; ++i) gd_matvec64_sum(rhs + DB * i, gd_blk(fs, NB, 0, i, 0), (long)DB * DB, rhs, DB, i);
+          stp.hit(5);
+        }
       } else {
       if (A.mode) scr = A.flat;
       // ---- block LU, left-looking over the panels
@@ -753,8 +780,9 @@ __device__ __forceinline__ void gd_newton(GsDenseArgs A_, double* __restrict__ s
       }
       }
       // ---- back substitution: x_j = D_j^-1 (r_j - sum_{k > j} U_jk x_k); x overwrites r block by block
-      for (int j = NB - 1; j >= 0; --j)
-        gd_backstep(rhs + DB * j, gd_blk(fs, NB, 1, j, j + 1), rhs + DB * (j + 1), NB - 1 - j, gd_blk(fs, NB, 2, j, 0), gjbuf);
+      if (!skip_subst)
+        for (int j = NB - 1; j >= 0; --j)
+          gd_backstep(rhs + DB * j, gd_blk(fs, NB, 1, j, j + 1), rhs + DB * (j + 1), NB - 1 - j, gd_blk(fs, NB, 2, j, 0), gjbuf);
       stp.hit(6);
       sing = gd_block_max(sing ? 1.0 : 0.0, red) != 0.0 ? 1 : 0;
       if (sing) { status = GS_STATUS_SINGULAR; break; }      // power_flow.py:188-190: keep the current voltages
