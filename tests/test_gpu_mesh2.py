@@ -282,3 +282,36 @@ def test_meshed_member_with_the_slack_in_the_middle_and_with_devices_equals_the_
         outs.append(got); env.close()
     for a, b in zip(*outs):
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-12
+
+
+def test_meshed_member_beyond_128_buses_keeps_the_flat_start_table_path():
+    """The matrix product of iteration 0 is laid out for at most 128 columns (n - 1 buses + the constant): a larger feeder the member
+    is still eligible for runs iteration 0 by elimination with the handle's flat-start table, as before -- same answers as the slab-row
+    sparse LU, equal iteration counts."""
+    spec = P.random_meshed(170, 8, seed=3)
+    B = 24
+    rng = np.random.default_rng(4)
+    acts = rng.uniform(-1, 1, (2, B, spec.action_dim))
+    seeds = np.arange(B, dtype=np.uint64) + 2
+    outs = []
+    import os
+    for no_mesh in (False, True):
+        if no_mesh:
+            os.environ["GS_NO_MESH2"] = "1"
+        try:
+            env = _env(spec, B)
+        finally:
+            os.environ.pop("GS_NO_MESH2", None)
+        d = env.handle.describe()
+        if not no_mesh and d["kernel"] != "nr_mesh2":
+            env.close()
+            pytest.skip("this feeder is not eligible for the meshed member: " + d["mesh2"])
+        env.reset(seed=seeds)
+        got = []
+        for t in range(2):
+            obs, rew, term, trunc, info = env.step(acts[t])
+            assert info["power_flow_converged"].all()
+            got.append((obs.copy(), info["iterations"].copy()))
+        outs.append(got); env.close()
+    for (o1, i1), (o2, i2) in zip(*outs):
+        assert np.array_equal(i1, i2) and np.max(np.abs(o1 - o2) / np.maximum(1.0, np.abs(o2))) < 1e-10
