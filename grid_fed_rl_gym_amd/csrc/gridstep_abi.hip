@@ -471,6 +471,77 @@ void copy_info(gs_handle* h, double* reward, uint8_t* term, uint8_t* trunc, cons
   if (info->status) memcpy(info->status, i32 + (size_t)SI_STATUS * Bp, B * sizeof(int32_t));
 }
 
+
+// The first Newton step from the flat start as a constant linear map of the injections (GsF2Tables::mesh_w): for a network whose
+// buses other than the slack are all PQ buses,  x = J0^-1 (S_spec - S_calc(flat)) = W [P_spec; 1]  with Q_spec = 0 -- W = the
+// angle-equation columns of J0^-1 and the constant term, (2 (n - 1)) x n.  J0: the exact Jacobian (power_flow.py:243-287) at |V| = 1,
+// angle 0 (the slack at its set point), inverted by Gauss-Jordan with partial pivoting.  Output in the operand order of
+// v_mfma_f64_16x16x4: [tiles row tiles][steps k-steps][64 lanes], A[row = lane & 15][k = lane >> 4], zero-padded.  false: J0 singular
+// or the sizes do not fit.
+static bool flat_newton_map(const HostTopology& ht, int tiles, int steps, std::vector<double>& wt) {
+  const int n_ = ht.n, sl = ht.slack, na = n_ - 1, N2 = 2 * na, K = na + 1;
+  if (na < 1 || N2 > 16 * tiles || K > 4 * steps) return false;
+  std::vector<double> v0(n_, 1.0);
+  if (ht.fixed_v[sl]) v0[sl] = ht.v_set[sl];
+  auto act = [&](int i) { return i < sl ? i : i - 1; };
+  std::vector<double> Pc(n_, 0.0), Qc(n_, 0.0), J((size_t)N2 * N2, 0.0);
+  for (int i = 0; i < n_; ++i)
+    for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+      const int j = ht.col[q];
+      const double g = i == j ? ht.Gd[i] : ht.G[q], bq = i == j ? ht.Bd[i] : ht.B[q];
+      Pc[i] += v0[i] * v0[j] * g; Qc[i] -= v0[i] * v0[j] * bq;
+    }
+  for (int i = 0; i < n_; ++i) {
+    if (i == sl) continue;
+    const int a = act(i);
+    const double vi = v0[i];
+    J[(size_t)(2 * a) * N2 + 2 * a] = -Qc[i] - vi * vi * ht.Bd[i];
+    J[(size_t)(2 * a) * N2 + 2 * a + 1] = Pc[i] / vi + vi * ht.Gd[i];
+    J[(size_t)(2 * a + 1) * N2 + 2 * a] = Pc[i] - vi * vi * ht.Gd[i];
+    J[(size_t)(2 * a + 1) * N2 + 2 * a + 1] = Qc[i] / vi - vi * ht.Bd[i];
+    for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
+      const int j = ht.col[q];
+      if (j == i || j == sl) continue;
+      const int aj = act(j);
+      const double aa = vi * v0[j], gs_bc = -ht.B[q] * aa, gc_bs = ht.G[q] * aa;
+      J[(size_t)(2 * a) * N2 + 2 * aj] += gs_bc; J[(size_t)(2 * a) * N2 + 2 * aj + 1] += gc_bs / v0[j];
+      J[(size_t)(2 * a + 1) * N2 + 2 * aj] += -gc_bs; J[(size_t)(2 * a + 1) * N2 + 2 * aj + 1] += gs_bc / v0[j];
+    }
+  }
+  std::vector<double> Ji((size_t)N2 * N2, 0.0);
+  for (int u = 0; u < N2; ++u) Ji[(size_t)u * N2 + u] = 1.0;
+  for (int c = 0; c < N2; ++c) {
+    int pr = c;
+    for (int r = c + 1; r < N2; ++r) if (std::fabs(J[(size_t)r * N2 + c]) > std::fabs(J[(size_t)pr * N2 + c])) pr = r;
+    const double pv = J[(size_t)pr * N2 + c];
+    if (!(pv != 0.0) || !std::isfinite(pv)) return false;
+    if (pr != c)
+      for (int k = 0; k < N2; ++k) { std::swap(J[(size_t)pr * N2 + k], J[(size_t)c * N2 + k]); std::swap(Ji[(size_t)pr * N2 + k], Ji[(size_t)c * N2 + k]); }
+    const double ip = 1.0 / pv;
+    for (int k = 0; k < N2; ++k) { J[(size_t)c * N2 + k] *= ip; Ji[(size_t)c * N2 + k] *= ip; }
+    for (int r = 0; r < N2; ++r) {
+      if (r == c) continue;
+      const double f = J[(size_t)r * N2 + c];
+      if (f == 0.0) continue;
+      for (int k = 0; k < N2; ++k) { J[(size_t)r * N2 + k] -= f * J[(size_t)c * N2 + k]; Ji[(size_t)r * N2 + k] -= f * Ji[(size_t)c * N2 + k]; }
+    }
+  }
+  std::vector<double> cst(N2, 0.0);
+  for (int u = 0; u < N2; ++u)
+    for (int a2 = 0; a2 < na; ++a2) {
+      const int bus = a2 < sl ? a2 : a2 + 1;
+      cst[u] -= Ji[(size_t)u * N2 + 2 * a2] * Pc[bus] + Ji[(size_t)u * N2 + 2 * a2 + 1] * Qc[bus];
+    }
+  wt.assign((size_t)tiles * steps * 64, 0.0);
+  for (int t = 0; t < tiles; ++t)
+    for (int s2 = 0; s2 < steps; ++s2)
+      for (int ln = 0; ln < 64; ++ln) {
+        const int u = 16 * t + (ln & 15), k = 4 * s2 + (ln >> 4);
+        if (u < N2 && k < K) wt[((size_t)t * steps + s2) * 64 + ln] = k < na ? Ji[(size_t)u * N2 + 2 * k] : cst[u];
+      }
+  return true;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1021,76 +1092,12 @@ int gs_create(const gs_topology* topo, const gs_config* cfg, int32_t batch, int3
     }
     if (why.empty()) {
       h->nrm = true; h->f2_small = false; h->f2_iw = IW; h->f2_nw = NW; h->f2_npos = NW * HV * NI;
-      // ---- iteration 0 as a matrix product (GsF2Tables::mesh_w): the flat-start Jacobian (power_flow.py:243-287, exact sign), inverted here
-      if (!getenv("GS_NR_NO_FLAT")) {
-        const int n_ = ht.n, sl = ht.slack, na = n_ - 1, N2 = 2 * na;
-        std::vector<double> v0(n_, 1.0);
-        if (ht.fixed_v[sl]) v0[sl] = ht.v_set[sl];
-        auto act = [&](int i) { return i < sl ? i : i - 1; };
-        std::vector<double> Pc(n_, 0.0), Qc(n_, 0.0), J((size_t)N2 * N2, 0.0);
-        for (int i = 0; i < n_; ++i)
-          for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
-            const int j = ht.col[q];
-            const double g = i == j ? ht.Gd[i] : ht.G[q], bq = i == j ? ht.Bd[i] : ht.B[q];
-            Pc[i] += v0[i] * v0[j] * g; Qc[i] -= v0[i] * v0[j] * bq;
-          }
-        for (int i = 0; i < n_; ++i) {
-          if (i == sl) continue;
-          const int a = act(i);
-          const double vi = v0[i];
-          J[(size_t)(2 * a) * N2 + 2 * a] = -Qc[i] - vi * vi * ht.Bd[i];
-          J[(size_t)(2 * a) * N2 + 2 * a + 1] = Pc[i] / vi + vi * ht.Gd[i];
-          J[(size_t)(2 * a + 1) * N2 + 2 * a] = Pc[i] - vi * vi * ht.Gd[i];
-          J[(size_t)(2 * a + 1) * N2 + 2 * a + 1] = Qc[i] / vi - vi * ht.Bd[i];
-          for (int q = ht.row_ptr[i]; q < ht.row_ptr[i + 1]; ++q) {
-            const int j = ht.col[q];
-            if (j == i || j == sl) continue;
-            const int aj = act(j);
-            const double aa = vi * v0[j], gs_bc = -ht.B[q] * aa, gc_bs = ht.G[q] * aa;
-            J[(size_t)(2 * a) * N2 + 2 * aj] += gs_bc; J[(size_t)(2 * a) * N2 + 2 * aj + 1] += gc_bs / v0[j];
-            J[(size_t)(2 * a + 1) * N2 + 2 * aj] += -gc_bs; J[(size_t)(2 * a + 1) * N2 + 2 * aj + 1] += gs_bc / v0[j];
-          }
-        }
-        // J^-1 by Gauss-Jordan with partial pivoting on [J | I]
-        std::vector<double> Ji((size_t)N2 * N2, 0.0);
-        for (int u = 0; u < N2; ++u) Ji[(size_t)u * N2 + u] = 1.0;
-        bool ok = N2 > 0;
-        for (int c = 0; c < N2 && ok; ++c) {
-          int pr = c;
-          for (int r = c + 1; r < N2; ++r) if (std::fabs(J[(size_t)r * N2 + c]) > std::fabs(J[(size_t)pr * N2 + c])) pr = r;
-          const double pv = J[(size_t)pr * N2 + c];
-          if (!(pv != 0.0) || !std::isfinite(pv)) { ok = false; break; }
-          if (pr != c)
-            for (int k = 0; k < N2; ++k) { std::swap(J[(size_t)pr * N2 + k], J[(size_t)c * N2 + k]); std::swap(Ji[(size_t)pr * N2 + k], Ji[(size_t)c * N2 + k]); }
-          const double ip = 1.0 / pv;
-          for (int k = 0; k < N2; ++k) { J[(size_t)c * N2 + k] *= ip; Ji[(size_t)c * N2 + k] *= ip; }
-          for (int r = 0; r < N2; ++r) {
-            if (r == c) continue;
-            const double f = J[(size_t)r * N2 + c];
-            if (f == 0.0) continue;
-            for (int k = 0; k < N2; ++k) { J[(size_t)r * N2 + k] -= f * J[(size_t)c * N2 + k]; Ji[(size_t)r * N2 + k] -= f * Ji[(size_t)c * N2 + k]; }
-          }
-        }
-        if (ok) {
-          const int K = na + 1, Sst = 32;                     // (the kernel's product is unrolled over 32 k-steps of 4: K <= 128)
-          std::vector<double> wt((size_t)16 * Sst * 64, 0.0);
-          auto W = [&](int u, int k) -> double {
-            if (u >= N2 || k >= K) return 0.0;
-            if (k < na) return Ji[(size_t)u * N2 + 2 * k];
-            double c0 = 0.0;
-            for (int a2 = 0; a2 < na; ++a2) {
-              const int bus = a2 < sl ? a2 : a2 + 1;
-              c0 -= Ji[(size_t)u * N2 + 2 * a2] * Pc[bus] + Ji[(size_t)u * N2 + 2 * a2 + 1] * Qc[bus];
-            }
-            return c0;
-          };
-          if (N2 <= 256 && K <= 128) {
-            for (int t = 0; t < 16; ++t)
-              for (int s2 = 0; s2 < Sst; ++s2)
-                for (int ln = 0; ln < 64; ++ln) wt[((size_t)t * Sst + s2) * 64 + ln] = W(16 * t + (ln & 15), 4 * s2 + (ln >> 4));
-            { const int rcw = dev_upload(h, &F.mesh_w, wt); if (rcw) return bail(rcw); }
-            F.mesh_w_steps = Sst; F.mesh_slack = sl;
-          }
+      // ---- iteration 0 as a matrix product (GsF2Tables::mesh_w): the flat-start Jacobian, inverted once on the host
+      if (!getenv("GS_NR_NO_FLAT") && ht.n <= 128) {
+        std::vector<double> wt;
+        if (flat_newton_map(ht, 16, 32, wt)) {
+          { const int rcw = dev_upload(h, &F.mesh_w, wt); if (rcw) return bail(rcw); }
+          F.mesh_w_steps = 32; F.mesh_slack = ht.slack;
         }
       }
       h->mesh_levels = S.n_levels; h->mesh_rows = S.n_rows; h->mesh_units = S.msg_units; h->mesh_messages = S.n_messages; h->mesh_accs = S.n_accumulators;
