@@ -114,6 +114,7 @@ SYMBOLS = [
     ("gs_comm_info", C.c_int, [_H, C.c_void_p]),
     ("gs_host_obs_bind", C.c_int, [_H, _dp]),
     ("gs_host_obs_unbind", C.c_int, [_H, _dp]),
+    ("gs_flat_newton_map_dump", C.c_int, [C.c_void_p, C.c_int32, _dp]),
     ("gs_mesh_schedule_dump_packed", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip, _ip, _dp, _ip]),
     ("gs_mesh_schedule_dump", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_char_p, C.c_int32,
                                         C.c_void_p, _ip, _ip, _dp]),
@@ -283,6 +284,18 @@ MESH_ITEM_DTYPE = np.dtype([("vk_off", "<i4"), ("vj_off", "<i4"), ("xk_off", "<i
                             ("adj_ptr", "<i4"), ("bus", "<i4"), ("ykj_g", "<f8"), ("ykj_b", "<f8"), ("ykk_g", "<f8"), ("ykk_b", "<f8"),
                             ("mout", "<i4", (8,)), ("cq_in", "<i4", (4,)), ("rw_in", "<i4", (4,)), ("cl_in", "<i4", (4,)),
                             ("nbr", "<i4"), ("pos", "<i4"), ("pad", "<i4", (10,))])      # GsMeshItem, csrc/gs_internal.h
+
+
+def flat_newton_map(spec, zero_z="open") -> np.ndarray:
+    """gs_flat_newton_map_dump: W [2 (n - 1), n] with x = W [P_spec (non-slack buses, bus order); 1] -- the first Newton step from the flat
+    start as the meshed step kernel takes it (host arithmetic, no GPU)."""
+    lib = load()
+    t, keep = _topology_of(spec)
+    out = np.zeros((2 * (spec.n - 1), spec.n))
+    rc = lib.gs_flat_newton_map_dump(C.byref(t), ZERO_Z[zero_z], _ptr(out, _dp))
+    if rc != GS_OK:
+        raise PowerFlowError(f"gs_flat_newton_map_dump failed ({rc}): {lib.gs_last_error(None).decode()}")
+    return out
 
 
 def mesh_schedule(spec: FeederSpec, nw: int = 4, ni: int = 10, acc_cap: int = 4, region_base: int = 0, slot_bytes: int = 144,

@@ -2414,6 +2414,26 @@ int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, i
   return GS_OK;
 }
 
+// The flat-start Newton map of the meshed member's iteration 0 (GsF2Tables::mesh_w), host arithmetic only (no GPU): out = W as a plain
+// row-major [2 (n - 1)][n] matrix (column n - 1: the constant term; rows = (d theta, d|V|) of the non-slack buses in bus order), so that
+// x = W [P_spec of the non-slack buses in bus order; 1].  Test aid.  GS_E_TOPOLOGY: the network has a bus that is neither the slack nor PQ,
+// or the flat-start Jacobian is singular.
+int gs_flat_newton_map_dump(const gs_topology* topo, int32_t zero_z_mode, double* out) {
+  if (!topo || !out) return fail(nullptr, GS_E_INVALID, "topology / out is NULL");
+  if (topo->struct_size != (int32_t)sizeof(gs_topology)) return fail(nullptr, GS_E_INVALID, "struct_size mismatch");
+  HostTopology ht;
+  const std::string err = gs_compile_topology(*topo, zero_z_mode, false, true, ht);
+  if (!err.empty()) return fail(nullptr, GS_E_INVALID, "topology: %s", err.c_str());
+  for (int i = 0; i < ht.n; ++i)
+    if (i != ht.slack && !(ht.th_free[i] && ht.vm_free[i])) return fail(nullptr, GS_E_TOPOLOGY, "a bus other than the slack is not a PQ bus");
+  const int na = ht.n - 1, N2 = 2 * na, K = na + 1, tiles = (N2 + 15) / 16, steps = (K + 3) / 4;
+  std::vector<double> wt;
+  if (!flat_newton_map(ht, tiles, steps, wt)) return fail(nullptr, GS_E_TOPOLOGY, "the flat-start Jacobian is singular");
+  for (int u = 0; u < N2; ++u)
+    for (int k = 0; k < K; ++k) out[(size_t)u * K + k] = wt[((size_t)(u / 16) * steps + k / 4) * 64 + (u % 16) + 16 * (k % 4)];
+  return GS_OK;
+}
+
 // ---- measurement ------------------------------------------------------------------------------------
 int gs_debug_stamps(gs_handle* h, uint64_t* cycles_out, int32_t n) {
   if (!h || !cycles_out || n < 1 || n > 16) return fail(h, GS_E_INVALID, "bad arguments");

@@ -366,6 +366,10 @@ int gs_mesh_schedule_dump(const gs_topology* topo, int32_t zero_z_mode, int32_t 
  * of the packed form, the Ybus table it stages in LDS ((n_pairs + 1) off-diagonal entries, then the diagonal entry of every
  * voltage slot) and the neighbour lists.  counts[4]: n_pairs, doubles of ytab, entries of adj_ent, words per item; arrays may be
  * NULL (first call).  GS_E_TOPOLOGY if the feeder is not eligible. */
+/* Test aid, host arithmetic only: the constant linear map of the meshed member's first Newton step from the flat start,
+ * x = W [P_spec of the non-slack buses in bus order; 1] (power_flow.py:125-134 flat start, :243-287 exact Jacobian, :186-190 solve; Q_spec = 0),
+ * W row-major [2 (n - 1)][n]: rows (d theta, d|V|) per non-slack bus, last column the constant term.  All-PQ networks only. */
+int gs_flat_newton_map_dump(const gs_topology* topo, int32_t zero_z_mode, double* out);
 int gs_mesh_schedule_dump_packed(const gs_topology* topo, int32_t zero_z_mode, int32_t nw, int32_t ni, int32_t acc_cap, int32_t unit_budget, int32_t region_base,
                                  int32_t slot_bytes, int32_t* counts, int32_t* packed, int32_t* rowinfo, double* ytab, int32_t* adj_ent);
 /* Diagnostic: (start, end) of each of the first n_blocks workgroups of the last step launch, in ticks of the GPU's 100 MHz

@@ -277,3 +277,37 @@ def test_level_search_lowers_the_peak_of_the_message_region():
             if ((r[hv, 1] >> 12) & 15) > 1 and r[hv, 1] & 3:
                 g.setdefault(int((r[hv, 1] >> 4) & 15), set()).add(int(r[hv, 14]))
         assert all(len(v) == 1 for v in g.values()) and len({next(iter(v)) for v in g.values()}) == len(g)
+
+
+@pytest.mark.parametrize("maker", [lambda: P.random_meshed(123, 26, seed=1), lambda: P.random_meshed(40, 6, seed=2), lambda: P.ieee13_like("epsilon")])
+def test_flat_start_newton_map_equals_the_oracles_first_newton_step(maker):
+    """Iteration 0 of the meshed step kernel is x = W [P_spec; 1] (gs_flat_newton_map_dump: W inverted once on the host).  Against the
+    NumPy oracle's own first Newton step from the flat start -- mismatch, exact Jacobian, np.linalg.solve (power_flow.py:125-190) -- for
+    random injections, with the slack renamed into the middle of the numbering as well (no GPU)."""
+    from oracle import oracle_np as O
+    from grid_fed_rl_gym_amd import _lib
+    import dataclasses
+    base = maker()
+    for relabel in (False, True):
+        spec = base
+        if relabel:
+            perm = np.arange(base.n); perm[[0, base.n // 2]] = perm[[base.n // 2, 0]]
+            inv = np.argsort(perm)
+            m = lambda a: perm[np.asarray(a)].astype(np.int32)
+            spec = dataclasses.replace(base, bus_type=base.bus_type[inv].copy(), v_set=base.v_set[inv].copy(), frm=m(base.frm), to=m(base.to),
+                                       load_bus=m(base.load_bus), gen_bus=m(base.gen_bus), bat_bus=m(base.bat_bus), bus_ids=[base.bus_ids[i] for i in inv])
+        W = _lib.flat_newton_map(spec)
+        n = spec.n
+        slack = int(np.flatnonzero(spec.bus_type == 2)[0])
+        ns = [i for i in range(n) if i != slack]
+        assert W.shape == (2 * (n - 1), n)
+        Y = O.admittance_matrix(n, spec.frm, spec.to, spec.r, spec.x)
+        V0 = np.ones(n, dtype=complex); V0[slack] = spec.v_set[slack]
+        J = O.jacobian(Y, V0, slack, [], ns, mode="exact")
+        rng = np.random.default_rng(7)
+        for _ in range(3):
+            Pn = np.zeros(n); Pn[ns] = -rng.uniform(0.0, 0.05, n - 1)
+            S, dP, dQ, mm = O.mismatch(Y, V0, Pn, np.zeros(n), slack, ns)
+            dx = np.linalg.solve(J, np.concatenate([dP[ns], dQ[ns]]))          # [d theta (non-slack); d|V| (non-slack)]
+            x = W @ np.concatenate([Pn[ns], [1.0]])                            # (d theta, d|V|) interleaved per bus
+            assert np.max(np.abs(x[0::2] - dx[:n - 1])) < 1e-11 and np.max(np.abs(x[1::2] - dx[n - 1:])) < 1e-11
