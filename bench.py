@@ -838,7 +838,7 @@ def main():
                                        ("scalable", lambda: make_feeder("meshed_scalable"), B, 5, 2)):
                 try:
                     fsm = mk()
-                    mm = measure(fsm, Bm, "nr", False, 3, warmup=W_, steps=K)
+                    mm = measure(fsm, Bm, "nr", False, max(3, args.repeats // (4 if key == "loops26" else 12)), warmup=W_, steps=K)      # (as the headline: the median over the regions; three regions sat on the clock ramp)
                     sm = summarize(mm, 1)
                     rl = roofline_of(mm, sm, f"meshed_{key}_b8192")
                     pairs = int(mm["desc"].get("lu_pairs", 0))
